@@ -1,0 +1,87 @@
+"""ctypes binding of libbibim_hip.so (C ABI declared in include/bibim_hip.h).
+
+There is no CPU fallback here or in the library: if the shared object is missing the import fails
+loudly, and every compute entry point fails with BBR_ERR_NO_DEVICE when no HIP device is present.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libbibim_hip.so")
+
+BBR_OK = 0
+STATUS = {0: "BBR_OK", -1: "BBR_ERR_INVALID_ARGUMENT", -2: "BBR_ERR_NO_DEVICE", -3: "BBR_ERR_HIP",
+          -4: "BBR_ERR_OUT_OF_MEMORY", -5: "BBR_ERR_BAD_HANDLE", -6: "BBR_ERR_NOT_IN_FRAME",
+          -7: "BBR_ERR_TOO_MANY_PRIMITIVES", -8: "BBR_ERR_CAPACITY"}
+
+
+class BbrImage(C.Structure):
+    _fields_ = [("rgba", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32)]
+
+
+class BbrStats(C.Structure):
+    _fields_ = [("n_prims", C.c_uint64), ("n_raster_tris", C.c_uint64), ("n_clipped_prims", C.c_uint64),
+                ("n_bin_refs", C.c_uint64), ("n_broad_tris", C.c_uint64), ("n_shaded", C.c_uint64),
+                ("bin_overflow", C.c_uint32), ("tile_w", C.c_uint32), ("tile_h", C.c_uint32), ("n_tiles", C.c_uint32)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+class BibimError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"{STATUS.get(code, code)}: {msg}")
+        self.code = code
+
+
+# every symbol include/bibim_hip.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+SIGNATURES = {
+    "bbr_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(_P)]),
+    "bbr_destroy": (C.c_int, [_P]),
+    "bbr_last_error": (C.c_char_p, [_P]),
+    "bbr_device_count": (C.c_int, []),
+    "bbr_upload_mesh": (C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint32, C.POINTER(C.c_int32)]),
+    "bbr_upload_material": (C.c_int, [_P, C.POINTER(BbrImage), C.POINTER(C.c_int32)]),
+    "bbr_free_mesh": (C.c_int, [_P, C.c_int32]),
+    "bbr_free_material": (C.c_int, [_P, C.c_int32]),
+    "bbr_set_frame_uniforms": (C.c_int, [_P, _P]),
+    "bbr_set_view_uniforms": (C.c_int, [_P, _P]),
+    "bbr_begin_frame": (C.c_int, [_P]),
+    "bbr_draw": (C.c_int, [_P, C.c_int32, C.c_int32, _P, C.c_uint32]),
+    "bbr_end_frame": (C.c_int, [_P]),
+    "bbr_replay_frame": (C.c_int, [_P]),
+    "bbr_synchronize": (C.c_int, [_P]),
+    "bbr_read_framebuffer": (C.c_int, [_P, _P]),
+    "bbr_framebuffer_device_ptr": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64)]),
+    "bbr_set_output_device_ptr": (C.c_int, [_P, _P, C.c_uint64]),
+    "bbr_set_stream": (C.c_int, [_P, _P]),
+    "bbr_set_partition": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32]),
+    "bbr_shard_rows": (C.c_int, [_P, C.POINTER(C.c_int32)]),
+    "bbr_read_shard": (C.c_int, [_P, _P]),
+    "bbr_unpack_gathered": (C.c_int, [_P, _P, _P]),
+    "bbr_tile_height": (C.c_int, [_P, C.POINTER(C.c_int32)]),
+    "bbr_get_stats": (C.c_int, [_P, C.POINTER(BbrStats)]),
+    "bbr_read_visibility": (C.c_int, [_P, _P, _P]),
+    "bbr_last_frame_time_ms": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "bbr_set_option": (C.c_int, [_P, C.c_char_p, C.c_int64]),
+    "bbr_tone_map": (C.c_int, [_P, C.c_int32, C.c_float]),
+}
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib

@@ -1,0 +1,159 @@
+// bb_types.h -- byte layouts of the forward path's inputs, exactly as the reference hands them to Vulkan,
+// plus the device-side records of the MI355X pipeline.  Shared by the HIP kernels, the C-ABI and the
+// C++ Scene/Camera/drawFrame shim.
+//
+// Reference layouts (sizes checked against the reference's headers compiled in the authoring container):
+//   Vertex            src/render.h:112-117   44 B   Pos@0 UV@12 Normal@20 Tangent@32
+//   InstanceBlock     src/render.h:96-99    128 B   ModelMat@0 InvModelMat@64
+//   Light             src/render.h:310-318   64 B   Pos@0 Type@12 Dir@16 Intensity@28 Color@32 Inner@44 Outer@48
+//   FrameUniformBlock src/render.h:321-327 6432 B   NumLights@0 Lights@16 ... EnableToneMapping@6420 Exposure@6424
+//   ViewUniformBlock  src/render.h:329-334  144 B   ViewMat@0 ProjMat@64 ViewPos@128 EnableNormalMap@140
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+namespace bbr {
+
+struct Mat4 {
+  float M[4][4];  // column-major M[col][row], src/vector_math.h:64
+};
+
+struct Vertex {
+  float pos[3];
+  float uv[2];
+  float normal[3];
+  float tangent[3];
+};
+
+struct InstanceBlock {
+  Mat4 model;
+  Mat4 inv_model;
+};
+
+struct alignas(16) Light {
+  float pos[3];
+  int32_t type;  // 0 point, 1 spot, 2 directional (src/shaders/standard_sets.glsl:8)
+  float dir[3];
+  float intensity;
+  float color[3];
+  float inner_cutoff;
+  float outer_cutoff;
+};
+
+constexpr int kMaxNumLights = 100;
+
+struct FrameUniformBlock {
+  int32_t num_lights;
+  Light lights[kMaxNumLights];
+  int32_t visualized_gbuffer_attachment_index;
+  int32_t enable_tone_mapping;
+  float exposure;
+};
+
+struct ViewUniformBlock {
+  Mat4 view;
+  Mat4 proj;
+  float view_pos[3];
+  int32_t enable_normal_map;
+};
+
+static_assert(sizeof(Mat4) == 64, "Mat4");
+static_assert(sizeof(Vertex) == 44 && offsetof(Vertex, uv) == 12 && offsetof(Vertex, normal) == 20 &&
+                  offsetof(Vertex, tangent) == 32, "Vertex");
+static_assert(sizeof(InstanceBlock) == 128, "InstanceBlock");
+static_assert(sizeof(Light) == 64 && offsetof(Light, type) == 12 && offsetof(Light, dir) == 16 &&
+                  offsetof(Light, intensity) == 28 && offsetof(Light, color) == 32 &&
+                  offsetof(Light, inner_cutoff) == 44 && offsetof(Light, outer_cutoff) == 48, "Light");
+static_assert(sizeof(FrameUniformBlock) == 6432 && offsetof(FrameUniformBlock, lights) == 16 &&
+                  offsetof(FrameUniformBlock, enable_tone_mapping) == 6420 &&
+                  offsetof(FrameUniformBlock, exposure) == 6424, "FrameUniformBlock");
+static_assert(sizeof(ViewUniformBlock) == 144 && offsetof(ViewUniformBlock, proj) == 64 &&
+                  offsetof(ViewUniformBlock, view_pos) == 128 && offsetof(ViewUniformBlock, enable_normal_map) == 140,
+              "ViewUniformBlock");
+
+// PBRMapType order, src/render.h:235-243
+enum MapType { kMapAlbedo = 0, kMapMetallic, kMapRoughness, kMapAO, kMapNormal, kMapHeight, kMapCount };
+
+// ------------------------------------------------------------------------------------------------
+// device-side records (implementation intermediates; not part of the ABI)
+// ------------------------------------------------------------------------------------------------
+
+constexpr int kNumVary = 14;  // uv(2) posWorld(3) N(3) T(3) B(3)
+constexpr int kSubpixelBits = 8;
+constexpr int kMaxSubTris = 8;  // visibility key low word = prim*8 + sub + 1
+constexpr uint32_t kMaxPrims = 1u << 29;
+constexpr int32_t kClippedSentinel = INT32_MIN;
+
+// One rasterisable triangle: 24.8 snapped coordinates + planes relative to vertex 0.  64 B.
+// When X0 == kClippedSentinel the primitive went through the clipper: Y0 = first clip-arena slot,
+// X1 = number of slots.
+struct RasterTri {
+  int32_t X0, Y0, X1, Y1, X2, Y2;
+  float z0, dzdx, dzdy;          // NDC depth plane, per sub-pixel unit
+  float l1dx, l1dy, l2dx, l2dy;  // screen-space barycentric planes
+  float rw0, rw1, rw2;           // 1/w at the triangle's own vertices
+};
+static_assert(sizeof(RasterTri) == 64, "RasterTri");
+
+// Sub-triangle produced by the polygon clipper.  112 B.
+struct ClipSlot {
+  RasterTri tri;
+  float bary[3][3];  // own vertex j -> barycentrics with respect to the unclipped primitive
+  uint32_t valid;
+  uint32_t pad[2];
+};
+static_assert(sizeof(ClipSlot) == 112, "ClipSlot");
+
+// Post-vertex-stage varyings of one primitive's three vertices.  176 B.
+struct PrimAttr {
+  float vary[3][kNumVary];
+  uint32_t material;
+  uint32_t pad;
+};
+static_assert(sizeof(PrimAttr) == 176, "PrimAttr");
+
+struct DrawDesc {
+  const Vertex *vertices;
+  const uint32_t *indices;  // nullptr => non-indexed
+  const InstanceBlock *instances;
+  uint32_t n_instances;
+  uint32_t tris_per_instance;
+  uint32_t first_prim;
+  uint32_t material;
+};
+
+struct TexDesc {
+  const uint8_t *texels;  // RGBA8, row-major
+  int32_t w, h;
+};
+
+struct MaterialDesc {
+  TexDesc maps[kMapCount];
+};
+
+// per-frame counters (one block per frame parity)
+struct Counters {
+  uint32_t n_broad;
+  uint32_t n_clip_slots;
+  uint32_t overflow;  // bit0 bins, bit1 broad list, bit2 clip arena
+  uint32_t pad0;
+  unsigned long long n_raster_tris;
+  unsigned long long n_clipped_prims;
+  unsigned long long n_bin_refs;
+  unsigned long long n_shaded;
+  unsigned long long pad1[2];
+};
+static_assert(sizeof(Counters) == 64, "Counters");
+
+struct FrameParams {
+  int32_t width, height;
+  float half_w, half_h;
+  int32_t tiles_x, tiles_y;          // tiles over the whole frame
+  uint32_t bin_cap, broad_cap, clip_cap;
+  uint32_t broad_threshold;          // triangles touching more tiles than this go to the broad list
+  // screen-band partition (band = band_tiles tile rows; band b belongs to rank b % world)
+  int32_t rank, world, band_tiles;
+  int32_t shard_rows;                // rows of the compact output when world > 1
+};
+
+}  // namespace bbr

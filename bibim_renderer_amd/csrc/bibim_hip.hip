@@ -1,0 +1,710 @@
+// bibim_hip.hip -- C-ABI (include/bibim_hip.h) over the HIP kernels in bb_kernels.hip.h.
+//
+// One context = one GPU, one HIP stream, all buffers resident in HBM for the context's lifetime.
+// A frame is: [H2D of instances + lights, one async copy from pinned staging] -> k_geometry per draw
+// -> k_tile.  No host synchronisation inside a frame; capacities (bins, broad list, clip arena) are
+// checked lazily at the next synchronising call and the frame is re-rendered once after growing them.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/bibim_hip.h"
+#include "bb_kernels.hip.h"
+
+using namespace bbr;
+
+namespace {
+
+std::string g_create_error;
+
+struct Mesh {
+  Vertex *d_vertices = nullptr;
+  uint32_t *d_indices = nullptr;
+  uint32_t n_vertices = 0, n_indices = 0;
+  bool alive = false;
+};
+
+struct Material {
+  uint8_t *d_texels[kMapCount] = {};
+  MaterialDesc desc = {};
+  bool alive = false;
+};
+
+struct RecordedDraw {
+  int32_t mesh, material;
+  uint32_t n_instances, first_instance, first_prim, tris_per_instance;
+};
+
+template <typename T>
+struct DeviceBuffer {
+  T *ptr = nullptr;
+  size_t cap = 0;  // elements
+  hipError_t ensure(size_t n, bool zero = false) {
+    if (n <= cap) return hipSuccess;
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    cap = 0;
+    hipError_t e = hipMalloc(&ptr, n * sizeof(T));
+    if (e != hipSuccess) return e;
+    cap = n;
+    if (zero) e = hipMemset(ptr, 0, n * sizeof(T));
+    return e;
+  }
+  void release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    cap = 0;
+  }
+};
+
+}  // namespace
+
+struct bbr_context {
+  int device = 0;
+  int32_t width = 0, height = 0;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  std::string last_error;
+
+  std::vector<Mesh> meshes;
+  std::vector<Material> materials;
+  uint8_t *d_default_texels = nullptr;  // 6 x RGBA8 (1x1 default maps)
+  DeviceBuffer<MaterialDesc> d_materials;
+  bool materials_dirty = true;
+
+  FrameUniformBlock frame_u = {};
+  ViewUniformBlock view_u = {};
+
+  bool in_frame = false, have_frame = false;
+  std::vector<RecordedDraw> draws;
+  std::vector<InstanceBlock> host_instances;
+  uint32_t n_prims = 0;
+
+  // staging (pinned) + device mirrors
+  void *h_staging = nullptr;
+  size_t staging_cap = 0;
+  DeviceBuffer<uint8_t> d_staging;
+
+  DeviceBuffer<RasterTri> d_tris;
+  DeviceBuffer<PrimAttr> d_attrs;
+  DeviceBuffer<ClipSlot> d_clip;
+  DeviceBuffer<Counters> d_counters;  // 2 blocks (frame parity)
+  DeviceBuffer<uint32_t> d_tile_count;
+  DeviceBuffer<uint32_t> d_bins;
+  DeviceBuffer<uint32_t> d_broad;
+  DeviceBuffer<float4> d_frame;
+  DeviceBuffer<uint32_t> d_vis_prim;
+  DeviceBuffer<float> d_vis_depth;
+  void *ext_out = nullptr;
+  uint64_t ext_out_bytes = 0;
+
+  int parity = 0;
+  int tile_mode = 0;  // 0: 64x64, 1: 32x32
+  uint32_t bin_cap = 2048, broad_cap = 4096, clip_cap = 4096, broad_threshold = 32;
+  int32_t rank = 0, world = 1, band_rows = 0;
+  bool dump_vis = false;
+  bool timing = false;
+  hipEvent_t ev[4] = {};
+  bool ev_valid = false;
+  int retries = 0;
+
+  int tile_w() const { return tile_mode == 0 ? 64 : 32; }
+  int tile_h() const { return tile_mode == 0 ? 64 : 32; }
+  int tiles_x() const { return (width + tile_w() - 1) / tile_w(); }
+  int tiles_y() const { return (height + tile_h() - 1) / tile_h(); }
+  int eff_band_rows() const { return band_rows > 0 ? band_rows : tile_h(); }
+  int n_bands() const { return (height + eff_band_rows() - 1) / eff_band_rows(); }
+  int local_bands() const { return world > 1 ? (n_bands() - rank + world - 1) / world : n_bands(); }
+  int shard_rows() const { return world > 1 ? ((n_bands() + world - 1) / world) * eff_band_rows() : height; }
+};
+
+namespace {
+
+int fail(bbr_context *ctx, int code, const std::string &msg) {
+  if (ctx) ctx->last_error = msg;
+  else g_create_error = msg;
+  return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                                     \
+  do {                                                                                                         \
+    hipError_t _e = (expr);                                                                                    \
+    if (_e != hipSuccess)                                                                                      \
+      return fail(ctx, _e == hipErrorOutOfMemory ? BBR_ERR_OUT_OF_MEMORY : BBR_ERR_HIP,                        \
+                  std::string(#expr) + ": " + hipGetErrorString(_e));                                          \
+  } while (0)
+
+// P*V exactly as the vertex stage's contract evaluates it (column j = P * V[j], fmaf chain)
+Mat4 proj_view(const ViewUniformBlock &v) {
+  Mat4 r;
+  for (int c = 0; c < 4; ++c) {
+    const float *col = v.view.M[c];
+    for (int i = 0; i < 4; ++i)
+      r.M[c][i] = std::fmaf(v.proj.M[3][i], col[3],
+                            std::fmaf(v.proj.M[2][i], col[2], std::fmaf(v.proj.M[1][i], col[1], v.proj.M[0][i] * col[0])));
+  }
+  return r;
+}
+
+FrameParams make_params(const bbr_context *c) {
+  FrameParams fp;
+  fp.width = c->width;
+  fp.height = c->height;
+  fp.half_w = 0.5f * (float)c->width;
+  fp.half_h = 0.5f * (float)c->height;
+  fp.tiles_x = c->tiles_x();
+  fp.tiles_y = c->tiles_y();
+  fp.bin_cap = c->bin_cap;
+  fp.broad_cap = c->broad_cap;
+  fp.clip_cap = c->clip_cap;
+  fp.broad_threshold = c->broad_threshold;
+  fp.rank = c->rank;
+  fp.world = c->world;
+  fp.band_tiles = c->eff_band_rows() / c->tile_h();
+  fp.shard_rows = c->shard_rows();
+  return fp;
+}
+
+int ensure_frame_buffers(bbr_context *c) {
+  size_t tiles = (size_t)c->tiles_x() * c->tiles_y();
+  size_t out_rows = (size_t)std::max(c->height, c->shard_rows());
+  HIP_TRY(c, c->d_tris.ensure(std::max<size_t>(c->n_prims, 1)));
+  HIP_TRY(c, c->d_attrs.ensure(std::max<size_t>(c->n_prims, 1)));
+  HIP_TRY(c, c->d_clip.ensure(c->clip_cap));
+  HIP_TRY(c, c->d_counters.ensure(2, true));
+  HIP_TRY(c, c->d_tile_count.ensure(tiles, true));
+  HIP_TRY(c, c->d_bins.ensure(tiles * c->bin_cap));
+  HIP_TRY(c, c->d_broad.ensure(c->broad_cap));
+  HIP_TRY(c, c->d_frame.ensure(out_rows * c->width));
+  if (c->dump_vis) {
+    HIP_TRY(c, c->d_vis_prim.ensure((size_t)c->width * c->height));
+    HIP_TRY(c, c->d_vis_depth.ensure((size_t)c->width * c->height));
+  }
+  return BBR_OK;
+}
+
+int upload_material_table(bbr_context *c) {
+  if (!c->materials_dirty) return BBR_OK;
+  size_t n = std::max<size_t>(c->materials.size(), 1);
+  std::vector<MaterialDesc> h(n);
+  for (size_t i = 0; i < c->materials.size(); ++i) h[i] = c->materials[i].desc;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, c->d_materials.ensure(n));
+  HIP_TRY(c, hipMemcpy(c->d_materials.ptr, h.data(), n * sizeof(MaterialDesc), hipMemcpyHostToDevice));
+  c->materials_dirty = false;
+  return BBR_OK;
+}
+
+template <int TW, int TH>
+void launch_frame(bbr_context *c, const FrameParams &fp, const Mat4 &pv, const ShadeParams &sp, const Light *d_lights,
+                  const InstanceBlock *d_inst, float4 *out) {
+  Counters *ctr = c->d_counters.ptr + c->parity;
+  Counters *ctr_next = c->d_counters.ptr + (c->parity ^ 1);
+  for (const RecordedDraw &rd : c->draws) {
+    const Mesh &m = c->meshes[rd.mesh];
+    DrawDesc d;
+    d.vertices = m.d_vertices;
+    d.indices = m.d_indices;
+    d.instances = d_inst + rd.first_instance;
+    d.n_instances = rd.n_instances;
+    d.tris_per_instance = rd.tris_per_instance;
+    d.first_prim = rd.first_prim;
+    d.material = (uint32_t)rd.material;
+    uint32_t n = rd.n_instances * rd.tris_per_instance;
+    if (!n) continue;
+    hipLaunchKernelGGL((k_geometry<TW, TH>), dim3((n + 255) / 256), dim3(256), 0, c->stream, d, pv, fp, c->d_tris.ptr,
+                       c->d_attrs.ptr, c->d_clip.ptr, ctr, c->d_tile_count.ptr, c->d_bins.ptr, c->d_broad.ptr);
+  }
+  if (c->timing) (void)hipEventRecord(c->ev[1], c->stream);
+  int grid_y = c->world > 1 ? c->local_bands() * fp.band_tiles : fp.tiles_y;
+  hipLaunchKernelGGL((k_tile<TW, TH>), dim3(fp.tiles_x, grid_y), dim3(kTileThreads), 0, c->stream, fp, sp, d_lights,
+                     c->d_tris.ptr, c->d_attrs.ptr, c->d_clip.ptr, ctr, ctr_next, c->d_tile_count.ptr, c->d_bins.ptr,
+                     c->d_broad.ptr, c->d_materials.ptr, out, c->dump_vis ? c->d_vis_prim.ptr : nullptr,
+                     c->dump_vis ? c->d_vis_depth.ptr : nullptr);
+  if (c->timing) (void)hipEventRecord(c->ev[2], c->stream);
+}
+
+// Queue the recorded frame.  Asynchronous.
+int submit_frame(bbr_context *c) {
+  if (!c->have_frame) return fail(c, BBR_ERR_NOT_IN_FRAME, "no recorded frame");
+  int rc = upload_material_table(c);
+  if (rc) return rc;
+  rc = ensure_frame_buffers(c);
+  if (rc) return rc;
+
+  // staging layout: [lights (100 * 64 B)] [instances]
+  size_t lights_bytes = sizeof(Light) * kMaxNumLights;
+  size_t inst_bytes = sizeof(InstanceBlock) * c->host_instances.size();
+  size_t total = lights_bytes + inst_bytes;
+  if (total > c->staging_cap) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->h_staging) (void)hipHostFree(c->h_staging);
+    c->h_staging = nullptr;
+    size_t cap = std::max<size_t>(total * 2, 1 << 16);
+    HIP_TRY(c, hipHostMalloc(&c->h_staging, cap, hipHostMallocDefault));
+    c->staging_cap = cap;
+    HIP_TRY(c, c->d_staging.ensure(cap));
+  }
+  // the previous frame's copy must have drained before the pinned buffer is rewritten
+  if (c->ev_valid) HIP_TRY(c, hipEventSynchronize(c->ev[3]));
+  std::memcpy(c->h_staging, c->frame_u.lights, lights_bytes);
+  if (inst_bytes) std::memcpy((uint8_t *)c->h_staging + lights_bytes, c->host_instances.data(), inst_bytes);
+
+  if (c->timing) HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->d_staging.ptr, c->h_staging, total, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipEventRecord(c->ev[3], c->stream));
+  c->ev_valid = true;
+
+  const Light *d_lights = reinterpret_cast<const Light *>(c->d_staging.ptr);
+  const InstanceBlock *d_inst = reinterpret_cast<const InstanceBlock *>(c->d_staging.ptr + lights_bytes);
+  FrameParams fp = make_params(c);
+  Mat4 pv = proj_view(c->view_u);
+  ShadeParams sp;
+  std::memcpy(sp.view_pos, c->view_u.view_pos, sizeof sp.view_pos);
+  sp.enable_normal_map = c->view_u.enable_normal_map;
+  sp.num_lights = std::min(std::max(c->frame_u.num_lights, 0), kMaxNumLights);
+  float4 *out = c->ext_out ? reinterpret_cast<float4 *>(c->ext_out) : c->d_frame.ptr;
+
+  if (c->tile_mode == 0) launch_frame<64, 64>(c, fp, pv, sp, d_lights, d_inst, out);
+  else launch_frame<32, 32>(c, fp, pv, sp, d_lights, d_inst, out);
+  HIP_TRY(c, hipGetLastError());
+  c->parity ^= 1;
+  return BBR_OK;
+}
+
+// Synchronise and, if a capacity overflowed, grow it and render the frame again.
+int sync_and_fix(bbr_context *c, Counters *out_counters) {
+  for (int attempt = 0; attempt < 8; ++attempt) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    Counters h = {};
+    if (c->have_frame && c->d_counters.ptr)
+      HIP_TRY(c, hipMemcpy(&h, c->d_counters.ptr + (c->parity ^ 1), sizeof h, hipMemcpyDeviceToHost));
+    if (out_counters) *out_counters = h;
+    if (!h.overflow) return BBR_OK;
+    if (h.overflow & 1u) c->bin_cap *= 2;
+    if (h.overflow & 2u) c->broad_cap *= 2;
+    if (h.overflow & 4u) c->clip_cap *= 2;
+    ++c->retries;
+    // tile counters may hold residue of refs that did not fit: clear and replay
+    HIP_TRY(c, hipMemset(c->d_tile_count.ptr, 0, c->d_tile_count.cap * sizeof(uint32_t)));
+    HIP_TRY(c, hipMemset(c->d_counters.ptr, 0, 2 * sizeof(Counters)));
+    int rc = submit_frame(c);
+    if (rc) return rc;
+  }
+  return fail(c, BBR_ERR_CAPACITY, "bin capacity still exceeded after 8 growth steps");
+}
+
+}  // namespace
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+
+extern "C" {
+
+int bbr_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char *bbr_last_error(const bbr_context *ctx) { return ctx ? ctx->last_error.c_str() : g_create_error.c_str(); }
+
+int bbr_create(int32_t width, int32_t height, int32_t device, bbr_context **out_ctx) {
+  if (!out_ctx) return fail(nullptr, BBR_ERR_INVALID_ARGUMENT, "out_ctx is NULL");
+  *out_ctx = nullptr;
+  if (width <= 0 || height <= 0 || width > 32768 || height > 32768)
+    return fail(nullptr, BBR_ERR_INVALID_ARGUMENT, "width/height out of range");
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    return fail(nullptr, BBR_ERR_NO_DEVICE, "no HIP device: this library has no CPU fallback");
+  if (device < 0 || device >= n) return fail(nullptr, BBR_ERR_INVALID_ARGUMENT, "device index out of range");
+  bbr_context *c = new bbr_context();
+  c->device = device;
+  c->width = width;
+  c->height = height;
+#define CREATE_TRY(expr)                                                                       \
+  do {                                                                                         \
+    hipError_t _e = (expr);                                                                    \
+    if (_e != hipSuccess) {                                                                    \
+      g_create_error = std::string(#expr) + ": " + hipGetErrorString(_e);                      \
+      delete c;                                                                                \
+      return _e == hipErrorOutOfMemory ? BBR_ERR_OUT_OF_MEMORY : BBR_ERR_HIP;                  \
+    }                                                                                          \
+  } while (0)
+  CREATE_TRY(hipSetDevice(device));
+  CREATE_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+  c->stream = c->own_stream;
+  for (auto &e : c->ev) CREATE_TRY(hipEventCreate(&e));
+  // `default` material maps (resources/pbr/default/*.png are uniform images): 1x1 RGBA8 each
+  static const uint8_t k_default[kMapCount][4] = {{255, 255, 255, 255}, {0, 0, 0, 255},       {0, 0, 0, 255},
+                                                  {255, 255, 255, 255}, {127, 127, 255, 255}, {0, 0, 0, 255}};
+  CREATE_TRY(hipMalloc(&c->d_default_texels, sizeof k_default));
+  CREATE_TRY(hipMemcpy(c->d_default_texels, k_default, sizeof k_default, hipMemcpyHostToDevice));
+#undef CREATE_TRY
+  *out_ctx = c;
+  return BBR_OK;
+}
+
+int bbr_destroy(bbr_context *c) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (Mesh &m : c->meshes) {
+    if (m.d_vertices) (void)hipFree(m.d_vertices);
+    if (m.d_indices) (void)hipFree(m.d_indices);
+  }
+  for (Material &m : c->materials)
+    for (auto &p : m.d_texels)
+      if (p) (void)hipFree(p);
+  if (c->d_default_texels) (void)hipFree(c->d_default_texels);
+  c->d_materials.release(); c->d_staging.release(); c->d_tris.release(); c->d_attrs.release(); c->d_clip.release();
+  c->d_counters.release(); c->d_tile_count.release(); c->d_bins.release(); c->d_broad.release(); c->d_frame.release();
+  c->d_vis_prim.release(); c->d_vis_depth.release();
+  if (c->h_staging) (void)hipHostFree(c->h_staging);
+  for (auto &e : c->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+  return BBR_OK;
+}
+
+int bbr_upload_mesh(bbr_context *c, const void *vertices, uint32_t n_vertices, const uint32_t *indices,
+                    uint32_t n_indices, int32_t *out_mesh) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  if (!vertices || !n_vertices || !out_mesh) return fail(c, BBR_ERR_INVALID_ARGUMENT, "upload_mesh: null/empty input");
+  if (indices) {
+    for (uint32_t i = 0; i < n_indices; ++i)
+      if (indices[i] >= n_vertices) return fail(c, BBR_ERR_INVALID_ARGUMENT, "upload_mesh: index out of range");
+  } else if (n_indices) {
+    return fail(c, BBR_ERR_INVALID_ARGUMENT, "upload_mesh: n_indices without indices");
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  Mesh m;
+  m.n_vertices = n_vertices;
+  m.n_indices = indices ? n_indices : 0;
+  HIP_TRY(c, hipMalloc(&m.d_vertices, (size_t)n_vertices * sizeof(Vertex)));
+  HIP_TRY(c, hipMemcpy(m.d_vertices, vertices, (size_t)n_vertices * sizeof(Vertex), hipMemcpyHostToDevice));
+  if (m.n_indices) {
+    HIP_TRY(c, hipMalloc(&m.d_indices, (size_t)n_indices * sizeof(uint32_t)));
+    HIP_TRY(c, hipMemcpy(m.d_indices, indices, (size_t)n_indices * sizeof(uint32_t), hipMemcpyHostToDevice));
+  }
+  m.alive = true;
+  c->meshes.push_back(m);
+  *out_mesh = (int32_t)c->meshes.size() - 1;
+  return BBR_OK;
+}
+
+int bbr_free_mesh(bbr_context *c, int32_t mesh) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  if (mesh < 0 || mesh >= (int32_t)c->meshes.size() || !c->meshes[mesh].alive)
+    return fail(c, BBR_ERR_BAD_HANDLE, "free_mesh: bad handle");
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  Mesh &m = c->meshes[mesh];
+  if (m.d_vertices) (void)hipFree(m.d_vertices);
+  if (m.d_indices) (void)hipFree(m.d_indices);
+  m = Mesh();
+  c->have_frame = false;
+  return BBR_OK;
+}
+
+int bbr_upload_material(bbr_context *c, const bbr_image maps[BBR_MAP_COUNT], int32_t *out_material) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  if (!maps || !out_material) return fail(c, BBR_ERR_INVALID_ARGUMENT, "upload_material: null input");
+  HIP_TRY(c, hipSetDevice(c->device));
+  Material m;
+  for (int i = 0; i < kMapCount; ++i) {
+    const bbr_image &im = maps[i];
+    if (im.rgba && im.width > 0 && im.height > 0) {
+      if (im.width > 16384 || im.height > 16384) return fail(c, BBR_ERR_INVALID_ARGUMENT, "upload_material: map too large");
+      size_t bytes = (size_t)im.width * im.height * 4;
+      HIP_TRY(c, hipMalloc(&m.d_texels[i], bytes));
+      HIP_TRY(c, hipMemcpy(m.d_texels[i], im.rgba, bytes, hipMemcpyHostToDevice));
+      m.desc.maps[i] = TexDesc{m.d_texels[i], im.width, im.height};
+    } else {
+      // missing map => the `default` material's map (src/render.cpp:1328-1336)
+      m.desc.maps[i] = TexDesc{c->d_default_texels + 4 * i, 1, 1};
+    }
+  }
+  m.alive = true;
+  c->materials.push_back(m);
+  c->materials_dirty = true;
+  *out_material = (int32_t)c->materials.size() - 1;
+  return BBR_OK;
+}
+
+int bbr_free_material(bbr_context *c, int32_t material) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  if (material < 0 || material >= (int32_t)c->materials.size() || !c->materials[material].alive)
+    return fail(c, BBR_ERR_BAD_HANDLE, "free_material: bad handle");
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  Material &m = c->materials[material];
+  for (auto &p : m.d_texels)
+    if (p) (void)hipFree(p);
+  m = Material();
+  c->materials_dirty = true;
+  c->have_frame = false;
+  return BBR_OK;
+}
+
+int bbr_set_frame_uniforms(bbr_context *c, const void *block) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  if (!block) return fail(c, BBR_ERR_INVALID_ARGUMENT, "set_frame_uniforms: NULL");
+  std::memcpy(&c->frame_u, block, sizeof(FrameUniformBlock));
+  // the reference asserts NumLights < MAX_NUM_LIGHTS (src/main.cpp:1289-1290)
+  if (c->frame_u.num_lights < 0 || c->frame_u.num_lights >= kMaxNumLights)
+    return fail(c, BBR_ERR_INVALID_ARGUMENT, "set_frame_uniforms: NumLights must be in [0, 100)");
+  return BBR_OK;
+}
+
+int bbr_set_view_uniforms(bbr_context *c, const void *block) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  if (!block) return fail(c, BBR_ERR_INVALID_ARGUMENT, "set_view_uniforms: NULL");
+  std::memcpy(&c->view_u, block, sizeof(ViewUniformBlock));
+  return BBR_OK;
+}
+
+int bbr_begin_frame(bbr_context *c) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  c->draws.clear();
+  c->host_instances.clear();
+  c->n_prims = 0;
+  c->in_frame = true;
+  c->have_frame = false;
+  return BBR_OK;
+}
+
+int bbr_draw(bbr_context *c, int32_t mesh, int32_t material, const void *instance_blocks, uint32_t n_instances) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  if (!c->in_frame) return fail(c, BBR_ERR_NOT_IN_FRAME, "draw outside begin_frame/end_frame");
+  if (mesh < 0 || mesh >= (int32_t)c->meshes.size() || !c->meshes[mesh].alive)
+    return fail(c, BBR_ERR_BAD_HANDLE, "draw: bad mesh handle");
+  if (material < 0 || material >= (int32_t)c->materials.size() || !c->materials[material].alive)
+    return fail(c, BBR_ERR_BAD_HANDLE, "draw: bad material handle");
+  if (n_instances && !instance_blocks) return fail(c, BBR_ERR_INVALID_ARGUMENT, "draw: NULL instance data");
+  const Mesh &m = c->meshes[mesh];
+  uint32_t tris = (m.d_indices ? m.n_indices : m.n_vertices) / 3;
+  uint64_t total = (uint64_t)c->n_prims + (uint64_t)tris * n_instances;
+  if (total >= kMaxPrims) return fail(c, BBR_ERR_TOO_MANY_PRIMITIVES, "draw: more than 2^29 primitives in one frame");
+  RecordedDraw rd;
+  rd.mesh = mesh;
+  rd.material = material;
+  rd.n_instances = n_instances;
+  rd.first_instance = (uint32_t)c->host_instances.size();
+  rd.first_prim = c->n_prims;
+  rd.tris_per_instance = tris;
+  const InstanceBlock *ib = static_cast<const InstanceBlock *>(instance_blocks);
+  c->host_instances.insert(c->host_instances.end(), ib, ib + n_instances);
+  c->draws.push_back(rd);
+  c->n_prims = (uint32_t)total;
+  return BBR_OK;
+}
+
+int bbr_end_frame(bbr_context *c) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  if (!c->in_frame) return fail(c, BBR_ERR_NOT_IN_FRAME, "end_frame without begin_frame");
+  c->in_frame = false;
+  c->have_frame = true;
+  HIP_TRY(c, hipSetDevice(c->device));
+  return submit_frame(c);
+}
+
+int bbr_replay_frame(bbr_context *c) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  if (!c->have_frame) return fail(c, BBR_ERR_NOT_IN_FRAME, "replay_frame: no recorded frame");
+  return submit_frame(c);
+}
+
+int bbr_synchronize(bbr_context *c) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  return sync_and_fix(c, nullptr);
+}
+
+int bbr_read_framebuffer(bbr_context *c, float *host) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  if (!host) return fail(c, BBR_ERR_INVALID_ARGUMENT, "read_framebuffer: NULL");
+  if (c->world > 1) return fail(c, BBR_ERR_INVALID_ARGUMENT, "read_framebuffer on a partitioned context: use bbr_read_shard");
+  if (!c->have_frame) return fail(c, BBR_ERR_NOT_IN_FRAME, "read_framebuffer: nothing rendered");
+  int rc = sync_and_fix(c, nullptr);
+  if (rc) return rc;
+  const void *src = c->ext_out ? c->ext_out : (const void *)c->d_frame.ptr;
+  HIP_TRY(c, hipMemcpy(host, src, (size_t)c->width * c->height * 16, hipMemcpyDeviceToHost));
+  return BBR_OK;
+}
+
+int bbr_read_shard(bbr_context *c, float *host) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  if (!host) return fail(c, BBR_ERR_INVALID_ARGUMENT, "read_shard: NULL");
+  if (!c->have_frame) return fail(c, BBR_ERR_NOT_IN_FRAME, "read_shard: nothing rendered");
+  int rc = sync_and_fix(c, nullptr);
+  if (rc) return rc;
+  const void *src = c->ext_out ? c->ext_out : (const void *)c->d_frame.ptr;
+  HIP_TRY(c, hipMemcpy(host, src, (size_t)c->width * c->shard_rows() * 16, hipMemcpyDeviceToHost));
+  return BBR_OK;
+}
+
+int bbr_framebuffer_device_ptr(bbr_context *c, void **out_ptr, uint64_t *out_bytes) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  if (!out_ptr) return fail(c, BBR_ERR_INVALID_ARGUMENT, "framebuffer_device_ptr: NULL");
+  uint64_t bytes = (uint64_t)c->width * std::max(c->height, c->shard_rows()) * 16;
+  if (!c->ext_out) HIP_TRY(c, c->d_frame.ensure(bytes / 16));
+  *out_ptr = c->ext_out ? c->ext_out : (void *)c->d_frame.ptr;
+  if (out_bytes) *out_bytes = c->ext_out ? c->ext_out_bytes : bytes;
+  return BBR_OK;
+}
+
+int bbr_set_output_device_ptr(bbr_context *c, void *device_ptr, uint64_t bytes) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  if (device_ptr) {
+    uint64_t need = (uint64_t)c->width * (c->world > 1 ? c->shard_rows() : c->height) * 16;
+    if (bytes < need) return fail(c, BBR_ERR_INVALID_ARGUMENT, "set_output_device_ptr: buffer too small");
+    if ((uintptr_t)device_ptr & 15u) return fail(c, BBR_ERR_INVALID_ARGUMENT, "set_output_device_ptr: need 16-byte alignment");
+  }
+  c->ext_out = device_ptr;
+  c->ext_out_bytes = device_ptr ? bytes : 0;
+  return BBR_OK;
+}
+
+int bbr_set_stream(bbr_context *c, void *stream) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->stream = stream ? (hipStream_t)stream : c->own_stream;
+  c->ev_valid = false;
+  return BBR_OK;
+}
+
+int bbr_tile_height(const bbr_context *c, int32_t *out) {
+  if (!c || !out) return BBR_ERR_INVALID_ARGUMENT;
+  *out = c->tile_h();
+  return BBR_OK;
+}
+
+int bbr_set_partition(bbr_context *c, int32_t rank, int32_t world, int32_t band_rows) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  if (world < 1 || rank < 0 || rank >= world) return fail(c, BBR_ERR_INVALID_ARGUMENT, "set_partition: bad rank/world");
+  if (band_rows <= 0) band_rows = c->tile_h();
+  if (band_rows % c->tile_h()) return fail(c, BBR_ERR_INVALID_ARGUMENT, "set_partition: band_rows must be a multiple of the tile height");
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->rank = rank;
+  c->world = world;
+  c->band_rows = band_rows;
+  if (c->ext_out) {
+    uint64_t need = (uint64_t)c->width * (world > 1 ? c->shard_rows() : c->height) * 16;
+    if (c->ext_out_bytes < need) {
+      c->ext_out = nullptr;
+      c->ext_out_bytes = 0;
+    }
+  }
+  return BBR_OK;
+}
+
+int bbr_shard_rows(const bbr_context *c, int32_t *out_rows) {
+  if (!c || !out_rows) return BBR_ERR_INVALID_ARGUMENT;
+  *out_rows = c->shard_rows();
+  return BBR_OK;
+}
+
+int bbr_unpack_gathered(bbr_context *c, const void *gathered, void *frame) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  if (!gathered || !frame) return fail(c, BBR_ERR_INVALID_ARGUMENT, "unpack_gathered: NULL");
+  size_t n = (size_t)c->width * c->height;
+  hipLaunchKernelGGL(k_unpack_gathered, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
+                     (const float4 *)gathered, (float4 *)frame, c->width, c->height, c->world, c->eff_band_rows(),
+                     c->shard_rows());
+  HIP_TRY(c, hipGetLastError());
+  return BBR_OK;
+}
+
+int bbr_get_stats(bbr_context *c, bbr_stats *out) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  if (!out) return fail(c, BBR_ERR_INVALID_ARGUMENT, "get_stats: NULL");
+  if (!c->have_frame) return fail(c, BBR_ERR_NOT_IN_FRAME, "get_stats: nothing rendered");
+  Counters h;
+  int rc = sync_and_fix(c, &h);
+  if (rc) return rc;
+  std::memset(out, 0, sizeof *out);
+  out->n_prims = c->n_prims;
+  out->n_raster_tris = h.n_raster_tris;
+  out->n_clipped_prims = h.n_clipped_prims;
+  out->n_bin_refs = h.n_bin_refs;
+  out->n_broad_tris = h.n_broad;
+  out->n_shaded = h.n_shaded;
+  out->bin_overflow = (uint32_t)c->retries;
+  out->tile_w = (uint32_t)c->tile_w();
+  out->tile_h = (uint32_t)c->tile_h();
+  out->n_tiles = (uint32_t)(c->tiles_x() * c->tiles_y());
+  return BBR_OK;
+}
+
+int bbr_read_visibility(bbr_context *c, uint32_t *prim_host, float *depth_host) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  if (!c->have_frame) return fail(c, BBR_ERR_NOT_IN_FRAME, "read_visibility: nothing rendered");
+  if (c->world > 1) return fail(c, BBR_ERR_INVALID_ARGUMENT, "read_visibility: not available on a partitioned context");
+  int rc = sync_and_fix(c, nullptr);
+  if (rc) return rc;
+  c->dump_vis = true;
+  rc = submit_frame(c);
+  if (!rc) rc = sync_and_fix(c, nullptr);
+  c->dump_vis = false;
+  if (rc) return rc;
+  size_t n = (size_t)c->width * c->height;
+  if (prim_host) HIP_TRY(c, hipMemcpy(prim_host, c->d_vis_prim.ptr, n * 4, hipMemcpyDeviceToHost));
+  if (depth_host) HIP_TRY(c, hipMemcpy(depth_host, c->d_vis_depth.ptr, n * 4, hipMemcpyDeviceToHost));
+  return BBR_OK;
+}
+
+int bbr_last_frame_time_ms(bbr_context *c, float *out_frame_ms, float *out_tile_ms) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  if (!c->timing) return fail(c, BBR_ERR_INVALID_ARGUMENT, "last_frame_time_ms: enable option \"timing\" first");
+  if (!c->have_frame) return fail(c, BBR_ERR_NOT_IN_FRAME, "last_frame_time_ms: nothing rendered");
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  float a = 0.f, b = 0.f;
+  HIP_TRY(c, hipEventElapsedTime(&a, c->ev[0], c->ev[2]));
+  HIP_TRY(c, hipEventElapsedTime(&b, c->ev[1], c->ev[2]));
+  if (out_frame_ms) *out_frame_ms = a;
+  if (out_tile_ms) *out_tile_ms = b;
+  return BBR_OK;
+}
+
+int bbr_set_option(bbr_context *c, const char *name, int64_t value) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  if (!name) return fail(c, BBR_ERR_INVALID_ARGUMENT, "set_option: NULL name");
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  std::string n(name);
+  if (n == "timing") c->timing = value != 0;
+  else if (n == "tile_mode") {
+    if (value != 0 && value != 1) return fail(c, BBR_ERR_INVALID_ARGUMENT, "tile_mode: 0 (64x64) or 1 (32x32)");
+    if (c->world > 1 && c->band_rows % (value == 0 ? 64 : 32))
+      return fail(c, BBR_ERR_INVALID_ARGUMENT, "tile_mode: band_rows not a multiple of the new tile height");
+    c->tile_mode = (int)value;
+    // bins are laid out per tile: drop them so that ensure() re-zeroes the counters
+    c->d_tile_count.release();
+    c->d_bins.release();
+  } else if (n == "bin_cap") {
+    if (value < 1 || value > (1 << 20)) return fail(c, BBR_ERR_INVALID_ARGUMENT, "bin_cap out of range");
+    c->bin_cap = (uint32_t)value;
+    c->d_bins.release();
+  } else if (n == "broad_threshold") {
+    if (value < 1) return fail(c, BBR_ERR_INVALID_ARGUMENT, "broad_threshold must be >= 1");
+    c->broad_threshold = (uint32_t)value;
+  } else {
+    return fail(c, BBR_ERR_INVALID_ARGUMENT, "unknown option: " + n);
+  }
+  return BBR_OK;
+}
+
+int bbr_tone_map(bbr_context *c, int32_t enable, float exposure) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  if (!c->have_frame) return fail(c, BBR_ERR_NOT_IN_FRAME, "tone_map: nothing rendered");
+  float4 *frame = c->ext_out ? (float4 *)c->ext_out : c->d_frame.ptr;
+  size_t n = (size_t)c->width * (c->world > 1 ? c->shard_rows() : c->height);
+  hipLaunchKernelGGL(k_tone_map, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, frame, n, enable, exposure);
+  HIP_TRY(c, hipGetLastError());
+  return BBR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,184 @@
+"""Thin object wrapper over the C ABI.  Names follow the reference's vocabulary: a mesh is a vertex
+(+ index) buffer, a material is the six-map PBRMaterial, a frame is begin -> draw* -> end."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from ._capi import BbrImage, BbrStats, BibimError, lib
+
+MAP_NAMES = ("albedo", "metallic", "roughness", "ao", "normal", "height")
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Renderer:
+    def __init__(self, width, height, device=0):
+        self._L = lib()
+        self._ctx = C.c_void_p()
+        rc = self._L.bbr_create(width, height, device, C.byref(self._ctx))
+        if rc != 0:
+            raise BibimError(rc, (self._L.bbr_last_error(None) or b"").decode())
+        self.width, self.height = int(width), int(height)
+
+    # -- plumbing --
+    def _check(self, rc):
+        if rc != 0:
+            raise BibimError(rc, (self._L.bbr_last_error(self._ctx) or b"").decode())
+
+    def close(self):
+        if self._ctx:
+            self._L.bbr_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- resources --
+    def upload_mesh(self, vertices, indices=None):
+        v = np.ascontiguousarray(vertices)
+        assert v.dtype.itemsize == 44 or (v.dtype == np.float32 and v.shape[-1] == 11)
+        n = v.shape[0]
+        idx = None if indices is None else np.ascontiguousarray(indices, np.uint32)
+        out = C.c_int32()
+        self._check(self._L.bbr_upload_mesh(self._ctx, _ptr(v), n, _ptr(idx), 0 if idx is None else len(idx), C.byref(out)))
+        return out.value
+
+    def upload_material(self, maps=None):
+        maps = maps or {}
+        arr = (BbrImage * 6)()
+        keep = []
+        for i, name in enumerate(MAP_NAMES):
+            a = maps.get(name)
+            if a is None:
+                arr[i] = BbrImage(None, 0, 0)
+            else:
+                a = np.ascontiguousarray(a, np.uint8)
+                assert a.ndim == 3 and a.shape[2] == 4
+                keep.append(a)
+                arr[i] = BbrImage(a.ctypes.data, a.shape[1], a.shape[0])
+        out = C.c_int32()
+        self._check(self._L.bbr_upload_material(self._ctx, arr, C.byref(out)))
+        return out.value
+
+    def free_mesh(self, mesh):
+        self._check(self._L.bbr_free_mesh(self._ctx, mesh))
+
+    def free_material(self, material):
+        self._check(self._L.bbr_free_material(self._ctx, material))
+
+    # -- frame --
+    def set_frame_uniforms(self, block):
+        b = np.ascontiguousarray(block)
+        assert b.nbytes == 6432
+        self._check(self._L.bbr_set_frame_uniforms(self._ctx, _ptr(b)))
+
+    def set_view_uniforms(self, block):
+        b = np.ascontiguousarray(block)
+        assert b.nbytes == 144
+        self._check(self._L.bbr_set_view_uniforms(self._ctx, _ptr(b)))
+
+    def begin_frame(self):
+        self._check(self._L.bbr_begin_frame(self._ctx))
+
+    def draw(self, mesh, material, instances):
+        inst = np.ascontiguousarray(instances)
+        assert inst.nbytes % 128 == 0
+        self._check(self._L.bbr_draw(self._ctx, mesh, material, _ptr(inst), inst.nbytes // 128))
+
+    def end_frame(self):
+        self._check(self._L.bbr_end_frame(self._ctx))
+
+    def replay_frame(self):
+        self._check(self._L.bbr_replay_frame(self._ctx))
+
+    def synchronize(self):
+        self._check(self._L.bbr_synchronize(self._ctx))
+
+    # -- output --
+    def read_framebuffer(self):
+        out = np.empty((self.height, self.width, 4), np.float32)
+        self._check(self._L.bbr_read_framebuffer(self._ctx, _ptr(out)))
+        return out
+
+    def read_visibility(self):
+        prim = np.empty((self.height, self.width), np.uint32)
+        depth = np.empty((self.height, self.width), np.float32)
+        self._check(self._L.bbr_read_visibility(self._ctx, _ptr(prim), _ptr(depth)))
+        return prim, depth
+
+    def stats(self):
+        s = BbrStats()
+        self._check(self._L.bbr_get_stats(self._ctx, C.byref(s)))
+        return s.as_dict()
+
+    def set_option(self, name, value):
+        self._check(self._L.bbr_set_option(self._ctx, name.encode(), int(value)))
+
+    def last_frame_time_ms(self):
+        a, b = C.c_float(), C.c_float()
+        self._check(self._L.bbr_last_frame_time_ms(self._ctx, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def tone_map(self, enable, exposure):
+        self._check(self._L.bbr_tone_map(self._ctx, int(enable), float(exposure)))
+
+    # -- multi-GPU partition --
+    def set_partition(self, rank, world, band_rows=0):
+        self._check(self._L.bbr_set_partition(self._ctx, rank, world, band_rows))
+
+    def shard_rows(self):
+        r = C.c_int32()
+        self._check(self._L.bbr_shard_rows(self._ctx, C.byref(r)))
+        return r.value
+
+    def tile_height(self):
+        r = C.c_int32()
+        self._check(self._L.bbr_tile_height(self._ctx, C.byref(r)))
+        return r.value
+
+    def read_shard(self):
+        out = np.empty((self.shard_rows(), self.width, 4), np.float32)
+        self._check(self._L.bbr_read_shard(self._ctx, _ptr(out)))
+        return out
+
+    def set_output_device_ptr(self, ptr, nbytes):
+        self._check(self._L.bbr_set_output_device_ptr(self._ctx, C.c_void_p(ptr), nbytes))
+
+    def set_stream(self, stream_handle):
+        self._check(self._L.bbr_set_stream(self._ctx, C.c_void_p(stream_handle)))
+
+    def framebuffer_device_ptr(self):
+        p, n = C.c_void_p(), C.c_uint64()
+        self._check(self._L.bbr_framebuffer_device_ptr(self._ctx, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def unpack_gathered(self, gathered_ptr, frame_ptr):
+        self._check(self._L.bbr_unpack_gathered(self._ctx, C.c_void_p(gathered_ptr), C.c_void_p(frame_ptr)))
+
+    # -- convenience: submit a scene description made of numpy inputs --
+    def render_scene(self, scene, handles=None):
+        """scene: object with .frame, .view and .draws, each draw having .vertices, .indices, .instances and
+        .material.maps (dict name -> uint8 [h, w, 4]).  Returns handles so that repeated frames reuse the
+        uploaded meshes / materials."""
+        if handles is None:
+            handles = {"mesh": {}, "mat": {}}
+        self.set_frame_uniforms(scene.frame)
+        self.set_view_uniforms(scene.view)
+        self.begin_frame()
+        for d in scene.draws:
+            mk = id(d.vertices)
+            if mk not in handles["mesh"]:
+                handles["mesh"][mk] = self.upload_mesh(d.vertices, d.indices)
+            tk = id(d.material)
+            if tk not in handles["mat"]:
+                handles["mat"][tk] = self.upload_material(d.material.maps)
+            self.draw(handles["mesh"][mk], handles["mat"][tk], d.instances)
+        self.end_frame()
+        return handles

@@ -1,0 +1,142 @@
+/*
+ * bibim_hip.h -- C ABI of the MI355X-native forward PBR path (libbibim_hip.so).
+ *
+ * The reference (chromedays/bibim-renderer) has no plugin / FFI layer: its forward path is reached
+ * through SceneBase::drawScene(const Frame&) (src/scene.h:84) and the DATA it hands to Vulkan.  Each
+ * entry point below replaces one of those hand-offs and consumes the reference's byte layouts unchanged:
+ *
+ *   bbr_upload_mesh          createVertexBuffer / createIndexBuffer            src/scene.h:86-108
+ *                            (bb::Vertex 44 B, src/render.h:112-117; VK_INDEX_TYPE_UINT32, src/scene.cpp:209)
+ *   bbr_upload_material      createPBRMaterialSet + set 2 binding               src/render.cpp:1243-1336,
+ *                            (6 RGBA8 images in PBRMapType order)               src/shaders/standard_sets.glsl:45-50
+ *   bbr_set_frame_uniforms   FrameUniformBlock map/memcpy (6432 B)              src/main.cpp:1288-1327
+ *   bbr_set_view_uniforms    ViewUniformBlock map/memcpy (144 B)                src/main.cpp:1329-1342
+ *   bbr_begin_frame          vkCmdBeginRenderPass, all clears = 0               src/main.cpp:78-86
+ *   bbr_draw                 updateInstanceBufferMemory + vkCmdDraw[Indexed]    src/scene.h:120-132,
+ *                            (bb::InstanceBlock 128 B, src/render.h:96-99)      src/scene.cpp:203-210
+ *   bbr_end_frame            vkCmdEndRenderPass + vkQueueSubmit                 src/main.cpp:174,1364
+ *   bbr_read_framebuffer     the HDR colour attachment (kept fp32 RGBA)         src/main.cpp:463-472
+ *   pipeline state           createPipeline + forward params (fixed here)       src/render.cpp:1044-1178,
+ *                                                                               src/main.cpp:332-350
+ *
+ * Conventions: every call returns BBR_OK (0) or a negative bbr_status; bbr_last_error() gives text.
+ * A context is externally synchronised (one thread at a time), as the reference's single render thread.
+ * Caller-owned host memory is copied before the call returns (as createDeviceLocalBufferFromMemory does,
+ * src/render.cpp:706-726).  All device work is queued on one HIP stream; bbr_end_frame does not block.
+ * There is NO CPU fallback: without a HIP device every compute entry point fails with BBR_ERR_NO_DEVICE.
+ */
+#ifndef BIBIM_HIP_H
+#define BIBIM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bbr_context bbr_context;
+
+typedef enum bbr_status {
+  BBR_OK = 0,
+  BBR_ERR_INVALID_ARGUMENT = -1,
+  BBR_ERR_NO_DEVICE = -2,
+  BBR_ERR_HIP = -3,
+  BBR_ERR_OUT_OF_MEMORY = -4,
+  BBR_ERR_BAD_HANDLE = -5,
+  BBR_ERR_NOT_IN_FRAME = -6,
+  BBR_ERR_TOO_MANY_PRIMITIVES = -7,
+  BBR_ERR_CAPACITY = -8
+} bbr_status;
+
+/* One RGBA8 image, stb_image STBI_rgb_alpha layout (src/resource.cpp:159-160).
+ * rgba == NULL selects the `default` material's map for that slot (src/render.cpp:1328-1336). */
+typedef struct bbr_image {
+  const uint8_t *rgba;
+  int32_t width;
+  int32_t height;
+} bbr_image;
+
+/* PBRMapType order (src/render.h:235-243) */
+enum { BBR_MAP_ALBEDO = 0, BBR_MAP_METALLIC, BBR_MAP_ROUGHNESS, BBR_MAP_AO, BBR_MAP_NORMAL, BBR_MAP_HEIGHT, BBR_MAP_COUNT };
+
+/* Byte sizes the ABI accepts verbatim */
+#define BBR_SIZEOF_VERTEX 44
+#define BBR_SIZEOF_INSTANCE_BLOCK 128
+#define BBR_SIZEOF_LIGHT 64
+#define BBR_SIZEOF_FRAME_UNIFORM_BLOCK 6432
+#define BBR_SIZEOF_VIEW_UNIFORM_BLOCK 144
+#define BBR_MAX_NUM_LIGHTS 100
+
+typedef struct bbr_stats {
+  uint64_t n_prims;        /* triangles submitted this frame */
+  uint64_t n_raster_tris;  /* (sub-)triangles that survived clip + cull + "covers a pixel centre" */
+  uint64_t n_clipped_prims;
+  uint64_t n_bin_refs;     /* (tile, triangle) pairs written to bins */
+  uint64_t n_broad_tris;   /* triangles routed to the every-tile list */
+  uint64_t n_shaded;       /* pixels of the owned rows whose winning fragment is geometry */
+  uint32_t bin_overflow;   /* non-zero if a capacity was exceeded (frame is re-rendered transparently) */
+  uint32_t tile_w, tile_h;
+  uint32_t n_tiles;
+} bbr_stats;
+
+/* ---- lifetime ---- */
+int bbr_create(int32_t width, int32_t height, int32_t device, bbr_context **out_ctx);
+int bbr_destroy(bbr_context *ctx);
+const char *bbr_last_error(const bbr_context *ctx); /* ctx may be NULL: last creation error */
+int bbr_device_count(void);
+
+/* ---- resources ---- */
+int bbr_upload_mesh(bbr_context *ctx, const void *vertices, uint32_t n_vertices, const uint32_t *indices_or_null,
+                    uint32_t n_indices, int32_t *out_mesh);
+int bbr_upload_material(bbr_context *ctx, const bbr_image maps[BBR_MAP_COUNT], int32_t *out_material);
+int bbr_free_mesh(bbr_context *ctx, int32_t mesh);
+int bbr_free_material(bbr_context *ctx, int32_t material);
+
+/* ---- per-frame state ---- */
+int bbr_set_frame_uniforms(bbr_context *ctx, const void *frame_uniform_block /* 6432 B */);
+int bbr_set_view_uniforms(bbr_context *ctx, const void *view_uniform_block /* 144 B */);
+
+/* ---- frame ---- */
+int bbr_begin_frame(bbr_context *ctx);
+int bbr_draw(bbr_context *ctx, int32_t mesh, int32_t material, const void *instance_blocks, uint32_t n_instances);
+int bbr_end_frame(bbr_context *ctx);   /* queues the kernels; asynchronous */
+int bbr_replay_frame(bbr_context *ctx); /* re-submit the last recorded frame (same draws and uniforms) */
+int bbr_synchronize(bbr_context *ctx);
+
+/* ---- output ---- */
+/* Full frame: height*width*4 floats, row-major, RGBA; on a partitioned context rows this rank does not own
+ * are left untouched in the internal buffer (use the shard accessors). */
+int bbr_read_framebuffer(bbr_context *ctx, float *rgba32f_host);
+int bbr_framebuffer_device_ptr(bbr_context *ctx, void **out_device_ptr, uint64_t *out_bytes);
+/* Render into caller-provided device memory instead (e.g. a torch tensor that RCCL all-gathers);
+ * NULL restores the internal buffer.  bytes must cover the frame (or the shard when partitioned). */
+int bbr_set_output_device_ptr(bbr_context *ctx, void *device_ptr, uint64_t bytes);
+int bbr_set_stream(bbr_context *ctx, void *hip_stream); /* NULL = context's own stream */
+
+/* ---- screen-band partition across GPUs (no reference counterpart) ---- */
+/* Band b (band_rows framebuffer rows, a multiple of the tile height) belongs to rank b % world.  The
+ * rank's output becomes a compact shard [local band][row in band][x][rgba]; every rank's shard is padded
+ * to bbr_shard_rows() rows so that an all-gather of equal-sized shards reassembles the frame. */
+int bbr_set_partition(bbr_context *ctx, int32_t rank, int32_t world, int32_t band_rows);
+int bbr_shard_rows(const bbr_context *ctx, int32_t *out_rows);
+int bbr_read_shard(bbr_context *ctx, float *rgba32f_host); /* shard_rows*width*4 floats */
+/* Device-side un-interleave of an all-gathered buffer [world][shard_rows][width][4] into a row-major frame. */
+int bbr_unpack_gathered(bbr_context *ctx, const void *gathered_device, void *frame_device);
+int bbr_tile_height(const bbr_context *ctx, int32_t *out_tile_h);
+
+/* ---- diagnostics ---- */
+int bbr_get_stats(bbr_context *ctx, bbr_stats *out);          /* synchronises */
+/* winning primitive (global API-order index, 0xFFFFFFFF = none) and depth per pixel; synchronises.
+ * Re-runs the frame once with the visibility dump enabled. */
+int bbr_read_visibility(bbr_context *ctx, uint32_t *prim_host, float *depth_host);
+/* device time of the last bbr_end_frame/bbr_replay_frame in ms, and of its dominant kernel; synchronises */
+int bbr_last_frame_time_ms(bbr_context *ctx, float *out_frame_ms, float *out_tile_kernel_ms);
+int bbr_set_option(bbr_context *ctx, const char *name, int64_t value);
+
+/* next row: hdr_tone_mapping.frag:9-18 on the fp32 frame, in place */
+int bbr_tone_map(bbr_context *ctx, int32_t enable_tone_mapping, float exposure);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,907 @@
+/*
+ * bb_oracle.c -- scalar CPU restatement of bibim-renderer's forward PBR path
+ * (vertex transform -> clip/cull/raster/depth -> Cook-Torrance/GGX fragment shade).
+ *
+ * TEST INFRASTRUCTURE ONLY (see bb_oracle.h).  The shipped HIP path never calls this.
+ *
+ * Parity status
+ *   - Row A0 (vector_math.cpp / camera.cpp): PINNED.  The bbo_mat4_* / bbo_camera_* functions are
+ *     checked bit-for-bit against the reference's own sources compiled unmodified into
+ *     oracle/_ref (see oracle/Makefile, oracle/ref_wrap.cpp) and against tests/golden/math_golden.json
+ *     generated from that build.
+ *   - Rows A2-A6 (GLSL stages + Vulkan fixed function): the reference holds no golden images, no tests
+ *     and no CPU implementation; glslc / a Vulkan driver do not exist in the authoring container, so
+ *     the shader arithmetic is a restatement of the GLSL text pinned by closed-form known-answer
+ *     vectors only (tests/test_oracle_kat.py).  Driver latitude (sub-pixel bits, FMA contraction,
+ *     filter weight precision, anisotropic taps) is "parity unpinned": the choices below ARE the contract.
+ *
+ * Arithmetic contract (shared, by construction, with the HIP kernels; compiled -ffp-contract=off):
+ *   IEEE binary32, round-to-nearest-even, denormals kept, correctly rounded / and sqrtf.
+ *   dot3(a,b)      = fmaf(a.z,b.z, fmaf(a.y,b.y, a.x*b.x))
+ *   cross(a,b).x   = fmaf(a.y,b.z, -(a.z*b.y))   (cyclic)
+ *   normalize(v)   = v * (1.0f / sqrtf(dot3(v,v)))
+ *   mat*vec        = fmaf(c3,w, fmaf(c2,z, fmaf(c1,y, c0*x)))   per row
+ *   mix(a,b,t)     = fmaf(b,t, a*(1-t));  pow(x,5) = ((x*x)*(x*x))*x;  x/PI = x*(float)(1/pi)
+ *   Setup quantities that are evaluated once per triangle use binary64 and are rounded once.
+ */
+#include "bb_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------ */
+/* small vector helpers                                                                       */
+/* ------------------------------------------------------------------------------------------ */
+
+typedef struct { float x, y, z; } v3;
+typedef struct { float x, y, z, w; } v4;
+
+static inline v3 v3_make(float x, float y, float z) { v3 r = {x, y, z}; return r; }
+static inline v3 v3_ld(const float *p) { v3 r = {p[0], p[1], p[2]}; return r; }
+static inline float dot3(v3 a, v3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+static inline v3 add3(v3 a, v3 b) { return v3_make(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline v3 sub3(v3 a, v3 b) { return v3_make(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline v3 scale3(v3 a, float s) { return v3_make(a.x * s, a.y * s, a.z * s); }
+static inline v3 neg3(v3 a) { return v3_make(-a.x, -a.y, -a.z); }
+static inline v3 cross3(v3 a, v3 b) {
+  return v3_make(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
+}
+static inline v3 normalize3(v3 a) { return scale3(a, 1.0f / sqrtf(dot3(a, a))); }
+static inline float max0(float a) { return a > 0.0f ? a : 0.0f; } /* GLSL max(a,0): NaN -> 0 */
+
+static inline v4 mat4_mul_v4(const bbo_mat4 *m, v4 v) {
+  v4 r;
+  r.x = fmaf(m->M[3][0], v.w, fmaf(m->M[2][0], v.z, fmaf(m->M[1][0], v.y, m->M[0][0] * v.x)));
+  r.y = fmaf(m->M[3][1], v.w, fmaf(m->M[2][1], v.z, fmaf(m->M[1][1], v.y, m->M[0][1] * v.x)));
+  r.z = fmaf(m->M[3][2], v.w, fmaf(m->M[2][2], v.z, fmaf(m->M[1][2], v.y, m->M[0][2] * v.x)));
+  r.w = fmaf(m->M[3][3], v.w, fmaf(m->M[2][3], v.z, fmaf(m->M[1][3], v.y, m->M[0][3] * v.x)));
+  return r;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* forward_brdf.vert (src/shaders/forward_brdf.vert:24-37)                                    */
+/* ------------------------------------------------------------------------------------------ */
+
+#define NVARY 14 /* uv(2) posWorld(3) N(3) T(3) B(3); vNormalWorld == vTBN[2] == N */
+
+void bbo_proj_view(const bbo_view_uniforms *view, bbo_mat4 *out) {
+  /* GLSL `uProjMat * uViewMat * posWorld` associates left: (P*V) first. forward_brdf.vert:27 */
+  for (int c = 0; c < 4; ++c) {
+    v4 col = {view->view.M[c][0], view->view.M[c][1], view->view.M[c][2], view->view.M[c][3]};
+    v4 r = mat4_mul_v4(&view->proj, col);
+    out->M[c][0] = r.x; out->M[c][1] = r.y; out->M[c][2] = r.z; out->M[c][3] = r.w;
+  }
+}
+
+static void vertex_stage(const bbo_mat4 *pv, const bbo_instance *inst, const bbo_vertex *v, float *clip,
+                         float *vary) {
+  v4 p = {v->pos[0], v->pos[1], v->pos[2], 1.0f};
+  v4 pw = mat4_mul_v4(&inst->model, p);   /* :25 */
+  v4 c = mat4_mul_v4(pv, pw);             /* :27 */
+  clip[0] = c.x; clip[1] = c.y; clip[2] = c.z; clip[3] = c.w;
+  /* normalMat = transpose(mat3(aInvModel)) (:31): (normalMat*n)_i = dot(InvModel column i, n) */
+  const bbo_mat4 *im = &inst->inv_model;
+  v3 n = v3_ld(v->normal), t = v3_ld(v->tangent);
+  v3 N = normalize3(v3_make(dot3(v3_ld(im->M[0]), n), dot3(v3_ld(im->M[1]), n), dot3(v3_ld(im->M[2]), n)));
+  v3 T = normalize3(v3_make(dot3(v3_ld(im->M[0]), t), dot3(v3_ld(im->M[1]), t), dot3(v3_ld(im->M[2]), t)));
+  v3 B = cross3(N, T);                    /* :35 */
+  vary[0] = v->uv[0]; vary[1] = v->uv[1];
+  vary[2] = pw.x; vary[3] = pw.y; vary[4] = pw.z;
+  vary[5] = N.x; vary[6] = N.y; vary[7] = N.z;
+  vary[8] = T.x; vary[9] = T.y; vary[10] = T.z;
+  vary[11] = B.x; vary[12] = B.y; vary[13] = B.z;
+}
+
+void bbo_vertex_stage(const bbo_view_uniforms *view, const bbo_instance *inst, const bbo_vertex *v,
+                      float *out_clip, float *out_vary) {
+  bbo_mat4 pv;
+  bbo_proj_view(view, &pv);
+  vertex_stage(&pv, inst, v, out_clip, out_vary);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* texture sampling: SMP_LINEAR, REPEAT, single mip (src/render.cpp:1338-1371, :860)          */
+/* ------------------------------------------------------------------------------------------ */
+
+/* `default` material maps, decoded from resources/pbr/default/*.png (all uniform 16x16):
+ * albedo 255 white, metallic 0, roughness 0, ao 255, normal (127,127,255), height 0. */
+static const uint8_t k_default_texel[BBO_MAP_COUNT][4] = {
+    {255, 255, 255, 255}, {0, 0, 0, 255}, {0, 0, 0, 255}, {255, 255, 255, 255}, {127, 127, 255, 255}, {0, 0, 0, 255}};
+
+static inline int wrap_repeat(int i, int n) {
+  int m = i % n;
+  return m < 0 ? m + n : m;
+}
+
+static void sample_bilinear(const bbo_image *img, int map_type, float u, float v, float *out) {
+  const uint8_t *px = img->rgba;
+  int w = img->w, h = img->h;
+  if (!px || w <= 0 || h <= 0) { /* missing map => default map (uniform => filter is the identity) */
+    px = k_default_texel[map_type];
+    w = 1; h = 1;
+  }
+  /* Vulkan: unnormalised = u*size, texel centre at +0.5, i0 = floor(x-0.5), weights = frac */
+  float x = fmaf(u, (float)w, -0.5f);
+  float y = fmaf(v, (float)h, -0.5f);
+  if (!(fabsf(x) < 1073741824.0f)) x = 0.0f; /* non-finite / absurd coordinates are undefined upstream */
+  if (!(fabsf(y) < 1073741824.0f)) y = 0.0f;
+  float xf = floorf(x), yf = floorf(y);
+  float fx = x - xf, fy = y - yf;
+  int ix = (int)xf, iy = (int)yf;
+  int x0 = wrap_repeat(ix, w), x1 = wrap_repeat(ix + 1, w);
+  int y0 = wrap_repeat(iy, h), y1 = wrap_repeat(iy + 1, h);
+  const uint8_t *t00 = px + 4 * ((size_t)y0 * w + x0);
+  const uint8_t *t10 = px + 4 * ((size_t)y0 * w + x1);
+  const uint8_t *t01 = px + 4 * ((size_t)y1 * w + x0);
+  const uint8_t *t11 = px + 4 * ((size_t)y1 * w + x1);
+  for (int c = 0; c < 4; ++c) {
+    float a = (float)t00[c], b = (float)t10[c], cc = (float)t01[c], d = (float)t11[c];
+    float top = fmaf(fx, b - a, a);
+    float bot = fmaf(fx, d - cc, cc);
+    out[c] = fmaf(fy, bot - top, top) * (1.0f / 255.0f);
+  }
+}
+
+void bbo_sample(const bbo_image *img, int map_type, float u, float v, float *out) {
+  sample_bilinear(img, map_type, u, v, out);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* brdf.glsl (src/shaders/brdf.glsl:2-36)                                                     */
+/* ------------------------------------------------------------------------------------------ */
+
+#define BB_PI 3.14159265358979323846f     /* brdf.glsl:2, rounds to 0x40490FDB */
+#define BB_INV_PI 0.31830988618379067154f /* (float)(1/pi) */
+
+static float distribution_ggx(v3 N, v3 H, float roughness) {
+  float a = roughness * roughness;
+  float a2 = a * a;
+  float NdotH = max0(dot3(N, H));
+  float NdotH2 = NdotH * NdotH;
+  float denom = fmaf(NdotH2, a2 - 1.0f, 1.0f);
+  denom = (BB_PI * denom) * denom;
+  return a2 / denom;
+}
+
+static float geometry_schlick_ggx(float NdotV, float roughness) {
+  float r = roughness + 1.0f;
+  float k = (r * r) * 0.125f;
+  float denom = fmaf(NdotV, 1.0f - k, k);
+  return NdotV / denom;
+}
+
+static float geometry_smith(v3 N, v3 V, v3 L, float roughness) {
+  float NdotV = max0(dot3(N, V));
+  float NdotL = max0(dot3(N, L));
+  return geometry_schlick_ggx(NdotV, roughness) * geometry_schlick_ggx(NdotL, roughness);
+}
+
+static v3 fresnel_schlick(v3 H, v3 V, v3 F0) {
+  float x = 1.0f - max0(dot3(H, V));
+  float x2 = x * x;
+  float p5 = (x2 * x2) * x;
+  return v3_make(fmaf(1.0f - F0.x, p5, F0.x), fmaf(1.0f - F0.y, p5, F0.y), fmaf(1.0f - F0.z, p5, F0.z));
+}
+
+float bbo_distribution_ggx(const float *N, const float *H, float roughness) {
+  return distribution_ggx(v3_ld(N), v3_ld(H), roughness);
+}
+float bbo_geometry_smith(const float *N, const float *V, const float *L, float roughness) {
+  return geometry_smith(v3_ld(N), v3_ld(V), v3_ld(L), roughness);
+}
+void bbo_fresnel_schlick(const float *H, const float *V, const float *F0, float *out) {
+  v3 f = fresnel_schlick(v3_ld(H), v3_ld(V), v3_ld(F0));
+  out[0] = f.x; out[1] = f.y; out[2] = f.z;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* forward_brdf.frag (src/shaders/forward_brdf.frag:15-76)                                    */
+/* ------------------------------------------------------------------------------------------ */
+
+static inline float mixf(float a, float b, float t) { return fmaf(b, t, a * (1.0f - t)); }
+static inline float clamp01(float x) { return x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x); }
+
+static void shade_fragment(const bbo_frame_uniforms *fu, const bbo_view_uniforms *vu, const bbo_material *mat,
+                           const float *vary, float *out) {
+  float u = vary[0], v = vary[1];
+  v3 P = v3_ld(vary + 2);
+  float tex[4];
+  sample_bilinear(&mat->maps[BBO_MAP_ALBEDO], BBO_MAP_ALBEDO, u, v, tex);       /* :16 */
+  v3 albedo = v3_make(tex[0], tex[1], tex[2]);
+  sample_bilinear(&mat->maps[BBO_MAP_METALLIC], BBO_MAP_METALLIC, u, v, tex);   /* :17 */
+  float metallic = tex[0];
+  sample_bilinear(&mat->maps[BBO_MAP_ROUGHNESS], BBO_MAP_ROUGHNESS, u, v, tex); /* :18 */
+  float roughness = tex[0];
+  sample_bilinear(&mat->maps[BBO_MAP_AO], BBO_MAP_AO, u, v, tex);               /* :19 */
+  float ao = tex[0];
+  v3 normal;
+  if (vu->enable_normal_map != 0) {                                             /* :21-22 */
+    sample_bilinear(&mat->maps[BBO_MAP_NORMAL], BBO_MAP_NORMAL, u, v, tex);
+    v3 nt = v3_make(fmaf(tex[0], 2.0f, -1.0f), fmaf(tex[1], 2.0f, -1.0f), fmaf(tex[2], 2.0f, -1.0f));
+    v3 N = v3_ld(vary + 5), T = v3_ld(vary + 8), B = v3_ld(vary + 11);
+    /* vTBN = mat3(T,B,N); vTBN * nt */
+    normal.x = fmaf(N.x, nt.z, fmaf(B.x, nt.y, T.x * nt.x));
+    normal.y = fmaf(N.y, nt.z, fmaf(B.y, nt.y, T.y * nt.x));
+    normal.z = fmaf(N.z, nt.z, fmaf(B.z, nt.y, T.z * nt.x));
+  } else {
+    normal = normalize3(v3_ld(vary + 5));                                       /* :24 */
+  }
+
+  v3 Lo = v3_make(0.0f, 0.0f, 0.0f);
+  int n_lights = fu->num_lights;
+  if (n_lights > BBO_MAX_LIGHTS) n_lights = BBO_MAX_LIGHTS;
+  for (int i = 0; i < n_lights; ++i) {                                          /* :29 */
+    const bbo_light *light = &fu->lights[i];
+    v3 L;
+    float att;
+    if (light->type == 0) {
+      v3 Lv = sub3(v3_ld(light->pos), P);
+      float d = sqrtf(dot3(Lv, Lv));
+      att = 1.0f / (d * d);
+      L = scale3(Lv, 1.0f / d);
+    } else if (light->type == 1) {
+      v3 Lv = sub3(v3_ld(light->pos), P);
+      float d = sqrtf(dot3(Lv, Lv));
+      att = 1.0f / (d * d);
+      L = scale3(Lv, 1.0f / d);
+      float theta = dot3(L, normalize3(neg3(v3_ld(light->dir))));
+      float epsilon = light->inner_cutoff - light->outer_cutoff;
+      att *= clamp01((theta - light->outer_cutoff) / epsilon);
+    } else if (light->type == 2) {
+      L = neg3(normalize3(v3_ld(light->dir)));
+      att = 1.0f;
+    } else {
+      continue; /* upstream leaves L/att uninitialised (undefined); the contract contributes nothing */
+    }
+
+    v3 V = normalize3(sub3(v3_ld(vu->view_pos), P));                            /* :51 */
+    v3 N = normalize3(normal);
+    v3 H = normalize3(add3(L, V));
+
+    float D = distribution_ggx(N, H, roughness);
+    v3 F0 = v3_make(mixf(0.04f, albedo.x, metallic), mixf(0.04f, albedo.y, metallic), mixf(0.04f, albedo.z, metallic));
+    v3 F = fresnel_schlick(H, V, F0);
+    float G = geometry_smith(N, V, L, roughness);
+
+    v3 radiance = v3_make((att * light->color[0]) * light->intensity, (att * light->color[1]) * light->intensity,
+                          (att * light->color[2]) * light->intensity);
+
+    float NdotV = max0(dot3(V, N));
+    float NdotL = max0(dot3(L, N));
+    float sden = (4.0f * NdotV) * NdotL;
+    if (!(sden > 0.001f)) sden = 0.001f;                                        /* max(.., 0.001) */
+    float rden = 1.0f / sden;
+    v3 spec = v3_make(((D * F.x) * G) * rden, ((D * F.y) * G) * rden, ((D * F.z) * G) * rden);
+    float om = 1.0f - metallic;
+    v3 kD = v3_make((1.0f - F.x) * om, (1.0f - F.y) * om, (1.0f - F.z) * om);
+
+    Lo.x = fmaf(fmaf(kD.x * albedo.x, BB_INV_PI, spec.x) * radiance.x, NdotL, Lo.x);
+    Lo.y = fmaf(fmaf(kD.y * albedo.y, BB_INV_PI, spec.y) * radiance.y, NdotL, Lo.y);
+    Lo.z = fmaf(fmaf(kD.z * albedo.z, BB_INV_PI, spec.z) * radiance.z, NdotL, Lo.z);
+  }
+
+  out[0] = fmaf(0.03f * albedo.x, ao, Lo.x);                                    /* :72-73 */
+  out[1] = fmaf(0.03f * albedo.y, ao, Lo.y);
+  out[2] = fmaf(0.03f * albedo.z, ao, Lo.z);
+  out[3] = 1.0f;
+}
+
+void bbo_shade_fragment(const bbo_frame_uniforms *frame, const bbo_view_uniforms *view, const bbo_material *mat,
+                        const float *vary, float *out_rgba) {
+  shade_fragment(frame, view, mat, vary, out_rgba);
+}
+
+void bbo_tone_map(float *rgba, uint64_t n_pixels, int32_t enable, float exposure) {
+  for (uint64_t i = 0; i < n_pixels; ++i) {
+    float *p = rgba + 4 * i;
+    if (enable) {
+      for (int c = 0; c < 3; ++c) p[c] = 1.0f - expf(-p[c] * exposure);
+    }
+    p[3] = 1.0f;
+  }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* fixed function: clip, viewport, snap, cull, coverage, depth                                */
+/* (state: src/render.cpp:1069-1125; forward params src/main.cpp:332-350; clears src/main.cpp:84)*/
+/* ------------------------------------------------------------------------------------------ */
+
+#define GUARD_BAND 32.0f  /* x/y clip planes sit at +-32w; the scissor does the rest */
+#define SUBPIXEL_BITS 8
+#define SUBPIXEL_ONE 256
+#define MAX_CLIP_VERTS 12
+#define MAX_SUBTRIS 8     /* primitive id occupies key >> 3 */
+
+typedef struct {
+  float c[4]; /* clip x y z w */
+  float b[3]; /* barycentrics with respect to the unclipped triangle */
+} clip_vert;
+
+typedef struct {
+  int32_t X[3], Y[3];         /* 24.8 snapped framebuffer coordinates */
+  float z0, dzdx, dzdy;       /* depth plane relative to vertex 0, per sub-pixel unit */
+  float l1dx, l1dy, l2dx, l2dy; /* screen-space barycentric planes relative to vertex 0 */
+  float rw[3];                /* 1/w at the (sub-)triangle's own vertices */
+  float bary[3][3];           /* own vertex j -> barycentrics wrt the original triangle */
+  int clipped;
+} raster_tri;
+
+static inline float plane_dist(const float *c, int plane) {
+  switch (plane) {
+  case 0: return c[3] - c[2];                 /* near: z <= w (reverse-Z: NDC z = 1) */
+  case 1: return c[2];                        /* far:  z >= 0 */
+  case 2: return fmaf(GUARD_BAND, c[3], c[0]);
+  case 3: return fmaf(GUARD_BAND, c[3], -c[0]);
+  case 4: return fmaf(GUARD_BAND, c[3], c[1]);
+  default: return fmaf(GUARD_BAND, c[3], -c[1]);
+  }
+}
+
+/* intersection is always evaluated from the inside vertex towards the outside one, so the two
+ * triangles sharing an edge produce the same new vertex */
+static void clip_lerp(const clip_vert *in, float din, const clip_vert *out, float dout, clip_vert *r) {
+  float t = din / (din - dout);
+  for (int k = 0; k < 4; ++k) r->c[k] = fmaf(t, out->c[k] - in->c[k], in->c[k]);
+  for (int k = 0; k < 3; ++k) r->b[k] = fmaf(t, out->b[k] - in->b[k], in->b[k]);
+}
+
+static int clip_polygon(clip_vert *poly, int n) {
+  clip_vert tmp[MAX_CLIP_VERTS];
+  for (int plane = 0; plane < 6; ++plane) {
+    int m = 0;
+    for (int i = 0; i < n; ++i) {
+      const clip_vert *a = &poly[i];
+      const clip_vert *b = &poly[(i + 1) % n];
+      float da = plane_dist(a->c, plane), db = plane_dist(b->c, plane);
+      int ina = da >= 0.0f, inb = db >= 0.0f;
+      if (ina) tmp[m++] = *a;
+      if (ina != inb) {
+        if (ina) clip_lerp(a, da, b, db, &tmp[m]);
+        else clip_lerp(b, db, a, da, &tmp[m]);
+        ++m;
+      }
+    }
+    n = m;
+    if (n < 3) return 0;
+    memcpy(poly, tmp, sizeof(clip_vert) * (size_t)n);
+  }
+  return n;
+}
+
+/* project + snap one clip-space vertex; returns 0 if it cannot be represented */
+static int project_vertex(const float *c, float half_w, float half_h, int32_t *X, int32_t *Y, float *rw, float *zndc) {
+  float w = c[3];
+  if (!(w > 0.0f)) return 0;
+  float r = 1.0f / w;
+  float xs = fmaf(c[0] * r, half_w, half_w);
+  float ys = fmaf(c[1] * r, half_h, half_h);
+  if (!(fabsf(xs) <= 4194304.0f) || !(fabsf(ys) <= 4194304.0f)) return 0;
+  *X = (int32_t)rintf(xs * 256.0f);
+  *Y = (int32_t)rintf(ys * 256.0f);
+  *rw = r;
+  *zndc = c[2] * r;
+  return 1;
+}
+
+/* Finish one (sub-)triangle: cull (front = CLOCKWISE in y-down framebuffer space = positive
+ * doubled area, src/render.cpp:1097-1098 + Vulkan 1.2 sec. 27.12.1), then planes. */
+static int setup_tri(raster_tri *t, const float *z) {
+  int64_t dx1 = (int64_t)t->X[1] - t->X[0], dy1 = (int64_t)t->Y[1] - t->Y[0];
+  int64_t dx2 = (int64_t)t->X[2] - t->X[0], dy2 = (int64_t)t->Y[2] - t->Y[0];
+  int64_t S = dx1 * dy2 - dx2 * dy1;
+  if (S <= 0) return 0; /* back-facing or zero area */
+  double rS = 1.0 / (double)S;
+  t->l1dx = (float)((double)dy2 * rS);
+  t->l1dy = (float)(-(double)dx2 * rS);
+  t->l2dx = (float)(-(double)dy1 * rS);
+  t->l2dy = (float)((double)dx1 * rS);
+  double dz1 = (double)z[1] - (double)z[0], dz2 = (double)z[2] - (double)z[0];
+  t->z0 = z[0];
+  t->dzdx = (float)((dz1 * (double)dy2 - dz2 * (double)dy1) * rS);
+  t->dzdy = (float)((dz2 * (double)dx1 - dz1 * (double)dx2) * rS);
+  return 1;
+}
+
+/* Build the raster triangles of one primitive from its three clip-space vertices. */
+static int build_prim(const float clip[3][4], float half_w, float half_h, raster_tri *out, int *was_clipped) {
+  *was_clipped = 0;
+  /* trivial reject against the true frustum planes (cannot change any pixel: the viewport scissor
+   * removes everything outside anyway) */
+  {
+    int o_l = 1, o_r = 1, o_t = 1, o_b = 1, o_n = 1, o_f = 1;
+    for (int i = 0; i < 3; ++i) {
+      const float *c = clip[i];
+      o_l &= (c[3] + c[0] < 0.0f); o_r &= (c[3] - c[0] < 0.0f);
+      o_t &= (c[3] + c[1] < 0.0f); o_b &= (c[3] - c[1] < 0.0f);
+      o_n &= (c[3] - c[2] < 0.0f); o_f &= (c[2] < 0.0f);
+    }
+    if (o_l | o_r | o_t | o_b | o_n | o_f) return 0;
+  }
+  int all_in = 1;
+  for (int i = 0; i < 3 && all_in; ++i)
+    for (int p = 0; p < 6; ++p)
+      if (!(plane_dist(clip[i], p) >= 0.0f)) { all_in = 0; break; }
+
+  if (all_in) {
+    raster_tri *t = &out[0];
+    float z[3];
+    for (int i = 0; i < 3; ++i)
+      if (!project_vertex(clip[i], half_w, half_h, &t->X[i], &t->Y[i], &t->rw[i], &z[i])) return 0;
+    t->clipped = 0;
+    memset(t->bary, 0, sizeof t->bary);
+    t->bary[0][0] = t->bary[1][1] = t->bary[2][2] = 1.0f;
+    return setup_tri(t, z);
+  }
+
+  *was_clipped = 1;
+  clip_vert poly[MAX_CLIP_VERTS];
+  for (int i = 0; i < 3; ++i) {
+    memcpy(poly[i].c, clip[i], sizeof(float) * 4);
+    poly[i].b[0] = poly[i].b[1] = poly[i].b[2] = 0.0f;
+    poly[i].b[i] = 1.0f;
+  }
+  int n = clip_polygon(poly, 3);
+  if (n < 3) return 0;
+  int32_t X[MAX_CLIP_VERTS], Y[MAX_CLIP_VERTS];
+  float rw[MAX_CLIP_VERTS], z[MAX_CLIP_VERTS];
+  for (int i = 0; i < n; ++i)
+    if (!project_vertex(poly[i].c, half_w, half_h, &X[i], &Y[i], &rw[i], &z[i])) return 0;
+  /* fan (0, i, i+1); slot index = i-1 is kept even when a fan triangle is culled so that the sub-triangle
+   * number is a pure function of the clipped polygon */
+  int count = 0;
+  for (int i = 1; i + 1 < n && i - 1 < MAX_SUBTRIS; ++i) {
+    raster_tri *t = &out[i - 1];
+    const int id[3] = {0, i, i + 1};
+    float zz[3];
+    for (int k = 0; k < 3; ++k) {
+      t->X[k] = X[id[k]]; t->Y[k] = Y[id[k]]; t->rw[k] = rw[id[k]]; zz[k] = z[id[k]];
+      memcpy(t->bary[k], poly[id[k]].b, sizeof(float) * 3);
+    }
+    t->clipped = setup_tri(t, zz) ? 1 : -1; /* -1 marks a culled slot */
+    count = i;
+  }
+  return count; /* number of slots (some may be culled) */
+}
+
+static inline int edge_top_left(int64_t dx, int64_t dy) { return dy < 0 || (dy == 0 && dx > 0); }
+
+/* coverage test of pixel centre (Xc,Yc) in 24.8 */
+static inline int covers(const raster_tri *t, int64_t Xc, int64_t Yc) {
+  for (int i = 0; i < 3; ++i) {
+    int j = i == 2 ? 0 : i + 1;
+    int64_t dx = (int64_t)t->X[j] - t->X[i], dy = (int64_t)t->Y[j] - t->Y[i];
+    int64_t E = dx * (Yc - t->Y[i]) - dy * (Xc - t->X[i]);
+    if (E < 0 || (E == 0 && !edge_top_left(dx, dy))) return 0;
+  }
+  return 1;
+}
+
+static inline float tri_depth(const raster_tri *t, int32_t Xc, int32_t Yc) {
+  float dxp = (float)(Xc - t->X[0]), dyp = (float)(Yc - t->Y[0]);
+  float z = fmaf(t->dzdx, dxp, fmaf(t->dzdy, dyp, t->z0));
+  if (!(z >= 0.0f)) z = 0.0f; /* depth is clamped to the [0,1] viewport range; NaN -> 0 */
+  if (z > 1.0f) z = 1.0f;
+  return z;
+}
+
+/* perspective-correct barycentrics wrt the ORIGINAL triangle at a pixel centre */
+static inline void tri_bary(const raster_tri *t, int32_t Xc, int32_t Yc, float *beta) {
+  float dxp = (float)(Xc - t->X[0]), dyp = (float)(Yc - t->Y[0]);
+  float l1 = fmaf(t->l1dx, dxp, t->l1dy * dyp);
+  float l2 = fmaf(t->l2dx, dxp, t->l2dy * dyp);
+  float l0 = (1.0f - l1) - l2;
+  float u0 = l0 * t->rw[0], u1 = l1 * t->rw[1], u2 = l2 * t->rw[2];
+  float r = 1.0f / ((u0 + u1) + u2);
+  float b0 = u0 * r, b1 = u1 * r, b2 = u2 * r;
+  if (t->clipped) {
+    for (int k = 0; k < 3; ++k) beta[k] = fmaf(b2, t->bary[2][k], fmaf(b1, t->bary[1][k], b0 * t->bary[0][k]));
+  } else {
+    beta[0] = b0; beta[1] = b1; beta[2] = b2;
+  }
+}
+
+static inline void interpolate(const float *beta, const float vary[3][NVARY], int n, float *out) {
+  for (int k = 0; k < n; ++k) out[k] = fmaf(beta[2], vary[2][k], fmaf(beta[1], vary[1][k], beta[0] * vary[0][k]));
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* frame driver                                                                               */
+/* ------------------------------------------------------------------------------------------ */
+
+typedef struct {
+  const bbo_draw *draw;
+  uint32_t first_prim; /* global primitive index of this draw's first triangle */
+  uint32_t tris_per_instance;
+} draw_info;
+
+typedef void (*prim_fetch_fn)(const void *ctx, uint32_t prim, float clip[3][4], float vary[3][NVARY], const void **mat);
+
+typedef struct {
+  const bbo_frame_uniforms *fu;
+  const bbo_view_uniforms *vu;
+  bbo_mat4 pv;
+  const draw_info *draws;
+  uint32_t n_draws;
+} pbr_ctx;
+
+static void pbr_fetch(const void *vctx, uint32_t prim, float clip[3][4], float vary[3][NVARY], const void **mat) {
+  const pbr_ctx *c = (const pbr_ctx *)vctx;
+  uint32_t d = 0;
+  while (d + 1 < c->n_draws && prim >= c->draws[d + 1].first_prim) ++d;
+  const draw_info *di = &c->draws[d];
+  uint32_t local = prim - di->first_prim;
+  uint32_t inst = local / di->tris_per_instance, tri = local % di->tris_per_instance;
+  for (int k = 0; k < 3; ++k) {
+    uint32_t vi = di->draw->indices ? di->draw->indices[3 * tri + k] : 3 * tri + k;
+    vertex_stage(&c->pv, &di->draw->instances[inst], &di->draw->vertices[vi], clip[k], vary[k]);
+  }
+  *mat = di->draw->material;
+}
+
+typedef struct {
+  const bbo_view_uniforms *vu;
+  bbo_mat4 view, pv;
+  const bbo_gizmo_vertex *verts;
+  const uint32_t *indices;
+} gizmo_ctx;
+
+static void gizmo_fetch(const void *vctx, uint32_t prim, float clip[3][4], float vary[3][NVARY], const void **mat) {
+  const gizmo_ctx *c = (const gizmo_ctx *)vctx;
+  for (int k = 0; k < 3; ++k) {
+    const bbo_gizmo_vertex *gv = &c->verts[c->indices ? c->indices[3 * prim + k] : 3 * prim + k];
+    v4 p = {gv->pos[0], gv->pos[1], gv->pos[2], 1.0f};
+    v4 pc = mat4_mul_v4(&c->pv, p); /* gl_Position = (projMat * viewMat) * pos, gizmo.vert:25 */
+    clip[k][0] = pc.x; clip[k][1] = pc.y; clip[k][2] = pc.z; clip[k][3] = pc.w;
+    memset(vary[k], 0, sizeof(float) * NVARY);
+    vary[k][0] = gv->color[0]; vary[k][1] = gv->color[1]; vary[k][2] = gv->color[2];
+    /* vNormal = mat3(viewMat) * aNormal (gizmo.vert:27) */
+    v3 n = v3_ld(gv->normal);
+    vary[k][3] = fmaf(c->view.M[2][0], n.z, fmaf(c->view.M[1][0], n.y, c->view.M[0][0] * n.x));
+    vary[k][4] = fmaf(c->view.M[2][1], n.z, fmaf(c->view.M[1][1], n.y, c->view.M[0][1] * n.x));
+    vary[k][5] = fmaf(c->view.M[2][2], n.z, fmaf(c->view.M[1][2], n.y, c->view.M[0][2] * n.x));
+  }
+  *mat = NULL;
+}
+
+static void gizmo_shade(const float *vary, float *out) {
+  /* gizmo.frag:10-17: L = -(0,0,1); diff = max(dot(L, normalize(vNormal)), 0) */
+  v3 N = normalize3(v3_ld(vary + 3));
+  float diff = max0(dot3(v3_make(-0.0f, -0.0f, -1.0f), N));
+  out[0] = vary[0] * diff; out[1] = vary[1] * diff; out[2] = vary[2] * diff; out[3] = 1.0f;
+}
+
+typedef struct {
+  int program; /* 0 = forward PBR, 1 = gizmo */
+  const void *ctx;
+  prim_fetch_fn fetch;
+  const bbo_frame_uniforms *fu;
+  const bbo_view_uniforms *vu;
+} pipeline;
+
+static void shade_pixel(const pipeline *pl, const raster_tri *t, const float vary[3][NVARY], const void *mat,
+                        int32_t px, int32_t py, float *out) {
+  float beta[3], attr[NVARY];
+  tri_bary(t, px * SUBPIXEL_ONE + SUBPIXEL_ONE / 2, py * SUBPIXEL_ONE + SUBPIXEL_ONE / 2, beta);
+  if (pl->program == 0) {
+    interpolate(beta, vary, NVARY, attr);
+    shade_fragment(pl->fu, pl->vu, (const bbo_material *)mat, attr, out);
+  } else {
+    interpolate(beta, vary, 6, attr);
+    gizmo_shade(attr, out);
+  }
+}
+
+static int render_core(const pipeline *pl, uint32_t n_prims, int32_t width, int32_t height, int32_t y0, int32_t y1,
+                       uint32_t flags, float *out_rgba, uint32_t *out_prim, float *out_depth, bbo_stats *stats) {
+  if (width <= 0 || height <= 0 || !out_rgba) return -1;
+  if (y0 < 0) y0 = 0;
+  if (y1 > height) y1 = height;
+  if (n_prims >= (1u << 29)) return -2;
+  size_t npx = (size_t)width * (size_t)height;
+  int own_depth = 0;
+  uint32_t *key = (uint32_t *)malloc(npx * sizeof(uint32_t)); /* (prim << 3 | sub) + 1, 0 = empty */
+  if (!key) return -3;
+  if (!out_depth) {
+    out_depth = (float *)malloc(npx * sizeof(float));
+    if (!out_depth) { free(key); return -3; }
+    own_depth = 1;
+  }
+  bbo_stats st;
+  memset(&st, 0, sizeof st);
+  st.n_prims = n_prims;
+  for (int32_t y = y0; y < y1; ++y) {
+    memset(out_rgba + 4 * (size_t)y * width, 0, sizeof(float) * 4 * (size_t)width);   /* clear colour 0 */
+    memset(out_depth + (size_t)y * width, 0, sizeof(float) * (size_t)width);            /* clear depth 0  */
+    memset(key + (size_t)y * width, 0, sizeof(uint32_t) * (size_t)width);
+  }
+  float half_w = 0.5f * (float)width, half_h = 0.5f * (float)height;
+
+  /* ---- pass 1: visibility in API order, depth op GREATER_OR_EQUAL (src/render.cpp:1121) ---- */
+  for (uint32_t prim = 0; prim < n_prims; ++prim) {
+    float clip[3][4], vary[3][NVARY];
+    const void *mat;
+    pl->fetch(pl->ctx, prim, clip, vary, &mat);
+    raster_tri tris[MAX_SUBTRIS];
+    int was_clipped;
+    int n = build_prim(clip, half_w, half_h, tris, &was_clipped);
+    st.n_clipped_prims += (uint64_t)was_clipped;
+    for (int s = 0; s < n; ++s) {
+      const raster_tri *t = &tris[s];
+      if (t->clipped < 0) continue;
+      ++st.n_raster_tris;
+      int32_t minX = t->X[0], maxX = t->X[0], minY = t->Y[0], maxY = t->Y[0];
+      for (int k = 1; k < 3; ++k) {
+        if (t->X[k] < minX) minX = t->X[k];
+        if (t->X[k] > maxX) maxX = t->X[k];
+        if (t->Y[k] < minY) minY = t->Y[k];
+        if (t->Y[k] > maxY) maxY = t->Y[k];
+      }
+      /* pixels whose centres px*256+128 lie in [min,max] (arithmetic shift = floor) */
+      int32_t px0 = (minX - 128 + 255) >> 8, px1 = (maxX - 128) >> 8;
+      int32_t py0 = (minY - 128 + 255) >> 8, py1 = (maxY - 128) >> 8;
+      if (px0 < 0) px0 = 0;
+      if (py0 < y0) py0 = y0;
+      if (px1 > width - 1) px1 = width - 1;
+      if (py1 > y1 - 1) py1 = y1 - 1;
+      for (int32_t py = py0; py <= py1; ++py) {
+        for (int32_t px = px0; px <= px1; ++px) {
+          int32_t Xc = px * SUBPIXEL_ONE + 128, Yc = py * SUBPIXEL_ONE + 128;
+          if (!covers(t, Xc, Yc)) continue;
+          ++st.n_fragments;
+          float z = tri_depth(t, Xc, Yc);
+          size_t o = (size_t)py * width + px;
+          if (z >= out_depth[o]) {
+            out_depth[o] = z;
+            key[o] = ((prim << 3) | (uint32_t)s) + 1u;
+            if (flags & BBO_FLAG_FORWARD_SHADE) shade_pixel(pl, t, vary, mat, px, py, out_rgba + 4 * o);
+          }
+        }
+      }
+    }
+  }
+
+  /* ---- pass 2: shade the winning fragment of every covered pixel ---- */
+  uint32_t cached_prim = BBO_NO_PRIM;
+  float clip[3][4], vary[3][NVARY];
+  const void *mat = NULL;
+  raster_tri tris[MAX_SUBTRIS];
+  int n_tris = 0;
+  for (int32_t py = y0; py < y1; ++py) {
+    for (int32_t px = 0; px < width; ++px) {
+      size_t o = (size_t)py * width + px;
+      uint32_t k = key[o];
+      if (out_prim) out_prim[o] = k ? (k - 1u) >> 3 : BBO_NO_PRIM;
+      if (!k) continue;
+      ++st.n_shaded;
+      if (flags & BBO_FLAG_FORWARD_SHADE) continue;
+      uint32_t prim = (k - 1u) >> 3, sub = (k - 1u) & 7u;
+      if (prim != cached_prim) {
+        int wc;
+        pl->fetch(pl->ctx, prim, clip, vary, &mat);
+        n_tris = build_prim(clip, half_w, half_h, tris, &wc);
+        cached_prim = prim;
+      }
+      if ((int)sub >= n_tris) { free(key); if (own_depth) free(out_depth); return -4; }
+      shade_pixel(pl, &tris[sub], vary, mat, px, py, out_rgba + 4 * o);
+    }
+  }
+  free(key);
+  if (own_depth) free(out_depth);
+  if (stats) *stats = st;
+  return 0;
+}
+
+int bbo_render(const bbo_frame_uniforms *frame, const bbo_view_uniforms *view, const bbo_draw *draws, uint32_t n_draws,
+               int32_t width, int32_t height, int32_t y0, int32_t y1, uint32_t flags, float *out_rgba,
+               uint32_t *out_prim, float *out_depth, bbo_stats *stats) {
+  if (!frame || !view || (!draws && n_draws)) return -1;
+  draw_info *di = (draw_info *)calloc(n_draws ? n_draws : 1, sizeof(draw_info));
+  if (!di) return -3;
+  uint64_t total = 0;
+  for (uint32_t d = 0; d < n_draws; ++d) {
+    uint32_t n = draws[d].indices ? draws[d].n_indices : draws[d].n_vertices;
+    di[d].draw = &draws[d];
+    di[d].first_prim = (uint32_t)total;
+    di[d].tris_per_instance = n / 3;
+    total += (uint64_t)(n / 3) * draws[d].n_instances;
+    if (draws[d].indices)
+      for (uint32_t i = 0; i < n / 3 * 3; ++i)
+        if (draws[d].indices[i] >= draws[d].n_vertices) { free(di); return -5; }
+  }
+  if (total >= (1u << 29)) { free(di); return -2; }
+  /* drop draws without triangles so pbr_fetch's search stays simple */
+  uint32_t m = 0;
+  for (uint32_t d = 0; d < n_draws; ++d)
+    if (di[d].tris_per_instance && draws[d].n_instances) di[m++] = di[d];
+  pbr_ctx ctx;
+  ctx.fu = frame; ctx.vu = view; ctx.draws = di; ctx.n_draws = m;
+  bbo_proj_view(view, &ctx.pv);
+  pipeline pl = {0, &ctx, pbr_fetch, frame, view};
+  int rc = render_core(&pl, (uint32_t)total, width, height, y0, y1, flags, out_rgba, out_prim, out_depth, stats);
+  free(di);
+  return rc;
+}
+
+int bbo_render_gizmo(const bbo_view_uniforms *view, const bbo_gizmo_vertex *vertices, uint32_t n_vertices,
+                     const uint32_t *indices, uint32_t n_indices, int32_t width, int32_t height, float *out_rgba,
+                     uint32_t *out_prim, float *out_depth, bbo_stats *stats) {
+  if (!view || !vertices) return -1;
+  uint32_t n = indices ? n_indices : n_vertices;
+  if (indices)
+    for (uint32_t i = 0; i < n / 3 * 3; ++i)
+      if (indices[i] >= n_vertices) return -5;
+  gizmo_ctx ctx;
+  ctx.vu = view; ctx.verts = vertices; ctx.indices = indices;
+  /* gizmo.vert:13-24 */
+  const bbo_mat4 *uv = &view->view;
+  v3 right = v3_make(uv->M[0][0], uv->M[1][0], uv->M[2][0]);
+  v3 up = v3_make(uv->M[0][1], uv->M[1][1], uv->M[2][1]);
+  v3 look = v3_make(uv->M[0][2], uv->M[1][2], uv->M[2][2]);
+  v3 view_pos = scale3(look, -27.0f);
+  ctx.view = *uv;
+  ctx.view.M[3][0] = -dot3(view_pos, right);
+  ctx.view.M[3][1] = -dot3(view_pos, up);
+  ctx.view.M[3][2] = -dot3(view_pos, look);
+  bbo_view_uniforms gv = *view;
+  gv.view = ctx.view;
+  float d = 1.0f / tanf(0.261799f);
+  gv.proj.M[0][0] = d;
+  gv.proj.M[1][1] = -d;
+  bbo_proj_view(&gv, &ctx.pv);
+  pipeline pl = {1, &ctx, gizmo_fetch, NULL, view};
+  return render_core(&pl, n / 3, width, height, 0, height, 0, out_rgba, out_prim, out_depth, stats);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* vector_math.cpp / camera.cpp restatement (src/vector_math.cpp:84-282, src/camera.cpp:5-20)  */
+/* plain mul/add order of the reference, no fused ops                                          */
+/* ------------------------------------------------------------------------------------------ */
+
+#define BB_PI32 3.141592f /* src/vector_math.h:6 */
+static inline float deg_to_rad(float d) { return d * BB_PI32 / 180.f; }
+
+void bbo_mat4_identity(bbo_mat4 *out) {
+  memset(out, 0, sizeof *out);
+  out->M[0][0] = out->M[1][1] = out->M[2][2] = out->M[3][3] = 1.f;
+}
+
+static inline float dot4_plain(const float *a, const float *b) {
+  return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]; /* src/vector_math.cpp:71-73 */
+}
+
+void bbo_mat4_mul(const bbo_mat4 *a, const bbo_mat4 *b, bbo_mat4 *out) {
+  bbo_mat4 r; /* src/vector_math.cpp:262-272: result.M[j][i] = dot(a.row(i), b.column(j)) */
+  for (int i = 0; i < 4; ++i) {
+    float row[4] = {a->M[0][i], a->M[1][i], a->M[2][i], a->M[3][i]};
+    for (int j = 0; j < 4; ++j) r.M[j][i] = dot4_plain(row, b->M[j]);
+  }
+  *out = r;
+}
+
+void bbo_mat4_transpose(const bbo_mat4 *a, bbo_mat4 *out) {
+  bbo_mat4 r;
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) r.M[j][i] = a->M[i][j];
+  *out = r;
+}
+
+static float det3(float m[3][3]) { /* src/vector_math.cpp:75-80 */
+  return m[0][0] * (m[1][1] * m[2][2] - m[2][1] * m[1][2]) - m[1][0] * (m[0][1] * m[2][2] - m[2][1] * m[0][2]) +
+         m[2][0] * (m[0][1] * m[1][2] - m[1][1] * m[0][2]);
+}
+
+static float cofactor(const bbo_mat4 *a, int row, int col) { /* src/vector_math.cpp:92-113 */
+  float minor[3][3];
+  int mr = 0, mc = 0;
+  for (int c = 0; c < 4; ++c)
+    for (int r = 0; r < 4; ++r)
+      if (r != row && c != col) {
+        minor[mc][mr++] = a->M[c][r];
+        if (mr == 3) { mr = 0; ++mc; }
+      }
+  float sign = ((row + col) % 2) ? -1.f : 1.f;
+  return det3(minor) * sign;
+}
+
+void bbo_mat4_inverse(const bbo_mat4 *a, bbo_mat4 *out) { /* src/vector_math.cpp:115-134 */
+  bbo_mat4 adj;
+  for (int c = 0; c < 4; ++c)
+    for (int r = 0; r < 4; ++r) adj.M[c][r] = cofactor(a, r, c);
+  float det = 0.f;
+  for (int i = 0; i < 4; ++i) det += a->M[i][0] * adj.M[i][0];
+  bbo_mat4 t;
+  bbo_mat4_transpose(&adj, &t);
+  for (int c = 0; c < 4; ++c)
+    for (int r = 0; r < 4; ++r) t.M[c][r] /= det;
+  *out = t;
+}
+
+void bbo_mat4_translate(float x, float y, float z, bbo_mat4 *out) {
+  bbo_mat4_identity(out);
+  out->M[3][0] = x; out->M[3][1] = y; out->M[3][2] = z;
+}
+
+void bbo_mat4_scale(float x, float y, float z, bbo_mat4 *out) {
+  bbo_mat4_identity(out);
+  out->M[0][0] = x; out->M[1][1] = y; out->M[2][2] = z;
+}
+
+void bbo_mat4_rotate_x(float degrees, bbo_mat4 *out) { /* src/vector_math.cpp:187-199 */
+  float r = deg_to_rad(degrees), cr = cosf(r), sr = sinf(r);
+  bbo_mat4_identity(out);
+  out->M[1][1] = cr; out->M[1][2] = sr; out->M[2][1] = -sr; out->M[2][2] = cr;
+}
+
+void bbo_mat4_rotate_y(float degrees, bbo_mat4 *out) { /* :201-213 */
+  float r = deg_to_rad(degrees), cr = cosf(r), sr = sinf(r);
+  bbo_mat4_identity(out);
+  out->M[0][0] = cr; out->M[0][2] = sr; out->M[2][0] = -sr; out->M[2][2] = cr;
+}
+
+void bbo_mat4_rotate_z(float degrees, bbo_mat4 *out) { /* :215-227 */
+  float r = deg_to_rad(degrees), cr = cosf(r), sr = sinf(r);
+  bbo_mat4_identity(out);
+  out->M[0][0] = cr; out->M[0][1] = sr; out->M[1][0] = -sr; out->M[1][1] = cr;
+}
+
+static inline float dot3_plain(const float *a, const float *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static inline void cross_plain(const float *a, const float *b, float *o) {
+  o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+}
+static inline void normalize_plain(float *v) { /* Float3::normalize = *this / length() */
+  float len = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+  v[0] /= len; v[1] /= len; v[2] /= len;
+}
+
+void bbo_mat4_look_at(const float *eye, const float *target, const float *up_axis, bbo_mat4 *out) {
+  float f[3] = {target[0] - eye[0], target[1] - eye[1], target[2] - eye[2]}; /* :231-245 */
+  normalize_plain(f);
+  float r[3], u[3];
+  cross_plain(up_axis, f, r);
+  normalize_plain(r);
+  cross_plain(f, r, u);
+  normalize_plain(u);
+  memset(out, 0, sizeof *out);
+  out->M[0][0] = r[0]; out->M[0][1] = u[0]; out->M[0][2] = f[0];
+  out->M[1][0] = r[1]; out->M[1][1] = u[1]; out->M[1][2] = f[1];
+  out->M[2][0] = r[2]; out->M[2][1] = u[2]; out->M[2][2] = f[2];
+  out->M[3][0] = -dot3_plain(eye, r); out->M[3][1] = -dot3_plain(eye, u); out->M[3][2] = -dot3_plain(eye, f);
+  out->M[3][3] = 1.f;
+}
+
+void bbo_mat4_perspective(float fov_degrees, float aspect, float near_z, float far_z, bbo_mat4 *out) {
+  /* :247-260 -- `tan` on a float argument resolves to the float overload under <cmath> */
+  float d = 1.f / tanf(deg_to_rad(fov_degrees) * 0.5f);
+  float f_sub_n = far_z - near_z;
+  memset(out, 0, sizeof *out);
+  out->M[0][0] = d / aspect;
+  out->M[1][1] = -d;
+  out->M[2][2] = -near_z / f_sub_n;
+  out->M[2][3] = 1.f;
+  out->M[3][2] = near_z * far_z / f_sub_n;
+}
+
+void bbo_camera_look(float yaw, float pitch, float *out3) { /* src/camera.cpp:14-20 */
+  float yr = deg_to_rad(yaw), pr = deg_to_rad(pitch), cp = cosf(pr);
+  out3[0] = -sinf(yr) * cp; out3[1] = sinf(pr); out3[2] = cosf(yr) * cp;
+}
+
+void bbo_camera_view(const float *pos, float yaw, float pitch, bbo_mat4 *out) { /* src/camera.cpp:5-7 */
+  float look[3], target[3], up[3] = {0.f, 1.f, 0.f};
+  bbo_camera_look(yaw, pitch, look);
+  for (int i = 0; i < 3; ++i) target[i] = pos[i] + look[i];
+  bbo_mat4_look_at(pos, target, up, out);
+}
+
+uint32_t bbo_sizeof(int what) {
+  switch (what) {
+  case 0: return (uint32_t)sizeof(bbo_vertex);
+  case 1: return (uint32_t)sizeof(bbo_instance);
+  case 2: return (uint32_t)sizeof(bbo_light);
+  case 3: return (uint32_t)sizeof(bbo_frame_uniforms);
+  case 4: return (uint32_t)sizeof(bbo_view_uniforms);
+  case 5: return (uint32_t)sizeof(bbo_gizmo_vertex);
+  default: return 0;
+  }
+}

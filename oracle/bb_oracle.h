@@ -1,0 +1,169 @@
+/*
+ * bb_oracle.h -- CPU restatement of bibim-renderer's forward PBR path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under bibim_renderer_amd/ may include, link or
+ * call this.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use
+ * it, and only as the checker.
+ *
+ * Byte layouts are the reference's own (all offsets verified against the reference's
+ * headers compiled in the authoring container):
+ *   bbo_vertex          = bb::Vertex            src/render.h:112-117      44 B
+ *   bbo_instance        = bb::InstanceBlock     src/render.h:96-99       128 B
+ *   bbo_light           = bb::Light             src/render.h:310-318      64 B
+ *   bbo_frame_uniforms  = bb::FrameUniformBlock src/render.h:321-327    6432 B
+ *   bbo_view_uniforms   = bb::ViewUniformBlock  src/render.h:329-334     144 B
+ *   bbo_gizmo_vertex    = bb::GizmoVertex       src/render.h:122-126      36 B
+ */
+#ifndef BB_ORACLE_H
+#define BB_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { float M[4][4]; } bbo_mat4; /* column-major M[col][row], src/vector_math.h:64 */
+
+typedef struct {
+  float pos[3];
+  float uv[2];
+  float normal[3];
+  float tangent[3];
+} bbo_vertex;
+
+typedef struct {
+  float pos[3];
+  float color[3];
+  float normal[3];
+} bbo_gizmo_vertex;
+
+typedef struct {
+  bbo_mat4 model;
+  bbo_mat4 inv_model;
+} bbo_instance;
+
+typedef struct {
+  float pos[3];
+  int32_t type; /* 0 point, 1 spot, 2 directional */
+  float dir[3];
+  float intensity;
+  float color[3];
+  float inner_cutoff;
+  float outer_cutoff;
+  float _pad[3];
+} bbo_light;
+
+#define BBO_MAX_LIGHTS 100
+typedef struct {
+  int32_t num_lights;
+  int32_t _pad0[3];
+  bbo_light lights[BBO_MAX_LIGHTS];
+  int32_t visualized_gbuffer_attachment_index;
+  int32_t enable_tone_mapping;
+  float exposure;
+  int32_t _pad1;
+} bbo_frame_uniforms;
+
+typedef struct {
+  bbo_mat4 view;
+  bbo_mat4 proj;
+  float view_pos[3];
+  int32_t enable_normal_map;
+} bbo_view_uniforms;
+
+/* One RGBA8 image (stb_image STBI_rgb_alpha layout, src/resource.cpp:159-160).  rgba == NULL
+ * selects the `default` material's map for that slot (src/render.cpp:1328-1336). */
+typedef struct {
+  const uint8_t *rgba;
+  int32_t w, h;
+} bbo_image;
+
+/* PBRMapType order, src/render.h:235-243 */
+enum { BBO_MAP_ALBEDO = 0, BBO_MAP_METALLIC, BBO_MAP_ROUGHNESS, BBO_MAP_AO, BBO_MAP_NORMAL, BBO_MAP_HEIGHT, BBO_MAP_COUNT };
+
+typedef struct {
+  bbo_image maps[BBO_MAP_COUNT];
+} bbo_material;
+
+/* One draw call, as ShaderBallScene::drawScene records it (src/scene.cpp:193-211). */
+typedef struct {
+  const bbo_vertex *vertices;
+  uint32_t n_vertices;
+  const uint32_t *indices; /* NULL => non-indexed vkCmdDraw */
+  uint32_t n_indices;
+  const bbo_instance *instances;
+  uint32_t n_instances;
+  const bbo_material *material;
+} bbo_draw;
+
+#define BBO_NO_PRIM 0xFFFFFFFFu
+
+/* flags for bbo_render */
+#define BBO_FLAG_FORWARD_SHADE 1 /* shade every fragment that passes the depth test, in API order
+                                    (literal forward pipeline) instead of shading the winner once */
+
+typedef struct {
+  uint64_t n_prims;         /* triangles submitted */
+  uint64_t n_raster_tris;   /* sub-triangles that survived clip + cull */
+  uint64_t n_clipped_prims; /* prims that went through the polygon clipper */
+  uint64_t n_fragments;     /* coverage hits inside [y0,y1) */
+  uint64_t n_shaded;        /* pixels in [y0,y1) whose winning fragment is geometry */
+} bbo_stats;
+
+/*
+ * Render rows [y0,y1) of a width x height frame.  Outputs are full-frame sized; only rows in
+ * range are written.  out_rgba: width*height*4 floats (cleared to 0 per src/main.cpp:84).
+ * out_prim (optional): width*height uint32, global primitive index in API order or BBO_NO_PRIM.
+ * out_depth (optional): width*height floats (cleared to 0).
+ */
+int bbo_render(const bbo_frame_uniforms *frame, const bbo_view_uniforms *view, const bbo_draw *draws,
+               uint32_t n_draws, int32_t width, int32_t height, int32_t y0, int32_t y1, uint32_t flags,
+               float *out_rgba, uint32_t *out_prim, float *out_depth, bbo_stats *stats);
+
+/* BASELINE config #1: gizmo.vert/.frag (src/shaders/gizmo.vert:12-28, gizmo.frag:10-17) rasterised
+ * with the same fixed-function rules into a width x height target (viewport = whole target). */
+int bbo_render_gizmo(const bbo_view_uniforms *view, const bbo_gizmo_vertex *vertices, uint32_t n_vertices,
+                     const uint32_t *indices, uint32_t n_indices, int32_t width, int32_t height,
+                     float *out_rgba, uint32_t *out_prim, float *out_depth, bbo_stats *stats);
+
+/* ---- stage-level entry points (known-answer tests, stage parity) ---- */
+
+/* forward_brdf.vert: out_clip[4], out_vary[14] = uv(2) posWorld(3) N(3) T(3) B(3) */
+void bbo_vertex_stage(const bbo_view_uniforms *view, const bbo_instance *inst, const bbo_vertex *v,
+                      float *out_clip, float *out_vary);
+/* P*V as the vertex stage uses it */
+void bbo_proj_view(const bbo_view_uniforms *view, bbo_mat4 *out);
+/* bilinear REPEAT sample of one map; out[4] in [0,1] */
+void bbo_sample(const bbo_image *img, int map_type, float u, float v, float *out);
+/* forward_brdf.frag on explicit varyings */
+void bbo_shade_fragment(const bbo_frame_uniforms *frame, const bbo_view_uniforms *view,
+                        const bbo_material *mat, const float *vary, float *out_rgba);
+/* brdf.glsl scalar pieces */
+float bbo_distribution_ggx(const float *N, const float *H, float roughness);
+float bbo_geometry_smith(const float *N, const float *V, const float *L, float roughness);
+void bbo_fresnel_schlick(const float *H, const float *V, const float *F0, float *out);
+/* hdr_tone_mapping.frag:9-18 applied in place on n RGBA pixels (alpha := 1) */
+void bbo_tone_map(float *rgba, uint64_t n_pixels, int32_t enable, float exposure);
+
+/* ---- vector_math.cpp / camera.cpp restatement (row A0) ---- */
+void bbo_mat4_identity(bbo_mat4 *out);
+void bbo_mat4_mul(const bbo_mat4 *a, const bbo_mat4 *b, bbo_mat4 *out);
+void bbo_mat4_inverse(const bbo_mat4 *a, bbo_mat4 *out);
+void bbo_mat4_transpose(const bbo_mat4 *a, bbo_mat4 *out);
+void bbo_mat4_translate(float x, float y, float z, bbo_mat4 *out);
+void bbo_mat4_scale(float x, float y, float z, bbo_mat4 *out);
+void bbo_mat4_rotate_x(float degrees, bbo_mat4 *out);
+void bbo_mat4_rotate_y(float degrees, bbo_mat4 *out);
+void bbo_mat4_rotate_z(float degrees, bbo_mat4 *out);
+void bbo_mat4_look_at(const float *eye, const float *target, const float *up, bbo_mat4 *out);
+void bbo_mat4_perspective(float fov_degrees, float aspect, float near_z, float far_z, bbo_mat4 *out);
+void bbo_camera_look(float yaw, float pitch, float *out3);
+void bbo_camera_view(const float *pos, float yaw, float pitch, bbo_mat4 *out);
+
+uint32_t bbo_sizeof(int what); /* 0 vertex 1 instance 2 light 3 frame 4 view 5 gizmo vertex */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,139 @@
+"""Mint the committed fixtures under tests/golden/ (authoring container only: reads /root/reference).
+
+  shaderball_vertices.npz  ShaderBall.fbx -> bb::Vertex[29328] (see tools/fbx_geometry.py)
+  math_golden.json         outputs of the REFERENCE's vector_math.cpp / camera.cpp (oracle/_ref)
+  default_texels.json      resources/pbr/default/*.png decoded by the reference's stb_image 2.25
+  gizmo.npz                gizmo.obj/.mtl expanded to bb::GizmoVertex[] + indices
+
+Fixtures are data (inputs / expected outputs); no reference source text is stored.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = os.environ.get("BB_REFERENCE", "/root/reference")
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def shaderball():
+    from tools.fbx_geometry import load_vertices
+    v, info = load_vertices(os.path.join(REF, "resources", "ShaderBall.fbx"))
+    info["sha256_f32le"] = hashlib.sha256(np.ascontiguousarray(v).tobytes()).hexdigest()
+    np.savez_compressed(os.path.join(GOLD, "shaderball_vertices.npz"), vertices=v)
+    json.dump(info, open(os.path.join(GOLD, "shaderball_vertices.json"), "w"), indent=1)
+    print("shaderball", info)
+
+
+def math_golden():
+    ref = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libbb_ref.so"))
+    f = C.c_float
+    P = C.c_void_p
+
+    def m():
+        return np.zeros((4, 4), np.float32)
+
+    def p(a):
+        return a.ctypes.data_as(P)
+
+    ref.ref_mat4_translate.argtypes = [f, f, f, P]; ref.ref_mat4_scale.argtypes = [f, f, f, P]
+    for n in "xyz":
+        getattr(ref, f"ref_mat4_rotate_{n}").argtypes = [f, P]
+    ref.ref_mat4_perspective.argtypes = [f, f, f, f, P]
+    ref.ref_mat4_mul.argtypes = [P, P, P]; ref.ref_mat4_inverse.argtypes = [P, P]
+    ref.ref_mat4_look_at.argtypes = [P, P, P, P]
+    ref.ref_camera_look.argtypes = [P, f, f, P]; ref.ref_camera_view.argtypes = [P, f, f, P]
+
+    def bits(a):
+        return [int(x) for x in np.ascontiguousarray(a, np.float32).view(np.uint32).ravel()]
+
+    out = {"note": "uint32 bit patterns of float32 results produced by the reference's own "
+                   "vector_math.cpp/camera.cpp (g++ -O2 -ffp-contract=off); column-major M[col][row]",
+           "cases": []}
+
+    def add(kind, args, result):
+        out["cases"].append({"op": kind, "args": args, "bits": bits(result)})
+
+    for fov, aspect, n_, f_ in [(60, 16 / 9, 0.1, 1000), (60, 1920 / 1080, 0.1, 1000), (60, 3840 / 2160, 0.1, 1000),
+                                (60, 1.0, 0.1, 1000), (60, 1280 / 720, 0.1, 1000), (45, 4 / 3, 0.5, 50),
+                                (90, 2.0, 1.0, 10), (30, 1.0, 0.01, 5000), (75.5, 1.25, 0.2, 300)]:
+        o = m(); ref.ref_mat4_perspective(fov, aspect, n_, f_, p(o))
+        add("perspective", [float(np.float32(fov)), float(np.float32(aspect)), float(np.float32(n_)), float(np.float32(f_))], o)
+    for d in (-90, 90, 30, -15, -20, 45, 180, 360, 0.5, 123.456):
+        for ax in "xyz":
+            o = m(); getattr(ref, f"ref_mat4_rotate_{ax}")(d, p(o))
+            add(f"rotate_{ax}", [float(np.float32(d))], o)
+    # instance chains: translate * rotateY(-90) * rotateX(-90) * scale(0.01), and their inverses
+    for (tx, ty, tz) in [(0, -1, 2), (2, -1, 2), (-3, -1, 2), (1, -1, 8), (7, -1, 16), (0, -10, 0)]:
+        t = m(); ry = m(); rx = m(); s = m(); a = m(); b = m(); c = m(); inv = m()
+        ref.ref_mat4_translate(tx, ty, tz, p(t)); ref.ref_mat4_rotate_y(-90, p(ry)); ref.ref_mat4_rotate_x(-90, p(rx))
+        ref.ref_mat4_scale(0.01, 0.01, 0.01, p(s))
+        ref.ref_mat4_mul(p(t), p(ry), p(a)); ref.ref_mat4_mul(p(a), p(rx), p(b)); ref.ref_mat4_mul(p(b), p(s), p(c))
+        ref.ref_mat4_inverse(p(c), p(inv))
+        add("instance_chain", [float(tx), float(ty), float(tz)], c)
+        add("instance_chain_inverse", [float(tx), float(ty), float(tz)], inv)
+    t = m(); s = m(); c = m(); inv = m()
+    ref.ref_mat4_translate(0, -10, 0, p(t)); ref.ref_mat4_scale(100, 100, 100, p(s)); ref.ref_mat4_mul(p(t), p(s), p(c))
+    ref.ref_mat4_inverse(p(c), p(inv))
+    add("plane_model", [], c); add("plane_model_inverse", [], inv)
+    rng = np.random.Generator(np.random.PCG64(1234))
+    for _ in range(8):
+        a = rng.standard_normal((4, 4)).astype(np.float32); b = rng.standard_normal((4, 4)).astype(np.float32)
+        o = m(); ref.ref_mat4_mul(p(a), p(b), p(o)); add("mul", [bits(a), bits(b)], o)
+        o = m(); ref.ref_mat4_inverse(p(a), p(o)); add("inverse", [bits(a)], o)
+    for pos, yaw, pitch in [((0, 0, 0), 0, 0), ((0, 2, -2), 0, -15), ((0, 4, -6), 0, -20), ((1, 2, 3), 30, 10),
+                            ((-5, 0.5, 2), -120, 45), ((0, 0, 0), 90, -89)]:
+        pa = np.asarray(pos, np.float32)
+        o3 = np.zeros(3, np.float32); ref.ref_camera_look(p(pa), yaw, pitch, p(o3))
+        add("camera_look", [float(yaw), float(pitch)], o3)
+        o = m(); ref.ref_camera_view(p(pa), yaw, pitch, p(o))
+        add("camera_view", [[float(x) for x in pos], float(yaw), float(pitch)], o)
+    for eye, tgt, up in [((0, 0, -5), (0, 0, 0), (0, 1, 0)), ((3, 4, 5), (-1, 0.5, 2), (0, 1, 0)), ((0, 10, 0), (1, 0, 1), (0, 0, 1))]:
+        o = m(); ref.ref_mat4_look_at(p(np.asarray(eye, np.float32)), p(np.asarray(tgt, np.float32)), p(np.asarray(up, np.float32)), p(o))
+        add("look_at", [list(map(float, eye)), list(map(float, tgt)), list(map(float, up))], o)
+    json.dump(out, open(os.path.join(GOLD, "math_golden.json"), "w"))
+    print("math_golden", len(out["cases"]), "cases")
+
+
+def default_texels():
+    stb = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libstb_ref.so"))
+    stb.stbi_load.restype = C.POINTER(C.c_ubyte)
+    stb.stbi_load.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]
+    out = {"note": "resources/pbr/default/<map>.png decoded with the reference's stb_image 2.25, STBI_rgb_alpha "
+                   "(src/resource.cpp:159-160); every file is a uniform image", "maps": {}}
+    d = os.path.join(REF, "resources", "pbr", "default")
+    for name in ("albedo", "metallic", "roughness", "ao", "normal", "height"):
+        path = os.path.join(d, name + ".png")
+        if not os.path.exists(path):
+            out["maps"][name] = None
+            continue
+        w, h, ch = C.c_int(), C.c_int(), C.c_int()
+        px = stb.stbi_load(path.encode(), C.byref(w), C.byref(h), C.byref(ch), 4)
+        a = np.ctypeslib.as_array(px, shape=(h.value, w.value, 4)).copy()
+        uniform = bool((a == a[0, 0]).all())
+        out["maps"][name] = {"w": w.value, "h": h.value, "file_channels": ch.value, "uniform": uniform,
+                             "texel": [int(x) for x in a[0, 0]]}
+    json.dump(out, open(os.path.join(GOLD, "default_texels.json"), "w"), indent=1)
+    print("default_texels", out["maps"])
+
+
+def gizmo():
+    from tools.obj_loader import load_gizmo
+    v, idx, info = load_gizmo(os.path.join(REF, "resources", "gizmo.obj"))
+    np.savez_compressed(os.path.join(GOLD, "gizmo.npz"), vertices=v, indices=idx)
+    json.dump(info, open(os.path.join(GOLD, "gizmo.json"), "w"), indent=1)
+    print("gizmo", info)
+
+
+if __name__ == "__main__":
+    os.makedirs(GOLD, exist_ok=True)
+    which = sys.argv[1:] or ["shaderball", "math_golden", "default_texels", "gizmo"]
+    for w in which:
+        globals()[w]()
