@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""bench.py -- Mpixels/s of the forward PBR path (BASELINE.json metric) on N MI355X GPUs of one node.
+
+A step = one frame of the workload through the C++ Scene/Camera/drawFrame shim and the C ABI:
+updateScene + uniform fill + bbr_begin_frame/draw/end_frame -> k_geometry + k_tile on the GPU, plus, for
+N > 1, the RCCL all-gather of the per-rank framebuffer shards over xGMI and the un-interleave kernel.
+Inputs (mesh, textures) are resident in HBM before the timed region; per-frame instance matrices and
+uniform blocks (8 KB) are the only host->device traffic, as in the reference's render loop.
+
+N = 1 workload: C3 = ShaderBall x16 + plane, 4 point lights, GGX PBR + normal map, 3840x2160 (the
+configuration BASELINE.json's metric "4K PBR ShaderBall" and its >=100 Mpixels/s target are quoted on).
+N > 1: the same frame (C4) split into interleaved screen bands => "scaling": "strong".
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+
+
+def algorithmic_bytes(cfg, n_shaded, n_ball_vertices):
+    """B_alg = W*H*16 + N_shaded*4*M + sum_draws n_inst*(n_vert*44 + 128) + n_idx*4 + 6432 + 144."""
+    m = 5 if cfg.enable_normal_map else 4
+    frame = cfg.width * cfg.height * 16
+    tex = n_shaded * 4 * m
+    geom = cfg.n_instances * (n_ball_vertices * 44 + 128) + 1 * (4 * 44 + 128) + 6 * 4
+    uniforms = 6432 + 144
+    return {"total": frame + tex + geom + uniforms, "tile_kernel": frame + tex + uniforms, "geometry": geom}
+
+
+def cpu_baseline(cfg, maps, budget_s=20.0):
+    """Oracle (CPU restatement, kind "port") on the host cores: bounded sample of the same workload."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from oracle import bbo, scenes
+
+    mat = bbo.MaterialData(maps)
+    sc = scenes.shaderball_scene(cfg, mat)
+    W, H = sc.width, sc.height
+    rgba = np.zeros((H, W, 4), np.float32)
+    arr = (bbo.Draw * len(sc.draws))(*[d.c_struct() for d in sc.draws])
+    L = bbo.lib()
+
+    def band(b):
+        st = bbo.Stats()
+        rc = L.bbo_render(bbo._p(sc.frame), bbo._p(sc.view), arr, len(sc.draws), W, H, b[0], b[1], 0, bbo._p(rgba), None,
+                          None, C.byref(st))
+        assert rc == 0
+        return st.n_shaded
+
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    bands = [(y, min(y + 32, H)) for y in range(0, H, 32)]
+    # single thread, whole frame in one call (the scalar port as written)
+    t0 = time.perf_counter()
+    n1 = band((0, H))
+    t_single = time.perf_counter() - t0
+    # all cores, bands from a queue; repeat until the budget is used
+    reps, t_multi = 0, 0.0
+    with ThreadPoolExecutor(cores) as ex:
+        while True:
+            t0 = time.perf_counter()
+            n = sum(ex.map(band, bands))
+            t_multi += time.perf_counter() - t0
+            assert n == n1
+            reps += 1
+            if reps >= 20 or t_single + t_multi + t_multi / reps > budget_s:
+                break
+    mpix = W * H / 1e6
+    return {"value": round(mpix * reps / t_multi, 3), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+            "sample": f"{reps} full {cfg.name} frame(s) ({W}x{H}), oracle/bb_oracle.c, {cores} threads over 32-row bands; "
+                      f"single-thread whole-frame run: {mpix / t_single:.3f} Mpixels/s",
+            "single_thread_value": round(mpix / t_single, 3), "n_shaded": int(n1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c5"])
+    ap.add_argument("--tile-mode", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--band-rows", type=int, default=0, help="screen band height for N > 1 (0 = tile height)")
+    ap.add_argument("--no-timing-events", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback exists)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from bibim_renderer_amd import Renderer, configs, textures
+    from bibim_renderer_amd import scene as S
+
+    cfg = configs.CONFIGS[args.workload]
+    maps = textures.make_material(cfg.texture_size)
+    ball = S.load_shaderball_vertices()
+
+    r = Renderer(cfg.width, cfg.height, device=local_rank)
+    if args.tile_mode is not None:
+        r.set_option("tile_mode", args.tile_mode)
+    stream = torch.cuda.current_stream()
+    r.set_stream(stream.cuda_stream)
+    material = r.upload_material(maps)
+    scene, cam, settings = S.config_scene(r, cfg, ball)
+
+    W, H = cfg.width, cfg.height
+    frame_t = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
+    if world > 1:
+        band_rows = args.band_rows or r.tile_height()
+        r.set_partition(rank, world, band_rows)
+        shard_rows = r.shard_rows()
+        shard_t = torch.empty((shard_rows, W, 4), dtype=torch.float32, device="cuda")
+        gathered_t = torch.empty((world, shard_rows, W, 4), dtype=torch.float32, device="cuda")
+        r.set_output_device_ptr(shard_t.data_ptr(), shard_t.numel() * 4)
+    else:
+        r.set_output_device_ptr(frame_t.data_ptr(), frame_t.numel() * 4)
+
+    def step():
+        S.draw_frame(r, scene, cam, settings, material)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered_t, shard_t)
+            r.unpack_gathered(gathered_t.data_ptr(), frame_t.data_ptr())
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # first frame sizes every capacity (bins etc.); synchronize() re-renders if one overflowed
+    step()
+    r.synchronize()
+    stats = r.stats()
+    for _ in range(args.warmup):
+        step()
+    use_events = not args.no_timing_events
+    fence()
+    if use_events:
+        r.set_option("timing", 1)
+        r.timing_reset()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        ns = torch.tensor([stats["n_shaded"]], dtype=torch.int64, device="cuda")
+        dist.all_reduce(ns)
+        n_shaded_total = int(ns.item())
+    else:
+        n_shaded_total = stats["n_shaded"]
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = W * H * args.steps / elapsed / 1e6
+
+    roofline = None
+    if use_events:
+        n_ev, avg_frame_ms, avg_geom_ms, avg_tile_ms = r.timing_summary()
+        # this rank's share of the dominant kernel's algorithmic bytes: its rows of the framebuffer + its shaded pixels
+        if world > 1:
+            from bibim_renderer_amd.partition import owned_rows
+            own_rows = len(owned_rows(H, rank, world, args.band_rows or r.tile_height()))
+        else:
+            own_rows = H
+        m = 5 if cfg.enable_normal_map else 4
+        tile_bytes = own_rows * W * 16 + stats["n_shaded"] * 4 * m + 6432 + 144
+        achieved = tile_bytes / (avg_tile_ms * 1e-3) / 1e9 if avg_tile_ms > 0 else 0.0
+        balg = algorithmic_bytes(cfg, n_shaded_total, ball.shape[0])
+        roofline = {"bound": "hbm", "kernel": "k_tile", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "algorithmic_bytes_per_launch": int(tile_bytes), "avg_kernel_ms": round(avg_tile_ms, 5),
+                    "launches_timed": int(n_ev), "avg_geometry_ms": round(avg_geom_ms, 5),
+                    "avg_device_frame_ms": round(avg_frame_ms, 5),
+                    "frame_algorithmic_bytes": int(balg["total"]),
+                    "frame_achieved_gbs": round(balg["total"] / (ms_per_step * 1e-3) / 1e9, 2),
+                    "frame_frac": round(balg["total"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "n_shaded": int(n_shaded_total)}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(cfg, maps, args.cpu_budget)
+        if cpu["n_shaded"] != n_shaded_total:
+            raise SystemExit(f"GPU shaded {n_shaded_total} pixels, oracle {cpu['n_shaded']}: parity broken")
+
+    if rank == 0:
+        out = {
+            "metric": "Mpixels/sec shaded (4K PBR ShaderBall)" if args.workload == "c3" else f"Mpixels/sec shaded ({cfg.name})",
+            "value": round(value, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{cfg.name}: {cfg.description}", "width": W, "height": H,
+                       "instances": cfg.n_instances, "lights": len(cfg.lights), "triangles": int(stats["n_prims"]),
+                       "textures": f"{cfg.texture_size}x{cfg.texture_size} RGBA8 x5 (seed 0x5EED)",
+                       "partition": "single GPU" if world == 1 else f"interleaved {args.band_rows or r.tile_height()}-row bands, "
+                                    f"{world} ranks, ncclAllGather + un-interleave",
+                       "tile": f"{stats['tile_w']}x{stats['tile_h']}"},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+
+    scene.close()
+    r.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

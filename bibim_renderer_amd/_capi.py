@@ -66,8 +66,34 @@ SIGNATURES = {
     "bbr_get_stats": (C.c_int, [_P, C.POINTER(BbrStats)]),
     "bbr_read_visibility": (C.c_int, [_P, _P, _P]),
     "bbr_last_frame_time_ms": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "bbr_timing_reset": (C.c_int, [_P]),
+    "bbr_timing_summary": (C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "bbr_set_option": (C.c_int, [_P, C.c_char_p, C.c_int64]),
     "bbr_tone_map": (C.c_int, [_P, C.c_int32, C.c_float]),
+}
+
+# every symbol include/bibim_scene.h declares (C surface of the C++ Scene/Camera/drawFrame shim)
+_F = C.c_float
+SCENE_SIGNATURES = {
+    "bbs_mat4_mul": (None, [_P, _P, _P]),
+    "bbs_mat4_inverse": (None, [_P, _P]),
+    "bbs_mat4_translate": (None, [_F, _F, _F, _P]),
+    "bbs_mat4_scale": (None, [_F, _F, _F, _P]),
+    "bbs_mat4_rotate": (None, [C.c_int, _F, _P]),
+    "bbs_mat4_look_at": (None, [_P, _P, _P, _P]),
+    "bbs_mat4_perspective": (None, [_F, _F, _F, _F, _P]),
+    "bbs_camera_look": (None, [_F, _F, _P]),
+    "bbs_camera_view": (None, [_P, _F, _F, _P]),
+    "bbs_plane_mesh": (None, [_P, _P]),
+    "bbs_shaderball_scene_create": (_P, [_P, _P, C.c_uint32, C.c_int32]),
+    "bbs_triangle_scene_create": (_P, [_P]),
+    "bbs_scene_destroy": (None, [_P]),
+    "bbs_scene_set_lights": (C.c_int, [_P, _P, C.c_uint32]),
+    "bbs_scene_num_lights": (C.c_uint32, [_P]),
+    "bbs_scene_get_lights": (C.c_int, [_P, _P]),
+    "bbs_scene_instances": (C.c_int, [_P, C.c_int32, _P, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "bbs_fill_uniforms": (C.c_int, [_P, _P, _F, _F, C.c_int32, C.c_int32, _F, _F, _F, _F, C.c_int32, C.c_int32, _P, _P]),
+    "bbs_draw_frame": (C.c_int, [_P, _P, _P, _F, _F, C.c_int32, C.c_int32, _F, _F, _F, _F, C.c_int32, C.c_int32, C.c_int32]),
 }
 
 _lib = None
@@ -80,7 +106,7 @@ def lib():
             raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
         L = C.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
+        for name, (res, args) in list(SIGNATURES.items()) + list(SCENE_SIGNATURES.items()):
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
         _lib = L

@@ -108,8 +108,12 @@ struct bbr_context {
   int32_t rank = 0, world = 1, band_rows = 0;
   bool dump_vis = false;
   bool timing = false;
-  hipEvent_t ev[4] = {};
+  hipEvent_t ev[4] = {};  // ev[3]: staging copy drained; ev[0..2]: unused when the timing ring is active
   bool ev_valid = false;
+  // timing ring: (frame start, geometry done, tile kernel done) per frame since the last reset
+  std::vector<hipEvent_t> ring;
+  uint32_t ring_frames = 0;
+  static constexpr uint32_t kRingCap = 512;
   int retries = 0;
 
   int tile_w() const { return tile_mode == 0 ? 64 : 32; }
@@ -219,13 +223,16 @@ void launch_frame(bbr_context *c, const FrameParams &fp, const Mat4 &pv, const S
     hipLaunchKernelGGL((k_geometry<TW, TH>), dim3((n + 255) / 256), dim3(256), 0, c->stream, d, pv, fp, c->d_tris.ptr,
                        c->d_attrs.ptr, c->d_clip.ptr, ctr, c->d_tile_count.ptr, c->d_bins.ptr, c->d_broad.ptr);
   }
-  if (c->timing) (void)hipEventRecord(c->ev[1], c->stream);
+  if (c->timing) (void)hipEventRecord(c->ring[3 * (c->ring_frames % bbr_context::kRingCap) + 1], c->stream);
   int grid_y = c->world > 1 ? c->local_bands() * fp.band_tiles : fp.tiles_y;
   hipLaunchKernelGGL((k_tile<TW, TH>), dim3(fp.tiles_x, grid_y), dim3(kTileThreads), 0, c->stream, fp, sp, d_lights,
                      c->d_tris.ptr, c->d_attrs.ptr, c->d_clip.ptr, ctr, ctr_next, c->d_tile_count.ptr, c->d_bins.ptr,
                      c->d_broad.ptr, c->d_materials.ptr, out, c->dump_vis ? c->d_vis_prim.ptr : nullptr,
                      c->dump_vis ? c->d_vis_depth.ptr : nullptr);
-  if (c->timing) (void)hipEventRecord(c->ev[2], c->stream);
+  if (c->timing) {
+    (void)hipEventRecord(c->ring[3 * (c->ring_frames % bbr_context::kRingCap) + 2], c->stream);
+    ++c->ring_frames;
+  }
 }
 
 // Queue the recorded frame.  Asynchronous.
@@ -254,7 +261,13 @@ int submit_frame(bbr_context *c) {
   std::memcpy(c->h_staging, c->frame_u.lights, lights_bytes);
   if (inst_bytes) std::memcpy((uint8_t *)c->h_staging + lights_bytes, c->host_instances.data(), inst_bytes);
 
-  if (c->timing) HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+  if (c->timing) {
+    if (c->ring.empty()) {
+      c->ring.resize(3 * bbr_context::kRingCap);
+      for (auto &e : c->ring) HIP_TRY(c, hipEventCreate(&e));
+    }
+    HIP_TRY(c, hipEventRecord(c->ring[3 * (c->ring_frames % bbr_context::kRingCap)], c->stream));
+  }
   HIP_TRY(c, hipMemcpyAsync(c->d_staging.ptr, c->h_staging, total, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipEventRecord(c->ev[3], c->stream));
   c->ev_valid = true;
@@ -367,6 +380,8 @@ int bbr_destroy(bbr_context *c) {
   c->d_vis_prim.release(); c->d_vis_depth.release();
   if (c->h_staging) (void)hipHostFree(c->h_staging);
   for (auto &e : c->ev)
+    if (e) (void)hipEventDestroy(e);
+  for (auto &e : c->ring)
     if (e) (void)hipEventDestroy(e);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
@@ -661,12 +676,43 @@ int bbr_last_frame_time_ms(bbr_context *c, float *out_frame_ms, float *out_tile_
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
   if (!c->timing) return fail(c, BBR_ERR_INVALID_ARGUMENT, "last_frame_time_ms: enable option \"timing\" first");
   if (!c->have_frame) return fail(c, BBR_ERR_NOT_IN_FRAME, "last_frame_time_ms: nothing rendered");
+  if (!c->ring_frames) return fail(c, BBR_ERR_NOT_IN_FRAME, "last_frame_time_ms: no timed frame yet");
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const hipEvent_t *e = &c->ring[3 * ((c->ring_frames - 1) % bbr_context::kRingCap)];
   float a = 0.f, b = 0.f;
-  HIP_TRY(c, hipEventElapsedTime(&a, c->ev[0], c->ev[2]));
-  HIP_TRY(c, hipEventElapsedTime(&b, c->ev[1], c->ev[2]));
+  HIP_TRY(c, hipEventElapsedTime(&a, e[0], e[2]));
+  HIP_TRY(c, hipEventElapsedTime(&b, e[1], e[2]));
   if (out_frame_ms) *out_frame_ms = a;
   if (out_tile_ms) *out_tile_ms = b;
+  return BBR_OK;
+}
+
+int bbr_timing_reset(bbr_context *c) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->ring_frames = 0;
+  return BBR_OK;
+}
+
+int bbr_timing_summary(bbr_context *c, uint32_t *out_frames, float *out_avg_frame_ms, float *out_avg_geometry_ms,
+                       float *out_avg_tile_ms) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  if (!c->timing) return fail(c, BBR_ERR_INVALID_ARGUMENT, "timing_summary: enable option \"timing\" first");
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  uint32_t n = std::min(c->ring_frames, bbr_context::kRingCap);
+  double f = 0, g = 0, t = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    const hipEvent_t *e = &c->ring[3 * i];
+    float a = 0.f, b = 0.f, d = 0.f;
+    HIP_TRY(c, hipEventElapsedTime(&a, e[0], e[2]));
+    HIP_TRY(c, hipEventElapsedTime(&b, e[0], e[1]));
+    HIP_TRY(c, hipEventElapsedTime(&d, e[1], e[2]));
+    f += a; g += b; t += d;
+  }
+  if (out_frames) *out_frames = n;
+  if (out_avg_frame_ms) *out_avg_frame_ms = n ? (float)(f / n) : 0.f;
+  if (out_avg_geometry_ms) *out_avg_geometry_ms = n ? (float)(g / n) : 0.f;
+  if (out_avg_tile_ms) *out_avg_tile_ms = n ? (float)(t / n) : 0.f;
   return BBR_OK;
 }
 

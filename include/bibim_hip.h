@@ -104,8 +104,8 @@ int bbr_replay_frame(bbr_context *ctx); /* re-submit the last recorded frame (sa
 int bbr_synchronize(bbr_context *ctx);
 
 /* ---- output ---- */
-/* Full frame: height*width*4 floats, row-major, RGBA; on a partitioned context rows this rank does not own
- * are left untouched in the internal buffer (use the shard accessors). */
+/* Full frame: height*width*4 floats, row-major, RGBA.  On a partitioned context (world > 1) this fails with
+ * BBR_ERR_INVALID_ARGUMENT: the output is a compact shard, use bbr_read_shard. */
 int bbr_read_framebuffer(bbr_context *ctx, float *rgba32f_host);
 int bbr_framebuffer_device_ptr(bbr_context *ctx, void **out_device_ptr, uint64_t *out_bytes);
 /* Render into caller-provided device memory instead (e.g. a torch tensor that RCCL all-gathers);
@@ -131,6 +131,12 @@ int bbr_get_stats(bbr_context *ctx, bbr_stats *out);          /* synchronises */
 int bbr_read_visibility(bbr_context *ctx, uint32_t *prim_host, float *depth_host);
 /* device time of the last bbr_end_frame/bbr_replay_frame in ms, and of its dominant kernel; synchronises */
 int bbr_last_frame_time_ms(bbr_context *ctx, float *out_frame_ms, float *out_tile_kernel_ms);
+/* With option "timing" = 1 every frame records HIP events on the context's stream (frame start, geometry
+ * kernels done, tile kernel done) into a ring of 512 frames.  bbr_timing_summary averages the frames recorded
+ * since bbr_timing_reset: whole frame, geometry kernels (incl. the H2D of instances/lights), tile kernel. */
+int bbr_timing_reset(bbr_context *ctx);
+int bbr_timing_summary(bbr_context *ctx, uint32_t *out_frames, float *out_avg_frame_ms, float *out_avg_geometry_ms,
+                       float *out_avg_tile_ms);
 int bbr_set_option(bbr_context *ctx, const char *name, int64_t value);
 
 /* next row: hdr_tone_mapping.frag:9-18 on the fp32 frame, in place */

@@ -104,7 +104,7 @@ void bbo_vertex_stage(const bbo_view_uniforms *view, const bbo_instance *inst, c
 /* texture sampling: SMP_LINEAR, REPEAT, single mip (src/render.cpp:1338-1371, :860)          */
 /* ------------------------------------------------------------------------------------------ */
 
-/* `default` material maps, decoded from resources/pbr/default/*.png (all uniform 16x16):
+/* `default` material maps, decoded from the PNGs under resources/pbr/default/ (all uniform 16x16):
  * albedo 255 white, metallic 0, roughness 0, ao 255, normal (127,127,255), height 0. */
 static const uint8_t k_default_texel[BBO_MAP_COUNT][4] = {
     {255, 255, 255, 255}, {0, 0, 0, 255}, {0, 0, 0, 255}, {255, 255, 255, 255}, {127, 127, 255, 255}, {0, 0, 0, 255}};
@@ -871,8 +871,10 @@ void bbo_mat4_look_at(const float *eye, const float *target, const float *up_axi
 }
 
 void bbo_mat4_perspective(float fov_degrees, float aspect, float near_z, float far_z, bbo_mat4 *out) {
-  /* :247-260 -- `tan` on a float argument resolves to the float overload under <cmath> */
-  float d = 1.f / tanf(deg_to_rad(fov_degrees) * 0.5f);
+  /* :247-260 -- the unqualified `tan` resolves to the C double function in the reference as compiled here
+   * (g++, oracle/_ref): d = (float)(1.0 / tan((double)x)).  Differs from tanf by 1 ulp for some fovs;
+   * pinned by tests/test_oracle_math.py against oracle/_ref on random fovs. */
+  float d = (float)(1.0 / tan((double)(deg_to_rad(fov_degrees) * 0.5f)));
   float f_sub_n = far_z - near_z;
   memset(out, 0, sizeof *out);
   out->M[0][0] = d / aspect;

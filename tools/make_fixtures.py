@@ -66,6 +66,11 @@ def math_golden():
                                 (90, 2.0, 1.0, 10), (30, 1.0, 0.01, 5000), (75.5, 1.25, 0.2, 300)]:
         o = m(); ref.ref_mat4_perspective(fov, aspect, n_, f_, p(o))
         add("perspective", [float(np.float32(fov)), float(np.float32(aspect)), float(np.float32(n_)), float(np.float32(f_))], o)
+    prng = np.random.Generator(np.random.PCG64(77))
+    for _ in range(48):  # random fovs: tan(double) vs tanf differ by 1 ulp on some of these
+        fov, aspect = float(np.float32(prng.uniform(5, 170))), float(np.float32(prng.uniform(0.2, 4)))
+        o = m(); ref.ref_mat4_perspective(fov, aspect, 0.1, 1000.0, p(o))
+        add("perspective", [fov, aspect, float(np.float32(0.1)), 1000.0], o)
     for d in (-90, 90, 30, -15, -20, 45, 180, 360, 0.5, 123.456):
         for ax in "xyz":
             o = m(); getattr(ref, f"ref_mat4_rotate_{ax}")(d, p(o))
