@@ -138,7 +138,7 @@ def main():
         r.set_partition(rank, world, band_rows)
         shard_rows = r.shard_rows()
         shard_t = torch.empty((shard_rows, W, 4), dtype=torch.float32, device="cuda")
-        gathered_t = torch.empty((world, shard_rows, W, 4), dtype=torch.float32, device="cuda")
+        gathered_t = torch.empty((world * shard_rows, W, 4), dtype=torch.float32, device="cuda")  # [rank][shard row]
         r.set_output_device_ptr(shard_t.data_ptr(), shard_t.numel() * 4)
     else:
         r.set_output_device_ptr(frame_t.data_ptr(), frame_t.numel() * 4)

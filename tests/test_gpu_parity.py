@@ -1,0 +1,237 @@
+"""Parity tests proper: the HIP path, called through the C ABI (ctypes on libbibim_hip.so), against the CPU
+oracle on the same seeded inputs.  Integer results (winning primitive, depth bits, coverage counts) must be
+bit-exact; colour must satisfy BASELINE's tolerance |d| <= 1e-4 * max(1, |ref|) per channel (the contract is
+written so that it is in fact bit-exact; the tests report when it is)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, assert_frame_close
+from bibim_renderer_amd import Renderer, BibimError, configs, textures
+from oracle import bbo, scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_render(scene, tile_mode=0, **opts):
+    r = Renderer(scene.width, scene.height)
+    r.set_option("tile_mode", tile_mode)
+    for k, v in opts.items():
+        r.set_option(k, v)
+    r.render_scene(scene)
+    img = r.read_framebuffer()
+    prim, depth = r.read_visibility()
+    st = r.stats()
+    r.close()
+    return img, prim, depth, st
+
+
+def check(scene, tile_mode=0, expect_exact=True, **opts):
+    ref, rprim, rdepth, rst = bbo.render(scene)
+    img, prim, depth, st = gpu_render(scene, tile_mode, **opts)
+    assert np.array_equal(prim, rprim), f"{int((prim != rprim).sum())} pixels pick another primitive"
+    assert np.array_equal(depth.view(np.uint32), rdepth.view(np.uint32))
+    assert st["n_shaded"] == rst["n_shaded"] and st["n_prims"] == rst["n_prims"]
+    assert st["n_clipped_prims"] == rst["n_clipped_prims"]
+    assert_frame_close(img, ref)
+    if expect_exact:
+        assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), "within tolerance but no longer bit-exact"
+    return img, ref, st
+
+
+@pytest.mark.parametrize("tile_mode", [0, 1])
+def test_c2_small(maps64, tile_mode):
+    check(scenes.shaderball_scene(configs.C2.scaled(320, 180, 64), bbo.MaterialData(maps64)), tile_mode)
+
+
+@pytest.mark.parametrize("tile_mode", [0, 1])
+def test_c3_small(maps256, tile_mode):
+    check(scenes.shaderball_scene(configs.C3.scaled(960, 540, 256), bbo.MaterialData(maps256)), tile_mode)
+
+
+def test_c5_small(maps64):
+    check(scenes.shaderball_scene(configs.C5.scaled(1024, 576, 64), bbo.MaterialData(maps64)))
+
+
+def test_golden_fixture_c2_160x90(maps64):
+    """against the committed fixture (no oracle run)"""
+    g = np.load(os.path.join(GOLDEN, "oracle_frames.npz"))
+    img, prim, depth, _ = gpu_render(scenes.shaderball_scene(configs.C2.scaled(160, 90, 64), bbo.MaterialData(maps64)))
+    assert np.array_equal(prim, g["c2_160x90_prim"])
+    assert np.array_equal(depth.view(np.uint32), g["c2_160x90_depth_bits"])
+    assert_frame_close(img, g["c2_160x90_rgba_bits"].view(np.float32))
+
+
+def test_triangle_scene_default_material():
+    g = np.load(os.path.join(GOLDEN, "oracle_frames.npz"))
+    img, prim, depth, _ = gpu_render(scenes.triangle_scene(64, 64))
+    assert np.array_equal(prim, g["triangle64_prim"])
+    assert_frame_close(img, g["triangle64_rgba_bits"].view(np.float32))
+
+
+def test_c2_full_size():
+    mat = bbo.MaterialData(textures.make_material(2048))
+    _, _, st = check(scenes.shaderball_scene(configs.C2, mat))
+    assert st["n_shaded"] == json.load(open(os.path.join(GOLDEN, "n_shaded.json")))["c2"]["n_shaded"]
+
+
+def test_c3_full_size_4k():
+    """BASELINE's headline configuration at full size: 3840x2160, 16 balls, 4 lights, 2048^2 maps."""
+    mat = bbo.MaterialData(textures.make_material(2048))
+    _, _, st = check(scenes.shaderball_scene(configs.C3, mat))
+    assert st["n_shaded"] == json.load(open(os.path.join(GOLDEN, "n_shaded.json")))["c3"]["n_shaded"]
+
+
+def test_normal_map_off_and_reference_default_lights(maps64):
+    """reference defaults: EnableNormalMap = 0, three lights incl. a directional one and the radians-as-cosine quirk"""
+    cfg = configs.C2.scaled(256, 144, 64)
+    sc = scenes.shaderball_scene(cfg, bbo.MaterialData(maps64))
+    sc.frame = scenes.frame_uniforms(scenes.reference_default_lights())
+    sc.view["enable_normal_map"] = 0
+    check(sc)
+
+
+def test_spot_directional_and_unknown_light_types(maps64):
+    cfg = configs.C2.scaled(200, 120, 64)
+    sc = scenes.shaderball_scene(cfg, bbo.MaterialData(maps64))
+    sc.frame = scenes.frame_uniforms([
+        scenes.light(1, pos=(0.5, 2, 1.5), dir=(0, -1, 0.2), color=(1, 1, 0.9), intensity=40, inner=0.95, outer=0.7),
+        scenes.light(2, dir=(-0.3, -1, 0.5), color=(0.2, 0.3, 0.9), intensity=2.0),
+        scenes.light(5, pos=(0, 1, 0), color=(1, 1, 1), intensity=100.0),
+        scenes.light(0, pos=(-1, 0.5, 1), color=(0.9, 0.2, 0.2), intensity=8.0)])
+    check(sc)
+
+
+def test_default_material_fallback_has_nans_in_the_same_places():
+    """NULL maps => `default` material: roughness 0 makes brdf.glsl produce 0/0 at specular peaks; the GPU must
+    put its NaNs exactly where the oracle does."""
+    sc = scenes.shaderball_scene(configs.C2.scaled(240, 135, 16), bbo.MaterialData())
+    img, ref, _ = check(sc, expect_exact=False)
+    assert np.array_equal(np.isnan(img), np.isnan(ref))
+
+
+def test_mixed_map_sizes_non_power_of_two_and_partial_material():
+    rng = np.random.Generator(np.random.PCG64(11))
+    maps = {"albedo": rng.integers(0, 256, (48, 80, 4), dtype=np.uint8),
+            "roughness": rng.integers(60, 256, (17, 5, 4), dtype=np.uint8),
+            "normal": textures.make_material(32)["normal"]}  # metallic / ao missing -> default maps
+    check(scenes.shaderball_scene(configs.C2.scaled(224, 126, 32), bbo.MaterialData(maps)))
+
+
+def test_two_materials_and_extra_indexed_draw(maps64):
+    cfg = configs.C3.scaled(320, 180, 64)
+    m1 = bbo.MaterialData(maps64)
+    m2 = bbo.MaterialData({"albedo": textures.make_material(32, seed=7)["albedo"], "roughness": maps64["roughness"]})
+    sc = scenes.shaderball_scene(cfg, m1)
+    sc.draws[1].material = m2
+    # a third draw: the plane mesh again, raised and tilted, sharing depth ties with nothing
+    pv, pi = scenes.plane_mesh()
+    inst = np.zeros(1, bbo.INSTANCE_DTYPE)
+    inst[0] = scenes.instance(bbo.mat_mul(bbo.mat_translate(0.0, 0.5, 6.0), bbo.mat_mul(bbo.mat_rotate_x(35.0), bbo.mat_scale(3.0))))
+    sc.draws.append(bbo.DrawData(pv, pi, inst, m2))
+    check(sc)
+
+
+def test_framebuffer_sizes_not_multiple_of_tile(maps64):
+    for w, h in ((1, 1), (7, 3), (65, 64), (64, 65), (130, 33), (333, 211)):
+        check(scenes.shaderball_scene(configs.C2.scaled(w, h, 64), bbo.MaterialData(maps64)))
+
+
+def test_empty_frame_and_culled_geometry():
+    fu = scenes.frame_uniforms([]); vu = scenes.view_uniforms((0, 0, 0), 0, 0, 96, 40, 0)
+    r = Renderer(96, 40)
+    r.set_frame_uniforms(fu); r.set_view_uniforms(vu)
+    r.begin_frame(); r.end_frame()
+    assert (r.read_framebuffer() == 0).all()
+    assert r.stats()["n_shaded"] == 0
+    r.close()
+    v = np.zeros(6, bbo.VERTEX_DTYPE)
+    v["pos"] = [(0, 0, 5), (0, 0, 5), (1, 1, 5), (0, 1, -5), (1, -1, -5), (-1, -1, -5)]  # zero area + behind the camera
+    inst = np.zeros(1, bbo.INSTANCE_DTYPE); inst[0]["model"] = np.eye(4); inst[0]["inv_model"] = np.eye(4)
+    sc = bbo.Scene(fu, vu, [bbo.DrawData(v, None, inst, bbo.MaterialData())], 96, 40)
+    img, _, st = check(sc)
+    assert (img == 0).all() and st["n_raster_tris"] == 0
+
+
+def test_camera_inside_geometry_heavy_clipping(maps64):
+    """camera between the balls, looking along the lattice: many primitives cross the near plane and the guard band"""
+    cfg = configs.C3.scaled(256, 144, 64)
+    sc = scenes.shaderball_scene(cfg, bbo.MaterialData(maps64))
+    sc.view = scenes.view_uniforms((-1.0, -0.55, 1.6), 35.0, -5.0, cfg.width, cfg.height, 1, near=0.05)
+    _, _, st = check(sc)
+    assert st["n_clipped_prims"] > 20
+
+
+def test_depth_ties_follow_api_order():
+    from test_oracle_kat import quad_scene
+    for order in ("ab", "ba"):
+        check(quad_scene(70, 50, 3.0, 3.0, order))
+    check(quad_scene(70, 50, 2.0, 4.0, "ba"))
+
+
+def test_bin_capacity_overflow_is_recovered(maps64):
+    """tiny bins force the overflow path: the frame is re-rendered with larger bins, result unchanged"""
+    sc = scenes.shaderball_scene(configs.C3.scaled(320, 180, 64), bbo.MaterialData(maps64))
+    _, _, st = check(sc, bin_cap=8)
+    assert st["bin_overflow"] >= 1
+
+
+def test_broad_list_threshold_extremes(maps64):
+    sc = scenes.shaderball_scene(configs.C3.scaled(400, 225, 64), bbo.MaterialData(maps64))
+    check(sc, broad_threshold=1)       # everything touching more than one tile goes to the every-tile list
+    check(sc, broad_threshold=100000)  # nothing does: the ground plane is binned into every tile it touches
+
+
+def test_replay_is_idempotent_and_frames_are_independent(maps64):
+    sc = scenes.shaderball_scene(configs.C3.scaled(384, 216, 64), bbo.MaterialData(maps64))
+    r = Renderer(sc.width, sc.height)
+    h = r.render_scene(sc)
+    a = r.read_framebuffer()
+    for _ in range(3):
+        r.replay_frame()
+    b = r.read_framebuffer()
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    # a different frame on the same context, then the first one again
+    sc2 = scenes.shaderball_scene(configs.C2.scaled(384, 216, 64), sc.draws[0].material)
+    r.render_scene(sc2, h)
+    c = r.read_framebuffer()
+    ref2, _, _, _ = bbo.render(sc2)
+    assert_frame_close(c, ref2)
+    r.render_scene(sc, h)
+    assert np.array_equal(r.read_framebuffer().view(np.uint32), a.view(np.uint32))
+    r.close()
+
+
+def test_error_codes():
+    r = Renderer(32, 32)
+    with pytest.raises(BibimError) as e:
+        r.draw(0, 0, np.zeros(32, np.float32))          # outside begin/end
+    assert e.value.code == -6
+    r.begin_frame()
+    with pytest.raises(BibimError) as e:
+        r.draw(3, 0, np.zeros(32, np.float32))          # bad mesh handle
+    assert e.value.code == -5
+    fu = np.zeros((), bbo.FRAME_DTYPE); fu["num_lights"] = 100
+    with pytest.raises(BibimError) as e:
+        r.set_frame_uniforms(fu)                         # reference asserts NumLights < 100
+    assert e.value.code == -1
+    v = np.zeros(3, bbo.VERTEX_DTYPE)
+    with pytest.raises(BibimError):
+        r.upload_mesh(v, np.array([0, 1, 3], np.uint32))  # index out of range
+    r.close()
+    with pytest.raises(BibimError):
+        Renderer(0, 10)
+
+
+def test_tone_map_next_row(maps64):
+    sc = scenes.shaderball_scene(configs.C2.scaled(160, 90, 64), bbo.MaterialData(maps64))
+    r = Renderer(sc.width, sc.height)
+    r.render_scene(sc)
+    hdr = r.read_framebuffer()
+    r.tone_map(1, 1.7)
+    ldr = r.read_framebuffer()
+    r.close()
+    want = bbo.tone_map(hdr, 1, 1.7)
+    np.testing.assert_allclose(ldr, want, rtol=2e-6, atol=2e-7)  # expf: device vs libm, not part of the bit-exact contract

@@ -137,8 +137,48 @@ def gizmo():
     print("gizmo", info)
 
 
+def golden_frames():
+    """Oracle outputs frozen as regression fixtures (so a change of the contract is a visible diff) and as
+    the CPU-side expected values the GPU tests compare against at sizes with no oracle run."""
+    from bibim_renderer_amd import configs, textures
+    from oracle import bbo, scenes
+
+    def pack(rgba, prim, depth):
+        return {"rgba_bits": rgba.view(np.uint32), "prim": prim, "depth_bits": depth.view(np.uint32)}
+
+    out = {}
+    rgba, prim, depth, st = bbo.render(scenes.triangle_scene(64, 64))
+    out.update({f"triangle64_{k}": v for k, v in pack(rgba, prim, depth).items()})
+    mat = bbo.MaterialData(textures.make_material(64))
+    rgba, prim, depth, st2 = bbo.render(scenes.shaderball_scene(configs.C2.scaled(160, 90, 64), mat))
+    out.update({f"c2_160x90_{k}": v for k, v in pack(rgba, prim, depth).items()})
+    g = np.load(os.path.join(GOLD, "gizmo.npz"))
+    v = np.zeros(len(g["vertices"]), bbo.GIZMO_VERTEX_DTYPE)
+    v["pos"], v["color"], v["normal"] = g["vertices"][:, 0:3], g["vertices"][:, 3:6], g["vertices"][:, 6:9]
+    vu = scenes.view_uniforms((0, 0, 0), 0.0, 0.0, 256, 256, 0)  # C1: identity camera rotation
+    rgba, prim, depth, st3 = bbo.render_gizmo(vu, v, g["indices"], 256, 256)
+    out.update({f"gizmo256_{k}": v_ for k, v_ in pack(rgba, prim, depth).items()})
+    np.savez_compressed(os.path.join(GOLD, "oracle_frames.npz"), **out)
+    json.dump({"triangle64": st, "c2_160x90": st2, "gizmo256": st3}, open(os.path.join(GOLD, "oracle_frames.json"), "w"), indent=1)
+    print("golden_frames", st, st2, st3)
+
+
+def n_shaded():
+    """N_shaded per BASELINE config (counted by the CPU oracle, stored with the fixtures)."""
+    from bibim_renderer_amd import configs, textures
+    from oracle import bbo, scenes
+    mat = bbo.MaterialData(textures.make_material(64))  # coverage does not depend on the texels
+    out = {}
+    for name in ("c2", "c3", "c5"):
+        cfg = configs.CONFIGS[name]
+        _, _, _, st = bbo.render(scenes.shaderball_scene(cfg, mat), flags=0, want_prim=False, want_depth=False)
+        out[name] = st
+        print(name, st)
+    json.dump(out, open(os.path.join(GOLD, "n_shaded.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["shaderball", "math_golden", "default_texels", "gizmo"]
+    which = sys.argv[1:] or ["shaderball", "math_golden", "default_texels", "gizmo", "golden_frames", "n_shaded"]
     for w in which:
         globals()[w]()
