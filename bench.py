@@ -2,7 +2,7 @@
 """bench.py -- Mpixels/s of the forward PBR path (BASELINE.json metric) on N MI355X GPUs of one node.
 
 A step = one frame of the workload through the C++ Scene/Camera/drawFrame shim and the C ABI:
-updateScene + uniform fill + bbr_begin_frame/draw/end_frame -> k_geometry + k_tile on the GPU, plus, for
+updateScene + uniform fill + bbr_begin_frame/draw/end_frame -> k_geometry + k_raster + k_shade on the GPU, plus, for
 N > 1, the RCCL all-gather of the per-rank framebuffer shards over xGMI and the un-interleave kernel.
 Inputs (mesh, textures) are resident in HBM before the timed region; per-frame instance matrices and
 uniform blocks (8 KB) are the only host->device traffic, as in the reference's render loop.
@@ -61,6 +61,7 @@ def cpu_baseline(cfg, maps, budget_s=20.0):
         return st.n_shaded
 
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(cores, 16))  # a one-GPU box's CPU share
     bands = [(y, min(y + 32, H)) for y in range(0, H, 32)]
     # single thread, whole frame in one call (the scalar port as written)
     t0 = time.perf_counter()
@@ -188,7 +189,7 @@ def main():
 
     roofline = None
     if use_events:
-        n_ev, avg_frame_ms, avg_geom_ms, avg_tile_ms = r.timing_summary()
+        n_ev, avg_frame_ms, avg_geom_ms, avg_raster_ms, avg_tile_ms = r.timing_summary()
         # this rank's share of the dominant kernel's algorithmic bytes: its rows of the framebuffer + its shaded pixels
         if world > 1:
             from bibim_renderer_amd.partition import owned_rows

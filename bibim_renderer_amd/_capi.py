@@ -67,7 +67,8 @@ SIGNATURES = {
     "bbr_read_visibility": (C.c_int, [_P, _P, _P]),
     "bbr_last_frame_time_ms": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "bbr_timing_reset": (C.c_int, [_P]),
-    "bbr_timing_summary": (C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "bbr_timing_summary": (C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                     C.POINTER(C.c_float)]),
     "bbr_set_option": (C.c_int, [_P, C.c_char_p, C.c_int64]),
     "bbr_tone_map": (C.c_int, [_P, C.c_int32, C.c_float]),
 }

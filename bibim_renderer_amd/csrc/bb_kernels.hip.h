@@ -41,7 +41,18 @@ BB_DEV f3 neg3(f3 a) { return f3{-a.x, -a.y, -a.z}; }
 BB_DEV f3 cross3(f3 a, f3 b) {
   return f3{fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x))};
 }
-BB_DEV f3 normalize3(f3 a) { return scale3(a, 1.0f / sqrtf(dot3(a, a))); }
+// GLSL inversesqrt as a fixed sequence (integer seed + three Newton steps, max error 1.1 ulp): the same bits as the
+// oracle's bb_rsqrt, at a third of the instruction count of IEEE sqrt + divide.
+BB_DEV float bb_rsqrt(float x) {
+  if (!(x >= 1.17549435e-38f && x <= 3.40282347e+38f)) return 1.0f / sqrtf(x);
+  float y = __uint_as_float(0x5F375A86u - (__float_as_uint(x) >> 1));
+  const float h = 0.5f * x;
+  y = y * fmaf(-(h * y), y, 1.5f);
+  y = y * fmaf(-(h * y), y, 1.5f);
+  y = y * fmaf(-(h * y), y, 1.5f);
+  return y;
+}
+BB_DEV f3 normalize3(f3 a) { return scale3(a, bb_rsqrt(dot3(a, a))); }
 BB_DEV float max0(float a) { return a > 0.0f ? a : 0.0f; }
 
 BB_DEV f4 mat4_mul(const Mat4 &m, f4 v) {
@@ -81,27 +92,37 @@ BB_DEV void clip_lerp(const ClipVert &in, float din, const ClipVert &out, float 
 
 constexpr int kMaxClipVerts = 12;
 
-// Sutherland-Hodgman against near, far and the four guard-band planes.  Rare path (a handful of
-// primitives per frame), so it is kept out of line and unoptimised.
-__device__ __noinline__ int clip_polygon(ClipVert *poly, int n) {
+// Per-wave LDS workspace of the polygon clipper.  The clipper indexes its vertex arrays dynamically; in
+// registers that would spill to scratch (and a kernel that owns scratch pays for it on every launch), in LDS
+// it is a plain ds_read/ds_write.  Clipped primitives are rare, so the lanes of a wave that need the clipper
+// take turns on the one workspace.
+struct ClipWork {
+  ClipVert poly[kMaxClipVerts];
   ClipVert tmp[kMaxClipVerts];
+  int32_t X[kMaxClipVerts], Y[kMaxClipVerts];
+  float rw[kMaxClipVerts], z[kMaxClipVerts];
+};
+
+// Sutherland-Hodgman against near, far and the four guard-band planes; w.poly holds n vertices on entry.
+BB_DEV int clip_polygon(ClipWork &w, int n) {
   for (int plane = 0; plane < 6; ++plane) {
     int m = 0;
     for (int i = 0; i < n; ++i) {
-      const ClipVert &a = poly[i];
-      const ClipVert &b = poly[(i + 1) % n];
+      const ClipVert a = w.poly[i];
+      const ClipVert b = w.poly[i + 1 == n ? 0 : i + 1];
       float da = plane_dist(a.c, plane), db = plane_dist(b.c, plane);
       bool ina = da >= 0.0f, inb = db >= 0.0f;
-      if (ina) tmp[m++] = a;
+      if (ina) w.tmp[m++] = a;
       if (ina != inb) {
-        if (ina) clip_lerp(a, da, b, db, tmp[m]);
-        else clip_lerp(b, db, a, da, tmp[m]);
-        ++m;
+        ClipVert r;
+        if (ina) clip_lerp(a, da, b, db, r);
+        else clip_lerp(b, db, a, da, r);
+        w.tmp[m++] = r;
       }
     }
     n = m;
     if (n < 3) return 0;
-    for (int i = 0; i < n; ++i) poly[i] = tmp[i];
+    for (int i = 0; i < n; ++i) w.poly[i] = w.tmp[i];
   }
   return n;
 }
@@ -139,76 +160,166 @@ BB_DEV bool setup_tri(RasterTri &t, float z0, float z1, float z2) {
   return true;
 }
 
+// ---- statistics: accumulated per workgroup in LDS, one global atomic per counter per workgroup ----
+struct BlockStats {
+  uint32_t raster_tris, clipped_prims, bin_refs;
+};
+
+struct TileRange {
+  int tx0, tx1, ty0, ty1;
+};
+
+// pixel-centre bounding box -> tile range; false if the box holds no pixel centre
 template <int TILE_W, int TILE_H>
-BB_DEV void bin_triangle(const RasterTri &t, uint32_t ref, const FrameParams &fp, Counters *ctr,
-                         uint32_t *tile_count, uint32_t *bins, uint32_t *broad_list) {
+BB_DEV bool tile_range(const RasterTri &t, const FrameParams &fp, TileRange &r) {
   int32_t minX = min(t.X0, min(t.X1, t.X2)), maxX = max(t.X0, max(t.X1, t.X2));
   int32_t minY = min(t.Y0, min(t.Y1, t.Y2)), maxY = max(t.Y0, max(t.Y1, t.Y2));
   int32_t px0 = max((minX - 128 + 255) >> 8, 0), px1 = min((maxX - 128) >> 8, fp.width - 1);
   int32_t py0 = max((minY - 128 + 255) >> 8, 0), py1 = min((maxY - 128) >> 8, fp.height - 1);
-  if (px0 > px1 || py0 > py1) return;  // no pixel centre inside the bounding box
-  atomicAdd(&ctr->n_raster_tris, 1ull);
-  int tx0 = px0 / TILE_W, tx1 = px1 / TILE_W, ty0 = py0 / TILE_H, ty1 = py1 / TILE_H;
-  uint32_t ntiles = (uint32_t)(tx1 - tx0 + 1) * (uint32_t)(ty1 - ty0 + 1);
-  if (ntiles > fp.broad_threshold) {
-    uint32_t slot = atomicAdd(&ctr->n_broad, 1u);
-    if (slot < fp.broad_cap) broad_list[slot] = ref;
-    else atomicOr(&ctr->overflow, 2u);
-    return;
-  }
-  for (int ty = ty0; ty <= ty1; ++ty) {
-    if (fp.world > 1 && ((ty / fp.band_tiles) % fp.world) != fp.rank) continue;
-    for (int tx = tx0; tx <= tx1; ++tx) {
-      uint32_t tile = (uint32_t)ty * (uint32_t)fp.tiles_x + (uint32_t)tx;
-      uint32_t slot = atomicAdd(&tile_count[tile], 1u);
-      if (slot < fp.bin_cap) bins[(size_t)tile * fp.bin_cap + slot] = ref;
-      else atomicOr(&ctr->overflow, 1u);
-    }
-  }
-  atomicAdd(&ctr->n_bin_refs, (unsigned long long)ntiles);
+  if (px0 > px1 || py0 > py1) return false;
+  r.tx0 = px0 / TILE_W; r.tx1 = px1 / TILE_W; r.ty0 = py0 / TILE_H; r.ty1 = py1 / TILE_H;
+  return true;
 }
 
-// Rare path: the primitive crosses a clip plane.
-template <int TILE_W, int TILE_H>
-__device__ __noinline__ void clip_and_bin(const float (*clip)[4], uint32_t prim, const FrameParams &fp, RasterTri *tris,
-                                          ClipSlot *clip_arena, Counters *ctr, uint32_t *tile_count, uint32_t *bins,
-                                          uint32_t *broad_list, bool &any_valid) {
-  any_valid = false;
-  atomicAdd(&ctr->n_clipped_prims, 1ull);
-  ClipVert poly[kMaxClipVerts];
-  for (int i = 0; i < 3; ++i) {
-    for (int k = 0; k < 4; ++k) poly[i].c[k] = clip[i][k];
-    poly[i].b[0] = poly[i].b[1] = poly[i].b[2] = 0.0f;
-    poly[i].b[i] = 1.0f;
+// Raster classes: how many lanes of k_raster work on one triangle.  Decided once per triangle from its
+// full pixel bounding box, so that every loop of the raster kernel runs over triangles of similar cost.
+//   0: tiny  (box <= 64 px, spans <= 32 px)      one triangle per lane, 32-bit stepped edge functions
+//   1: small (spans <= 64 px)                    16 lanes per triangle, 4x4 pixel blocks, 24-bit multiply-adds
+//   2: large                                     one wave per triangle, 8x8 blocks, trivial accept / reject
+constexpr uint32_t kBinClasses = 3;
+
+BB_DEV uint32_t raster_class(const RasterTri &t, const FrameParams &fp) {
+  int32_t minX = min(t.X0, min(t.X1, t.X2)), maxX = max(t.X0, max(t.X1, t.X2));
+  int32_t minY = min(t.Y0, min(t.Y1, t.Y2)), maxY = max(t.Y0, max(t.Y1, t.Y2));
+  int32_t px0 = max((minX - 128 + 255) >> 8, 0), px1 = min((maxX - 128) >> 8, fp.width - 1);
+  int32_t py0 = max((minY - 128 + 255) >> 8, 0), py1 = min((maxY - 128) >> 8, fp.height - 1);
+  int ext = max(maxX - minX, maxY - minY);
+  int area = (px1 - px0 + 1) * (py1 - py0 + 1);
+  if (ext <= 32 * 256 && area <= 64) return 0u;
+  if (ext <= 64 * 256) return 1u;
+  return 2u;
+}
+
+BB_DEV void broad_insert(const RasterTri &t, uint32_t ref, const FrameParams &fp, Counters *ctr, BroadTri *broad_list) {
+  uint32_t slot = atomicAdd(&ctr->n_broad, 1u);
+  if (slot < fp.broad_cap) {
+    BroadTri b;
+    b.tri = t;
+    b.ref = ref;
+    b.pad[0] = b.pad[1] = b.pad[2] = 0;
+    broad_list[slot] = b;
+  } else {
+    atomicOr(&ctr->overflow, 2u);
   }
-  int n = clip_polygon(poly, 3);
-  if (n < 3) return;
-  int32_t X[kMaxClipVerts], Y[kMaxClipVerts];
-  float rw[kMaxClipVerts], z[kMaxClipVerts];
-  for (int i = 0; i < n; ++i)
-    if (!project_vertex(poly[i].c, fp.half_w, fp.half_h, X[i], Y[i], rw[i], z[i])) return;
+}
+
+// Wave-aggregated bin insertion.  Consecutive primitives of a mesh land in the same few tiles, so the lanes of
+// a wave that target one bin segment are grouped (ballot loop, ALU only) and the lowest lane of each group
+// reserves all the group's slots with ONE returning atomic; the leaders of all groups issue their atomics in the
+// same instruction, so a wave pays one memory round trip however many tiles it touches, and a tile that
+// receives thousands of tiny triangles sees tens of atomics instead of thousands.
+// Must be called by all lanes of the wave (has = false for lanes with nothing to insert).
+BB_DEV uint32_t wave_bin_insert(bool has, uint32_t seg, uint32_t ref, const FrameParams &fp, Counters *ctr,
+                                uint32_t *tile_count, uint32_t *bins) {
+  const int lane = threadIdx.x & 63;
+  unsigned long long pending = __ballot(has);
+  const uint32_t inserted = (uint32_t)__popcll(pending);
+  int leader = lane;
+  uint32_t rank = 0, gsize = 0;
+  while (pending) {
+    int l = __builtin_amdgcn_readfirstlane(__ffsll((long long)pending) - 1);
+    uint32_t ls = (uint32_t)__builtin_amdgcn_readlane((int)seg, l);
+    bool mine = has && seg == ls;
+    unsigned long long m = __ballot(mine);
+    if (mine) {
+      leader = l;
+      rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+      gsize = (uint32_t)__popcll(m);
+    }
+    pending &= ~m;
+  }
+  uint32_t base = 0;
+  if (has && lane == leader) base = atomicAdd(&tile_count[seg], gsize);
+  base = (uint32_t)__shfl((int)base, leader);
+  if (has) {
+    uint32_t slot = base + rank;
+    if (slot < fp.bin_cap) {
+      bins[(size_t)seg * fp.bin_cap + slot] = ref;
+    } else {
+      atomicOr(&ctr->overflow, 1u);
+      atomicMax(&ctr->bin_need, slot + 1u);
+    }
+  }
+  return inserted;
+}
+
+// Rare path: the primitive crosses a clip plane.  Sub-triangles always go to the every-tile list (one atomic
+// for all of them) -- a clipped primitive is typically huge (the ground plane).  Runs on ONE lane with the
+// wave's LDS workspace.  Returns the number of valid sub-triangles.
+template <int TILE_W, int TILE_H>
+BB_DEV int clip_and_route(ClipWork &w, const float (*clip)[4], uint32_t prim, const FrameParams &fp, RasterTri *tris,
+                          ClipSlot *clip_arena, Counters *ctr, BroadTri *broad_list) {
+  for (int i = 0; i < 3; ++i) {
+    ClipVert v;
+    for (int k = 0; k < 4; ++k) v.c[k] = clip[i][k];
+    v.b[0] = i == 0 ? 1.0f : 0.0f;
+    v.b[1] = i == 1 ? 1.0f : 0.0f;
+    v.b[2] = i == 2 ? 1.0f : 0.0f;
+    w.poly[i] = v;
+  }
+  int n = clip_polygon(w, 3);
+  if (n < 3) return 0;
+  for (int i = 0; i < n; ++i) {
+    const ClipVert v = w.poly[i];
+    int32_t X, Y;
+    float rw, z;
+    if (!project_vertex(v.c, fp.half_w, fp.half_h, X, Y, rw, z)) return 0;
+    w.X[i] = X; w.Y[i] = Y; w.rw[i] = rw; w.z[i] = z;
+  }
   int n_slots = min(n - 2, kMaxSubTris);
   uint32_t base = atomicAdd(&ctr->n_clip_slots, (uint32_t)n_slots);
   if (base + n_slots > fp.clip_cap) {
     atomicOr(&ctr->overflow, 4u);
-    return;
+    return 0;
   }
+  int n_valid = 0;
+  uint32_t valid_mask = 0;
   for (int i = 1; i <= n_slots; ++i) {
     ClipSlot s;
-    const int id[3] = {0, i, i + 1};
-    s.tri.X0 = X[id[0]]; s.tri.Y0 = Y[id[0]];
-    s.tri.X1 = X[id[1]]; s.tri.Y1 = Y[id[1]];
-    s.tri.X2 = X[id[2]]; s.tri.Y2 = Y[id[2]];
-    s.tri.rw0 = rw[id[0]]; s.tri.rw1 = rw[id[1]]; s.tri.rw2 = rw[id[2]];
-    for (int k = 0; k < 3; ++k)
-      for (int c = 0; c < 3; ++c) s.bary[k][c] = poly[id[k]].b[c];
+    s.tri.X0 = w.X[0]; s.tri.Y0 = w.Y[0];
+    s.tri.X1 = w.X[i]; s.tri.Y1 = w.Y[i];
+    s.tri.X2 = w.X[i + 1]; s.tri.Y2 = w.Y[i + 1];
+    s.tri.rw0 = w.rw[0]; s.tri.rw1 = w.rw[i]; s.tri.rw2 = w.rw[i + 1];
+    const ClipVert v0 = w.poly[0], v1 = w.poly[i], v2 = w.poly[i + 1];
+    for (int c = 0; c < 3; ++c) {
+      s.bary[0][c] = v0.b[c];
+      s.bary[1][c] = v1.b[c];
+      s.bary[2][c] = v2.b[c];
+    }
     s.pad[0] = s.pad[1] = 0;
-    bool ok = setup_tri(s.tri, z[id[0]], z[id[1]], z[id[2]]);
+    bool ok = setup_tri(s.tri, w.z[0], w.z[i], w.z[i + 1]);
+    TileRange tr;
+    ok = ok && tile_range<TILE_W, TILE_H>(s.tri, fp, tr);
     s.valid = ok ? 1u : 0u;
     clip_arena[base + i - 1] = s;
     if (ok) {
-      any_valid = true;
-      bin_triangle<TILE_W, TILE_H>(s.tri, (prim << 3) | (uint32_t)(i - 1), fp, ctr, tile_count, bins, broad_list);
+      ++n_valid;
+      valid_mask |= 1u << (i - 1);
+    }
+  }
+  if (n_valid) {
+    uint32_t slot = atomicAdd(&ctr->n_broad, (uint32_t)n_valid);
+    if (slot + n_valid <= fp.broad_cap) {
+      for (int i = 0; i < n_slots; ++i)
+        if (valid_mask & (1u << i)) {
+          BroadTri b;
+          b.tri = clip_arena[base + i].tri;
+          b.ref = (prim << 3) | (uint32_t)i;
+          b.pad[0] = b.pad[1] = b.pad[2] = 0;
+          broad_list[slot++] = b;
+        }
+    } else {
+      atomicOr(&ctr->overflow, 2u);
     }
   }
   RasterTri head;
@@ -219,80 +330,133 @@ __device__ __noinline__ void clip_and_bin(const float (*clip)[4], uint32_t prim,
   head.z0 = head.dzdx = head.dzdy = head.l1dx = head.l1dy = head.l2dx = head.l2dy = 0.0f;
   head.rw0 = head.rw1 = head.rw2 = 0.0f;
   tris[prim] = head;
+  return n_valid;
 }
 
-// One thread per primitive of one draw call.
+// One thread per primitive, all draw calls of the frame in one launch (API order = primitive index order).
 template <int TILE_W, int TILE_H>
-__global__ __launch_bounds__(256) void k_geometry(DrawDesc draw, Mat4 pv, FrameParams fp, RasterTri *__restrict__ tris,
+__global__ __launch_bounds__(256) void k_geometry(const DrawDesc *__restrict__ draws, uint32_t n_draws, uint32_t n_prims,
+                                                  Mat4 pv, FrameParams fp, RasterTri *__restrict__ tris,
                                                   PrimAttr *__restrict__ attrs, ClipSlot *__restrict__ clip_arena,
                                                   Counters *__restrict__ ctr, uint32_t *__restrict__ tile_count,
-                                                  uint32_t *__restrict__ bins, uint32_t *__restrict__ broad_list) {
-  uint32_t local = blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t n_local = draw.n_instances * draw.tris_per_instance;
-  if (local >= n_local) return;
-  uint32_t inst = local / draw.tris_per_instance;
-  uint32_t tri = local - inst * draw.tris_per_instance;
-  uint32_t prim = draw.first_prim + local;
-
-  const InstanceBlock &ib = draw.instances[inst];
+                                                  uint32_t *__restrict__ bins, BroadTri *__restrict__ broad_list,
+                                                  const MaterialDesc *__restrict__ materials) {
+  __shared__ BlockStats bs;
+  __shared__ ClipWork s_clip[4];  // one per wave
+  if (threadIdx.x == 0) bs = BlockStats{0u, 0u, 0u};
+  __syncthreads();
+  const uint32_t prim = blockIdx.x * blockDim.x + threadIdx.x;
+  bool needs_clip = false;
   float clip[3][4];
   PrimAttr pa;
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    uint32_t vi = draw.indices ? draw.indices[3 * tri + k] : 3 * tri + k;
-    const Vertex &v = draw.vertices[vi];
-    // forward_brdf.vert:25,27
-    f4 pw = mat4_mul(ib.model, f4{v.pos[0], v.pos[1], v.pos[2], 1.0f});
-    f4 c = mat4_mul(pv, pw);
-    clip[k][0] = c.x; clip[k][1] = c.y; clip[k][2] = c.z; clip[k][3] = c.w;
-    // :31-36  normalMat = transpose(mat3(aInvModel))
-    f3 n = ld3(v.normal), t = ld3(v.tangent);
-    const Mat4 &im = ib.inv_model;
-    f3 N = normalize3(mk3(dot3(ld3(im.M[0]), n), dot3(ld3(im.M[1]), n), dot3(ld3(im.M[2]), n)));
-    f3 T = normalize3(mk3(dot3(ld3(im.M[0]), t), dot3(ld3(im.M[1]), t), dot3(ld3(im.M[2]), t)));
-    f3 B = cross3(N, T);
-    float *o = pa.vary[k];
-    o[0] = v.uv[0]; o[1] = v.uv[1];
-    o[2] = pw.x; o[3] = pw.y; o[4] = pw.z;
-    o[5] = N.x; o[6] = N.y; o[7] = N.z;
-    o[8] = T.x; o[9] = T.y; o[10] = T.z;
-    o[11] = B.x; o[12] = B.y; o[13] = B.z;
-  }
-  pa.material = draw.material;
-  pa.pad = 0;
+  bool binned = false;  // this lane holds an unclipped, set-up triangle that goes to tile bins
+  uint32_t cls = 0;     // raster class of the triangle: bin segment (kBinClasses per tile)
+  TileRange tr = {0, -1, 0, -1};
+  uint32_t n_raster = 0, n_clipped = 0;
+  if (prim < n_prims) {
+    uint32_t d = 0;
+    while (d + 1 < n_draws && prim >= draws[d + 1].first_prim) ++d;
+    const DrawDesc draw = draws[d];
+    const uint32_t local = prim - draw.first_prim;
+    const uint32_t inst = local / draw.tris_per_instance;
+    const uint32_t tri = local - inst * draw.tris_per_instance;
 
-  // trivial reject against the true frustum (cannot change any pixel)
-  {
-    bool o_l = true, o_r = true, o_t = true, o_b = true, o_n = true, o_f = true;
+    const InstanceBlock &ib = draw.instances[inst];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      uint32_t vi = draw.indices ? draw.indices[3 * tri + k] : 3 * tri + k;
+      const Vertex &v = draw.vertices[vi];
+      // forward_brdf.vert:25,27
+      f4 pw = mat4_mul(ib.model, f4{v.pos[0], v.pos[1], v.pos[2], 1.0f});
+      f4 c = mat4_mul(pv, pw);
+      clip[k][0] = c.x; clip[k][1] = c.y; clip[k][2] = c.z; clip[k][3] = c.w;
+      // :31-36  normalMat = transpose(mat3(aInvModel))
+      f3 n = ld3(v.normal), t = ld3(v.tangent);
+      const Mat4 &im = ib.inv_model;
+      f3 N = normalize3(mk3(dot3(ld3(im.M[0]), n), dot3(ld3(im.M[1]), n), dot3(ld3(im.M[2]), n)));
+      f3 T = normalize3(mk3(dot3(ld3(im.M[0]), t), dot3(ld3(im.M[1]), t), dot3(ld3(im.M[2]), t)));
+      f3 B = cross3(N, T);
+      float *o = pa.vary[k];
+      o[0] = v.uv[0]; o[1] = v.uv[1];
+      o[2] = pw.x; o[3] = pw.y; o[4] = pw.z;
+      o[5] = N.x; o[6] = N.y; o[7] = N.z;
+      o[8] = T.x; o[9] = T.y; o[10] = T.z;
+      o[11] = B.x; o[12] = B.y; o[13] = B.z;
+    }
+    {
+      const MaterialDesc &md = materials[draw.material];
+      pa.material = draw.material;
+      pa.packed = md.packed;
+      pa.packed_dims = md.packed ? ((uint32_t)md.pw | ((uint32_t)md.ph << 16)) : 0u;
+      pa.pad[0] = pa.pad[1] = 0;
+    }
+
+    // trivial reject against the true frustum (cannot change any pixel)
+    bool o_l = true, o_r = true, o_t = true, o_b = true, o_n = true, o_f = true, all_in = true;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const float *c = clip[i];
       o_l &= (c[3] + c[0] < 0.0f); o_r &= (c[3] - c[0] < 0.0f);
       o_t &= (c[3] + c[1] < 0.0f); o_b &= (c[3] - c[1] < 0.0f);
       o_n &= (c[3] - c[2] < 0.0f); o_f &= (c[2] < 0.0f);
+#pragma unroll
+      for (int p = 0; p < 6; ++p) all_in &= (plane_dist(c, p) >= 0.0f);
     }
-    if (o_l | o_r | o_t | o_b | o_n | o_f) return;
+    if (!(o_l | o_r | o_t | o_b | o_n | o_f)) {
+      if (all_in) {
+        RasterTri t;
+        float z0, z1, z2;
+        if (project_vertex(clip[0], fp.half_w, fp.half_h, t.X0, t.Y0, t.rw0, z0) &&
+            project_vertex(clip[1], fp.half_w, fp.half_h, t.X1, t.Y1, t.rw1, z1) &&
+            project_vertex(clip[2], fp.half_w, fp.half_h, t.X2, t.Y2, t.rw2, z2) && setup_tri(t, z0, z1, z2) &&
+            tile_range<TILE_W, TILE_H>(t, fp, tr)) {
+          if (!(fp.ablate & 64u)) {
+            tris[prim] = t;
+            attrs[prim] = pa;
+          }
+          n_raster = 1;
+          uint32_t ntiles = (uint32_t)(tr.tx1 - tr.tx0 + 1) * (uint32_t)(tr.ty1 - tr.ty0 + 1);
+          if (ntiles > fp.broad_threshold) broad_insert(t, prim << 3, fp, ctr, broad_list);
+          else binned = true;
+          cls = raster_class(t, fp);
+        }
+      } else if (!(fp.ablate & 128u)) {
+        needs_clip = true;
+      }
+    }
   }
-  bool all_in = true;
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int p = 0; p < 6; ++p) all_in &= (plane_dist(clip[i], p) >= 0.0f);
+  // ---- clipper: lanes that need it take turns on the wave's LDS workspace ----
+  for (unsigned long long cm = __ballot(needs_clip); cm; cm &= cm - 1ull) {
+    if ((int)(threadIdx.x & 63) == __ffsll((long long)cm) - 1) {
+      n_clipped = 1;
+      int nv = clip_and_route<TILE_W, TILE_H>(s_clip[threadIdx.x >> 6], clip, prim, fp, tris, clip_arena, ctr, broad_list);
+      if (nv) attrs[prim] = pa;
+      n_raster = (uint32_t)nv;
+    }
+  }
 
-  if (all_in) {
-    RasterTri t;
-    float z0, z1, z2;
-    if (!project_vertex(clip[0], fp.half_w, fp.half_h, t.X0, t.Y0, t.rw0, z0)) return;
-    if (!project_vertex(clip[1], fp.half_w, fp.half_h, t.X1, t.Y1, t.rw1, z1)) return;
-    if (!project_vertex(clip[2], fp.half_w, fp.half_h, t.X2, t.Y2, t.rw2, z2)) return;
-    if (!setup_tri(t, z0, z1, z2)) return;
-    tris[prim] = t;
-    attrs[prim] = pa;
-    bin_triangle<TILE_W, TILE_H>(t, prim << 3, fp, ctr, tile_count, bins, broad_list);
-  } else {
-    bool any_valid;
-    clip_and_bin<TILE_W, TILE_H>(clip, prim, fp, tris, clip_arena, ctr, tile_count, bins, broad_list, any_valid);
-    if (any_valid) attrs[prim] = pa;
+  // ---- tile bins: walk each lane's tile range in lock-step, aggregating per tile across the wave ----
+  uint32_t refs = 0;
+  {
+    const int tw = binned ? tr.tx1 - tr.tx0 + 1 : 0;
+    const int nt = (binned && !(fp.ablate & 32u)) ? tw * (tr.ty1 - tr.ty0 + 1) : 0;
+    for (int k = 0; __ballot(k < nt) != 0ull; ++k) {
+      bool has = k < nt;
+      int ty = has ? tr.ty0 + k / tw : 0, tx = has ? tr.tx0 + k % tw : 0;
+      if (has && fp.world > 1 && ((ty / fp.band_tiles) % fp.world) != fp.rank) has = false;  // another rank's band
+      uint32_t seg = ((uint32_t)ty * (uint32_t)fp.tiles_x + (uint32_t)tx) * kBinClasses + cls;
+      uint32_t n = wave_bin_insert(has, seg, prim << 3, fp, ctr, tile_count, bins);
+      refs += n;
+    }
+  }
+  if ((threadIdx.x & 63) == 0 && refs) atomicAdd(&bs.bin_refs, refs);
+  if (n_raster) atomicAdd(&bs.raster_tris, n_raster);
+  if (n_clipped) atomicAdd(&bs.clipped_prims, n_clipped);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (bs.raster_tris) atomicAdd(&ctr->n_raster_tris, (unsigned long long)bs.raster_tris);
+    if (bs.clipped_prims) atomicAdd(&ctr->n_clipped_prims, (unsigned long long)bs.clipped_prims);
+    if (bs.bin_refs) atomicAdd(&ctr->n_bin_refs, (unsigned long long)bs.bin_refs);
   }
 }
 
@@ -328,10 +492,12 @@ BB_DEV BilinearTaps bilinear_taps(float u, float v, int w, int h) {
     x0 = wrap_repeat(ix, w); x1 = wrap_repeat(ix + 1, w);
     y0 = wrap_repeat(iy, h); y1 = wrap_repeat(iy + 1, h);
   }
-  t.o00 = (uint32_t)y0 * (uint32_t)w + (uint32_t)x0;
-  t.o10 = (uint32_t)y0 * (uint32_t)w + (uint32_t)x1;
-  t.o01 = (uint32_t)y1 * (uint32_t)w + (uint32_t)x0;
-  t.o11 = (uint32_t)y1 * (uint32_t)w + (uint32_t)x1;
+  // sizes are <= 16384 (checked at upload): 24-bit multiplies are exact and full rate
+  const uint32_t row0 = (uint32_t)__mul24(y0, w), row1 = (uint32_t)__mul24(y1, w);
+  t.o00 = row0 + (uint32_t)x0;
+  t.o10 = row0 + (uint32_t)x1;
+  t.o01 = row1 + (uint32_t)x0;
+  t.o11 = row1 + (uint32_t)x1;
   return t;
 }
 
@@ -388,31 +554,7 @@ BB_DEV RasterTri load_tri(const RasterTri *__restrict__ tris, const ClipSlot *__
   return t;
 }
 
-// Exact coverage of one pixel centre + depth; updates the LDS key with ds_max_u64.
-BB_DEV void raster_pixel(const RasterTri &t, long long b0, long long b1, long long b2, int px, int py, uint32_t ref,
-                         unsigned long long *keys, int key_index) {
-  int Xc = px * 256 + 128, Yc = py * 256 + 128;
-  long long dx0 = (long long)t.X1 - t.X0, dy0 = (long long)t.Y1 - t.Y0;
-  long long dx1 = (long long)t.X2 - t.X1, dy1 = (long long)t.Y2 - t.Y1;
-  long long dx2 = (long long)t.X0 - t.X2, dy2 = (long long)t.Y0 - t.Y2;
-  long long E0 = dx0 * (long long)(Yc - t.Y0) - dy0 * (long long)(Xc - t.X0) + b0;
-  long long E1 = dx1 * (long long)(Yc - t.Y1) - dy1 * (long long)(Xc - t.X1) + b1;
-  long long E2 = dx2 * (long long)(Yc - t.Y2) - dy2 * (long long)(Xc - t.X2) + b2;
-  if ((E0 | E1 | E2) < 0) return;
-  float dxp = (float)(Xc - t.X0), dyp = (float)(Yc - t.Y0);
-  float z = fmaf(t.dzdx, dxp, fmaf(t.dzdy, dyp, t.z0));
-  if (!(z >= 0.0f)) z = 0.0f;
-  if (z > 1.0f) z = 1.0f;
-  unsigned long long key = ((unsigned long long)__float_as_uint(z) << 32) | (unsigned long long)(ref + 1u);
-  atomicMax(&keys[key_index], key);
-}
-
-BB_DEV long long edge_bias(long long dx, long long dy) {
-  // top-left rule: a pixel centre exactly on an edge belongs to the triangle only for top/left edges
-  return (dy < 0 || (dy == 0 && dx > 0)) ? 0ll : -1ll;
-}
-
-// pixel index inside the tile, 8x8-blocked so that 64 consecutive indices form one 8x8 quad block
+// pixel index inside the tile, 8x8-blocked so that 64 consecutive indices form one 8x8 pixel block
 template <int TILE_W>
 BB_DEV void tile_pixel(int p, int &x, int &y) {
   int block = p >> 6, within = p & 63;
@@ -426,6 +568,56 @@ BB_DEV int tile_index(int x, int y) {
   return (((y >> 3) * BX + (x >> 3)) << 6) | ((y & 7) << 3) | (x & 7);
 }
 
+// A triangle against a rectangle of pixel centres [x0,x1] x [y0,y1]: 0 = no centre covered, 1 = some, 2 = all.
+// Edge functions are affine, so their extrema over the rectangle sit at corners picked by the gradient signs.
+struct EdgeSetup {
+  int dx[3], dy[3], bias[3];
+  int X[3], Y[3];
+};
+
+BB_DEV EdgeSetup edge_setup(const RasterTri &t) {
+  EdgeSetup e;
+  e.X[0] = t.X0; e.Y[0] = t.Y0; e.X[1] = t.X1; e.Y[1] = t.Y1; e.X[2] = t.X2; e.Y[2] = t.Y2;
+  e.dx[0] = t.X1 - t.X0; e.dy[0] = t.Y1 - t.Y0;  // |coordinates| < 2^30 (project_vertex), differences fit 32 bits
+  e.dx[1] = t.X2 - t.X1; e.dy[1] = t.Y2 - t.Y1;
+  e.dx[2] = t.X0 - t.X2; e.dy[2] = t.Y0 - t.Y2;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) e.bias[i] = (e.dy[i] < 0 || (e.dy[i] == 0 && e.dx[i] > 0)) ? 0 : -1;  // top-left rule
+  return e;
+}
+
+// exact: 32x32 -> 64-bit products (v_mad_i64_i32)
+BB_DEV long long edge_eval(const EdgeSetup &e, int i, int px, int py) {
+  int Xc = px * 256 + 128, Yc = py * 256 + 128;
+  return (long long)e.dx[i] * (long long)(Yc - e.Y[i]) - (long long)e.dy[i] * (long long)(Xc - e.X[i]) + (long long)e.bias[i];
+}
+
+BB_DEV int classify_rect(const EdgeSetup &e, int x0, int x1, int y0, int y1) {
+  bool all_in = true;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    // dE/dx = -dy*256, dE/dy = +dx*256
+    int xmax = e.dy[i] <= 0 ? x1 : x0, xmin = e.dy[i] <= 0 ? x0 : x1;
+    int ymax = e.dx[i] >= 0 ? y1 : y0, ymin = e.dx[i] >= 0 ? y0 : y1;
+    if (edge_eval(e, i, xmax, ymax) < 0) return 0;
+    all_in &= edge_eval(e, i, xmin, ymin) >= 0;
+  }
+  return all_in ? 2 : 1;
+}
+
+BB_DEV void depth_max(const RasterTri &t, int px, int py, uint32_t ref, unsigned long long *keys, int key_index) {
+  int Xc = px * 256 + 128, Yc = py * 256 + 128;
+  float dxp = (float)(Xc - t.X0), dyp = (float)(Yc - t.Y0);
+  float z = fmaf(t.dzdx, dxp, fmaf(t.dzdy, dyp, t.z0));
+  if (!(z >= 0.0f)) z = 0.0f;
+  if (z > 1.0f) z = 1.0f;
+  unsigned long long key = ((unsigned long long)__float_as_uint(z) << 32) | (unsigned long long)(ref + 1u);
+  atomicMax(&keys[key_index], key);
+}
+
+// One wave rasterises one (wave-uniform) triangle into the tile's LDS keys: 8x8 pixel blocks of bounding box ^ tile,
+// one pixel per lane.  Rectangles fully inside the triangle skip the edge tests.  Triangles spanning <= 64 px use
+// 32-bit edge functions stepped with 24-bit multiply-adds (exact: every term < 2^30); larger ones use 64-bit products.
 template <int TILE_W, int TILE_H>
 BB_DEV void raster_triangle_wave(const RasterTri &t, uint32_t ref, int tile_x0, int tile_y0, const FrameParams &fp,
                                  unsigned long long *keys, int lane) {
@@ -436,128 +628,249 @@ BB_DEV void raster_triangle_wave(const RasterTri &t, uint32_t ref, int tile_x0, 
   int py0 = max(max((minY - 128 + 255) >> 8, 0), tile_y0);
   int py1 = min(min((maxY - 128) >> 8, fp.height - 1), tile_y0 + TILE_H - 1);
   if (px0 > px1 || py0 > py1) return;
-  long long b0 = edge_bias((long long)t.X1 - t.X0, (long long)t.Y1 - t.Y0);
-  long long b1 = edge_bias((long long)t.X2 - t.X1, (long long)t.Y2 - t.Y1);
-  long long b2 = edge_bias((long long)t.X0 - t.X2, (long long)t.Y0 - t.Y2);
-  // sweep the clipped bounding box in 8x8 blocks, one pixel per lane
-  int bx0 = px0 & ~7, by0 = py0 & ~7;
-  for (int by = by0; by <= py1; by += 8) {
-    for (int bx = bx0; bx <= px1; bx += 8) {
-      int px = bx + (lane & 7), py = by + (lane >> 3);
-      if (px >= px0 && px <= px1 && py >= py0 && py <= py1)
-        raster_pixel(t, b0, b1, b2, px, py, ref, keys, tile_index<TILE_W>(px - tile_x0, py - tile_y0));
+  const EdgeSetup e = edge_setup(t);
+  const int w = px1 - px0 + 1, h = py1 - py0 + 1;
+  const int lx = lane & 7, ly = lane >> 3;
+  if (max(maxX - minX, maxY - minY) <= (1 << 14)) {
+    const int Xc0 = px0 * 256 + 128, Yc0 = py0 * 256 + 128;
+    int o[3], sx[3], sy[3];
+    bool none = false, all = true;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      o[i] = e.dx[i] * (Yc0 - e.Y[i]) - e.dy[i] * (Xc0 - e.X[i]) + e.bias[i];
+      sx[i] = -e.dy[i] * 256;
+      sy[i] = e.dx[i] * 256;
+      int hi = o[i] + (sx[i] > 0 ? sx[i] * (w - 1) : 0) + (sy[i] > 0 ? sy[i] * (h - 1) : 0);
+      int lo = o[i] + (sx[i] < 0 ? sx[i] * (w - 1) : 0) + (sy[i] < 0 ? sy[i] * (h - 1) : 0);
+      none |= hi < 0;
+      all &= lo >= 0;
+    }
+    if (none) return;
+    for (int by = 0; by < h; by += 8) {
+      for (int bx = 0; bx < w; bx += 8) {
+        int x = bx + lx, y = by + ly;
+        bool in = x < w && y < h;
+        if (in && !all) {
+          int e0 = __mul24(x, sx[0]) + __mul24(y, sy[0]) + o[0];
+          int e1 = __mul24(x, sx[1]) + __mul24(y, sy[1]) + o[1];
+          int e2 = __mul24(x, sx[2]) + __mul24(y, sy[2]) + o[2];
+          in = (e0 | e1 | e2) >= 0;
+        }
+        if (in) depth_max(t, px0 + x, py0 + y, ref, keys, tile_index<TILE_W>(px0 + x - tile_x0, py0 + y - tile_y0));
+      }
+    }
+    return;
+  }
+  const int cls = classify_rect(e, px0, px1, py0, py1);
+  if (cls == 0) return;
+  for (int by = 0; by < h; by += 8) {
+    for (int bx = 0; bx < w; bx += 8) {
+      int px = px0 + bx + lx, py = py0 + by + ly;
+      bool in = px <= px1 && py <= py1;
+      if (in && cls == 1) in = (edge_eval(e, 0, px, py) | edge_eval(e, 1, px, py) | edge_eval(e, 2, px, py)) >= 0;
+      if (in) depth_max(t, px, py, ref, keys, tile_index<TILE_W>(px - tile_x0, py - tile_y0));
     }
   }
-}
-
-template <int TILE_W, int TILE_H>
-BB_DEV void raster_triangle_lane(const RasterTri &t, uint32_t ref, int tile_x0, int tile_y0, const FrameParams &fp,
-                                 unsigned long long *keys, int px0, int px1, int py0, int py1) {
-  long long b0 = edge_bias((long long)t.X1 - t.X0, (long long)t.Y1 - t.Y0);
-  long long b1 = edge_bias((long long)t.X2 - t.X1, (long long)t.Y2 - t.Y1);
-  long long b2 = edge_bias((long long)t.X0 - t.X2, (long long)t.Y0 - t.Y2);
-  for (int py = py0; py <= py1; ++py)
-    for (int px = px0; px <= px1; ++px)
-      raster_pixel(t, b0, b1, b2, px, py, ref, keys, tile_index<TILE_W>(px - tile_x0, py - tile_y0));
 }
 
 constexpr int kTileThreads = 256;
-constexpr int kSmallTriPixels = 48;  // bounding boxes up to this many pixels are rasterised one triangle per lane
+constexpr int kTileWaves = kTileThreads / 64;
 
+// lane `l` (wave-uniform) hands its triangle to the whole wave through v_readlane: no memory round trip
+BB_DEV RasterTri broadcast_tri(const RasterTri &t, int l) {
+  RasterTri r;
+  r.X0 = __builtin_amdgcn_readlane(t.X0, l); r.Y0 = __builtin_amdgcn_readlane(t.Y0, l);
+  r.X1 = __builtin_amdgcn_readlane(t.X1, l); r.Y1 = __builtin_amdgcn_readlane(t.Y1, l);
+  r.X2 = __builtin_amdgcn_readlane(t.X2, l); r.Y2 = __builtin_amdgcn_readlane(t.Y2, l);
+  r.z0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t.z0), l));
+  r.dzdx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t.dzdx), l));
+  r.dzdy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t.dzdy), l));
+  r.l1dx = r.l1dy = r.l2dx = r.l2dy = r.rw0 = r.rw1 = r.rw2 = 0.0f;  // not needed for coverage / depth
+  return r;
+}
+
+// One lane rasterises one small triangle into the tile's LDS keys.  Bounding box <= 16 px in each direction
+// => every edge-function term fits 32 bits and steps are plain adds.
 template <int TILE_W, int TILE_H>
-__global__ __launch_bounds__(kTileThreads) void k_tile(
-    FrameParams fp, ShadeParams sp, const Light *__restrict__ lights, const RasterTri *__restrict__ tris,
-    const PrimAttr *__restrict__ attrs, const ClipSlot *__restrict__ clip_arena, Counters *__restrict__ ctr,
-    Counters *__restrict__ ctr_next, uint32_t *__restrict__ tile_count, const uint32_t *__restrict__ bins,
-    const uint32_t *__restrict__ broad_list, const MaterialDesc *__restrict__ materials, float4 *__restrict__ out,
+BB_DEV void raster_triangle_lane(const RasterTri &t, uint32_t ref, int px0, int px1, int py0, int py1, int tile_x0,
+                                 int tile_y0, unsigned long long *keys) {
+  const int dx0 = t.X1 - t.X0, dy0 = t.Y1 - t.Y0;
+  const int dx1 = t.X2 - t.X1, dy1 = t.Y2 - t.Y1;
+  const int dx2 = t.X0 - t.X2, dy2 = t.Y0 - t.Y2;
+  const int Xc0 = px0 * 256 + 128, Yc0 = py0 * 256 + 128;
+  // top-left rule folded into the edge value: E' = E + (top-left ? 0 : -1); covered <=> all E' >= 0
+  int r0 = dx0 * (Yc0 - t.Y0) - dy0 * (Xc0 - t.X0) + ((dy0 < 0 || (dy0 == 0 && dx0 > 0)) ? 0 : -1);
+  int r1 = dx1 * (Yc0 - t.Y1) - dy1 * (Xc0 - t.X1) + ((dy1 < 0 || (dy1 == 0 && dx1 > 0)) ? 0 : -1);
+  int r2 = dx2 * (Yc0 - t.Y2) - dy2 * (Xc0 - t.X2) + ((dy2 < 0 || (dy2 == 0 && dx2 > 0)) ? 0 : -1);
+  const int sx0 = dy0 * 256, sx1 = dy1 * 256, sx2 = dy2 * 256;  // E(x+1) = E - sx
+  const int sy0 = dx0 * 256, sy1 = dx1 * 256, sy2 = dx2 * 256;  // E(y+1) = E + sy
+  const int w = px1 - px0 + 1, n = w * (py1 - py0 + 1);
+  int e0 = r0, e1 = r1, e2 = r2, x = 0, py = py0;
+  for (int i = 0; i < n; ++i) {
+    if ((e0 | e1 | e2) >= 0) {
+      int px = px0 + x;
+      depth_max(t, px, py, ref, keys, tile_index<TILE_W>(px - tile_x0, py - tile_y0));
+    }
+    ++x;
+    e0 -= sx0; e1 -= sx1; e2 -= sx2;
+    if (x == w) {
+      x = 0;
+      ++py;
+      r0 += sy0; r1 += sy1; r2 += sy2;
+      e0 = r0; e1 = r1; e2 = r2;
+    }
+  }
+}
+
+// Sixteen lanes rasterise one small triangle (spans <= 64 px): 4x4 pixel blocks over bounding box ^ tile, one pixel
+// per lane, 32-bit edge functions evaluated with 24-bit multiply-adds (exact: |step| < 2^23, offsets < 64).
+template <int TILE_W, int TILE_H>
+BB_DEV void raster_triangle_group16(const RasterTri &t, uint32_t ref, int px0, int px1, int py0, int py1, int tile_x0,
+                                    int tile_y0, unsigned long long *keys, int gl) {
+  const EdgeSetup e = edge_setup(t);
+  const int Xc0 = px0 * 256 + 128, Yc0 = py0 * 256 + 128;
+  const int w = px1 - px0 + 1, h = py1 - py0 + 1;
+  int o[3], sx[3], sy[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    o[i] = e.dx[i] * (Yc0 - e.Y[i]) - e.dy[i] * (Xc0 - e.X[i]) + e.bias[i];
+    sx[i] = -e.dy[i] * 256;
+    sy[i] = e.dx[i] * 256;
+  }
+  const int lx = gl & 3, ly = gl >> 2;
+  for (int by = 0; by < h; by += 4) {
+    for (int bx = 0; bx < w; bx += 4) {
+      int x = bx + lx, y = by + ly;
+      if (x < w && y < h) {
+        int e0 = __mul24(x, sx[0]) + __mul24(y, sy[0]) + o[0];
+        int e1 = __mul24(x, sx[1]) + __mul24(y, sy[1]) + o[1];
+        int e2 = __mul24(x, sx[2]) + __mul24(y, sy[2]) + o[2];
+        if ((e0 | e1 | e2) >= 0)
+          depth_max(t, px0 + x, py0 + y, ref, keys, tile_index<TILE_W>(px0 + x - tile_x0, py0 + y - tile_y0));
+      }
+    }
+  }
+}
+
+// owned tile row (grid y) -> global tile row; false if past the frame
+BB_DEV bool tile_row(const FrameParams &fp, int grid_y, int &ty, int &out_tile_row) {
+  if (fp.world > 1) {
+    int lb = grid_y / fp.band_tiles, r = grid_y - lb * fp.band_tiles;
+    ty = (lb * fp.world + fp.rank) * fp.band_tiles + r;
+  } else {
+    ty = grid_y;
+  }
+  out_tile_row = grid_y;
+  return ty < fp.tiles_y;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_raster: one workgroup per screen tile.  LDS-resident 64-bit keys (depth bits << 32 | primitive) filled with
+// ds_max_u64 -- depth op GREATER_OR_EQUAL with "later primitive wins ties" falls out of the key order -- then
+// ballot/popcount compaction of the covered pixels into the tile's fragment list.  Background pixels get the
+// clear colour here; covered pixels are coloured by k_shade.
+// No workgroup barrier inside the raster loops: each wave pulls 64 bin entries, lanes rasterise the small
+// triangles themselves and the wave then sweeps its larger ones cooperatively.
+// ------------------------------------------------------------------------------------------------
+template <int TILE_W, int TILE_H>
+__global__ __launch_bounds__(kTileThreads) void k_raster(
+    FrameParams fp, const RasterTri *__restrict__ tris, const ClipSlot *__restrict__ clip_arena,
+    Counters *__restrict__ ctr, Counters *__restrict__ ctr_next, uint32_t *__restrict__ tile_count,
+    const uint32_t *__restrict__ bins, const BroadTri *__restrict__ broad_list,
+    unsigned long long *__restrict__ frags, uint32_t *__restrict__ frag_count, float4 *__restrict__ out,
     uint32_t *__restrict__ vis_prim, float *__restrict__ vis_depth) {
   constexpr int TILE_PIXELS = TILE_W * TILE_H;
   __shared__ unsigned long long keys[TILE_PIXELS];
-  __shared__ uint16_t list[TILE_PIXELS];
-  __shared__ uint32_t big_list[kTileThreads * 4];
-  __shared__ uint32_t s_count, s_big;
+  __shared__ uint32_t s_count;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tx = blockIdx.x;
-  // owned tile row -> global tile row
   int ty, out_tile_row;
-  if (fp.world > 1) {
-    int lb = blockIdx.y / fp.band_tiles, r = blockIdx.y - lb * fp.band_tiles;
-    ty = (lb * fp.world + fp.rank) * fp.band_tiles + r;
-    out_tile_row = blockIdx.y;
-  } else {
-    ty = blockIdx.y;
-    out_tile_row = ty;
-  }
+  const bool live = tile_row(fp, blockIdx.y, ty, out_tile_row);
   if (blockIdx.x == 0 && blockIdx.y == 0 && tid < (int)(sizeof(Counters) / 4))
     reinterpret_cast<uint32_t *>(ctr_next)[tid] = 0;  // next frame's counter block
-  if (ty >= fp.tiles_y) return;
+  if (!live) return;
   const uint32_t tile = (uint32_t)ty * (uint32_t)fp.tiles_x + (uint32_t)tx;
   const int tile_x0 = tx * TILE_W, tile_y0 = ty * TILE_H;
+  const int out_y0 = out_tile_row * TILE_H;
+  const int rx1 = min(tile_x0 + TILE_W, fp.width) - 1, ry1 = min(tile_y0 + TILE_H, fp.height) - 1;
 
-  for (int i = tid; i < TILE_PIXELS; i += kTileThreads) keys[i] = 0ull;
-  if (tid == 0) {
-    s_count = 0;
-    s_big = 0;
-  }
-  const uint32_t n_bin = min(tile_count[tile], fp.bin_cap);
-  const uint32_t n_broad = min(ctr->n_broad, fp.broad_cap);
+  uint32_t n_cls[kBinClasses];
+#pragma unroll
+  for (uint32_t c = 0; c < kBinClasses; ++c)
+    n_cls[c] = (fp.ablate & (1u | (256u << c))) ? 0u : min(tile_count[tile * kBinClasses + c], fp.bin_cap);
+  const uint32_t n_broad = (fp.ablate & 5u) ? 0u : min(ctr->n_broad, fp.broad_cap);
+  for (int p = tid; p < TILE_PIXELS; p += kTileThreads) keys[p] = 0ull;
+  if (tid == 0) s_count = 0;
   __syncthreads();
-  if (tid == 0) tile_count[tile] = 0;  // ready for the next frame
+  if (tid < (int)kBinClasses && n_cls[tid]) tile_count[tile * kBinClasses + tid] = 0;  // ready for the next frame
 
-  // ---- raster phase A: one triangle per lane for small bounding boxes; big ones are deferred ----
-  const uint32_t *my_bin = bins + (size_t)tile * fp.bin_cap;
-  for (uint32_t base = 0; base < n_bin; base += kTileThreads) {
-    uint32_t i = base + tid;
-    if (i < n_bin) {
-      uint32_t ref = my_bin[i];
-      bool clipped;
-      uint32_t slot;
-      RasterTri t = load_tri(tris, clip_arena, ref, clipped, slot);
+  // clamp of a triangle's pixel box to this tile (pixel centres)
+  auto tile_box = [&](const RasterTri &t, int &px0, int &px1, int &py0, int &py1) {
+    int32_t minX = min(t.X0, min(t.X1, t.X2)), maxX = max(t.X0, max(t.X1, t.X2));
+    int32_t minY = min(t.Y0, min(t.Y1, t.Y2)), maxY = max(t.Y0, max(t.Y1, t.Y2));
+    px0 = max((minX - 128 + 255) >> 8, tile_x0); px1 = min((maxX - 128) >> 8, rx1);
+    py0 = max((minY - 128 + 255) >> 8, tile_y0); py1 = min((maxY - 128) >> 8, ry1);
+    return px0 <= px1 && py0 <= py1;
+  };
+
+  // ---- class 0: one tiny triangle per lane ----
+  {
+    const uint32_t *bin = bins + (size_t)(tile * kBinClasses + 0u) * fp.bin_cap;
+    for (uint32_t i = (uint32_t)tid; i < n_cls[0]; i += kTileThreads) {
+      const uint32_t ref = bin[i];
+      const RasterTri t = tris[ref >> 3];  // binned triangles are never clipped
+      int px0, px1, py0, py1;
+      if (tile_box(t, px0, px1, py0, py1)) raster_triangle_lane<TILE_W, TILE_H>(t, ref, px0, px1, py0, py1, tile_x0, tile_y0, keys);
+    }
+  }
+  // ---- class 1: sixteen lanes per small triangle ----
+  {
+    const uint32_t *bin = bins + (size_t)(tile * kBinClasses + 1u) * fp.bin_cap;
+    for (uint32_t i = (uint32_t)(tid >> 4); i < n_cls[1]; i += kTileThreads / 16) {
+      const uint32_t ref = bin[i];
+      const RasterTri t = tris[ref >> 3];
+      int px0, px1, py0, py1;
+      if (tile_box(t, px0, px1, py0, py1))
+        raster_triangle_group16<TILE_W, TILE_H>(t, ref, px0, px1, py0, py1, tile_x0, tile_y0, keys, tid & 15);
+    }
+  }
+  // ---- class 2: one wave per large triangle ----
+  {
+    const uint32_t *bin = bins + (size_t)(tile * kBinClasses + 2u) * fp.bin_cap;
+    for (uint32_t i = (uint32_t)wave; i < n_cls[2]; i += kTileWaves) {
+      const uint32_t ref = (uint32_t)__builtin_amdgcn_readfirstlane((int)bin[i]);
+      const RasterTri t = tris[ref >> 3];
+      raster_triangle_wave<TILE_W, TILE_H>(t, ref, tile_x0, tile_y0, fp, keys, lane);
+    }
+  }
+  // ---- every-tile list: lanes classify against this tile's rectangle, the wave sweeps the survivors ----
+  for (uint32_t base = (uint32_t)wave * 64u; base < n_broad; base += kTileThreads) {
+    const uint32_t j = base + (uint32_t)lane;
+    bool hit = false;
+    uint32_t ref = 0;
+    RasterTri t = {};
+    if (j < n_broad) {
+      t = broad_list[j].tri;
+      ref = broad_list[j].ref;
       int32_t minX = min(t.X0, min(t.X1, t.X2)), maxX = max(t.X0, max(t.X1, t.X2));
       int32_t minY = min(t.Y0, min(t.Y1, t.Y2)), maxY = max(t.Y0, max(t.Y1, t.Y2));
-      int px0 = max(max((minX - 128 + 255) >> 8, 0), tile_x0);
-      int px1 = min(min((maxX - 128) >> 8, fp.width - 1), tile_x0 + TILE_W - 1);
-      int py0 = max(max((minY - 128 + 255) >> 8, 0), tile_y0);
-      int py1 = min(min((maxY - 128) >> 8, fp.height - 1), tile_y0 + TILE_H - 1);
-      if (px0 <= px1 && py0 <= py1) {
-        int area = (px1 - px0 + 1) * (py1 - py0 + 1);
-        if (area <= kSmallTriPixels) {
-          raster_triangle_lane<TILE_W, TILE_H>(t, ref, tile_x0, tile_y0, fp, keys, px0, px1, py0, py1);
-        } else {
-          uint32_t s = atomicAdd(&s_big, 1u);
-          big_list[s & (kTileThreads * 4 - 1)] = ref;  // capacity handled by flushing below
-        }
-      }
+      int px0 = max((minX - 128 + 255) >> 8, tile_x0), px1 = min((maxX - 128) >> 8, rx1);
+      int py0 = max((minY - 128 + 255) >> 8, tile_y0), py1 = min((maxY - 128) >> 8, ry1);
+      hit = px0 <= px1 && py0 <= py1 && classify_rect(edge_setup(t), px0, px1, py0, py1) != 0;
     }
-    // flush deferred big triangles whenever the list could overflow on the next round
-    __syncthreads();
-    uint32_t nb = s_big;
-    if (nb > kTileThreads * 3 || base + kTileThreads >= n_bin) {
-      for (uint32_t j = wave; j < nb; j += kTileThreads / 64) {
-        uint32_t ref = big_list[j];
-        bool clipped;
-        uint32_t slot;
-        RasterTri t = load_tri(tris, clip_arena, ref, clipped, slot);
-        raster_triangle_wave<TILE_W, TILE_H>(t, ref, tile_x0, tile_y0, fp, keys, lane);
-      }
-      __syncthreads();
-      if (tid == 0) s_big = 0;
-      __syncthreads();
+    unsigned long long m = __ballot(hit);
+    while (m) {
+      int l = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
+      m &= m - 1ull;
+      uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)ref, l);
+      raster_triangle_wave<TILE_W, TILE_H>(broadcast_tri(t, l), r, tile_x0, tile_y0, fp, keys, lane);
     }
-  }
-  // ---- raster phase B: broad list (triangles that touch many tiles), one triangle per wave ----
-  for (uint32_t j = wave; j < n_broad; j += kTileThreads / 64) {
-    uint32_t ref = broad_list[j];
-    bool clipped;
-    uint32_t slot;
-    RasterTri t = load_tri(tris, clip_arena, ref, clipped, slot);
-    raster_triangle_wave<TILE_W, TILE_H>(t, ref, tile_x0, tile_y0, fp, keys, lane);
   }
   __syncthreads();
 
-  // ---- compaction: covered pixels -> list (ballot + popcount prefix); background written here ----
-  const int out_y0 = out_tile_row * TILE_H;
+  // ---- compaction: covered pixels -> fragment list (ballot + popcount prefix); background written here ----
+  unsigned long long *my_frags = frags + (size_t)tile * TILE_PIXELS;
   for (int base = 0; base < TILE_PIXELS; base += kTileThreads) {
     int p = base + tid;
     int x, y;
@@ -569,10 +882,10 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(
     unsigned long long mask = __ballot(covered);
     uint32_t wave_base = 0;
     if (lane == 0 && mask) wave_base = atomicAdd(&s_count, (uint32_t)__popcll(mask));
-    wave_base = __shfl(wave_base, 0);
+    wave_base = (uint32_t)__shfl((int)wave_base, 0);
     if (covered) {
       uint32_t rank_in_wave = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-      list[wave_base + rank_in_wave] = (uint16_t)p;
+      my_frags[wave_base + rank_in_wave] = ((unsigned long long)(uint32_t)p << 32) | (unsigned long long)((uint32_t)key - 1u);
     } else if (in_frame) {
       size_t o = (size_t)(out_y0 + y) * (size_t)fp.width + (size_t)gx;
       out[o] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // clear colour, src/main.cpp:84
@@ -584,17 +897,44 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(
     }
   }
   __syncthreads();
-  const uint32_t n_cov = s_count;
-  if (tid == 0 && n_cov) atomicAdd(&ctr->n_shaded, (unsigned long long)n_cov);
+  if (tid == 0) {
+    const uint32_t n_cov = s_count;
+    frag_count[tile] = n_cov;
+    if (n_cov) atomicAdd(&ctr->n_shaded, (unsigned long long)n_cov);
+  }
+}
 
-  // ---- shading: forward_brdf.frag once per visible pixel ----
-  for (uint32_t i = tid; i < n_cov; i += kTileThreads) {
-    int p = list[i];
-    int x, y;
-    tile_pixel<TILE_W>(p, x, y);
-    int gx = tile_x0 + x, gy = tile_y0 + y;
-    uint32_t ref = (uint32_t)keys[p] - 1u;
-    uint32_t prim = ref >> 3;
+// ------------------------------------------------------------------------------------------------
+// k_shade: forward_brdf.frag + brdf.glsl once per visible pixel.  One lane per fragment of the compacted lists,
+// 256 consecutive fragments of one tile per workgroup: no LDS, no barriers, every wave does the same amount of
+// work, so the hardware dispatcher balances the frame by itself.
+// ------------------------------------------------------------------------------------------------
+template <int TILE_W, int TILE_H>
+__global__ __launch_bounds__(kTileThreads) void k_shade(
+    FrameParams fp, ShadeParams sp, const Light *__restrict__ lights, const RasterTri *__restrict__ tris,
+    const PrimAttr *__restrict__ attrs, const ClipSlot *__restrict__ clip_arena,
+    const unsigned long long *__restrict__ frags, const uint32_t *__restrict__ frag_count,
+    const MaterialDesc *__restrict__ materials, float4 *__restrict__ out) {
+  constexpr int TILE_PIXELS = TILE_W * TILE_H;
+  constexpr int CHUNKS = TILE_PIXELS / kTileThreads;
+  const int tx = blockIdx.x / CHUNKS, chunk = blockIdx.x - tx * CHUNKS;
+  int ty, out_tile_row;
+  if (!tile_row(fp, blockIdx.y, ty, out_tile_row)) return;
+  const uint32_t tile = (uint32_t)ty * (uint32_t)fp.tiles_x + (uint32_t)tx;
+  const uint32_t i = (uint32_t)chunk * kTileThreads + threadIdx.x;
+  if (i >= frag_count[tile]) return;
+  const unsigned long long frag = frags[(size_t)tile * TILE_PIXELS + i];
+  const uint32_t ref = (uint32_t)frag;
+  int x, y;
+  tile_pixel<TILE_W>((int)(frag >> 32), x, y);
+  const int gx = tx * TILE_W + x, gy = ty * TILE_H + y;
+  const size_t o = (size_t)(out_tile_row * TILE_H + y) * (size_t)fp.width + (size_t)gx;
+  if (fp.ablate & 2u) {
+    out[o] = make_float4(1.f, 1.f, 1.f, 1.f);
+    return;
+  }
+  {
+    const uint32_t prim = ref >> 3;
     bool clipped;
     uint32_t slot;
     RasterTri t = load_tri(tris, clip_arena, ref, clipped, slot);
@@ -616,58 +956,80 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(
       b0 = c0; b1 = c1; b2 = c2;
     }
 
-    const PrimAttr &pa = attrs[prim];
+    const PrimAttr &pa = attrs[(fp.ablate & 16u) ? 0u : prim];
     float a[kNumVary];
 #pragma unroll
     for (int k = 0; k < kNumVary; ++k) a[k] = fmaf(b2, pa.vary[2][k], fmaf(b1, pa.vary[1][k], b0 * pa.vary[0][k]));
-    const MaterialDesc &md = materials[pa.material];
-
     // texture fetches, forward_brdf.frag:16-22
-    const float u = a[0], v = a[1];
-    f3 albedo;
+    const float u = (fp.ablate & 8u) ? 0.5f : a[0], v = (fp.ablate & 8u) ? 0.5f : a[1];
+    f3 albedo, normal;
     float metallic, roughness, ao;
-    {
-      const TexDesc &td = md.maps[kMapAlbedo];
-      BilinearTaps tp = bilinear_taps(u, v, td.w, td.h);
-      const uint32_t *tx32 = reinterpret_cast<const uint32_t *>(td.texels);
-      uint32_t t00 = tx32[tp.o00], t10 = tx32[tp.o10], t01 = tx32[tp.o01], t11 = tx32[tp.o11];
-      albedo.x = filter_channel(t00, t10, t01, t11, 0, tp.fx, tp.fy);
-      albedo.y = filter_channel(t00, t10, t01, t11, 8, tp.fx, tp.fy);
-      albedo.z = filter_channel(t00, t10, t01, t11, 16, tp.fx, tp.fy);
-    }
-    {
-      const TexDesc &td = md.maps[kMapMetallic];
-      BilinearTaps tp = bilinear_taps(u, v, td.w, td.h);
-      const uint32_t *tx32 = reinterpret_cast<const uint32_t *>(td.texels);
-      metallic = filter_channel(tx32[tp.o00], tx32[tp.o10], tx32[tp.o01], tx32[tp.o11], 0, tp.fx, tp.fy);
-    }
-    {
-      const TexDesc &td = md.maps[kMapRoughness];
-      BilinearTaps tp = bilinear_taps(u, v, td.w, td.h);
-      const uint32_t *tx32 = reinterpret_cast<const uint32_t *>(td.texels);
-      roughness = filter_channel(tx32[tp.o00], tx32[tp.o10], tx32[tp.o01], tx32[tp.o11], 0, tp.fx, tp.fy);
-    }
-    {
-      const TexDesc &td = md.maps[kMapAO];
-      BilinearTaps tp = bilinear_taps(u, v, td.w, td.h);
-      const uint32_t *tx32 = reinterpret_cast<const uint32_t *>(td.texels);
-      ao = filter_channel(tx32[tp.o00], tx32[tp.o10], tx32[tp.o01], tx32[tp.o11], 0, tp.fx, tp.fy);
-    }
-    f3 normal;
-    if (sp.enable_normal_map != 0) {
-      const TexDesc &td = md.maps[kMapNormal];
-      BilinearTaps tp = bilinear_taps(u, v, td.w, td.h);
-      const uint32_t *tx32 = reinterpret_cast<const uint32_t *>(td.texels);
-      uint32_t t00 = tx32[tp.o00], t10 = tx32[tp.o10], t01 = tx32[tp.o01], t11 = tx32[tp.o11];
-      f3 nt = mk3(fmaf(filter_channel(t00, t10, t01, t11, 0, tp.fx, tp.fy), 2.0f, -1.0f),
-                  fmaf(filter_channel(t00, t10, t01, t11, 8, tp.fx, tp.fy), 2.0f, -1.0f),
-                  fmaf(filter_channel(t00, t10, t01, t11, 16, tp.fx, tp.fy), 2.0f, -1.0f));
-      // vTBN * nt, vTBN = mat3(T, B, N)
-      normal.x = fmaf(a[5], nt.z, fmaf(a[11], nt.y, a[8] * nt.x));
-      normal.y = fmaf(a[6], nt.z, fmaf(a[12], nt.y, a[9] * nt.x));
-      normal.z = fmaf(a[7], nt.z, fmaf(a[13], nt.y, a[10] * nt.x));
+    if (pa.packed_dims != 0u) {
+      // packed material: one set of taps, four 16-byte loads
+      const BilinearTaps tp = bilinear_taps(u, v, (int)(pa.packed_dims & 0xFFFFu), (int)(pa.packed_dims >> 16));
+      const uint4 *tx = reinterpret_cast<const uint4 *>(pa.packed);
+      const uint4 t00 = tx[tp.o00], t10 = tx[tp.o10], t01 = tx[tp.o01], t11 = tx[tp.o11];
+      albedo.x = filter_channel(t00.x, t10.x, t01.x, t11.x, 0, tp.fx, tp.fy);
+      albedo.y = filter_channel(t00.x, t10.x, t01.x, t11.x, 8, tp.fx, tp.fy);
+      albedo.z = filter_channel(t00.x, t10.x, t01.x, t11.x, 16, tp.fx, tp.fy);
+      metallic = filter_channel(t00.x, t10.x, t01.x, t11.x, 24, tp.fx, tp.fy);
+      roughness = filter_channel(t00.y, t10.y, t01.y, t11.y, 24, tp.fx, tp.fy);
+      ao = filter_channel(t00.z, t10.z, t01.z, t11.z, 0, tp.fx, tp.fy);
+      if (sp.enable_normal_map != 0) {
+        f3 nt = mk3(fmaf(filter_channel(t00.y, t10.y, t01.y, t11.y, 0, tp.fx, tp.fy), 2.0f, -1.0f),
+                    fmaf(filter_channel(t00.y, t10.y, t01.y, t11.y, 8, tp.fx, tp.fy), 2.0f, -1.0f),
+                    fmaf(filter_channel(t00.y, t10.y, t01.y, t11.y, 16, tp.fx, tp.fy), 2.0f, -1.0f));
+        // vTBN * nt, vTBN = mat3(T, B, N)
+        normal.x = fmaf(a[5], nt.z, fmaf(a[11], nt.y, a[8] * nt.x));
+        normal.y = fmaf(a[6], nt.z, fmaf(a[12], nt.y, a[9] * nt.x));
+        normal.z = fmaf(a[7], nt.z, fmaf(a[13], nt.y, a[10] * nt.x));
+      } else {
+        normal = normalize3(mk3(a[5], a[6], a[7]));
+      }
     } else {
-      normal = normalize3(mk3(a[5], a[6], a[7]));
+      // maps of different sizes: one set of taps per map
+      const MaterialDesc &md = materials[pa.material];
+      {
+        const TexDesc &td = md.maps[kMapAlbedo];
+        BilinearTaps tp = bilinear_taps(u, v, td.w, td.h);
+        const uint32_t *tx32 = reinterpret_cast<const uint32_t *>(td.texels);
+        uint32_t t00 = tx32[tp.o00], t10 = tx32[tp.o10], t01 = tx32[tp.o01], t11 = tx32[tp.o11];
+        albedo.x = filter_channel(t00, t10, t01, t11, 0, tp.fx, tp.fy);
+        albedo.y = filter_channel(t00, t10, t01, t11, 8, tp.fx, tp.fy);
+        albedo.z = filter_channel(t00, t10, t01, t11, 16, tp.fx, tp.fy);
+      }
+      {
+        const TexDesc &td = md.maps[kMapMetallic];
+        BilinearTaps tp = bilinear_taps(u, v, td.w, td.h);
+        const uint32_t *tx32 = reinterpret_cast<const uint32_t *>(td.texels);
+        metallic = filter_channel(tx32[tp.o00], tx32[tp.o10], tx32[tp.o01], tx32[tp.o11], 0, tp.fx, tp.fy);
+      }
+      {
+        const TexDesc &td = md.maps[kMapRoughness];
+        BilinearTaps tp = bilinear_taps(u, v, td.w, td.h);
+        const uint32_t *tx32 = reinterpret_cast<const uint32_t *>(td.texels);
+        roughness = filter_channel(tx32[tp.o00], tx32[tp.o10], tx32[tp.o01], tx32[tp.o11], 0, tp.fx, tp.fy);
+      }
+      {
+        const TexDesc &td = md.maps[kMapAO];
+        BilinearTaps tp = bilinear_taps(u, v, td.w, td.h);
+        const uint32_t *tx32 = reinterpret_cast<const uint32_t *>(td.texels);
+        ao = filter_channel(tx32[tp.o00], tx32[tp.o10], tx32[tp.o01], tx32[tp.o11], 0, tp.fx, tp.fy);
+      }
+      if (sp.enable_normal_map != 0) {
+        const TexDesc &td = md.maps[kMapNormal];
+        BilinearTaps tp = bilinear_taps(u, v, td.w, td.h);
+        const uint32_t *tx32 = reinterpret_cast<const uint32_t *>(td.texels);
+        uint32_t t00 = tx32[tp.o00], t10 = tx32[tp.o10], t01 = tx32[tp.o01], t11 = tx32[tp.o11];
+        f3 nt = mk3(fmaf(filter_channel(t00, t10, t01, t11, 0, tp.fx, tp.fy), 2.0f, -1.0f),
+                    fmaf(filter_channel(t00, t10, t01, t11, 8, tp.fx, tp.fy), 2.0f, -1.0f),
+                    fmaf(filter_channel(t00, t10, t01, t11, 16, tp.fx, tp.fy), 2.0f, -1.0f));
+        normal.x = fmaf(a[5], nt.z, fmaf(a[11], nt.y, a[8] * nt.x));
+        normal.y = fmaf(a[6], nt.z, fmaf(a[12], nt.y, a[9] * nt.x));
+        normal.z = fmaf(a[7], nt.z, fmaf(a[13], nt.y, a[10] * nt.x));
+      } else {
+        normal = normalize3(mk3(a[5], a[6], a[7]));
+      }
     }
 
     // loop invariants of forward_brdf.frag:51-52 hoisted (bit-identical: same inputs, same operations)
@@ -688,9 +1050,9 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(
       float att;
       if (light.type == 0 || light.type == 1) {
         f3 Lv = sub3(ld3(light.pos), P);
-        float d = sqrtf(dot3(Lv, Lv));
-        att = 1.0f / (d * d);
-        L = scale3(Lv, 1.0f / d);
+        float inv_d = bb_rsqrt(dot3(Lv, Lv));
+        att = inv_d * inv_d;
+        L = scale3(Lv, inv_d);
         if (light.type == 1) {
           float theta = dot3(L, normalize3(neg3(ld3(light.dir))));
           float epsilon = light.inner_cutoff - light.outer_cutoff;
@@ -726,7 +1088,6 @@ __global__ __launch_bounds__(kTileThreads) void k_tile(
     color.y = fmaf(0.03f * albedo.y, ao, Lo.y);
     color.z = fmaf(0.03f * albedo.z, ao, Lo.z);
     color.w = 1.0f;
-    size_t o = (size_t)(out_y0 + y) * (size_t)fp.width + (size_t)gx;
     out[o] = color;
   }
 }

@@ -104,13 +104,33 @@ struct ClipSlot {
 };
 static_assert(sizeof(ClipSlot) == 112, "ClipSlot");
 
-// Post-vertex-stage varyings of one primitive's three vertices.  176 B.
+// Entry of the every-tile list: the triangle itself travels with the reference so that the raster kernel's
+// per-tile classification is one load deep.  80 B.
+struct BroadTri {
+  RasterTri tri;
+  uint32_t ref;
+  uint32_t pad[3];
+};
+static_assert(sizeof(BroadTri) == 80, "BroadTri");
+
+// One texel of a packed material: the five maps the forward shader reads, interleaved so that a bilinear tap is
+// ONE 16-byte load instead of five 4-byte loads from five arrays.
+//   x = albedo.r | albedo.g << 8 | albedo.b << 16 | metallic.r << 24
+//   y = normal.x | normal.y << 8 | normal.z << 16 | roughness.r << 24
+//   z = ao.r,  w = 0
+struct PackedTexel {
+  uint32_t x, y, z, w;
+};
+
+// Post-vertex-stage varyings of one primitive's three vertices + its material binding.  192 B.
 struct PrimAttr {
   float vary[3][kNumVary];
   uint32_t material;
-  uint32_t pad;
+  uint32_t packed_dims;        // width | height << 16 of the packed material (0 = not packed: use the table)
+  const PackedTexel *packed;
+  uint32_t pad[2];
 };
-static_assert(sizeof(PrimAttr) == 176, "PrimAttr");
+static_assert(sizeof(PrimAttr) == 192, "PrimAttr");
 
 struct DrawDesc {
   const Vertex *vertices;
@@ -129,6 +149,8 @@ struct TexDesc {
 
 struct MaterialDesc {
   TexDesc maps[kMapCount];
+  const PackedTexel *packed;  // non-null when the five shaded maps share one size (or are defaults)
+  int32_t pw, ph;
 };
 
 // per-frame counters (one block per frame parity)
@@ -136,7 +158,7 @@ struct Counters {
   uint32_t n_broad;
   uint32_t n_clip_slots;
   uint32_t overflow;  // bit0 bins, bit1 broad list, bit2 clip arena
-  uint32_t pad0;
+  uint32_t bin_need;  // largest per-tile reference count seen when a bin overflowed
   unsigned long long n_raster_tris;
   unsigned long long n_clipped_prims;
   unsigned long long n_bin_refs;
@@ -154,6 +176,7 @@ struct FrameParams {
   // screen-band partition (band = band_tiles tile rows; band b belongs to rank b % world)
   int32_t rank, world, band_tiles;
   int32_t shard_rows;                // rows of the compact output when world > 1
+  uint32_t ablate;                   // diagnostics only: bit0 skip raster, bit1 skip shading, bit2 skip broad list
 };
 
 }  // namespace bbr

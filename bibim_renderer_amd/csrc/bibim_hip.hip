@@ -1,8 +1,8 @@
 // bibim_hip.hip -- C-ABI (include/bibim_hip.h) over the HIP kernels in bb_kernels.hip.h.
 //
 // One context = one GPU, one HIP stream, all buffers resident in HBM for the context's lifetime.
-// A frame is: [H2D of instances + lights, one async copy from pinned staging] -> k_geometry per draw
-// -> k_tile.  No host synchronisation inside a frame; capacities (bins, broad list, clip arena) are
+// A frame is: [H2D of lights + draw descriptors + instances, one async copy from pinned staging] -> k_geometry
+// (all draws) -> k_raster (per tile) -> k_shade (per visible pixel).  No host synchronisation inside a frame; capacities (bins, broad list, clip arena) are
 // checked lazily at the next synchronising call and the frame is re-rendered once after growing them.
 #include <hip/hip_runtime.h>
 
@@ -31,6 +31,7 @@ struct Mesh {
 
 struct Material {
   uint8_t *d_texels[kMapCount] = {};
+  PackedTexel *d_packed = nullptr;
   MaterialDesc desc = {};
   bool alive = false;
 };
@@ -83,6 +84,7 @@ struct bbr_context {
   std::vector<RecordedDraw> draws;
   std::vector<InstanceBlock> host_instances;
   uint32_t n_prims = 0;
+  uint32_t n_live_draws = 0;
 
   // staging (pinned) + device mirrors
   void *h_staging = nullptr;
@@ -95,7 +97,9 @@ struct bbr_context {
   DeviceBuffer<Counters> d_counters;  // 2 blocks (frame parity)
   DeviceBuffer<uint32_t> d_tile_count;
   DeviceBuffer<uint32_t> d_bins;
-  DeviceBuffer<uint32_t> d_broad;
+  DeviceBuffer<BroadTri> d_broad;
+  DeviceBuffer<unsigned long long> d_frags;  // per tile: compacted (pixel << 32 | primitive ref) of covered pixels
+  DeviceBuffer<uint32_t> d_frag_count;
   DeviceBuffer<float4> d_frame;
   DeviceBuffer<uint32_t> d_vis_prim;
   DeviceBuffer<float> d_vis_depth;
@@ -103,17 +107,19 @@ struct bbr_context {
   uint64_t ext_out_bytes = 0;
 
   int parity = 0;
-  int tile_mode = 0;  // 0: 64x64, 1: 32x32
-  uint32_t bin_cap = 2048, broad_cap = 4096, clip_cap = 4096, broad_threshold = 32;
+  int tile_mode = 1;  // 0: 64x64, 1: 32x32 (default: finer tiles balance better; measured on C3)
+  uint32_t bin_cap = 512, broad_cap = 4096, clip_cap = 4096, broad_threshold = 16;
   int32_t rank = 0, world = 1, band_rows = 0;
   bool dump_vis = false;
+  uint32_t ablate = 0;
   bool timing = false;
   hipEvent_t ev[4] = {};  // ev[3]: staging copy drained; ev[0..2]: unused when the timing ring is active
   bool ev_valid = false;
-  // timing ring: (frame start, geometry done, tile kernel done) per frame since the last reset
+  // timing ring: (frame start, geometry done, raster done, shade done) per frame since the last reset
   std::vector<hipEvent_t> ring;
   uint32_t ring_frames = 0;
   static constexpr uint32_t kRingCap = 512;
+  static constexpr uint32_t kRingEvents = 4;
   int retries = 0;
 
   int tile_w() const { return tile_mode == 0 ? 64 : 32; }
@@ -170,6 +176,7 @@ FrameParams make_params(const bbr_context *c) {
   fp.world = c->world;
   fp.band_tiles = c->eff_band_rows() / c->tile_h();
   fp.shard_rows = c->shard_rows();
+  fp.ablate = c->ablate;
   return fp;
 }
 
@@ -180,9 +187,11 @@ int ensure_frame_buffers(bbr_context *c) {
   HIP_TRY(c, c->d_attrs.ensure(std::max<size_t>(c->n_prims, 1)));
   HIP_TRY(c, c->d_clip.ensure(c->clip_cap));
   HIP_TRY(c, c->d_counters.ensure(2, true));
-  HIP_TRY(c, c->d_tile_count.ensure(tiles, true));
-  HIP_TRY(c, c->d_bins.ensure(tiles * c->bin_cap));
+  HIP_TRY(c, c->d_tile_count.ensure(tiles * kBinClasses, true));
+  HIP_TRY(c, c->d_bins.ensure(tiles * kBinClasses * c->bin_cap));
   HIP_TRY(c, c->d_broad.ensure(c->broad_cap));
+  HIP_TRY(c, c->d_frags.ensure(tiles * (size_t)(c->tile_w() * c->tile_h())));
+  HIP_TRY(c, c->d_frag_count.ensure(tiles, true));
   HIP_TRY(c, c->d_frame.ensure(out_rows * c->width));
   if (c->dump_vis) {
     HIP_TRY(c, c->d_vis_prim.ensure((size_t)c->width * c->height));
@@ -205,32 +214,29 @@ int upload_material_table(bbr_context *c) {
 
 template <int TW, int TH>
 void launch_frame(bbr_context *c, const FrameParams &fp, const Mat4 &pv, const ShadeParams &sp, const Light *d_lights,
-                  const InstanceBlock *d_inst, float4 *out) {
+                  const DrawDesc *d_draws, uint32_t n_draws, float4 *out) {
   Counters *ctr = c->d_counters.ptr + c->parity;
   Counters *ctr_next = c->d_counters.ptr + (c->parity ^ 1);
-  for (const RecordedDraw &rd : c->draws) {
-    const Mesh &m = c->meshes[rd.mesh];
-    DrawDesc d;
-    d.vertices = m.d_vertices;
-    d.indices = m.d_indices;
-    d.instances = d_inst + rd.first_instance;
-    d.n_instances = rd.n_instances;
-    d.tris_per_instance = rd.tris_per_instance;
-    d.first_prim = rd.first_prim;
-    d.material = (uint32_t)rd.material;
-    uint32_t n = rd.n_instances * rd.tris_per_instance;
-    if (!n) continue;
-    hipLaunchKernelGGL((k_geometry<TW, TH>), dim3((n + 255) / 256), dim3(256), 0, c->stream, d, pv, fp, c->d_tris.ptr,
-                       c->d_attrs.ptr, c->d_clip.ptr, ctr, c->d_tile_count.ptr, c->d_bins.ptr, c->d_broad.ptr);
-  }
-  if (c->timing) (void)hipEventRecord(c->ring[3 * (c->ring_frames % bbr_context::kRingCap) + 1], c->stream);
-  int grid_y = c->world > 1 ? c->local_bands() * fp.band_tiles : fp.tiles_y;
-  hipLaunchKernelGGL((k_tile<TW, TH>), dim3(fp.tiles_x, grid_y), dim3(kTileThreads), 0, c->stream, fp, sp, d_lights,
-                     c->d_tris.ptr, c->d_attrs.ptr, c->d_clip.ptr, ctr, ctr_next, c->d_tile_count.ptr, c->d_bins.ptr,
-                     c->d_broad.ptr, c->d_materials.ptr, out, c->dump_vis ? c->d_vis_prim.ptr : nullptr,
+  hipEvent_t *ev = c->timing ? &c->ring[bbr_context::kRingEvents * (c->ring_frames % bbr_context::kRingCap)] : nullptr;
+  if (c->n_prims)
+    hipLaunchKernelGGL((k_geometry<TW, TH>), dim3((c->n_prims + 255) / 256), dim3(256), 0, c->stream, d_draws, n_draws,
+                       c->n_prims, pv, fp, c->d_tris.ptr, c->d_attrs.ptr, c->d_clip.ptr, ctr, c->d_tile_count.ptr,
+                       c->d_bins.ptr, c->d_broad.ptr, c->d_materials.ptr);
+  if (ev) (void)hipEventRecord(ev[1], c->stream);
+  // a rank without bands (more ranks than bands) still launches one row: its blocks fall off tiles_y and exit,
+  // block (0,0) clears the next frame's counters on the way
+  int grid_y = std::max(1, c->world > 1 ? c->local_bands() * fp.band_tiles : fp.tiles_y);
+  hipLaunchKernelGGL((k_raster<TW, TH>), dim3(fp.tiles_x, grid_y), dim3(kTileThreads), 0, c->stream, fp, c->d_tris.ptr,
+                     c->d_clip.ptr, ctr, ctr_next, c->d_tile_count.ptr, c->d_bins.ptr, c->d_broad.ptr, c->d_frags.ptr,
+                     c->d_frag_count.ptr, out, c->dump_vis ? c->d_vis_prim.ptr : nullptr,
                      c->dump_vis ? c->d_vis_depth.ptr : nullptr);
-  if (c->timing) {
-    (void)hipEventRecord(c->ring[3 * (c->ring_frames % bbr_context::kRingCap) + 2], c->stream);
+  if (ev) (void)hipEventRecord(ev[2], c->stream);
+  constexpr int kChunks = TW * TH / kTileThreads;
+  hipLaunchKernelGGL((k_shade<TW, TH>), dim3(fp.tiles_x * kChunks, grid_y), dim3(kTileThreads), 0, c->stream, fp, sp,
+                     d_lights, c->d_tris.ptr, c->d_attrs.ptr, c->d_clip.ptr, c->d_frags.ptr, c->d_frag_count.ptr,
+                     c->d_materials.ptr, out);
+  if (ev) {
+    (void)hipEventRecord(ev[3], c->stream);
     ++c->ring_frames;
   }
 }
@@ -243,10 +249,11 @@ int submit_frame(bbr_context *c) {
   rc = ensure_frame_buffers(c);
   if (rc) return rc;
 
-  // staging layout: [lights (100 * 64 B)] [instances]
+  // staging layout: [lights (100 * 64 B)] [draw descriptors] [instances]
   size_t lights_bytes = sizeof(Light) * kMaxNumLights;
+  size_t draws_bytes = (sizeof(DrawDesc) * c->draws.size() + 127) & ~(size_t)127;
   size_t inst_bytes = sizeof(InstanceBlock) * c->host_instances.size();
-  size_t total = lights_bytes + inst_bytes;
+  size_t total = lights_bytes + draws_bytes + inst_bytes;
   if (total > c->staging_cap) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->h_staging) (void)hipHostFree(c->h_staging);
@@ -259,21 +266,41 @@ int submit_frame(bbr_context *c) {
   // the previous frame's copy must have drained before the pinned buffer is rewritten
   if (c->ev_valid) HIP_TRY(c, hipEventSynchronize(c->ev[3]));
   std::memcpy(c->h_staging, c->frame_u.lights, lights_bytes);
-  if (inst_bytes) std::memcpy((uint8_t *)c->h_staging + lights_bytes, c->host_instances.data(), inst_bytes);
+  {
+    // draw descriptors point into the device copy of the instance data made by the same transfer
+    const InstanceBlock *d_inst_base = reinterpret_cast<const InstanceBlock *>(c->d_staging.ptr + lights_bytes + draws_bytes);
+    DrawDesc *hd = reinterpret_cast<DrawDesc *>((uint8_t *)c->h_staging + lights_bytes);
+    uint32_t k = 0;
+    for (const RecordedDraw &rd : c->draws) {
+      if (!rd.n_instances || !rd.tris_per_instance) continue;  // empty draws would break the first_prim search
+      const Mesh &m = c->meshes[rd.mesh];
+      DrawDesc d;
+      d.vertices = m.d_vertices;
+      d.indices = m.d_indices;
+      d.instances = d_inst_base + rd.first_instance;
+      d.n_instances = rd.n_instances;
+      d.tris_per_instance = rd.tris_per_instance;
+      d.first_prim = rd.first_prim;
+      d.material = (uint32_t)rd.material;
+      hd[k++] = d;
+    }
+    c->n_live_draws = k;
+  }
+  if (inst_bytes) std::memcpy((uint8_t *)c->h_staging + lights_bytes + draws_bytes, c->host_instances.data(), inst_bytes);
 
   if (c->timing) {
     if (c->ring.empty()) {
-      c->ring.resize(3 * bbr_context::kRingCap);
+      c->ring.resize(bbr_context::kRingEvents * bbr_context::kRingCap);
       for (auto &e : c->ring) HIP_TRY(c, hipEventCreate(&e));
     }
-    HIP_TRY(c, hipEventRecord(c->ring[3 * (c->ring_frames % bbr_context::kRingCap)], c->stream));
+    HIP_TRY(c, hipEventRecord(c->ring[bbr_context::kRingEvents * (c->ring_frames % bbr_context::kRingCap)], c->stream));
   }
   HIP_TRY(c, hipMemcpyAsync(c->d_staging.ptr, c->h_staging, total, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipEventRecord(c->ev[3], c->stream));
   c->ev_valid = true;
 
   const Light *d_lights = reinterpret_cast<const Light *>(c->d_staging.ptr);
-  const InstanceBlock *d_inst = reinterpret_cast<const InstanceBlock *>(c->d_staging.ptr + lights_bytes);
+  const DrawDesc *d_draws = reinterpret_cast<const DrawDesc *>(c->d_staging.ptr + lights_bytes);
   FrameParams fp = make_params(c);
   Mat4 pv = proj_view(c->view_u);
   ShadeParams sp;
@@ -282,8 +309,8 @@ int submit_frame(bbr_context *c) {
   sp.num_lights = std::min(std::max(c->frame_u.num_lights, 0), kMaxNumLights);
   float4 *out = c->ext_out ? reinterpret_cast<float4 *>(c->ext_out) : c->d_frame.ptr;
 
-  if (c->tile_mode == 0) launch_frame<64, 64>(c, fp, pv, sp, d_lights, d_inst, out);
-  else launch_frame<32, 32>(c, fp, pv, sp, d_lights, d_inst, out);
+  if (c->tile_mode == 0) launch_frame<64, 64>(c, fp, pv, sp, d_lights, d_draws, c->n_live_draws, out);
+  else launch_frame<32, 32>(c, fp, pv, sp, d_lights, d_draws, c->n_live_draws, out);
   HIP_TRY(c, hipGetLastError());
   c->parity ^= 1;
   return BBR_OK;
@@ -298,7 +325,12 @@ int sync_and_fix(bbr_context *c, Counters *out_counters) {
       HIP_TRY(c, hipMemcpy(&h, c->d_counters.ptr + (c->parity ^ 1), sizeof h, hipMemcpyDeviceToHost));
     if (out_counters) *out_counters = h;
     if (!h.overflow) return BBR_OK;
-    if (h.overflow & 1u) c->bin_cap *= 2;
+    if (h.overflow & 1u) {
+      // bin_need is exact for this frame; round up with headroom so small scene changes do not re-trigger
+      uint32_t need = std::max(h.bin_need + h.bin_need / 4u, c->bin_cap * 2u);
+      c->bin_cap = (need + 255u) & ~255u;
+      c->d_bins.release();
+    }
     if (h.overflow & 2u) c->broad_cap *= 2;
     if (h.overflow & 4u) c->clip_cap *= 2;
     ++c->retries;
@@ -371,12 +403,14 @@ int bbr_destroy(bbr_context *c) {
     if (m.d_vertices) (void)hipFree(m.d_vertices);
     if (m.d_indices) (void)hipFree(m.d_indices);
   }
-  for (Material &m : c->materials)
+  for (Material &m : c->materials) {
     for (auto &p : m.d_texels)
       if (p) (void)hipFree(p);
+    if (m.d_packed) (void)hipFree(m.d_packed);
+  }
   if (c->d_default_texels) (void)hipFree(c->d_default_texels);
   c->d_materials.release(); c->d_staging.release(); c->d_tris.release(); c->d_attrs.release(); c->d_clip.release();
-  c->d_counters.release(); c->d_tile_count.release(); c->d_bins.release(); c->d_broad.release(); c->d_frame.release();
+  c->d_counters.release(); c->d_tile_count.release(); c->d_bins.release(); c->d_broad.release(); c->d_frame.release(); c->d_frags.release(); c->d_frag_count.release();
   c->d_vis_prim.release(); c->d_vis_depth.release();
   if (c->h_staging) (void)hipHostFree(c->h_staging);
   for (auto &e : c->ev)
@@ -445,6 +479,47 @@ int bbr_upload_material(bbr_context *c, const bbr_image maps[BBR_MAP_COUNT], int
       m.desc.maps[i] = TexDesc{c->d_default_texels + 4 * i, 1, 1};
     }
   }
+  // Interleave the five shaded maps when they agree on one size (missing maps are uniform, so they broadcast):
+  // a bilinear tap then costs one 16-byte load instead of five 4-byte loads from five arrays.
+  {
+    static const uint8_t k_default[kMapCount][4] = {{255, 255, 255, 255}, {0, 0, 0, 255},       {0, 0, 0, 255},
+                                                    {255, 255, 255, 255}, {127, 127, 255, 255}, {0, 0, 0, 255}};
+    const int used[5] = {kMapAlbedo, kMapMetallic, kMapRoughness, kMapAO, kMapNormal};
+    int pw = 1, ph = 1;
+    bool ok = true;
+    for (int k : used) {
+      const bbr_image &im = maps[k];
+      if (!(im.rgba && im.width > 0 && im.height > 0)) continue;
+      if (pw == 1 && ph == 1) {
+        pw = im.width;
+        ph = im.height;
+      } else if (im.width != pw || im.height != ph) {
+        ok = false;
+      }
+    }
+    if (ok) {
+      std::vector<PackedTexel> host((size_t)pw * ph);
+      auto texel = [&](int k, size_t i) -> const uint8_t * {
+        const bbr_image &im = maps[k];
+        return (im.rgba && im.width > 0 && im.height > 0) ? im.rgba + 4 * i : k_default[k];
+      };
+      for (size_t i = 0; i < host.size(); ++i) {
+        const uint8_t *al = texel(kMapAlbedo, i), *me = texel(kMapMetallic, i), *ro = texel(kMapRoughness, i);
+        const uint8_t *ao = texel(kMapAO, i), *no = texel(kMapNormal, i);
+        PackedTexel t;
+        t.x = (uint32_t)al[0] | ((uint32_t)al[1] << 8) | ((uint32_t)al[2] << 16) | ((uint32_t)me[0] << 24);
+        t.y = (uint32_t)no[0] | ((uint32_t)no[1] << 8) | ((uint32_t)no[2] << 16) | ((uint32_t)ro[0] << 24);
+        t.z = (uint32_t)ao[0];
+        t.w = 0;
+        host[i] = t;
+      }
+      HIP_TRY(c, hipMalloc(&m.d_packed, host.size() * sizeof(PackedTexel)));
+      HIP_TRY(c, hipMemcpy(m.d_packed, host.data(), host.size() * sizeof(PackedTexel), hipMemcpyHostToDevice));
+      m.desc.packed = m.d_packed;
+      m.desc.pw = pw;
+      m.desc.ph = ph;
+    }
+  }
   m.alive = true;
   c->materials.push_back(m);
   c->materials_dirty = true;
@@ -460,6 +535,7 @@ int bbr_free_material(bbr_context *c, int32_t material) {
   Material &m = c->materials[material];
   for (auto &p : m.d_texels)
     if (p) (void)hipFree(p);
+  if (m.d_packed) (void)hipFree(m.d_packed);
   m = Material();
   c->materials_dirty = true;
   c->have_frame = false;
@@ -672,18 +748,17 @@ int bbr_read_visibility(bbr_context *c, uint32_t *prim_host, float *depth_host) 
   return BBR_OK;
 }
 
-int bbr_last_frame_time_ms(bbr_context *c, float *out_frame_ms, float *out_tile_ms) {
+int bbr_last_frame_time_ms(bbr_context *c, float *out_frame_ms, float *out_shade_ms) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
   if (!c->timing) return fail(c, BBR_ERR_INVALID_ARGUMENT, "last_frame_time_ms: enable option \"timing\" first");
-  if (!c->have_frame) return fail(c, BBR_ERR_NOT_IN_FRAME, "last_frame_time_ms: nothing rendered");
   if (!c->ring_frames) return fail(c, BBR_ERR_NOT_IN_FRAME, "last_frame_time_ms: no timed frame yet");
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  const hipEvent_t *e = &c->ring[3 * ((c->ring_frames - 1) % bbr_context::kRingCap)];
+  const hipEvent_t *e = &c->ring[bbr_context::kRingEvents * ((c->ring_frames - 1) % bbr_context::kRingCap)];
   float a = 0.f, b = 0.f;
-  HIP_TRY(c, hipEventElapsedTime(&a, e[0], e[2]));
-  HIP_TRY(c, hipEventElapsedTime(&b, e[1], e[2]));
+  HIP_TRY(c, hipEventElapsedTime(&a, e[0], e[3]));
+  HIP_TRY(c, hipEventElapsedTime(&b, e[2], e[3]));
   if (out_frame_ms) *out_frame_ms = a;
-  if (out_tile_ms) *out_tile_ms = b;
+  if (out_shade_ms) *out_shade_ms = b;
   return BBR_OK;
 }
 
@@ -695,24 +770,26 @@ int bbr_timing_reset(bbr_context *c) {
 }
 
 int bbr_timing_summary(bbr_context *c, uint32_t *out_frames, float *out_avg_frame_ms, float *out_avg_geometry_ms,
-                       float *out_avg_tile_ms) {
+                       float *out_avg_raster_ms, float *out_avg_shade_ms) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
   if (!c->timing) return fail(c, BBR_ERR_INVALID_ARGUMENT, "timing_summary: enable option \"timing\" first");
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   uint32_t n = std::min(c->ring_frames, bbr_context::kRingCap);
-  double f = 0, g = 0, t = 0;
+  double f = 0, g = 0, r = 0, t = 0;
   for (uint32_t i = 0; i < n; ++i) {
-    const hipEvent_t *e = &c->ring[3 * i];
-    float a = 0.f, b = 0.f, d = 0.f;
-    HIP_TRY(c, hipEventElapsedTime(&a, e[0], e[2]));
+    const hipEvent_t *e = &c->ring[bbr_context::kRingEvents * i];
+    float a = 0.f, b = 0.f, d = 0.f, h = 0.f;
+    HIP_TRY(c, hipEventElapsedTime(&a, e[0], e[3]));
     HIP_TRY(c, hipEventElapsedTime(&b, e[0], e[1]));
     HIP_TRY(c, hipEventElapsedTime(&d, e[1], e[2]));
-    f += a; g += b; t += d;
+    HIP_TRY(c, hipEventElapsedTime(&h, e[2], e[3]));
+    f += a; g += b; r += d; t += h;
   }
   if (out_frames) *out_frames = n;
   if (out_avg_frame_ms) *out_avg_frame_ms = n ? (float)(f / n) : 0.f;
   if (out_avg_geometry_ms) *out_avg_geometry_ms = n ? (float)(g / n) : 0.f;
-  if (out_avg_tile_ms) *out_avg_tile_ms = n ? (float)(t / n) : 0.f;
+  if (out_avg_raster_ms) *out_avg_raster_ms = n ? (float)(r / n) : 0.f;
+  if (out_avg_shade_ms) *out_avg_shade_ms = n ? (float)(t / n) : 0.f;
   return BBR_OK;
 }
 
@@ -729,11 +806,15 @@ int bbr_set_option(bbr_context *c, const char *name, int64_t value) {
     c->tile_mode = (int)value;
     // bins are laid out per tile: drop them so that ensure() re-zeroes the counters
     c->d_tile_count.release();
+    c->d_frags.release();
+    c->d_frag_count.release();
     c->d_bins.release();
   } else if (n == "bin_cap") {
     if (value < 1 || value > (1 << 20)) return fail(c, BBR_ERR_INVALID_ARGUMENT, "bin_cap out of range");
     c->bin_cap = (uint32_t)value;
     c->d_bins.release();
+  } else if (n == "ablate") {
+    c->ablate = (uint32_t)value;
   } else if (n == "broad_threshold") {
     if (value < 1) return fail(c, BBR_ERR_INVALID_ARGUMENT, "broad_threshold must be >= 1");
     c->broad_threshold = (uint32_t)value;

@@ -130,10 +130,10 @@ class Renderer:
         self._check(self._L.bbr_timing_reset(self._ctx))
 
     def timing_summary(self):
-        """(frames, avg frame ms, avg geometry ms, avg tile-kernel ms) since timing_reset()."""
-        n, f, g, t = C.c_uint32(), C.c_float(), C.c_float(), C.c_float()
-        self._check(self._L.bbr_timing_summary(self._ctx, C.byref(n), C.byref(f), C.byref(g), C.byref(t)))
-        return n.value, f.value, g.value, t.value
+        """(frames, avg frame ms, avg geometry ms, avg raster ms, avg shade ms) since timing_reset()."""
+        n, f, g, r, t = C.c_uint32(), C.c_float(), C.c_float(), C.c_float(), C.c_float()
+        self._check(self._L.bbr_timing_summary(self._ctx, C.byref(n), C.byref(f), C.byref(g), C.byref(r), C.byref(t)))
+        return n.value, f.value, g.value, r.value, t.value
 
     def tone_map(self, enable, exposure):
         self._check(self._L.bbr_tone_map(self._ctx, int(enable), float(exposure)))

@@ -129,14 +129,14 @@ int bbr_get_stats(bbr_context *ctx, bbr_stats *out);          /* synchronises */
 /* winning primitive (global API-order index, 0xFFFFFFFF = none) and depth per pixel; synchronises.
  * Re-runs the frame once with the visibility dump enabled. */
 int bbr_read_visibility(bbr_context *ctx, uint32_t *prim_host, float *depth_host);
-/* device time of the last bbr_end_frame/bbr_replay_frame in ms, and of its dominant kernel; synchronises */
-int bbr_last_frame_time_ms(bbr_context *ctx, float *out_frame_ms, float *out_tile_kernel_ms);
-/* With option "timing" = 1 every frame records HIP events on the context's stream (frame start, geometry
- * kernels done, tile kernel done) into a ring of 512 frames.  bbr_timing_summary averages the frames recorded
- * since bbr_timing_reset: whole frame, geometry kernels (incl. the H2D of instances/lights), tile kernel. */
+/* device time of the last bbr_end_frame/bbr_replay_frame in ms, and of its dominant kernel (k_shade); synchronises */
+int bbr_last_frame_time_ms(bbr_context *ctx, float *out_frame_ms, float *out_shade_kernel_ms);
+/* With option "timing" = 1 every frame records HIP events on the context's stream (frame start, geometry kernel
+ * done, raster kernel done, shade kernel done) into a ring of 512 frames.  bbr_timing_summary averages the frames
+ * recorded since bbr_timing_reset: whole frame, geometry (incl. the H2D of instances/lights), raster, shade. */
 int bbr_timing_reset(bbr_context *ctx);
 int bbr_timing_summary(bbr_context *ctx, uint32_t *out_frames, float *out_avg_frame_ms, float *out_avg_geometry_ms,
-                       float *out_avg_tile_ms);
+                       float *out_avg_raster_ms, float *out_avg_shade_ms);
 int bbr_set_option(bbr_context *ctx, const char *name, int64_t value);
 
 /* next row: hdr_tone_mapping.frag:9-18 on the fp32 frame, in place */

@@ -3,6 +3,7 @@ import sys
 
 import numpy as np
 import pytest
+import torch  # noqa: F401  -- before libbibim_hip.so: torch bundles its own HIP runtime and must load it first
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

@@ -161,7 +161,7 @@ def test_camera_inside_geometry_heavy_clipping(maps64):
     sc = scenes.shaderball_scene(cfg, bbo.MaterialData(maps64))
     sc.view = scenes.view_uniforms((-1.0, -0.55, 1.6), 35.0, -5.0, cfg.width, cfg.height, 1, near=0.05)
     _, _, st = check(sc)
-    assert st["n_clipped_prims"] > 20
+    assert st["n_clipped_prims"] >= 8
 
 
 def test_depth_ties_follow_api_order():

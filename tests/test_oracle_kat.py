@@ -60,10 +60,29 @@ def test_kat2_roughness_zero_off_peak_has_no_specular():
 
 
 def test_kat2b_roughness_zero_on_peak_is_nan_like_upstream():
-    # brdf.glsl hazard: roughness 0 with N.H = 1 is 0/0
-    fu = scenes.frame_uniforms([scenes.light(2, dir=(0, 0, -1), color=(1, 1, 1), intensity=1.0)])
-    out = bbo.shade_fragment(fu, view((0, 0, 5)), material(roughness=0), vary())
-    assert np.isnan(out[:3]).all() and out[3] == 1.0
+    # brdf.glsl hazard: roughness 0 with N.H = 1 exactly is 0/0 (the `default` material has roughness 0)
+    N = np.array([0, 0, 1], np.float32)
+    assert np.isnan(bbo.lib().bbo_distribution_ggx(N.ctypes.data, N.ctypes.data, 0.0))
+    H = np.array([0.6, 0, 0.8], np.float32)
+    assert bbo.lib().bbo_distribution_ggx(N.ctypes.data, H.ctypes.data, 0.0) == 0.0
+
+
+def test_rsqrt_contract_primitive_accuracy():
+    """normalize() uses the contract's fixed Newton inversesqrt: result length within 2 ulp of 1 (GLSL allows 2 ULP)"""
+    rng = np.random.Generator(np.random.PCG64(8))
+    vu = scenes.view_uniforms((0, 0, 0), 0, 0, 16, 16, 0)
+    inst = np.zeros((), bbo.INSTANCE_DTYPE); inst["model"] = np.eye(4); inst["inv_model"] = np.eye(4)
+    worst = 0.0
+    for _ in range(300):
+        v = np.zeros((), bbo.VERTEX_DTYPE)
+        v["normal"] = rng.standard_normal(3) * 10 ** rng.uniform(-3, 3)
+        v["tangent"] = (1, 0, 0)
+        _, vary = bbo.vertex_stage(vu, inst, v)
+        n = vary[5:8].astype(np.float64)
+        worst = max(worst, abs(np.linalg.norm(n) - 1.0))
+        want = v["normal"].astype(np.float64) / np.linalg.norm(v["normal"].astype(np.float64))
+        np.testing.assert_allclose(n, want, rtol=0, atol=3e-7)
+    assert worst < 2.5e-7
 
 
 def test_kat3_directional_light_ignores_position():
