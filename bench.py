@@ -96,6 +96,8 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--band-rows", type=int, default=0, help="screen band height for N > 1 (0 = tile height)")
     ap.add_argument("--no-timing-events", action="store_true")
+    ap.add_argument("--frames-in-flight", type=int, default=2, choices=[1, 2])
+    ap.add_argument("--force-dist", action="store_true", help="exercise the all-gather path with WORLD_SIZE = 1")
     args = ap.parse_args()
 
     import torch
@@ -112,10 +114,11 @@ def main():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback exists)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from bibim_renderer_amd import Renderer, configs, textures
     from bibim_renderer_amd import scene as S
@@ -127,30 +130,45 @@ def main():
     r = Renderer(cfg.width, cfg.height, device=local_rank)
     if args.tile_mode is not None:
         r.set_option("tile_mode", args.tile_mode)
-    stream = torch.cuda.current_stream()
-    r.set_stream(stream.cuda_stream)
+    r.set_option("frames_in_flight", args.frames_in_flight)
     material = r.upload_material(maps)
     scene, cam, settings = S.config_scene(r, cfg, ball)
 
     W, H = cfg.width, cfg.height
-    frame_t = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
-    if world > 1:
+    dist_path = world > 1 or args.force_dist
+    if dist_path:
+        # Each rank renders its interleaved screen bands into a compact shard; RCCL all-gathers the shards over xGMI
+        # and a copy kernel un-interleaves them into the row-major frame.  Two shard / gather buffers alternate so that
+        # the gather of frame N (on its own stream) overlaps the rendering of frame N+1.
         band_rows = args.band_rows or r.tile_height()
         r.set_partition(rank, world, band_rows)
         shard_rows = r.shard_rows()
-        shard_t = torch.empty((shard_rows, W, 4), dtype=torch.float32, device="cuda")
-        gathered_t = torch.empty((world * shard_rows, W, 4), dtype=torch.float32, device="cuda")  # [rank][shard row]
-        r.set_output_device_ptr(shard_t.data_ptr(), shard_t.numel() * 4)
-    else:
-        r.set_output_device_ptr(frame_t.data_ptr(), frame_t.numel() * 4)
+        shard_t = [torch.empty((shard_rows, W, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
+        gathered_t = [torch.empty((world * shard_rows, W, 4), dtype=torch.float32, device="cuda") for _ in range(2)]  # [rank][shard row]
+        frame_t = [torch.empty((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
+        ag_stream = torch.cuda.Stream()
+        consumed = [torch.cuda.Event(), torch.cuda.Event()]
+    step_no = [0]
 
     def step():
+        n = step_no[0]
+        step_no[0] = n + 1
+        if not dist_path:
+            S.draw_frame(r, scene, cam, settings, material)  # asynchronous; internal double-buffered framebuffer
+            return
+        b = n & 1
+        if n >= 2:
+            r.wait_event(consumed[b].cuda_event)             # shard[b] is free again once gather n-2 has read it
+        r.set_output_device_ptr(shard_t[b].data_ptr(), shard_t[b].numel() * 4)
         S.draw_frame(r, scene, cam, settings, material)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered_t, shard_t)
-            r.unpack_gathered(gathered_t.data_ptr(), frame_t.data_ptr())
+        r.stream_wait_frame(ag_stream.cuda_stream)
+        with torch.cuda.stream(ag_stream):
+            dist.all_gather_into_tensor(gathered_t[b], shard_t[b])
+            r.unpack_gathered(gathered_t[b].data_ptr(), frame_t[b].data_ptr(), ag_stream.cuda_stream)
+            consumed[b].record(ag_stream)
 
     def fence():
+        r.synchronize()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -158,7 +176,7 @@ def main():
 
     # first frame sizes every capacity (bins etc.); synchronize() re-renders if one overflowed
     step()
-    r.synchronize()
+    fence()
     stats = r.stats()
     for _ in range(args.warmup):
         step()
@@ -189,22 +207,21 @@ def main():
 
     roofline = None
     if use_events:
-        n_ev, avg_frame_ms, avg_geom_ms, avg_raster_ms, avg_tile_ms = r.timing_summary()
-        # this rank's share of the dominant kernel's algorithmic bytes: its rows of the framebuffer + its shaded pixels
-        if world > 1:
-            from bibim_renderer_amd.partition import owned_rows
-            own_rows = len(owned_rows(H, rank, world, args.band_rows or r.tile_height()))
-        else:
-            own_rows = H
+        n_ev, avg_frame_ms, avg_geom_ms, avg_raster_ms, avg_shade_ms = r.timing_summary()
+        # Dominant kernel: k_shade.  Its algorithmic bytes (SURVEY.md 8(d) per-pixel figures x the pixels one launch
+        # shades on this rank): 16 B framebuffer write + 4 B x M texel reads per shaded pixel, + the uniform blocks.
+        # The background pixels' 16 B are written by k_raster, vertex streams are read by k_geometry; the whole frame's
+        # B_alg against the whole step time is reported beside it (frame_*).
         m = 5 if cfg.enable_normal_map else 4
-        tile_bytes = own_rows * W * 16 + stats["n_shaded"] * 4 * m + 6432 + 144
-        achieved = tile_bytes / (avg_tile_ms * 1e-3) / 1e9 if avg_tile_ms > 0 else 0.0
+        shade_bytes = stats["n_shaded"] * (16 + 4 * m) + 6432 + 144
+        achieved = shade_bytes / (avg_shade_ms * 1e-3) / 1e9 if avg_shade_ms > 0 else 0.0
         balg = algorithmic_bytes(cfg, n_shaded_total, ball.shape[0])
-        roofline = {"bound": "hbm", "kernel": "k_tile", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+        roofline = {"bound": "hbm", "kernel": "k_shade", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                    "algorithmic_bytes_per_launch": int(tile_bytes), "avg_kernel_ms": round(avg_tile_ms, 5),
+                    "algorithmic_bytes_per_launch": int(shade_bytes), "avg_kernel_ms": round(avg_shade_ms, 5),
                     "launches_timed": int(n_ev), "avg_geometry_ms": round(avg_geom_ms, 5),
-                    "avg_device_frame_ms": round(avg_frame_ms, 5),
+                    "avg_raster_ms": round(avg_raster_ms, 5), "avg_device_frame_latency_ms": round(avg_frame_ms, 5),
+                    "frames_in_flight": args.frames_in_flight,
                     "frame_algorithmic_bytes": int(balg["total"]),
                     "frame_achieved_gbs": round(balg["total"] / (ms_per_step * 1e-3) / 1e9, 2),
                     "frame_frac": round(balg["total"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -234,7 +251,7 @@ def main():
 
     scene.close()
     r.close()
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 

@@ -61,7 +61,9 @@ SIGNATURES = {
     "bbr_set_partition": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32]),
     "bbr_shard_rows": (C.c_int, [_P, C.POINTER(C.c_int32)]),
     "bbr_read_shard": (C.c_int, [_P, _P]),
-    "bbr_unpack_gathered": (C.c_int, [_P, _P, _P]),
+    "bbr_unpack_gathered": (C.c_int, [_P, _P, _P, _P]),
+    "bbr_wait_event": (C.c_int, [_P, _P]),
+    "bbr_stream_wait_frame": (C.c_int, [_P, _P]),
     "bbr_tile_height": (C.c_int, [_P, C.POINTER(C.c_int32)]),
     "bbr_get_stats": (C.c_int, [_P, C.POINTER(BbrStats)]),
     "bbr_read_visibility": (C.c_int, [_P, _P, _P]),

@@ -775,7 +775,7 @@ BB_DEV bool tile_row(const FrameParams &fp, int grid_y, int &ty, int &out_tile_r
 template <int TILE_W, int TILE_H>
 __global__ __launch_bounds__(kTileThreads) void k_raster(
     FrameParams fp, const RasterTri *__restrict__ tris, const ClipSlot *__restrict__ clip_arena,
-    Counters *__restrict__ ctr, Counters *__restrict__ ctr_next, uint32_t *__restrict__ tile_count,
+    Counters *__restrict__ ctr, uint32_t *__restrict__ tile_count,
     const uint32_t *__restrict__ bins, const BroadTri *__restrict__ broad_list,
     unsigned long long *__restrict__ frags, uint32_t *__restrict__ frag_count, float4 *__restrict__ out,
     uint32_t *__restrict__ vis_prim, float *__restrict__ vis_depth) {
@@ -787,8 +787,6 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
   const int tx = blockIdx.x;
   int ty, out_tile_row;
   const bool live = tile_row(fp, blockIdx.y, ty, out_tile_row);
-  if (blockIdx.x == 0 && blockIdx.y == 0 && tid < (int)(sizeof(Counters) / 4))
-    reinterpret_cast<uint32_t *>(ctr_next)[tid] = 0;  // next frame's counter block
   if (!live) return;
   const uint32_t tile = (uint32_t)ty * (uint32_t)fp.tiles_x + (uint32_t)tx;
   const int tile_x0 = tx * TILE_W, tile_y0 = ty * TILE_H;

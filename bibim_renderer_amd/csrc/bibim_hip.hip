@@ -65,10 +65,43 @@ struct DeviceBuffer {
 
 }  // namespace
 
+// Everything one frame in flight owns.
+struct FrameSlot {
+  void *h_staging = nullptr;  // pinned: lights, draw descriptors, instances
+  size_t staging_cap = 0;
+  DeviceBuffer<uint8_t> d_staging;
+  DeviceBuffer<RasterTri> d_tris;
+  DeviceBuffer<PrimAttr> d_attrs;
+  DeviceBuffer<ClipSlot> d_clip;
+  DeviceBuffer<Counters> d_counters;
+  DeviceBuffer<uint32_t> d_tile_count;
+  DeviceBuffer<uint32_t> d_bins;
+  DeviceBuffer<BroadTri> d_broad;
+  DeviceBuffer<unsigned long long> d_frags;  // per tile: compacted (pixel << 32 | primitive ref) of covered pixels
+  DeviceBuffer<uint32_t> d_frag_count;
+  DeviceBuffer<float4> d_frame;
+  hipEvent_t ev_raster_done = nullptr, ev_shade_done = nullptr;
+  bool in_flight = false;
+  float4 *out_used = nullptr;  // where the frame in this slot wrote its pixels
+  uint32_t n_prims = 0;
+
+  void release_tile_buffers() {
+    d_tile_count.release(); d_bins.release(); d_frags.release(); d_frag_count.release();
+  }
+  void release_all() {
+    d_staging.release(); d_tris.release(); d_attrs.release(); d_clip.release(); d_counters.release();
+    release_tile_buffers(); d_broad.release(); d_frame.release();
+    if (h_staging) (void)hipHostFree(h_staging);
+    h_staging = nullptr;
+    staging_cap = 0;
+  }
+};
+
 struct bbr_context {
   int device = 0;
   int32_t width = 0, height = 0;
-  hipStream_t own_stream = nullptr, stream = nullptr;
+  hipStream_t s_geom = nullptr, s_shade = nullptr;  // context-owned streams
+  hipStream_t user_stream = nullptr;                 // bbr_set_stream: everything on the caller's stream, 1 frame in flight
   std::string last_error;
 
   std::vector<Mesh> meshes;
@@ -86,35 +119,22 @@ struct bbr_context {
   uint32_t n_prims = 0;
   uint32_t n_live_draws = 0;
 
-  // staging (pinned) + device mirrors
-  void *h_staging = nullptr;
-  size_t staging_cap = 0;
-  DeviceBuffer<uint8_t> d_staging;
+  FrameSlot slots[2];
+  int frames_in_flight = 2;
+  uint64_t frame_counter = 0;
+  int last_slot = -1;
 
-  DeviceBuffer<RasterTri> d_tris;
-  DeviceBuffer<PrimAttr> d_attrs;
-  DeviceBuffer<ClipSlot> d_clip;
-  DeviceBuffer<Counters> d_counters;  // 2 blocks (frame parity)
-  DeviceBuffer<uint32_t> d_tile_count;
-  DeviceBuffer<uint32_t> d_bins;
-  DeviceBuffer<BroadTri> d_broad;
-  DeviceBuffer<unsigned long long> d_frags;  // per tile: compacted (pixel << 32 | primitive ref) of covered pixels
-  DeviceBuffer<uint32_t> d_frag_count;
-  DeviceBuffer<float4> d_frame;
   DeviceBuffer<uint32_t> d_vis_prim;
   DeviceBuffer<float> d_vis_depth;
   void *ext_out = nullptr;
   uint64_t ext_out_bytes = 0;
 
-  int parity = 0;
   int tile_mode = 1;  // 0: 64x64, 1: 32x32 (default: finer tiles balance better; measured on C3)
   uint32_t bin_cap = 512, broad_cap = 4096, clip_cap = 4096, broad_threshold = 16;
   int32_t rank = 0, world = 1, band_rows = 0;
   bool dump_vis = false;
   uint32_t ablate = 0;
   bool timing = false;
-  hipEvent_t ev[4] = {};  // ev[3]: staging copy drained; ev[0..2]: unused when the timing ring is active
-  bool ev_valid = false;
   // timing ring: (frame start, geometry done, raster done, shade done) per frame since the last reset
   std::vector<hipEvent_t> ring;
   uint32_t ring_frames = 0;
@@ -122,6 +142,9 @@ struct bbr_context {
   static constexpr uint32_t kRingEvents = 4;
   int retries = 0;
 
+  hipStream_t geom_stream() const { return user_stream ? user_stream : s_geom; }
+  hipStream_t shade_stream() const { return user_stream ? user_stream : (frames_in_flight > 1 ? s_shade : s_geom); }
+  int n_slots() const { return user_stream ? 1 : frames_in_flight; }
   int tile_w() const { return tile_mode == 0 ? 64 : 32; }
   int tile_h() const { return tile_mode == 0 ? 64 : 32; }
   int tiles_x() const { return (width + tile_w() - 1) / tile_w(); }
@@ -180,23 +203,33 @@ FrameParams make_params(const bbr_context *c) {
   return fp;
 }
 
-int ensure_frame_buffers(bbr_context *c) {
+// Wait for everything this context has queued.
+int drain(bbr_context *c) {
+  HIP_TRY(c, hipStreamSynchronize(c->geom_stream()));
+  if (c->shade_stream() != c->geom_stream()) HIP_TRY(c, hipStreamSynchronize(c->shade_stream()));
+  for (FrameSlot &s : c->slots) s.in_flight = false;
+  return BBR_OK;
+}
+
+int ensure_slot_buffers(bbr_context *c, FrameSlot &s) {
   size_t tiles = (size_t)c->tiles_x() * c->tiles_y();
   size_t out_rows = (size_t)std::max(c->height, c->shard_rows());
-  HIP_TRY(c, c->d_tris.ensure(std::max<size_t>(c->n_prims, 1)));
-  HIP_TRY(c, c->d_attrs.ensure(std::max<size_t>(c->n_prims, 1)));
-  HIP_TRY(c, c->d_clip.ensure(c->clip_cap));
-  HIP_TRY(c, c->d_counters.ensure(2, true));
-  HIP_TRY(c, c->d_tile_count.ensure(tiles * kBinClasses, true));
-  HIP_TRY(c, c->d_bins.ensure(tiles * kBinClasses * c->bin_cap));
-  HIP_TRY(c, c->d_broad.ensure(c->broad_cap));
-  HIP_TRY(c, c->d_frags.ensure(tiles * (size_t)(c->tile_w() * c->tile_h())));
-  HIP_TRY(c, c->d_frag_count.ensure(tiles, true));
-  HIP_TRY(c, c->d_frame.ensure(out_rows * c->width));
+  HIP_TRY(c, s.d_tris.ensure(std::max<size_t>(c->n_prims, 1)));
+  HIP_TRY(c, s.d_attrs.ensure(std::max<size_t>(c->n_prims, 1)));
+  HIP_TRY(c, s.d_clip.ensure(c->clip_cap));
+  HIP_TRY(c, s.d_counters.ensure(1, true));
+  HIP_TRY(c, s.d_tile_count.ensure(tiles * kBinClasses, true));
+  HIP_TRY(c, s.d_bins.ensure(tiles * kBinClasses * c->bin_cap));
+  HIP_TRY(c, s.d_broad.ensure(c->broad_cap));
+  HIP_TRY(c, s.d_frags.ensure(tiles * (size_t)(c->tile_w() * c->tile_h())));
+  HIP_TRY(c, s.d_frag_count.ensure(tiles, true));
+  if (!c->ext_out) HIP_TRY(c, s.d_frame.ensure(out_rows * c->width));
   if (c->dump_vis) {
     HIP_TRY(c, c->d_vis_prim.ensure((size_t)c->width * c->height));
     HIP_TRY(c, c->d_vis_depth.ensure((size_t)c->width * c->height));
   }
+  if (!s.ev_raster_done) HIP_TRY(c, hipEventCreateWithFlags(&s.ev_raster_done, hipEventDisableTiming));
+  if (!s.ev_shade_done) HIP_TRY(c, hipEventCreateWithFlags(&s.ev_shade_done, hipEventDisableTiming));
   return BBR_OK;
 }
 
@@ -205,7 +238,8 @@ int upload_material_table(bbr_context *c) {
   size_t n = std::max<size_t>(c->materials.size(), 1);
   std::vector<MaterialDesc> h(n);
   for (size_t i = 0; i < c->materials.size(); ++i) h[i] = c->materials[i].desc;
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  int rc = drain(c);
+  if (rc) return rc;
   HIP_TRY(c, c->d_materials.ensure(n));
   HIP_TRY(c, hipMemcpy(c->d_materials.ptr, h.data(), n * sizeof(MaterialDesc), hipMemcpyHostToDevice));
   c->materials_dirty = false;
@@ -213,40 +247,51 @@ int upload_material_table(bbr_context *c) {
 }
 
 template <int TW, int TH>
-void launch_frame(bbr_context *c, const FrameParams &fp, const Mat4 &pv, const ShadeParams &sp, const Light *d_lights,
-                  const DrawDesc *d_draws, uint32_t n_draws, float4 *out) {
-  Counters *ctr = c->d_counters.ptr + c->parity;
-  Counters *ctr_next = c->d_counters.ptr + (c->parity ^ 1);
+void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const FrameParams &fp, const Mat4 &pv,
+                  const ShadeParams &sp, const Light *d_lights, const DrawDesc *d_draws, uint32_t n_draws, float4 *out) {
+  hipStream_t sg = c->geom_stream(), ss = c->shade_stream();
   hipEvent_t *ev = c->timing ? &c->ring[bbr_context::kRingEvents * (c->ring_frames % bbr_context::kRingCap)] : nullptr;
   if (c->n_prims)
-    hipLaunchKernelGGL((k_geometry<TW, TH>), dim3((c->n_prims + 255) / 256), dim3(256), 0, c->stream, d_draws, n_draws,
-                       c->n_prims, pv, fp, c->d_tris.ptr, c->d_attrs.ptr, c->d_clip.ptr, ctr, c->d_tile_count.ptr,
-                       c->d_bins.ptr, c->d_broad.ptr, c->d_materials.ptr);
-  if (ev) (void)hipEventRecord(ev[1], c->stream);
-  // a rank without bands (more ranks than bands) still launches one row: its blocks fall off tiles_y and exit,
-  // block (0,0) clears the next frame's counters on the way
+    hipLaunchKernelGGL((k_geometry<TW, TH>), dim3((c->n_prims + 255) / 256), dim3(256), 0, sg, d_draws, n_draws,
+                       c->n_prims, pv, fp, s.d_tris.ptr, s.d_attrs.ptr, s.d_clip.ptr, s.d_counters.ptr, s.d_tile_count.ptr,
+                       s.d_bins.ptr, s.d_broad.ptr, c->d_materials.ptr);
+  if (ev) (void)hipEventRecord(ev[1], sg);
+  // k_raster writes the background pixels of `out`: if the frame still shading on the other stream writes the
+  // same buffer (single external output), raster has to wait for it; geometry above still overlapped
+  if (prev && prev->in_flight && prev->out_used == out && ss != sg) (void)hipStreamWaitEvent(sg, prev->ev_shade_done, 0);
+  // a rank without bands (more ranks than bands) still launches one row: its blocks fall off tiles_y and exit
   int grid_y = std::max(1, c->world > 1 ? c->local_bands() * fp.band_tiles : fp.tiles_y);
-  hipLaunchKernelGGL((k_raster<TW, TH>), dim3(fp.tiles_x, grid_y), dim3(kTileThreads), 0, c->stream, fp, c->d_tris.ptr,
-                     c->d_clip.ptr, ctr, ctr_next, c->d_tile_count.ptr, c->d_bins.ptr, c->d_broad.ptr, c->d_frags.ptr,
-                     c->d_frag_count.ptr, out, c->dump_vis ? c->d_vis_prim.ptr : nullptr,
+  hipLaunchKernelGGL((k_raster<TW, TH>), dim3(fp.tiles_x, grid_y), dim3(kTileThreads), 0, sg, fp, s.d_tris.ptr,
+                     s.d_clip.ptr, s.d_counters.ptr, s.d_tile_count.ptr, s.d_bins.ptr, s.d_broad.ptr, s.d_frags.ptr,
+                     s.d_frag_count.ptr, out, c->dump_vis ? c->d_vis_prim.ptr : nullptr,
                      c->dump_vis ? c->d_vis_depth.ptr : nullptr);
-  if (ev) (void)hipEventRecord(ev[2], c->stream);
+  if (ev) (void)hipEventRecord(ev[2], sg);
+  if (ss != sg) {
+    (void)hipEventRecord(s.ev_raster_done, sg);
+    (void)hipStreamWaitEvent(ss, s.ev_raster_done, 0);
+  }
   constexpr int kChunks = TW * TH / kTileThreads;
-  hipLaunchKernelGGL((k_shade<TW, TH>), dim3(fp.tiles_x * kChunks, grid_y), dim3(kTileThreads), 0, c->stream, fp, sp,
-                     d_lights, c->d_tris.ptr, c->d_attrs.ptr, c->d_clip.ptr, c->d_frags.ptr, c->d_frag_count.ptr,
-                     c->d_materials.ptr, out);
+  hipLaunchKernelGGL((k_shade<TW, TH>), dim3(fp.tiles_x * kChunks, grid_y), dim3(kTileThreads), 0, ss, fp, sp, d_lights,
+                     s.d_tris.ptr, s.d_attrs.ptr, s.d_clip.ptr, s.d_frags.ptr, s.d_frag_count.ptr, c->d_materials.ptr, out);
+  (void)hipEventRecord(s.ev_shade_done, ss);
   if (ev) {
-    (void)hipEventRecord(ev[3], c->stream);
+    (void)hipEventRecord(ev[3], ss);
     ++c->ring_frames;
   }
 }
 
-// Queue the recorded frame.  Asynchronous.
-int submit_frame(bbr_context *c) {
+// Queue the recorded frame into slot `slot_index`.  Asynchronous.
+int submit_frame_into(bbr_context *c, int slot_index) {
   if (!c->have_frame) return fail(c, BBR_ERR_NOT_IN_FRAME, "no recorded frame");
   int rc = upload_material_table(c);
   if (rc) return rc;
-  rc = ensure_frame_buffers(c);
+  FrameSlot &s = c->slots[slot_index];
+  // the slot's previous frame (two frames ago) must have left the GPU before its buffers are reused
+  if (s.in_flight) {
+    HIP_TRY(c, hipEventSynchronize(s.ev_shade_done));
+    s.in_flight = false;
+  }
+  rc = ensure_slot_buffers(c, s);
   if (rc) return rc;
 
   // staging layout: [lights (100 * 64 B)] [draw descriptors] [instances]
@@ -254,22 +299,19 @@ int submit_frame(bbr_context *c) {
   size_t draws_bytes = (sizeof(DrawDesc) * c->draws.size() + 127) & ~(size_t)127;
   size_t inst_bytes = sizeof(InstanceBlock) * c->host_instances.size();
   size_t total = lights_bytes + draws_bytes + inst_bytes;
-  if (total > c->staging_cap) {
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (c->h_staging) (void)hipHostFree(c->h_staging);
-    c->h_staging = nullptr;
+  if (total > s.staging_cap) {
+    if (s.h_staging) (void)hipHostFree(s.h_staging);
+    s.h_staging = nullptr;
     size_t cap = std::max<size_t>(total * 2, 1 << 16);
-    HIP_TRY(c, hipHostMalloc(&c->h_staging, cap, hipHostMallocDefault));
-    c->staging_cap = cap;
-    HIP_TRY(c, c->d_staging.ensure(cap));
+    HIP_TRY(c, hipHostMalloc(&s.h_staging, cap, hipHostMallocDefault));
+    s.staging_cap = cap;
+    HIP_TRY(c, s.d_staging.ensure(cap));
   }
-  // the previous frame's copy must have drained before the pinned buffer is rewritten
-  if (c->ev_valid) HIP_TRY(c, hipEventSynchronize(c->ev[3]));
-  std::memcpy(c->h_staging, c->frame_u.lights, lights_bytes);
+  std::memcpy(s.h_staging, c->frame_u.lights, lights_bytes);
   {
     // draw descriptors point into the device copy of the instance data made by the same transfer
-    const InstanceBlock *d_inst_base = reinterpret_cast<const InstanceBlock *>(c->d_staging.ptr + lights_bytes + draws_bytes);
-    DrawDesc *hd = reinterpret_cast<DrawDesc *>((uint8_t *)c->h_staging + lights_bytes);
+    const InstanceBlock *d_inst_base = reinterpret_cast<const InstanceBlock *>(s.d_staging.ptr + lights_bytes + draws_bytes);
+    DrawDesc *hd = reinterpret_cast<DrawDesc *>((uint8_t *)s.h_staging + lights_bytes);
     uint32_t k = 0;
     for (const RecordedDraw &rd : c->draws) {
       if (!rd.n_instances || !rd.tris_per_instance) continue;  // empty draws would break the first_prim search
@@ -286,61 +328,77 @@ int submit_frame(bbr_context *c) {
     }
     c->n_live_draws = k;
   }
-  if (inst_bytes) std::memcpy((uint8_t *)c->h_staging + lights_bytes + draws_bytes, c->host_instances.data(), inst_bytes);
+  if (inst_bytes) std::memcpy((uint8_t *)s.h_staging + lights_bytes + draws_bytes, c->host_instances.data(), inst_bytes);
 
+  hipStream_t sg = c->geom_stream();
   if (c->timing) {
     if (c->ring.empty()) {
       c->ring.resize(bbr_context::kRingEvents * bbr_context::kRingCap);
       for (auto &e : c->ring) HIP_TRY(c, hipEventCreate(&e));
     }
-    HIP_TRY(c, hipEventRecord(c->ring[bbr_context::kRingEvents * (c->ring_frames % bbr_context::kRingCap)], c->stream));
+    HIP_TRY(c, hipEventRecord(c->ring[bbr_context::kRingEvents * (c->ring_frames % bbr_context::kRingCap)], sg));
   }
-  HIP_TRY(c, hipMemcpyAsync(c->d_staging.ptr, c->h_staging, total, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipEventRecord(c->ev[3], c->stream));
-  c->ev_valid = true;
+  HIP_TRY(c, hipMemsetAsync(s.d_counters.ptr, 0, sizeof(Counters), sg));
+  HIP_TRY(c, hipMemcpyAsync(s.d_staging.ptr, s.h_staging, total, hipMemcpyHostToDevice, sg));
 
-  const Light *d_lights = reinterpret_cast<const Light *>(c->d_staging.ptr);
-  const DrawDesc *d_draws = reinterpret_cast<const DrawDesc *>(c->d_staging.ptr + lights_bytes);
+  const Light *d_lights = reinterpret_cast<const Light *>(s.d_staging.ptr);
+  const DrawDesc *d_draws = reinterpret_cast<const DrawDesc *>(s.d_staging.ptr + lights_bytes);
   FrameParams fp = make_params(c);
   Mat4 pv = proj_view(c->view_u);
   ShadeParams sp;
   std::memcpy(sp.view_pos, c->view_u.view_pos, sizeof sp.view_pos);
   sp.enable_normal_map = c->view_u.enable_normal_map;
   sp.num_lights = std::min(std::max(c->frame_u.num_lights, 0), kMaxNumLights);
-  float4 *out = c->ext_out ? reinterpret_cast<float4 *>(c->ext_out) : c->d_frame.ptr;
+  float4 *out = c->ext_out ? reinterpret_cast<float4 *>(c->ext_out) : s.d_frame.ptr;
+  const FrameSlot *prev = (c->last_slot >= 0 && c->last_slot != slot_index) ? &c->slots[c->last_slot] : nullptr;
 
-  if (c->tile_mode == 0) launch_frame<64, 64>(c, fp, pv, sp, d_lights, d_draws, c->n_live_draws, out);
-  else launch_frame<32, 32>(c, fp, pv, sp, d_lights, d_draws, c->n_live_draws, out);
+  if (c->tile_mode == 0) launch_frame<64, 64>(c, s, prev, fp, pv, sp, d_lights, d_draws, c->n_live_draws, out);
+  else launch_frame<32, 32>(c, s, prev, fp, pv, sp, d_lights, d_draws, c->n_live_draws, out);
   HIP_TRY(c, hipGetLastError());
-  c->parity ^= 1;
+  s.in_flight = true;
+  s.out_used = out;
+  s.n_prims = c->n_prims;
+  c->last_slot = slot_index;
   return BBR_OK;
 }
 
-// Synchronise and, if a capacity overflowed, grow it and render the frame again.
+int submit_frame(bbr_context *c) {
+  int slot = (int)(c->frame_counter % (uint64_t)c->n_slots());
+  int rc = submit_frame_into(c, slot);
+  if (rc == BBR_OK) ++c->frame_counter;
+  return rc;
+}
+
+// Synchronise and, if a capacity overflowed in the most recent frame, grow it and render that frame again.
 int sync_and_fix(bbr_context *c, Counters *out_counters) {
   for (int attempt = 0; attempt < 8; ++attempt) {
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    int rc = drain(c);
+    if (rc) return rc;
     Counters h = {};
-    if (c->have_frame && c->d_counters.ptr)
-      HIP_TRY(c, hipMemcpy(&h, c->d_counters.ptr + (c->parity ^ 1), sizeof h, hipMemcpyDeviceToHost));
+    if (c->have_frame && c->last_slot >= 0 && c->slots[c->last_slot].d_counters.ptr)
+      HIP_TRY(c, hipMemcpy(&h, c->slots[c->last_slot].d_counters.ptr, sizeof h, hipMemcpyDeviceToHost));
     if (out_counters) *out_counters = h;
     if (!h.overflow) return BBR_OK;
     if (h.overflow & 1u) {
       // bin_need is exact for this frame; round up with headroom so small scene changes do not re-trigger
       uint32_t need = std::max(h.bin_need + h.bin_need / 4u, c->bin_cap * 2u);
       c->bin_cap = (need + 255u) & ~255u;
-      c->d_bins.release();
+      for (FrameSlot &s : c->slots) s.d_bins.release();
     }
     if (h.overflow & 2u) c->broad_cap *= 2;
     if (h.overflow & 4u) c->clip_cap *= 2;
     ++c->retries;
-    // tile counters may hold residue of refs that did not fit: clear and replay
-    HIP_TRY(c, hipMemset(c->d_tile_count.ptr, 0, c->d_tile_count.cap * sizeof(uint32_t)));
-    HIP_TRY(c, hipMemset(c->d_counters.ptr, 0, 2 * sizeof(Counters)));
-    int rc = submit_frame(c);
+    // tile counters may hold residue of refs that did not fit: clear and replay into the same slot
+    FrameSlot &s = c->slots[c->last_slot];
+    if (s.d_tile_count.ptr) HIP_TRY(c, hipMemset(s.d_tile_count.ptr, 0, s.d_tile_count.cap * sizeof(uint32_t)));
+    rc = submit_frame_into(c, c->last_slot);
     if (rc) return rc;
   }
   return fail(c, BBR_ERR_CAPACITY, "bin capacity still exceeded after 8 growth steps");
+}
+
+const void *last_output(const bbr_context *c) {
+  return c->last_slot >= 0 ? (const void *)c->slots[c->last_slot].out_used : nullptr;
 }
 
 }  // namespace
@@ -382,9 +440,8 @@ int bbr_create(int32_t width, int32_t height, int32_t device, bbr_context **out_
     }                                                                                          \
   } while (0)
   CREATE_TRY(hipSetDevice(device));
-  CREATE_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
-  c->stream = c->own_stream;
-  for (auto &e : c->ev) CREATE_TRY(hipEventCreate(&e));
+  CREATE_TRY(hipStreamCreateWithFlags(&c->s_geom, hipStreamNonBlocking));
+  CREATE_TRY(hipStreamCreateWithFlags(&c->s_shade, hipStreamNonBlocking));
   // `default` material maps (resources/pbr/default/*.png are uniform images): 1x1 RGBA8 each
   static const uint8_t k_default[kMapCount][4] = {{255, 255, 255, 255}, {0, 0, 0, 255},       {0, 0, 0, 255},
                                                   {255, 255, 255, 255}, {127, 127, 255, 255}, {0, 0, 0, 255}};
@@ -398,7 +455,7 @@ int bbr_create(int32_t width, int32_t height, int32_t device, bbr_context **out_
 int bbr_destroy(bbr_context *c) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
   (void)hipSetDevice(c->device);
-  (void)hipStreamSynchronize(c->stream);
+  (void)drain(c);
   for (Mesh &m : c->meshes) {
     if (m.d_vertices) (void)hipFree(m.d_vertices);
     if (m.d_indices) (void)hipFree(m.d_indices);
@@ -409,15 +466,18 @@ int bbr_destroy(bbr_context *c) {
     if (m.d_packed) (void)hipFree(m.d_packed);
   }
   if (c->d_default_texels) (void)hipFree(c->d_default_texels);
-  c->d_materials.release(); c->d_staging.release(); c->d_tris.release(); c->d_attrs.release(); c->d_clip.release();
-  c->d_counters.release(); c->d_tile_count.release(); c->d_bins.release(); c->d_broad.release(); c->d_frame.release(); c->d_frags.release(); c->d_frag_count.release();
-  c->d_vis_prim.release(); c->d_vis_depth.release();
-  if (c->h_staging) (void)hipHostFree(c->h_staging);
-  for (auto &e : c->ev)
-    if (e) (void)hipEventDestroy(e);
+  c->d_materials.release();
+  c->d_vis_prim.release();
+  c->d_vis_depth.release();
+  for (FrameSlot &s : c->slots) {
+    s.release_all();
+    if (s.ev_raster_done) (void)hipEventDestroy(s.ev_raster_done);
+    if (s.ev_shade_done) (void)hipEventDestroy(s.ev_shade_done);
+  }
   for (auto &e : c->ring)
     if (e) (void)hipEventDestroy(e);
-  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  if (c->s_geom) (void)hipStreamDestroy(c->s_geom);
+  if (c->s_shade) (void)hipStreamDestroy(c->s_shade);
   delete c;
   return BBR_OK;
 }
@@ -452,7 +512,8 @@ int bbr_free_mesh(bbr_context *c, int32_t mesh) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
   if (mesh < 0 || mesh >= (int32_t)c->meshes.size() || !c->meshes[mesh].alive)
     return fail(c, BBR_ERR_BAD_HANDLE, "free_mesh: bad handle");
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  int rc = drain(c);
+  if (rc) return rc;
   Mesh &m = c->meshes[mesh];
   if (m.d_vertices) (void)hipFree(m.d_vertices);
   if (m.d_indices) (void)hipFree(m.d_indices);
@@ -531,7 +592,8 @@ int bbr_free_material(bbr_context *c, int32_t material) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
   if (material < 0 || material >= (int32_t)c->materials.size() || !c->materials[material].alive)
     return fail(c, BBR_ERR_BAD_HANDLE, "free_material: bad handle");
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  int rc = drain(c);
+  if (rc) return rc;
   Material &m = c->materials[material];
   for (auto &p : m.d_texels)
     if (p) (void)hipFree(p);
@@ -622,8 +684,7 @@ int bbr_read_framebuffer(bbr_context *c, float *host) {
   if (!c->have_frame) return fail(c, BBR_ERR_NOT_IN_FRAME, "read_framebuffer: nothing rendered");
   int rc = sync_and_fix(c, nullptr);
   if (rc) return rc;
-  const void *src = c->ext_out ? c->ext_out : (const void *)c->d_frame.ptr;
-  HIP_TRY(c, hipMemcpy(host, src, (size_t)c->width * c->height * 16, hipMemcpyDeviceToHost));
+  HIP_TRY(c, hipMemcpy(host, last_output(c), (size_t)c->width * c->height * 16, hipMemcpyDeviceToHost));
   return BBR_OK;
 }
 
@@ -633,18 +694,17 @@ int bbr_read_shard(bbr_context *c, float *host) {
   if (!c->have_frame) return fail(c, BBR_ERR_NOT_IN_FRAME, "read_shard: nothing rendered");
   int rc = sync_and_fix(c, nullptr);
   if (rc) return rc;
-  const void *src = c->ext_out ? c->ext_out : (const void *)c->d_frame.ptr;
-  HIP_TRY(c, hipMemcpy(host, src, (size_t)c->width * c->shard_rows() * 16, hipMemcpyDeviceToHost));
+  HIP_TRY(c, hipMemcpy(host, last_output(c), (size_t)c->width * c->shard_rows() * 16, hipMemcpyDeviceToHost));
   return BBR_OK;
 }
 
 int bbr_framebuffer_device_ptr(bbr_context *c, void **out_ptr, uint64_t *out_bytes) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
   if (!out_ptr) return fail(c, BBR_ERR_INVALID_ARGUMENT, "framebuffer_device_ptr: NULL");
-  uint64_t bytes = (uint64_t)c->width * std::max(c->height, c->shard_rows()) * 16;
-  if (!c->ext_out) HIP_TRY(c, c->d_frame.ensure(bytes / 16));
-  *out_ptr = c->ext_out ? c->ext_out : (void *)c->d_frame.ptr;
-  if (out_bytes) *out_bytes = c->ext_out ? c->ext_out_bytes : bytes;
+  if (!c->have_frame || c->last_slot < 0) return fail(c, BBR_ERR_NOT_IN_FRAME, "framebuffer_device_ptr: nothing rendered");
+  *out_ptr = (void *)c->slots[c->last_slot].out_used;
+  if (out_bytes)
+    *out_bytes = c->ext_out ? c->ext_out_bytes : (uint64_t)c->width * std::max(c->height, c->shard_rows()) * 16;
   return BBR_OK;
 }
 
@@ -662,9 +722,24 @@ int bbr_set_output_device_ptr(bbr_context *c, void *device_ptr, uint64_t bytes) 
 
 int bbr_set_stream(bbr_context *c, void *stream) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  c->stream = stream ? (hipStream_t)stream : c->own_stream;
-  c->ev_valid = false;
+  int rc = drain(c);
+  if (rc) return rc;
+  c->user_stream = (hipStream_t)stream;
+  c->frame_counter = 0;
+  return BBR_OK;
+}
+
+int bbr_wait_event(bbr_context *c, void *hip_event) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  if (!hip_event) return fail(c, BBR_ERR_INVALID_ARGUMENT, "wait_event: NULL");
+  HIP_TRY(c, hipStreamWaitEvent(c->geom_stream(), (hipEvent_t)hip_event, 0));
+  return BBR_OK;
+}
+
+int bbr_stream_wait_frame(bbr_context *c, void *stream) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  if (!c->have_frame || c->last_slot < 0) return fail(c, BBR_ERR_NOT_IN_FRAME, "stream_wait_frame: nothing rendered");
+  HIP_TRY(c, hipStreamWaitEvent((hipStream_t)stream, c->slots[c->last_slot].ev_shade_done, 0));
   return BBR_OK;
 }
 
@@ -679,7 +754,8 @@ int bbr_set_partition(bbr_context *c, int32_t rank, int32_t world, int32_t band_
   if (world < 1 || rank < 0 || rank >= world) return fail(c, BBR_ERR_INVALID_ARGUMENT, "set_partition: bad rank/world");
   if (band_rows <= 0) band_rows = c->tile_h();
   if (band_rows % c->tile_h()) return fail(c, BBR_ERR_INVALID_ARGUMENT, "set_partition: band_rows must be a multiple of the tile height");
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  int rc = drain(c);
+  if (rc) return rc;
   c->rank = rank;
   c->world = world;
   c->band_rows = band_rows;
@@ -699,13 +775,13 @@ int bbr_shard_rows(const bbr_context *c, int32_t *out_rows) {
   return BBR_OK;
 }
 
-int bbr_unpack_gathered(bbr_context *c, const void *gathered, void *frame) {
+int bbr_unpack_gathered(bbr_context *c, const void *gathered, void *frame, void *stream) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
   if (!gathered || !frame) return fail(c, BBR_ERR_INVALID_ARGUMENT, "unpack_gathered: NULL");
   size_t n = (size_t)c->width * c->height;
-  hipLaunchKernelGGL(k_unpack_gathered, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
-                     (const float4 *)gathered, (float4 *)frame, c->width, c->height, c->world, c->eff_band_rows(),
-                     c->shard_rows());
+  hipStream_t st = stream ? (hipStream_t)stream : c->shade_stream();
+  hipLaunchKernelGGL(k_unpack_gathered, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float4 *)gathered,
+                     (float4 *)frame, c->width, c->height, c->world, c->eff_band_rows(), c->shard_rows());
   HIP_TRY(c, hipGetLastError());
   return BBR_OK;
 }
@@ -738,7 +814,7 @@ int bbr_read_visibility(bbr_context *c, uint32_t *prim_host, float *depth_host) 
   int rc = sync_and_fix(c, nullptr);
   if (rc) return rc;
   c->dump_vis = true;
-  rc = submit_frame(c);
+  rc = submit_frame_into(c, c->last_slot);
   if (!rc) rc = sync_and_fix(c, nullptr);
   c->dump_vis = false;
   if (rc) return rc;
@@ -752,7 +828,8 @@ int bbr_last_frame_time_ms(bbr_context *c, float *out_frame_ms, float *out_shade
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
   if (!c->timing) return fail(c, BBR_ERR_INVALID_ARGUMENT, "last_frame_time_ms: enable option \"timing\" first");
   if (!c->ring_frames) return fail(c, BBR_ERR_NOT_IN_FRAME, "last_frame_time_ms: no timed frame yet");
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  int rc = drain(c);
+  if (rc) return rc;
   const hipEvent_t *e = &c->ring[bbr_context::kRingEvents * ((c->ring_frames - 1) % bbr_context::kRingCap)];
   float a = 0.f, b = 0.f;
   HIP_TRY(c, hipEventElapsedTime(&a, e[0], e[3]));
@@ -764,7 +841,8 @@ int bbr_last_frame_time_ms(bbr_context *c, float *out_frame_ms, float *out_shade
 
 int bbr_timing_reset(bbr_context *c) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  int rc = drain(c);
+  if (rc) return rc;
   c->ring_frames = 0;
   return BBR_OK;
 }
@@ -773,7 +851,8 @@ int bbr_timing_summary(bbr_context *c, uint32_t *out_frames, float *out_avg_fram
                        float *out_avg_raster_ms, float *out_avg_shade_ms) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
   if (!c->timing) return fail(c, BBR_ERR_INVALID_ARGUMENT, "timing_summary: enable option \"timing\" first");
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  int rc = drain(c);
+  if (rc) return rc;
   uint32_t n = std::min(c->ring_frames, bbr_context::kRingCap);
   double f = 0, g = 0, r = 0, t = 0;
   for (uint32_t i = 0; i < n; ++i) {
@@ -796,23 +875,25 @@ int bbr_timing_summary(bbr_context *c, uint32_t *out_frames, float *out_avg_fram
 int bbr_set_option(bbr_context *c, const char *name, int64_t value) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
   if (!name) return fail(c, BBR_ERR_INVALID_ARGUMENT, "set_option: NULL name");
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  int rc = drain(c);
+  if (rc) return rc;
   std::string n(name);
   if (n == "timing") c->timing = value != 0;
-  else if (n == "tile_mode") {
+  else if (n == "frames_in_flight") {
+    if (value != 1 && value != 2) return fail(c, BBR_ERR_INVALID_ARGUMENT, "frames_in_flight: 1 or 2");
+    c->frames_in_flight = (int)value;
+    c->frame_counter = 0;
+  } else if (n == "tile_mode") {
     if (value != 0 && value != 1) return fail(c, BBR_ERR_INVALID_ARGUMENT, "tile_mode: 0 (64x64) or 1 (32x32)");
     if (c->world > 1 && c->band_rows % (value == 0 ? 64 : 32))
       return fail(c, BBR_ERR_INVALID_ARGUMENT, "tile_mode: band_rows not a multiple of the new tile height");
     c->tile_mode = (int)value;
-    // bins are laid out per tile: drop them so that ensure() re-zeroes the counters
-    c->d_tile_count.release();
-    c->d_frags.release();
-    c->d_frag_count.release();
-    c->d_bins.release();
+    // bins and fragment lists are laid out per tile: drop them so that ensure() re-zeroes the counters
+    for (FrameSlot &s : c->slots) s.release_tile_buffers();
   } else if (n == "bin_cap") {
     if (value < 1 || value > (1 << 20)) return fail(c, BBR_ERR_INVALID_ARGUMENT, "bin_cap out of range");
     c->bin_cap = (uint32_t)value;
-    c->d_bins.release();
+    for (FrameSlot &s : c->slots) s.d_bins.release();
   } else if (n == "ablate") {
     c->ablate = (uint32_t)value;
   } else if (n == "broad_threshold") {
@@ -826,10 +907,11 @@ int bbr_set_option(bbr_context *c, const char *name, int64_t value) {
 
 int bbr_tone_map(bbr_context *c, int32_t enable, float exposure) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
-  if (!c->have_frame) return fail(c, BBR_ERR_NOT_IN_FRAME, "tone_map: nothing rendered");
-  float4 *frame = c->ext_out ? (float4 *)c->ext_out : c->d_frame.ptr;
+  if (!c->have_frame || c->last_slot < 0) return fail(c, BBR_ERR_NOT_IN_FRAME, "tone_map: nothing rendered");
+  float4 *frame = c->slots[c->last_slot].out_used;
   size_t n = (size_t)c->width * (c->world > 1 ? c->shard_rows() : c->height);
-  hipLaunchKernelGGL(k_tone_map, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, frame, n, enable, exposure);
+  // same stream as the frame's shade kernel: ordered after it
+  hipLaunchKernelGGL(k_tone_map, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->shade_stream(), frame, n, enable, exposure);
   HIP_TRY(c, hipGetLastError());
   return BBR_OK;
 }

@@ -168,8 +168,15 @@ class Renderer:
         self._check(self._L.bbr_framebuffer_device_ptr(self._ctx, C.byref(p), C.byref(n)))
         return p.value, n.value
 
-    def unpack_gathered(self, gathered_ptr, frame_ptr):
-        self._check(self._L.bbr_unpack_gathered(self._ctx, C.c_void_p(gathered_ptr), C.c_void_p(frame_ptr)))
+    def unpack_gathered(self, gathered_ptr, frame_ptr, stream_handle=None):
+        self._check(self._L.bbr_unpack_gathered(self._ctx, C.c_void_p(gathered_ptr), C.c_void_p(frame_ptr),
+                                                C.c_void_p(stream_handle) if stream_handle else None))
+
+    def wait_event(self, event_handle):
+        self._check(self._L.bbr_wait_event(self._ctx, C.c_void_p(event_handle)))
+
+    def stream_wait_frame(self, stream_handle):
+        self._check(self._L.bbr_stream_wait_frame(self._ctx, C.c_void_p(stream_handle)))
 
     # -- convenience: submit a scene description made of numpy inputs --
     def render_scene(self, scene, handles=None):

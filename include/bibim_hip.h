@@ -111,7 +111,19 @@ int bbr_framebuffer_device_ptr(bbr_context *ctx, void **out_device_ptr, uint64_t
 /* Render into caller-provided device memory instead (e.g. a torch tensor that RCCL all-gathers);
  * NULL restores the internal buffer.  bytes must cover the frame (or the shard when partitioned). */
 int bbr_set_output_device_ptr(bbr_context *ctx, void *device_ptr, uint64_t bytes);
-int bbr_set_stream(bbr_context *ctx, void *hip_stream); /* NULL = context's own stream */
+/* By default a context owns two HIP streams and keeps two frames in flight (geometry + raster of frame N+1
+ * overlap the shading of frame N; option "frames_in_flight" = 1 turns that off).  Each in-flight frame has its own
+ * internal framebuffer; bbr_read_framebuffer / bbr_framebuffer_device_ptr refer to the most recently submitted frame.
+ * bbr_set_stream(stream != NULL) puts ALL of the context's work on the caller's stream instead (one frame in flight,
+ * plain stream ordering with the caller's other work); NULL returns to the context's own streams. */
+int bbr_set_stream(bbr_context *ctx, void *hip_stream);
+/* Cross-stream hand-offs for callers that pipeline frames against their own streams (e.g. an RCCL all-gather of
+ * frame N overlapping the rendering of frame N+1):
+ *   bbr_wait_event        device work submitted after this call waits for `hip_event` (a hipEvent_t the caller recorded,
+ *                         e.g. "the consumer of the output buffer has finished with it");
+ *   bbr_stream_wait_frame `hip_stream` (a hipStream_t) waits until the most recently submitted frame is complete. */
+int bbr_wait_event(bbr_context *ctx, void *hip_event);
+int bbr_stream_wait_frame(bbr_context *ctx, void *hip_stream);
 
 /* ---- screen-band partition across GPUs (no reference counterpart) ---- */
 /* Band b (band_rows framebuffer rows, a multiple of the tile height) belongs to rank b % world.  The
@@ -120,8 +132,9 @@ int bbr_set_stream(bbr_context *ctx, void *hip_stream); /* NULL = context's own 
 int bbr_set_partition(bbr_context *ctx, int32_t rank, int32_t world, int32_t band_rows);
 int bbr_shard_rows(const bbr_context *ctx, int32_t *out_rows);
 int bbr_read_shard(bbr_context *ctx, float *rgba32f_host); /* shard_rows*width*4 floats */
-/* Device-side un-interleave of an all-gathered buffer [world][shard_rows][width][4] into a row-major frame. */
-int bbr_unpack_gathered(bbr_context *ctx, const void *gathered_device, void *frame_device);
+/* Device-side un-interleave of an all-gathered buffer [world][shard_rows][width][4] into a row-major frame, queued on
+ * `hip_stream` (NULL = the context's shading stream). */
+int bbr_unpack_gathered(bbr_context *ctx, const void *gathered_device, void *frame_device, void *hip_stream);
 int bbr_tile_height(const bbr_context *ctx, int32_t *out_tile_h);
 
 /* ---- diagnostics ---- */

@@ -15,9 +15,10 @@ from oracle import bbo, scenes
 pytestmark = pytest.mark.gpu
 
 
-def gpu_render(scene, tile_mode=0, **opts):
+def gpu_render(scene, tile_mode=None, **opts):
     r = Renderer(scene.width, scene.height)
-    r.set_option("tile_mode", tile_mode)
+    if tile_mode is not None:
+        r.set_option("tile_mode", tile_mode)  # default: the library's own (32x32)
     for k, v in opts.items():
         r.set_option(k, v)
     r.render_scene(scene)
@@ -28,7 +29,7 @@ def gpu_render(scene, tile_mode=0, **opts):
     return img, prim, depth, st
 
 
-def check(scene, tile_mode=0, expect_exact=True, **opts):
+def check(scene, tile_mode=None, expect_exact=True, **opts):
     ref, rprim, rdepth, rst = bbo.render(scene)
     img, prim, depth, st = gpu_render(scene, tile_mode, **opts)
     assert np.array_equal(prim, rprim), f"{int((prim != rprim).sum())} pixels pick another primitive"
@@ -182,6 +183,35 @@ def test_broad_list_threshold_extremes(maps64):
     sc = scenes.shaderball_scene(configs.C3.scaled(400, 225, 64), bbo.MaterialData(maps64))
     check(sc, broad_threshold=1)       # everything touching more than one tile goes to the every-tile list
     check(sc, broad_threshold=100000)  # nothing does: the ground plane is binned into every tile it touches
+
+
+@pytest.mark.parametrize("frames_in_flight", [1, 2])
+def test_frames_in_flight_streams_of_different_frames(maps64, frames_in_flight):
+    """two frames in flight on two streams: alternating scenes back to back, no synchronisation in between,
+    every frame must still come out exactly as when rendered alone"""
+    sa = scenes.shaderball_scene(configs.C3.scaled(448, 252, 64), bbo.MaterialData(maps64))
+    sb = scenes.shaderball_scene(configs.C2.scaled(448, 252, 64), sa.draws[0].material)
+    ra, _, _, _ = bbo.render(sa)
+    rb, _, _, _ = bbo.render(sb)
+    r = Renderer(sa.width, sa.height)
+    r.set_option("frames_in_flight", frames_in_flight)
+    h = None
+    for i in range(9):
+        h = r.render_scene(sa if i % 2 == 0 else sb, h)
+    last = r.read_framebuffer()            # frame 8 = scene a
+    assert np.array_equal(last.view(np.uint32), ra.view(np.uint32))
+    h = r.render_scene(sb, h)
+    assert np.array_equal(r.read_framebuffer().view(np.uint32), rb.view(np.uint32))
+    # single external output buffer shared by consecutive frames: raster of N+1 must wait for shade of N
+    import torch
+    out = torch.zeros((sa.height, sa.width, 4), dtype=torch.float32, device="cuda")
+    r.set_output_device_ptr(out.data_ptr(), out.numel() * 4)
+    for i in range(6):
+        h = r.render_scene(sb if i % 2 == 0 else sa, h)
+    r.synchronize()
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), ra.view(np.uint32))
+    r.close()
 
 
 def test_replay_is_idempotent_and_frames_are_independent(maps64):
