@@ -160,10 +160,7 @@ BB_DEV bool setup_tri(RasterTri &t, float z0, float z1, float z2) {
   return true;
 }
 
-// ---- statistics: accumulated per workgroup in LDS, one global atomic per counter per workgroup ----
-struct BlockStats {
-  uint32_t raster_tris, clipped_prims, bin_refs;
-};
+// ---- statistics: accumulated per workgroup in LDS, written out as one BlockStats record per workgroup ----
 
 struct TileRange {
   int tx0, tx1, ty0, ty1;
@@ -340,9 +337,10 @@ __global__ __launch_bounds__(256) void k_geometry(const DrawDesc *__restrict__ d
                                                   PrimAttr *__restrict__ attrs, ClipSlot *__restrict__ clip_arena,
                                                   Counters *__restrict__ ctr, uint32_t *__restrict__ tile_count,
                                                   uint32_t *__restrict__ bins, BroadTri *__restrict__ broad_list,
-                                                  const MaterialDesc *__restrict__ materials) {
+                                                  const MaterialDesc *__restrict__ materials,
+                                                  BlockStats *__restrict__ block_stats) {
   __shared__ BlockStats bs;
-  __shared__ ClipWork s_clip[4];  // one per wave
+  __shared__ ClipWork s_clip[8];  // two per wave
   if (threadIdx.x == 0) bs = BlockStats{0u, 0u, 0u};
   __syncthreads();
   const uint32_t prim = blockIdx.x * blockDim.x + threadIdx.x;
@@ -425,16 +423,6 @@ __global__ __launch_bounds__(256) void k_geometry(const DrawDesc *__restrict__ d
       }
     }
   }
-  // ---- clipper: lanes that need it take turns on the wave's LDS workspace ----
-  for (unsigned long long cm = __ballot(needs_clip); cm; cm &= cm - 1ull) {
-    if ((int)(threadIdx.x & 63) == __ffsll((long long)cm) - 1) {
-      n_clipped = 1;
-      int nv = clip_and_route<TILE_W, TILE_H>(s_clip[threadIdx.x >> 6], clip, prim, fp, tris, clip_arena, ctr, broad_list);
-      if (nv) attrs[prim] = pa;
-      n_raster = (uint32_t)nv;
-    }
-  }
-
   // ---- tile bins: walk each lane's tile range in lock-step, aggregating per tile across the wave ----
   uint32_t refs = 0;
   {
@@ -449,15 +437,29 @@ __global__ __launch_bounds__(256) void k_geometry(const DrawDesc *__restrict__ d
       refs += n;
     }
   }
+  // ---- clipper (after the bins, so the other lanes' insertions never wait for it): lanes that need it take
+  // turns, two at a time, on the wave's LDS workspaces ----
+  for (unsigned long long cm = __ballot(needs_clip); cm;) {
+    const int l0 = __ffsll((long long)cm) - 1;
+    cm &= cm - 1ull;
+    const int l1 = cm ? __ffsll((long long)cm) - 1 : -1;
+    if (cm) cm &= cm - 1ull;
+    const int me = (int)(threadIdx.x & 63);
+    if (me == l0 || me == l1) {
+      n_clipped = 1;
+      ClipWork &w = s_clip[(threadIdx.x >> 6) * 2 + (me == l0 ? 0 : 1)];
+      int nv = clip_and_route<TILE_W, TILE_H>(w, clip, prim, fp, tris, clip_arena, ctr, broad_list);
+      if (nv) attrs[prim] = pa;
+      n_raster = (uint32_t)nv;
+    }
+  }
   if ((threadIdx.x & 63) == 0 && refs) atomicAdd(&bs.bin_refs, refs);
   if (n_raster) atomicAdd(&bs.raster_tris, n_raster);
   if (n_clipped) atomicAdd(&bs.clipped_prims, n_clipped);
   __syncthreads();
-  if (threadIdx.x == 0) {
-    if (bs.raster_tris) atomicAdd(&ctr->n_raster_tris, (unsigned long long)bs.raster_tris);
-    if (bs.clipped_prims) atomicAdd(&ctr->n_clipped_prims, (unsigned long long)bs.clipped_prims);
-    if (bs.bin_refs) atomicAdd(&ctr->n_bin_refs, (unsigned long long)bs.bin_refs);
-  }
+  // statistics leave the kernel as one record per workgroup (summed on the host on demand): a few thousand
+  // atomics on ONE counter word would serialise at ~90 per microsecond and dominate this kernel
+  if (threadIdx.x == 0) block_stats[blockIdx.x] = bs;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -676,19 +678,6 @@ BB_DEV void raster_triangle_wave(const RasterTri &t, uint32_t ref, int tile_x0, 
 constexpr int kTileThreads = 256;
 constexpr int kTileWaves = kTileThreads / 64;
 
-// lane `l` (wave-uniform) hands its triangle to the whole wave through v_readlane: no memory round trip
-BB_DEV RasterTri broadcast_tri(const RasterTri &t, int l) {
-  RasterTri r;
-  r.X0 = __builtin_amdgcn_readlane(t.X0, l); r.Y0 = __builtin_amdgcn_readlane(t.Y0, l);
-  r.X1 = __builtin_amdgcn_readlane(t.X1, l); r.Y1 = __builtin_amdgcn_readlane(t.Y1, l);
-  r.X2 = __builtin_amdgcn_readlane(t.X2, l); r.Y2 = __builtin_amdgcn_readlane(t.Y2, l);
-  r.z0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t.z0), l));
-  r.dzdx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t.dzdx), l));
-  r.dzdy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t.dzdy), l));
-  r.l1dx = r.l1dy = r.l2dx = r.l2dy = r.rw0 = r.rw1 = r.rw2 = 0.0f;  // not needed for coverage / depth
-  return r;
-}
-
 // One lane rasterises one small triangle into the tile's LDS keys.  Bounding box <= 16 px in each direction
 // => every edge-function term fits 32 bits and steps are plain adds.
 template <int TILE_W, int TILE_H>
@@ -769,9 +758,29 @@ BB_DEV bool tile_row(const FrameParams &fp, int grid_y, int &ty, int &out_tile_r
 // ds_max_u64 -- depth op GREATER_OR_EQUAL with "later primitive wins ties" falls out of the key order -- then
 // ballot/popcount compaction of the covered pixels into the tile's fragment list.  Background pixels get the
 // clear colour here; covered pixels are coloured by k_shade.
-// No workgroup barrier inside the raster loops: each wave pulls 64 bin entries, lanes rasterise the small
-// triangles themselves and the wave then sweeps its larger ones cooperatively.
+//
+// The kernel is latency-bound (bin -> triangle record -> LDS atomics), so the triangle data of up to 256 bin
+// entries is staged through LDS by all threads at once: two memory round trips per chunk however the entries
+// split over the raster classes, instead of two per loop iteration.  The every-tile list rides along as extra
+// "large" entries after a per-tile accept/reject test.
 // ------------------------------------------------------------------------------------------------
+constexpr int kStage = kTileThreads;  // staged entries per chunk (one per thread)
+
+struct StagedTri {  // struct-of-arrays in LDS: thread j owns column j when filling
+  int X0[kStage], Y0[kStage], X1[kStage], Y1[kStage], X2[kStage], Y2[kStage];
+  float z0[kStage], dzdx[kStage], dzdy[kStage];
+  uint32_t ref[kStage];
+  uint32_t box[kStage];  // px0 | px1 << 8 | py0 << 16 | py1 << 24 relative to the tile; 0xFFFFFFFF = skip
+};
+
+BB_DEV RasterTri staged_tri(const StagedTri &st, int j) {
+  RasterTri t;
+  t.X0 = st.X0[j]; t.Y0 = st.Y0[j]; t.X1 = st.X1[j]; t.Y1 = st.Y1[j]; t.X2 = st.X2[j]; t.Y2 = st.Y2[j];
+  t.z0 = st.z0[j]; t.dzdx = st.dzdx[j]; t.dzdy = st.dzdy[j];
+  t.l1dx = t.l1dy = t.l2dx = t.l2dy = t.rw0 = t.rw1 = t.rw2 = 0.0f;  // not needed for coverage / depth
+  return t;
+}
+
 template <int TILE_W, int TILE_H>
 __global__ __launch_bounds__(kTileThreads) void k_raster(
     FrameParams fp, const RasterTri *__restrict__ tris, const ClipSlot *__restrict__ clip_arena,
@@ -781,6 +790,7 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
     uint32_t *__restrict__ vis_prim, float *__restrict__ vis_depth) {
   constexpr int TILE_PIXELS = TILE_W * TILE_H;
   __shared__ unsigned long long keys[TILE_PIXELS];
+  __shared__ StagedTri st;
   __shared__ uint32_t s_count;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -800,69 +810,86 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
   const uint32_t n_broad = (fp.ablate & 5u) ? 0u : min(ctr->n_broad, fp.broad_cap);
   for (int p = tid; p < TILE_PIXELS; p += kTileThreads) keys[p] = 0ull;
   if (tid == 0) s_count = 0;
-  __syncthreads();
   if (tid < (int)kBinClasses && n_cls[tid]) tile_count[tile * kBinClasses + tid] = 0;  // ready for the next frame
 
-  // clamp of a triangle's pixel box to this tile (pixel centres)
-  auto tile_box = [&](const RasterTri &t, int &px0, int &px1, int &py0, int &py1) {
-    int32_t minX = min(t.X0, min(t.X1, t.X2)), maxX = max(t.X0, max(t.X1, t.X2));
-    int32_t minY = min(t.Y0, min(t.Y1, t.Y2)), maxY = max(t.Y0, max(t.Y1, t.Y2));
-    px0 = max((minX - 128 + 255) >> 8, tile_x0); px1 = min((maxX - 128) >> 8, rx1);
-    py0 = max((minY - 128 + 255) >> 8, tile_y0); py1 = min((maxY - 128) >> 8, ry1);
-    return px0 <= px1 && py0 <= py1;
-  };
+  // entry order: class 0 | class 1 | class 2 | every-tile list
+  const uint32_t e1 = n_cls[0], e2 = e1 + n_cls[1], e3 = e2 + n_cls[2], e_end = e3 + n_broad;
+  const uint32_t *bin0 = bins + (size_t)(tile * kBinClasses) * fp.bin_cap;
 
-  // ---- class 0: one tiny triangle per lane ----
-  {
-    const uint32_t *bin = bins + (size_t)(tile * kBinClasses + 0u) * fp.bin_cap;
-    for (uint32_t i = (uint32_t)tid; i < n_cls[0]; i += kTileThreads) {
-      const uint32_t ref = bin[i];
-      const RasterTri t = tris[ref >> 3];  // binned triangles are never clipped
-      int px0, px1, py0, py1;
-      if (tile_box(t, px0, px1, py0, py1)) raster_triangle_lane<TILE_W, TILE_H>(t, ref, px0, px1, py0, py1, tile_x0, tile_y0, keys);
+  for (uint32_t base = 0; base < e_end; base += kStage) {
+    __syncthreads();  // keys initialised / previous chunk consumed
+    // ---- stage: every thread fetches one entry (reference -> triangle record), all loads in flight together ----
+    {
+      const uint32_t e = base + (uint32_t)tid;
+      uint32_t box = 0xFFFFFFFFu;
+      if (e < e_end) {
+        RasterTri t;
+        uint32_t ref;
+        if (e < e3) {
+          const uint32_t c = e < e1 ? 0u : (e < e2 ? 1u : 2u);
+          const uint32_t i = e - (c == 0u ? 0u : (c == 1u ? e1 : e2));
+          ref = bin0[(size_t)c * fp.bin_cap + i];
+          t = tris[ref >> 3];  // binned triangles are never clipped
+        } else {
+          const BroadTri &b = broad_list[e - e3];
+          t = b.tri;
+          ref = b.ref;
+        }
+        int32_t minX = min(t.X0, min(t.X1, t.X2)), maxX = max(t.X0, max(t.X1, t.X2));
+        int32_t minY = min(t.Y0, min(t.Y1, t.Y2)), maxY = max(t.Y0, max(t.Y1, t.Y2));
+        int px0 = max((minX - 128 + 255) >> 8, tile_x0), px1 = min((maxX - 128) >> 8, rx1);
+        int py0 = max((minY - 128 + 255) >> 8, tile_y0), py1 = min((maxY - 128) >> 8, ry1);
+        bool ok = px0 <= px1 && py0 <= py1;
+        if (ok && e >= e3) ok = classify_rect(edge_setup(t), px0, px1, py0, py1) != 0;  // every-tile list: accept / reject
+        if (ok) {
+          box = (uint32_t)(px0 - tile_x0) | ((uint32_t)(px1 - tile_x0) << 8) | ((uint32_t)(py0 - tile_y0) << 16) |
+                ((uint32_t)(py1 - tile_y0) << 24);
+          st.X0[tid] = t.X0; st.Y0[tid] = t.Y0; st.X1[tid] = t.X1; st.Y1[tid] = t.Y1; st.X2[tid] = t.X2; st.Y2[tid] = t.Y2;
+          st.z0[tid] = t.z0; st.dzdx[tid] = t.dzdx; st.dzdy[tid] = t.dzdy;
+          st.ref[tid] = ref;
+        }
+      }
+      st.box[tid] = box;
     }
-  }
-  // ---- class 1: sixteen lanes per small triangle ----
-  {
-    const uint32_t *bin = bins + (size_t)(tile * kBinClasses + 1u) * fp.bin_cap;
-    for (uint32_t i = (uint32_t)(tid >> 4); i < n_cls[1]; i += kTileThreads / 16) {
-      const uint32_t ref = bin[i];
-      const RasterTri t = tris[ref >> 3];
-      int px0, px1, py0, py1;
-      if (tile_box(t, px0, px1, py0, py1))
-        raster_triangle_group16<TILE_W, TILE_H>(t, ref, px0, px1, py0, py1, tile_x0, tile_y0, keys, tid & 15);
+    __syncthreads();
+    const uint32_t hi = min(base + (uint32_t)kStage, e_end);
+    // ---- class 0: one tiny triangle per lane ----
+    {
+      const uint32_t lo = base, h0 = min(hi, e1);
+      const uint32_t e = lo + (uint32_t)tid;
+      if (e < h0) {
+        const int j = (int)(e - base);
+        const uint32_t box = st.box[j];
+        if (box != 0xFFFFFFFFu) {
+          const RasterTri t = staged_tri(st, j);
+          raster_triangle_lane<TILE_W, TILE_H>(t, st.ref[j], tile_x0 + (int)(box & 255u), tile_x0 + (int)((box >> 8) & 255u),
+                                               tile_y0 + (int)((box >> 16) & 255u), tile_y0 + (int)(box >> 24), tile_x0,
+                                               tile_y0, keys);
+        }
+      }
     }
-  }
-  // ---- class 2: one wave per large triangle ----
-  {
-    const uint32_t *bin = bins + (size_t)(tile * kBinClasses + 2u) * fp.bin_cap;
-    for (uint32_t i = (uint32_t)wave; i < n_cls[2]; i += kTileWaves) {
-      const uint32_t ref = (uint32_t)__builtin_amdgcn_readfirstlane((int)bin[i]);
-      const RasterTri t = tris[ref >> 3];
-      raster_triangle_wave<TILE_W, TILE_H>(t, ref, tile_x0, tile_y0, fp, keys, lane);
+    // ---- class 1: sixteen lanes per small triangle ----
+    {
+      const uint32_t lo = max(base, e1), h1 = min(hi, e2);
+      for (uint32_t e = lo + (uint32_t)(tid >> 4); e < h1; e += kTileThreads / 16) {
+        const int j = (int)(e - base);
+        const uint32_t box = st.box[j];
+        if (box == 0xFFFFFFFFu) continue;
+        const RasterTri t = staged_tri(st, j);
+        raster_triangle_group16<TILE_W, TILE_H>(t, st.ref[j], tile_x0 + (int)(box & 255u), tile_x0 + (int)((box >> 8) & 255u),
+                                                tile_y0 + (int)((box >> 16) & 255u), tile_y0 + (int)(box >> 24), tile_x0,
+                                                tile_y0, keys, tid & 15);
+      }
     }
-  }
-  // ---- every-tile list: lanes classify against this tile's rectangle, the wave sweeps the survivors ----
-  for (uint32_t base = (uint32_t)wave * 64u; base < n_broad; base += kTileThreads) {
-    const uint32_t j = base + (uint32_t)lane;
-    bool hit = false;
-    uint32_t ref = 0;
-    RasterTri t = {};
-    if (j < n_broad) {
-      t = broad_list[j].tri;
-      ref = broad_list[j].ref;
-      int32_t minX = min(t.X0, min(t.X1, t.X2)), maxX = max(t.X0, max(t.X1, t.X2));
-      int32_t minY = min(t.Y0, min(t.Y1, t.Y2)), maxY = max(t.Y0, max(t.Y1, t.Y2));
-      int px0 = max((minX - 128 + 255) >> 8, tile_x0), px1 = min((maxX - 128) >> 8, rx1);
-      int py0 = max((minY - 128 + 255) >> 8, tile_y0), py1 = min((maxY - 128) >> 8, ry1);
-      hit = px0 <= px1 && py0 <= py1 && classify_rect(edge_setup(t), px0, px1, py0, py1) != 0;
-    }
-    unsigned long long m = __ballot(hit);
-    while (m) {
-      int l = __builtin_amdgcn_readfirstlane(__ffsll((long long)m) - 1);
-      m &= m - 1ull;
-      uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)ref, l);
-      raster_triangle_wave<TILE_W, TILE_H>(broadcast_tri(t, l), r, tile_x0, tile_y0, fp, keys, lane);
+    // ---- class 2 and the every-tile list: one wave per large triangle ----
+    {
+      const uint32_t lo = max(base, e2);
+      for (uint32_t e = lo + (uint32_t)wave; e < hi; e += kTileWaves) {
+        const int j = __builtin_amdgcn_readfirstlane((int)(e - base));
+        if (st.box[j] == 0xFFFFFFFFu) continue;
+        const RasterTri t = staged_tri(st, j);
+        raster_triangle_wave<TILE_W, TILE_H>(t, st.ref[j], tile_x0, tile_y0, fp, keys, lane);
+      }
     }
   }
   __syncthreads();
@@ -895,11 +922,7 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
     }
   }
   __syncthreads();
-  if (tid == 0) {
-    const uint32_t n_cov = s_count;
-    frag_count[tile] = n_cov;
-    if (n_cov) atomicAdd(&ctr->n_shaded, (unsigned long long)n_cov);
-  }
+  if (tid == 0) frag_count[tile] = s_count;  // (N_shaded = sum of these, taken on the host on demand)
 }
 
 // ------------------------------------------------------------------------------------------------

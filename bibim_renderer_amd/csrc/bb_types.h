@@ -153,19 +153,21 @@ struct MaterialDesc {
   int32_t pw, ph;
 };
 
-// per-frame counters (one block per frame parity)
+// per-frame allocation counters and flags (one block per frame slot).  Statistics are NOT accumulated here:
+// same-address atomics from thousands of workgroups serialise; they travel as per-workgroup records instead.
 struct Counters {
   uint32_t n_broad;
   uint32_t n_clip_slots;
   uint32_t overflow;  // bit0 bins, bit1 broad list, bit2 clip arena
   uint32_t bin_need;  // largest per-tile reference count seen when a bin overflowed
-  unsigned long long n_raster_tris;
-  unsigned long long n_clipped_prims;
-  unsigned long long n_bin_refs;
-  unsigned long long n_shaded;
-  unsigned long long pad1[2];
+  uint32_t pad[12];
 };
 static_assert(sizeof(Counters) == 64, "Counters");
+
+// k_geometry statistics of one workgroup
+struct BlockStats {
+  uint32_t raster_tris, clipped_prims, bin_refs;
+};
 
 struct FrameParams {
   int32_t width, height;

@@ -5,9 +5,9 @@ from bibim_renderer_amd import configs, textures, Renderer
 from bibim_renderer_amd import scene as S
 cfg = configs.C3
 maps = textures.make_material(2048)
-for tile_mode in (0, 1):
+for tile_mode in (1,):
     r = Renderer(cfg.width, cfg.height)
-    r.set_option('tile_mode', tile_mode)
+    r.set_option('tile_mode', tile_mode); r.set_option('frames_in_flight', 1)
     material = r.upload_material(maps)
     scene, cam, settings = S.config_scene(r, cfg)
     S.draw_frame(r, scene, cam, settings, material); r.synchronize()
