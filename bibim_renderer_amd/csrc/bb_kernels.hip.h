@@ -52,6 +52,16 @@ BB_DEV float bb_rsqrt(float x) {
   y = y * fmaf(-(h * y), y, 1.5f);
   return y;
 }
+// Reciprocal as a fixed sequence (integer seed + three fma Newton steps, max error 0.5004 ulp): the oracle's bb_rcp.
+BB_DEV float bb_rcp(float x) {
+  const float ax = fabsf(x);
+  if (!(ax >= 1.17549435e-38f && ax <= 8.5e37f)) return 1.0f / x;
+  float r = __uint_as_float(0x7EF311C7u - __float_as_uint(ax));
+  r = fmaf(r, fmaf(-ax, r, 1.0f), r);
+  r = fmaf(r, fmaf(-ax, r, 1.0f), r);
+  r = fmaf(r, fmaf(-ax, r, 1.0f), r);
+  return copysignf(r, x);
+}
 BB_DEV f3 normalize3(f3 a) { return scale3(a, bb_rsqrt(dot3(a, a))); }
 BB_DEV float max0(float a) { return a > 0.0f ? a : 0.0f; }
 
@@ -522,12 +532,12 @@ BB_DEV float distribution_ggx(float NdotH_raw, float roughness) {
   float NdotH2 = NdotH * NdotH;
   float denom = fmaf(NdotH2, a2 - 1.0f, 1.0f);
   denom = (kPi * denom) * denom;
-  return a2 / denom;
+  return a2 * bb_rcp(denom);
 }
 
 BB_DEV float geometry_schlick_ggx(float NdotX, float k) {
   float denom = fmaf(NdotX, 1.0f - k, k);
-  return NdotX / denom;
+  return NdotX * bb_rcp(denom);
 }
 
 BB_DEV float mixf(float a, float b, float t) { return fmaf(b, t, a * (1.0f - t)); }
@@ -929,6 +939,10 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
 // k_shade: forward_brdf.frag + brdf.glsl once per visible pixel.  One lane per fragment of the compacted lists,
 // 256 consecutive fragments of one tile per workgroup: no LDS, no barriers, every wave does the same amount of
 // work, so the hardware dispatcher balances the frame by itself.
+//
+// Measured dead ends (kept out of the code, recorded in DESIGN.md): shading two fragments per lane with packed
+// FP32 (v_pk_fma_f32 issues at ~10 cycles per wave instruction on gfx950 against ~2.4 for v_fma_f32: tools/
+// microbench/pk_rate.hip), and a persistent grid walking the work items (+15 % from its batch barriers).
 // ------------------------------------------------------------------------------------------------
 template <int TILE_W, int TILE_H>
 __global__ __launch_bounds__(kTileThreads) void k_shade(
@@ -967,7 +981,7 @@ __global__ __launch_bounds__(kTileThreads) void k_shade(
     float l2 = fmaf(t.l2dx, dxp, t.l2dy * dyp);
     float l0 = (1.0f - l1) - l2;
     float u0 = l0 * t.rw0, u1 = l1 * t.rw1, u2 = l2 * t.rw2;
-    float r = 1.0f / ((u0 + u1) + u2);
+    float r = bb_rcp((u0 + u1) + u2);
     float b0 = u0 * r, b1 = u1 * r, b2 = u2 * r;
     if (clipped) {
       const ClipSlot &cs = clip_arena[slot];
@@ -1077,7 +1091,7 @@ __global__ __launch_bounds__(kTileThreads) void k_shade(
         if (light.type == 1) {
           float theta = dot3(L, normalize3(neg3(ld3(light.dir))));
           float epsilon = light.inner_cutoff - light.outer_cutoff;
-          att *= clamp01((theta - light.outer_cutoff) / epsilon);
+          att *= clamp01((theta - light.outer_cutoff) * bb_rcp(epsilon));
         }
       } else if (light.type == 2) {
         L = neg3(normalize3(ld3(light.dir)));
@@ -1097,7 +1111,7 @@ __global__ __launch_bounds__(kTileThreads) void k_shade(
                         (att * light.color[2]) * light.intensity);
       float sden = (4.0f * NdotV) * NdotL;
       if (!(sden > 0.001f)) sden = 0.001f;
-      float rden = 1.0f / sden;
+      float rden = bb_rcp(sden);
       f3 spec = mk3(((D * F.x) * G) * rden, ((D * F.y) * G) * rden, ((D * F.z) * G) * rden);
       f3 kD = mk3((1.0f - F.x) * om, (1.0f - F.y) * om, (1.0f - F.z) * om);
       Lo.x = fmaf(fmaf(kD.x * albedo.x, kInvPi, spec.x) * radiance.x, NdotL, Lo.x);

@@ -273,8 +273,7 @@ void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const Fra
     (void)hipEventRecord(s.ev_raster_done, sg);
     (void)hipStreamWaitEvent(ss, s.ev_raster_done, 0);
   }
-  // one workgroup per (tile, 256-fragment chunk); empty ones exit after one load.  (A persistent grid walking the
-  // items was measured 15 % SLOWER on MI355X: its batch barriers cost more than the empty launches it saves.)
+  // one workgroup per (tile, 256-fragment chunk); empty ones exit after one load
   constexpr int kChunks = TW * TH / kTileThreads;
   hipLaunchKernelGGL((k_shade<TW, TH>), dim3(fp.tiles_x * kChunks, grid_y), dim3(kTileThreads), 0, ss, fp, sp, d_lights,
                      s.d_tris.ptr, s.d_attrs.ptr, s.d_clip.ptr, s.d_frags.ptr, s.d_frag_count.ptr, c->d_materials.ptr, out);

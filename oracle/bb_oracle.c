@@ -24,6 +24,12 @@
  *                    unlike a hardware v_rsq_f32 or a correctly rounded 1/sqrt -- it is the same bits on CPU and
  *                    GPU at a third of the GPU instruction cost of IEEE sqrt + divide.  Arguments outside the
  *                    normal positive range fall back to 1.0f / sqrtf(x) (zero -> inf, negative -> NaN).
+ *   rcp(x)         = reciprocal as a FIXED sequence: seed 0x7EF311C7 - bits(|x|), three Newton steps
+ *                    r = fma(r, fma(-|x|, r, 1), r), sign restored.  Max error 0.5004 ulp (i.e. the correctly
+ *                    rounded result except for rare last-bit ties); |x| outside [FLT_MIN, 8.5e37] falls back to
+ *                    1.0f / x (zero -> inf, inf -> 0, NaN -> NaN).  GLSL divisions a / b of the fragment stage are
+ *                    evaluated as a * rcp(b) (GLSL allows 2.5 ulp), which is what shader compilers emit; unlike the
+ *                    IEEE divide sequence it consists of fma only, so the GPU can run it packed two pixels at a time.
  *   normalize(v)   = v * rsqrt(dot3(v,v));  length-based attenuation 1/(d*d) = rsqrt(d2)^2
  *   mat*vec        = fmaf(c3,w, fmaf(c2,z, fmaf(c1,y, c0*x)))   per row
  *   mix(a,b,t)     = fmaf(b,t, a*(1-t));  pow(x,5) = ((x*x)*(x*x))*x;  x/PI = x*(float)(1/pi)
@@ -63,6 +69,18 @@ static inline float bb_rsqrt(float x) {
   y = y * fmaf(-(h * y), y, 1.5f);
   y = y * fmaf(-(h * y), y, 1.5f);
   return y;
+}
+static inline float bb_rcp(float x) {
+  const float ax = fabsf(x);
+  if (!(ax >= 1.17549435e-38f && ax <= 8.5e37f)) return 1.0f / x;
+  union { float f; uint32_t u; } c;
+  c.f = ax;
+  c.u = 0x7EF311C7u - c.u;
+  float r = c.f;
+  r = fmaf(r, fmaf(-ax, r, 1.0f), r);
+  r = fmaf(r, fmaf(-ax, r, 1.0f), r);
+  r = fmaf(r, fmaf(-ax, r, 1.0f), r);
+  return copysignf(r, x);
 }
 static inline v3 normalize3(v3 a) { return scale3(a, bb_rsqrt(dot3(a, a))); }
 static inline float max0(float a) { return a > 0.0f ? a : 0.0f; } /* GLSL max(a,0): NaN -> 0 */
@@ -178,14 +196,14 @@ static float distribution_ggx(v3 N, v3 H, float roughness) {
   float NdotH2 = NdotH * NdotH;
   float denom = fmaf(NdotH2, a2 - 1.0f, 1.0f);
   denom = (BB_PI * denom) * denom;
-  return a2 / denom;
+  return a2 * bb_rcp(denom);
 }
 
 static float geometry_schlick_ggx(float NdotV, float roughness) {
   float r = roughness + 1.0f;
   float k = (r * r) * 0.125f;
   float denom = fmaf(NdotV, 1.0f - k, k);
-  return NdotV / denom;
+  return NdotV * bb_rcp(denom);
 }
 
 static float geometry_smith(v3 N, v3 V, v3 L, float roughness) {
@@ -265,7 +283,7 @@ static void shade_fragment(const bbo_frame_uniforms *fu, const bbo_view_uniforms
       L = scale3(Lv, inv_d);
       float theta = dot3(L, normalize3(neg3(v3_ld(light->dir))));
       float epsilon = light->inner_cutoff - light->outer_cutoff;
-      att *= clamp01((theta - light->outer_cutoff) / epsilon);
+      att *= clamp01((theta - light->outer_cutoff) * bb_rcp(epsilon));
     } else if (light->type == 2) {
       L = neg3(normalize3(v3_ld(light->dir)));
       att = 1.0f;
@@ -289,7 +307,7 @@ static void shade_fragment(const bbo_frame_uniforms *fu, const bbo_view_uniforms
     float NdotL = max0(dot3(L, N));
     float sden = (4.0f * NdotV) * NdotL;
     if (!(sden > 0.001f)) sden = 0.001f;                                        /* max(.., 0.001) */
-    float rden = 1.0f / sden;
+    float rden = bb_rcp(sden);
     v3 spec = v3_make(((D * F.x) * G) * rden, ((D * F.y) * G) * rden, ((D * F.z) * G) * rden);
     float om = 1.0f - metallic;
     v3 kD = v3_make((1.0f - F.x) * om, (1.0f - F.y) * om, (1.0f - F.z) * om);
@@ -510,7 +528,7 @@ static inline void tri_bary(const raster_tri *t, int32_t Xc, int32_t Yc, float *
   float l2 = fmaf(t->l2dx, dxp, t->l2dy * dyp);
   float l0 = (1.0f - l1) - l2;
   float u0 = l0 * t->rw[0], u1 = l1 * t->rw[1], u2 = l2 * t->rw[2];
-  float r = 1.0f / ((u0 + u1) + u2);
+  float r = bb_rcp((u0 + u1) + u2);
   float b0 = u0 * r, b1 = u1 * r, b2 = u2 * r;
   if (t->clipped) {
     for (int k = 0; k < 3; ++k) beta[k] = fmaf(b2, t->bary[2][k], fmaf(b1, t->bary[1][k], b0 * t->bary[0][k]));
