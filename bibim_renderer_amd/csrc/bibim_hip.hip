@@ -137,11 +137,11 @@ struct bbr_context {
   bool dump_vis = false;
   uint32_t ablate = 0;
   bool timing = false;
-  // timing ring: (frame start, geometry done, raster done, shade done) per frame since the last reset
+  // timing ring: (frame start, geometry done, raster done, shade start, shade done) per frame since the last reset
   std::vector<hipEvent_t> ring;
   uint32_t ring_frames = 0;
   static constexpr uint32_t kRingCap = 512;
-  static constexpr uint32_t kRingEvents = 4;
+  static constexpr uint32_t kRingEvents = 5;
   int retries = 0;
 
   hipStream_t geom_stream() const { return user_stream ? user_stream : s_geom; }
@@ -274,12 +274,17 @@ void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const Fra
     (void)hipStreamWaitEvent(ss, s.ev_raster_done, 0);
   }
   // one workgroup per (tile, 256-fragment chunk); empty ones exit after one load
+  if (ev) (void)hipEventRecord(ev[3], ss);  // completes when the shade stream has seen "raster done"
+  // Workgroup -> tile mapping is the plain launch order, i.e. round-robin over the 8 XCDs.  XCD-aware remaps were
+  // measured and rejected: contiguous eighths of the screen put the sky on some XCDs and the geometry on others
+  // (k_shade 102 -> 169 us), interleaved 2-row bands still leave a 3:2 imbalance (132 us); the L2-miss traffic they
+  // save (FETCH_SIZE -20 %) does not matter to kernels that are issue- and latency-bound, not L2-bandwidth-bound.
   constexpr int kChunks = TW * TH / kTileThreads;
   hipLaunchKernelGGL((k_shade<TW, TH>), dim3(fp.tiles_x * kChunks, grid_y), dim3(kTileThreads), 0, ss, fp, sp, d_lights,
                      s.d_tris.ptr, s.d_attrs.ptr, s.d_clip.ptr, s.d_frags.ptr, s.d_frag_count.ptr, c->d_materials.ptr, out);
   (void)hipEventRecord(s.ev_shade_done, ss);
   if (ev) {
-    (void)hipEventRecord(ev[3], ss);
+    (void)hipEventRecord(ev[4], ss);
     ++c->ring_frames;
   }
 }
@@ -860,8 +865,8 @@ int bbr_last_frame_time_ms(bbr_context *c, float *out_frame_ms, float *out_shade
   if (rc) return rc;
   const hipEvent_t *e = &c->ring[bbr_context::kRingEvents * ((c->ring_frames - 1) % bbr_context::kRingCap)];
   float a = 0.f, b = 0.f;
-  HIP_TRY(c, hipEventElapsedTime(&a, e[0], e[3]));
-  HIP_TRY(c, hipEventElapsedTime(&b, e[2], e[3]));
+  HIP_TRY(c, hipEventElapsedTime(&a, e[0], e[4]));
+  HIP_TRY(c, hipEventElapsedTime(&b, e[3], e[4]));
   if (out_frame_ms) *out_frame_ms = a;
   if (out_shade_ms) *out_shade_ms = b;
   return BBR_OK;
@@ -886,10 +891,10 @@ int bbr_timing_summary(bbr_context *c, uint32_t *out_frames, float *out_avg_fram
   for (uint32_t i = 0; i < n; ++i) {
     const hipEvent_t *e = &c->ring[bbr_context::kRingEvents * i];
     float a = 0.f, b = 0.f, d = 0.f, h = 0.f;
-    HIP_TRY(c, hipEventElapsedTime(&a, e[0], e[3]));
+    HIP_TRY(c, hipEventElapsedTime(&a, e[0], e[4]));
     HIP_TRY(c, hipEventElapsedTime(&b, e[0], e[1]));
     HIP_TRY(c, hipEventElapsedTime(&d, e[1], e[2]));
-    HIP_TRY(c, hipEventElapsedTime(&h, e[2], e[3]));
+    HIP_TRY(c, hipEventElapsedTime(&h, e[3], e[4]));
     f += a; g += b; r += d; t += h;
   }
   if (out_frames) *out_frames = n;
