@@ -265,7 +265,8 @@ BB_DEV uint32_t wave_bin_insert(bool has, uint32_t seg, uint32_t ref, const Fram
 // wave's LDS workspace.  Returns the number of valid sub-triangles.
 template <int TILE_W, int TILE_H>
 BB_DEV int clip_and_route(ClipWork &w, const float (*clip)[4], uint32_t prim, const FrameParams &fp, RasterTri *tris,
-                          ClipSlot *clip_arena, Counters *ctr, BroadTri *broad_list) {
+                          ClipSlot *clip_arena, Counters *ctr, BroadTri *broad_list, uint32_t &out_base) {
+  out_base = kNotClipped;
   for (int i = 0; i < 3; ++i) {
     ClipVert v;
     for (int k = 0; k < 4; ++k) v.c[k] = clip[i][k];
@@ -289,6 +290,7 @@ BB_DEV int clip_and_route(ClipWork &w, const float (*clip)[4], uint32_t prim, co
     atomicOr(&ctr->overflow, 4u);
     return 0;
   }
+  out_base = base;
   int n_valid = 0;
   uint32_t valid_mask = 0;
   for (int i = 1; i <= n_slots; ++i) {
@@ -344,7 +346,7 @@ BB_DEV int clip_and_route(ClipWork &w, const float (*clip)[4], uint32_t prim, co
 template <int TILE_W, int TILE_H>
 __global__ __launch_bounds__(256) void k_geometry(const DrawDesc *__restrict__ draws, uint32_t n_draws, uint32_t n_prims,
                                                   Mat4 pv, FrameParams fp, RasterTri *__restrict__ tris,
-                                                  PrimAttr *__restrict__ attrs, ClipSlot *__restrict__ clip_arena,
+                                                  ShadeRec *__restrict__ recs, ClipSlot *__restrict__ clip_arena,
                                                   Counters *__restrict__ ctr, uint32_t *__restrict__ tile_count,
                                                   uint32_t *__restrict__ bins, BroadTri *__restrict__ broad_list,
                                                   const MaterialDesc *__restrict__ materials,
@@ -356,7 +358,7 @@ __global__ __launch_bounds__(256) void k_geometry(const DrawDesc *__restrict__ d
   const uint32_t prim = blockIdx.x * blockDim.x + threadIdx.x;
   bool needs_clip = false;
   float clip[3][4];
-  PrimAttr pa;
+  ShadeRec pa;
   bool binned = false;  // this lane holds an unclipped, set-up triangle that goes to tile bins
   uint32_t cls = 0;     // raster class of the triangle: bin segment (kBinClasses per tile)
   TileRange tr = {0, -1, 0, -1};
@@ -396,7 +398,7 @@ __global__ __launch_bounds__(256) void k_geometry(const DrawDesc *__restrict__ d
       pa.material = draw.material;
       pa.packed = md.packed;
       pa.packed_dims = md.packed ? ((uint32_t)md.pw | ((uint32_t)md.ph << 16)) : 0u;
-      pa.pad[0] = pa.pad[1] = 0;
+      pa.clip_base = kNotClipped;
     }
 
     // trivial reject against the true frustum (cannot change any pixel)
@@ -420,7 +422,10 @@ __global__ __launch_bounds__(256) void k_geometry(const DrawDesc *__restrict__ d
             tile_range<TILE_W, TILE_H>(t, fp, tr)) {
           if (!(fp.ablate & 64u)) {
             tris[prim] = t;
-            attrs[prim] = pa;
+            pa.X0 = t.X0; pa.Y0 = t.Y0;
+            pa.l1dx = t.l1dx; pa.l1dy = t.l1dy; pa.l2dx = t.l2dx; pa.l2dy = t.l2dy;
+            pa.rw0 = t.rw0; pa.rw1 = t.rw1; pa.rw2 = t.rw2;
+            recs[prim] = pa;
           }
           n_raster = 1;
           uint32_t ntiles = (uint32_t)(tr.tx1 - tr.tx0 + 1) * (uint32_t)(tr.ty1 - tr.ty0 + 1);
@@ -458,8 +463,14 @@ __global__ __launch_bounds__(256) void k_geometry(const DrawDesc *__restrict__ d
     if (me == l0 || me == l1) {
       n_clipped = 1;
       ClipWork &w = s_clip[(threadIdx.x >> 6) * 2 + (me == l0 ? 0 : 1)];
-      int nv = clip_and_route<TILE_W, TILE_H>(w, clip, prim, fp, tris, clip_arena, ctr, broad_list);
-      if (nv) attrs[prim] = pa;
+      uint32_t base;
+      int nv = clip_and_route<TILE_W, TILE_H>(w, clip, prim, fp, tris, clip_arena, ctr, broad_list, base);
+      if (nv) {
+        pa.X0 = pa.Y0 = 0;
+        pa.l1dx = pa.l1dy = pa.l2dx = pa.l2dy = pa.rw0 = pa.rw1 = pa.rw2 = 0.0f;
+        pa.clip_base = base;
+        recs[prim] = pa;
+      }
       n_raster = (uint32_t)nv;
     }
   }
@@ -944,54 +955,70 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
 // FP32 (v_pk_fma_f32 issues at ~10 cycles per wave instruction on gfx950 against ~2.4 for v_fma_f32: tools/
 // microbench/pk_rate.hip), and a persistent grid walking the work items (+15 % from its batch barriers).
 // ------------------------------------------------------------------------------------------------
+#ifndef BB_SHADE_THREADS
+#define BB_SHADE_THREADS 256
+#endif
+constexpr int kShadeThreads = BB_SHADE_THREADS;
+
 template <int TILE_W, int TILE_H>
-__global__ __launch_bounds__(kTileThreads) void k_shade(
-    FrameParams fp, ShadeParams sp, const Light *__restrict__ lights, const RasterTri *__restrict__ tris,
-    const PrimAttr *__restrict__ attrs, const ClipSlot *__restrict__ clip_arena,
-    const unsigned long long *__restrict__ frags, const uint32_t *__restrict__ frag_count,
-    const MaterialDesc *__restrict__ materials, float4 *__restrict__ out) {
+__global__ __launch_bounds__(kShadeThreads) void k_shade(
+    FrameParams fp, ShadeParams sp, const Light *__restrict__ lights, const ShadeRec *__restrict__ recs,
+    const ClipSlot *__restrict__ clip_arena, const unsigned long long *__restrict__ frags,
+    const uint32_t *__restrict__ frag_count, const MaterialDesc *__restrict__ materials, float4 *__restrict__ out) {
   constexpr int TILE_PIXELS = TILE_W * TILE_H;
-  constexpr int CHUNKS = TILE_PIXELS / kTileThreads;
+  constexpr int CHUNKS = TILE_PIXELS / kShadeThreads;
   const int tx = blockIdx.x / CHUNKS, chunk = blockIdx.x - tx * CHUNKS;
   int ty, out_tile_row;
   if (!tile_row(fp, blockIdx.y, ty, out_tile_row)) return;
   const uint32_t tile = (uint32_t)ty * (uint32_t)fp.tiles_x + (uint32_t)tx;
-  const uint32_t i = (uint32_t)chunk * kTileThreads + threadIdx.x;
-  if (i >= frag_count[tile]) return;
+  const uint32_t i = (uint32_t)chunk * kShadeThreads + threadIdx.x;
+  // the fragment is fetched together with the count (entries past the count are stale but mapped memory)
   const unsigned long long frag = frags[(size_t)tile * TILE_PIXELS + i];
+  const uint32_t n_frag = frag_count[tile];
+  if ((uint32_t)chunk * kShadeThreads + (threadIdx.x & ~63u) >= n_frag) return;  // whole wave past the end
+  const bool valid = i < n_frag;
   const uint32_t ref = (uint32_t)frag;
+  const uint32_t prim = (fp.ablate & 16u) ? 0u : (ref >> 3);
   int x, y;
-  tile_pixel<TILE_W>((int)(frag >> 32), x, y);
+  tile_pixel<TILE_W>((int)(frag >> 32) & (TILE_PIXELS - 1), x, y);
   const int gx = tx * TILE_W + x, gy = ty * TILE_H + y;
   const size_t o = (size_t)(out_tile_row * TILE_H + y) * (size_t)fp.width + (size_t)gx;
   if (fp.ablate & 2u) {
-    out[o] = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (valid) out[o] = make_float4(1.f, 1.f, 1.f, 1.f);
     return;
   }
-  {
-    const uint32_t prim = ref >> 3;
-    bool clipped;
-    uint32_t slot;
-    RasterTri t = load_tri(tris, clip_arena, ref, clipped, slot);
 
+  if (!valid) return;
+  // One 224-byte record per fragment, gathered directly (neighbouring pixels share primitives, so most of these
+  // loads hit the same L1 lines).  Staging each distinct record of the wave through LDS first was measured
+  // SLOWER (112 vs 100 us): the ballot loop and the extra LDS round trip cost more than the L1 gather.
+  const ShadeRec pa = recs[prim];
+  {
     // perspective-correct barycentrics
+    const bool clipped = pa.clip_base != kNotClipped;
+    const ClipSlot *cs = clipped ? &clip_arena[pa.clip_base + (ref & 7u)] : nullptr;
+    int X0 = pa.X0, Y0 = pa.Y0;
+    float l1dx = pa.l1dx, l1dy = pa.l1dy, l2dx = pa.l2dx, l2dy = pa.l2dy, rw0 = pa.rw0, rw1 = pa.rw1, rw2 = pa.rw2;
+    if (clipped) {  // the sub-triangle's own planes
+      X0 = cs->tri.X0; Y0 = cs->tri.Y0;
+      l1dx = cs->tri.l1dx; l1dy = cs->tri.l1dy; l2dx = cs->tri.l2dx; l2dy = cs->tri.l2dy;
+      rw0 = cs->tri.rw0; rw1 = cs->tri.rw1; rw2 = cs->tri.rw2;
+    }
     int Xc = gx * 256 + 128, Yc = gy * 256 + 128;
-    float dxp = (float)(Xc - t.X0), dyp = (float)(Yc - t.Y0);
-    float l1 = fmaf(t.l1dx, dxp, t.l1dy * dyp);
-    float l2 = fmaf(t.l2dx, dxp, t.l2dy * dyp);
+    float dxp = (float)(Xc - X0), dyp = (float)(Yc - Y0);
+    float l1 = fmaf(l1dx, dxp, l1dy * dyp);
+    float l2 = fmaf(l2dx, dxp, l2dy * dyp);
     float l0 = (1.0f - l1) - l2;
-    float u0 = l0 * t.rw0, u1 = l1 * t.rw1, u2 = l2 * t.rw2;
+    float u0 = l0 * rw0, u1 = l1 * rw1, u2 = l2 * rw2;
     float r = bb_rcp((u0 + u1) + u2);
     float b0 = u0 * r, b1 = u1 * r, b2 = u2 * r;
     if (clipped) {
-      const ClipSlot &cs = clip_arena[slot];
-      float c0 = fmaf(b2, cs.bary[2][0], fmaf(b1, cs.bary[1][0], b0 * cs.bary[0][0]));
-      float c1 = fmaf(b2, cs.bary[2][1], fmaf(b1, cs.bary[1][1], b0 * cs.bary[0][1]));
-      float c2 = fmaf(b2, cs.bary[2][2], fmaf(b1, cs.bary[1][2], b0 * cs.bary[0][2]));
+      float c0 = fmaf(b2, cs->bary[2][0], fmaf(b1, cs->bary[1][0], b0 * cs->bary[0][0]));
+      float c1 = fmaf(b2, cs->bary[2][1], fmaf(b1, cs->bary[1][1], b0 * cs->bary[0][1]));
+      float c2 = fmaf(b2, cs->bary[2][2], fmaf(b1, cs->bary[1][2], b0 * cs->bary[0][2]));
       b0 = c0; b1 = c1; b2 = c2;
     }
 
-    const PrimAttr &pa = attrs[(fp.ablate & 16u) ? 0u : prim];
     float a[kNumVary];
 #pragma unroll
     for (int k = 0; k < kNumVary; ++k) a[k] = fmaf(b2, pa.vary[2][k], fmaf(b1, pa.vary[1][k], b0 * pa.vary[0][k]));

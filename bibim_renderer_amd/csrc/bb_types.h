@@ -122,15 +122,23 @@ struct PackedTexel {
   uint32_t x, y, z, w;
 };
 
-// Post-vertex-stage varyings of one primitive's three vertices + its material binding.  192 B.
-struct PrimAttr {
+// Everything k_shade needs about one primitive, in ONE 224-byte record (56 dwords): the post-vertex-stage varyings
+// of its three vertices, the screen-space barycentric planes and 1/w of the (unclipped) triangle, and its material
+// binding.  A wave fetches the record of each DISTINCT primitive among its 64 fragments once, fully coalesced, into
+// LDS (neighbouring pixels share primitives), instead of 64 lanes gathering 16 x 16 B each through the L1.
+struct ShadeRec {
   float vary[3][kNumVary];
+  int32_t X0, Y0;                // vertex 0 of the triangle, 24.8 (planes are relative to it)
+  float l1dx, l1dy, l2dx, l2dy;  // screen-space barycentric planes
+  float rw0, rw1, rw2;           // 1/w at the vertices
   uint32_t material;
-  uint32_t packed_dims;        // width | height << 16 of the packed material (0 = not packed: use the table)
-  const PackedTexel *packed;
-  uint32_t pad[2];
+  const PackedTexel *packed;     // packed material texels (nullptr: use the material table)
+  uint32_t packed_dims;          // width | height << 16, 0 = not packed
+  uint32_t clip_base;            // first clip-arena slot of a clipped primitive, kNotClipped otherwise
 };
-static_assert(sizeof(PrimAttr) == 192, "PrimAttr");
+static_assert(sizeof(ShadeRec) == 224 && offsetof(ShadeRec, packed) == 208, "ShadeRec");
+constexpr uint32_t kNotClipped = 0xFFFFFFFFu;
+constexpr int kShadeRecDwords = sizeof(ShadeRec) / 4;
 
 struct DrawDesc {
   const Vertex *vertices;

@@ -71,7 +71,7 @@ struct FrameSlot {
   size_t staging_cap = 0;
   DeviceBuffer<uint8_t> d_staging;
   DeviceBuffer<RasterTri> d_tris;
-  DeviceBuffer<PrimAttr> d_attrs;
+  DeviceBuffer<ShadeRec> d_attrs;
   DeviceBuffer<ClipSlot> d_clip;
   DeviceBuffer<Counters> d_counters;
   DeviceBuffer<BlockStats> d_block_stats;  // one record per k_geometry workgroup
@@ -279,9 +279,9 @@ void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const Fra
   // measured and rejected: contiguous eighths of the screen put the sky on some XCDs and the geometry on others
   // (k_shade 102 -> 169 us), interleaved 2-row bands still leave a 3:2 imbalance (132 us); the L2-miss traffic they
   // save (FETCH_SIZE -20 %) does not matter to kernels that are issue- and latency-bound, not L2-bandwidth-bound.
-  constexpr int kChunks = TW * TH / kTileThreads;
-  hipLaunchKernelGGL((k_shade<TW, TH>), dim3(fp.tiles_x * kChunks, grid_y), dim3(kTileThreads), 0, ss, fp, sp, d_lights,
-                     s.d_tris.ptr, s.d_attrs.ptr, s.d_clip.ptr, s.d_frags.ptr, s.d_frag_count.ptr, c->d_materials.ptr, out);
+  constexpr int kChunks = TW * TH / kShadeThreads;
+  hipLaunchKernelGGL((k_shade<TW, TH>), dim3(fp.tiles_x * kChunks, grid_y), dim3(kShadeThreads), 0, ss, fp, sp, d_lights,
+                     s.d_attrs.ptr, s.d_clip.ptr, s.d_frags.ptr, s.d_frag_count.ptr, c->d_materials.ptr, out);
   (void)hipEventRecord(s.ev_shade_done, ss);
   if (ev) {
     (void)hipEventRecord(ev[4], ss);

@@ -3,6 +3,7 @@
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -23,6 +24,7 @@ class Renderer:
         if rc != 0:
             raise BibimError(rc, (self._L.bbr_last_error(None) or b"").decode())
         self.width, self.height = int(width), int(height)
+        self._scenes = weakref.WeakSet()  # host-shim scenes hold meshes of this context: they must go first
 
     # -- plumbing --
     def _check(self, rc):
@@ -31,6 +33,8 @@ class Renderer:
 
     def close(self):
         if self._ctx:
+            for sc in list(self._scenes):
+                sc.close()
             self._L.bbr_destroy(self._ctx)
             self._ctx = C.c_void_p()
 

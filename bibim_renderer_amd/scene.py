@@ -62,6 +62,8 @@ class _Scene:
             raise BibimError(-1, "scene creation failed")
         self._h = C.c_void_p(handle)
         self._r = renderer  # keeps the context alive
+        if renderer is not None:
+            renderer._scenes.add(self)  # the renderer closes its scenes before destroying the context
 
     def close(self):
         if self._h:

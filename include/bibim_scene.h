@@ -193,6 +193,7 @@ extern "C" {
 #endif /* __cplusplus */
 
 /* ---- C surface over the shim (used by the Python harness and by non-C++ hosts) ---- */
+/* A scene owns meshes of the context it was created on: destroy scenes BEFORE bbr_destroy(ctx). */
 typedef struct bbs_scene bbs_scene;
 
 void bbs_mat4_mul(const float *a, const float *b, float *out);
