@@ -104,37 +104,56 @@ constexpr int kMaxClipVerts = 12;
 
 // Per-wave LDS workspace of the polygon clipper.  The clipper indexes its vertex arrays dynamically; in
 // registers that would spill to scratch (and a kernel that owns scratch pays for it on every launch), in LDS
-// it is a plain ds_read/ds_write.  Clipped primitives are rare, so the lanes of a wave that need the clipper
-// take turns on the one workspace.
+// it is a plain ds_read/ds_write.  Clipped primitives are rare; the wave clips them one after the other,
+// all lanes working on the same polygon.
 struct ClipWork {
-  ClipVert poly[kMaxClipVerts];
-  ClipVert tmp[kMaxClipVerts];
+  ClipVert poly[2][kMaxClipVerts];  // ping-pong
   int32_t X[kMaxClipVerts], Y[kMaxClipVerts];
   float rw[kMaxClipVerts], z[kMaxClipVerts];
+  uint32_t prim, base;  // primitive being clipped, its first clip-arena slot
+  int32_t n_slots;      // fan triangles of the clipped polygon (0: nothing survived)
+  int32_t n_valid;      // of which front-facing and covering a pixel centre
 };
 
-// Sutherland-Hodgman against near, far and the four guard-band planes; w.poly holds n vertices on entry.
-BB_DEV int clip_polygon(ClipWork &w, int n) {
+// Wave-parallel Sutherland-Hodgman against near, far and the four guard-band planes: lane i owns edge
+// (v_i, v_i+1), emits 0, 1 or 2 vertices, and a ballot/popcount prefix gives every lane its output position -- the
+// same vertices in the same order as the serial algorithm, in six steps instead of six loops over the polygon.
+// The input polygon (n vertices) is in w.poly[0]; returns the buffer index holding the result and its size.
+BB_DEV int clip_polygon_wave(ClipWork &w, int &n) {
+  const int lane = threadIdx.x & 63;
+  int cur = 0;
   for (int plane = 0; plane < 6; ++plane) {
-    int m = 0;
-    for (int i = 0; i < n; ++i) {
-      const ClipVert a = w.poly[i];
-      const ClipVert b = w.poly[i + 1 == n ? 0 : i + 1];
-      float da = plane_dist(a.c, plane), db = plane_dist(b.c, plane);
-      bool ina = da >= 0.0f, inb = db >= 0.0f;
-      if (ina) w.tmp[m++] = a;
-      if (ina != inb) {
-        ClipVert r;
-        if (ina) clip_lerp(a, da, b, db, r);
-        else clip_lerp(b, db, a, da, r);
-        w.tmp[m++] = r;
-      }
+    bool ina = false, cross = false;
+    ClipVert a, b;
+    float da = 0.0f, db = 0.0f;
+    if (lane < n) {
+      a = w.poly[cur][lane];
+      b = w.poly[cur][lane + 1 == n ? 0 : lane + 1];
+      da = plane_dist(a.c, plane);
+      db = plane_dist(b.c, plane);
+      ina = da >= 0.0f;
+      cross = ina != (db >= 0.0f);
     }
-    n = m;
-    if (n < 3) return 0;
-    for (int i = 0; i < n; ++i) w.poly[i] = w.tmp[i];
+    const unsigned long long ma = __ballot(ina), mx = __ballot(cross);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int pos = (int)__popcll(ma & lt) + (int)__popcll(mx & lt);
+    __builtin_amdgcn_wave_barrier();
+    if (ina) w.poly[cur ^ 1][pos++] = a;
+    if (cross) {
+      ClipVert r;
+      if (ina) clip_lerp(a, da, b, db, r);
+      else clip_lerp(b, db, a, da, r);
+      w.poly[cur ^ 1][pos] = r;
+    }
+    __builtin_amdgcn_wave_barrier();
+    n = (int)__popcll(ma) + (int)__popcll(mx);
+    cur ^= 1;
+    if (n < 3) {
+      n = 0;
+      break;
+    }
   }
-  return n;
+  return cur;
 }
 
 BB_DEV bool project_vertex(const float *c, float half_w, float half_h, int32_t &X, int32_t &Y, float &rw,
@@ -226,30 +245,43 @@ BB_DEV void broad_insert(const RasterTri &t, uint32_t ref, const FrameParams &fp
 // same instruction, so a wave pays one memory round trip however many tiles it touches, and a tile that
 // receives thousands of tiny triangles sees tens of atomics instead of thousands.
 // Must be called by all lanes of the wave (has = false for lanes with nothing to insert).
-BB_DEV uint32_t wave_bin_insert(bool has, uint32_t seg, uint32_t ref, const FrameParams &fp, Counters *ctr,
-                                uint32_t *tile_count, uint32_t *bins) {
+// The reservation is split from the write so that a caller with several insertions per lane can issue all their
+// atomics before waiting for the first result (one memory round trip for the batch instead of one per insertion).
+struct BinTicket {
+  uint32_t base;   // valid in the group's leader lane until redeemed
+  uint32_t rank;
+  int leader;
+};
+
+BB_DEV BinTicket wave_bin_reserve(bool has, uint32_t seg, uint32_t *tile_count) {
   const int lane = threadIdx.x & 63;
   unsigned long long pending = __ballot(has);
-  const uint32_t inserted = (uint32_t)__popcll(pending);
-  int leader = lane;
-  uint32_t rank = 0, gsize = 0;
+  BinTicket t;
+  t.leader = lane;
+  t.rank = 0;
+  t.base = 0;
+  uint32_t gsize = 0;
   while (pending) {
     int l = __builtin_amdgcn_readfirstlane(__ffsll((long long)pending) - 1);
     uint32_t ls = (uint32_t)__builtin_amdgcn_readlane((int)seg, l);
     bool mine = has && seg == ls;
     unsigned long long m = __ballot(mine);
     if (mine) {
-      leader = l;
-      rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+      t.leader = l;
+      t.rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
       gsize = (uint32_t)__popcll(m);
     }
     pending &= ~m;
   }
-  uint32_t base = 0;
-  if (has && lane == leader) base = atomicAdd(&tile_count[seg], gsize);
-  base = (uint32_t)__shfl((int)base, leader);
+  if (has && lane == t.leader) t.base = atomicAdd(&tile_count[seg], gsize);
+  return t;
+}
+
+BB_DEV void wave_bin_write(bool has, uint32_t seg, uint32_t ref, const BinTicket &t, const FrameParams &fp, Counters *ctr,
+                           uint32_t *bins) {
+  const uint32_t base = (uint32_t)__shfl((int)t.base, t.leader);
   if (has) {
-    uint32_t slot = base + rank;
+    uint32_t slot = base + t.rank;
     if (slot < fp.bin_cap) {
       bins[(size_t)seg * fp.bin_cap + slot] = ref;
     } else {
@@ -257,89 +289,97 @@ BB_DEV uint32_t wave_bin_insert(bool has, uint32_t seg, uint32_t ref, const Fram
       atomicMax(&ctr->bin_need, slot + 1u);
     }
   }
-  return inserted;
 }
 
-// Rare path: the primitive crosses a clip plane.  Sub-triangles always go to the every-tile list (one atomic
-// for all of them) -- a clipped primitive is typically huge (the ground plane).  Runs on ONE lane with the
-// wave's LDS workspace.  Returns the number of valid sub-triangles.
+// Rare path: the primitive of lane `owner` crosses a clip plane.  The whole wave works on it: parallel polygon
+// clip, lane i projects vertex i and then sets up fan triangle i (binary64 planes), stores its ClipSlot and its
+// entry of the every-tile list -- a clipped primitive is typically huge (the ground plane), so its sub-triangles skip
+// the bins.  One atomic reserves the arena slots, one the list entries.  Results in w.n_valid / w.base.
 template <int TILE_W, int TILE_H>
-BB_DEV int clip_and_route(ClipWork &w, const float (*clip)[4], uint32_t prim, const FrameParams &fp, RasterTri *tris,
-                          ClipSlot *clip_arena, Counters *ctr, BroadTri *broad_list, uint32_t &out_base) {
-  out_base = kNotClipped;
-  for (int i = 0; i < 3; ++i) {
-    ClipVert v;
-    for (int k = 0; k < 4; ++k) v.c[k] = clip[i][k];
-    v.b[0] = i == 0 ? 1.0f : 0.0f;
-    v.b[1] = i == 1 ? 1.0f : 0.0f;
-    v.b[2] = i == 2 ? 1.0f : 0.0f;
-    w.poly[i] = v;
+BB_DEV void clip_primitive_wave(ClipWork &w, int owner, const float (*clip)[4], uint32_t prim, const FrameParams &fp,
+                                ClipSlot *clip_arena, Counters *ctr, BroadTri *broad_list) {
+  const int lane = threadIdx.x & 63;
+  if (lane == owner) {
+    w.prim = prim;
+    w.n_slots = 0;
+    w.n_valid = 0;
+    w.base = kNotClipped;
+    for (int i = 0; i < 3; ++i) {
+      ClipVert v;
+      for (int k = 0; k < 4; ++k) v.c[k] = clip[i][k];
+      v.b[0] = i == 0 ? 1.0f : 0.0f;
+      v.b[1] = i == 1 ? 1.0f : 0.0f;
+      v.b[2] = i == 2 ? 1.0f : 0.0f;
+      w.poly[0][i] = v;
+    }
   }
-  int n = clip_polygon(w, 3);
-  if (n < 3) return 0;
-  for (int i = 0; i < n; ++i) {
-    const ClipVert v = w.poly[i];
-    int32_t X, Y;
-    float rw, z;
-    if (!project_vertex(v.c, fp.half_w, fp.half_h, X, Y, rw, z)) return 0;
-    w.X[i] = X; w.Y[i] = Y; w.rw[i] = rw; w.z[i] = z;
+  __builtin_amdgcn_wave_barrier();
+  int n = 3;
+  const int cur = clip_polygon_wave(w, n);
+  if (n < 3) return;
+  // projection: lane i -> vertex i
+  bool bad = false;
+  if (lane < n) {
+    const ClipVert v = w.poly[cur][lane];
+    int32_t X = 0, Y = 0;
+    float rw = 0.0f, z = 0.0f;
+    bad = !project_vertex(v.c, fp.half_w, fp.half_h, X, Y, rw, z);
+    w.X[lane] = X; w.Y[lane] = Y; w.rw[lane] = rw; w.z[lane] = z;
   }
-  int n_slots = min(n - 2, kMaxSubTris);
-  uint32_t base = atomicAdd(&ctr->n_clip_slots, (uint32_t)n_slots);
-  if (base + n_slots > fp.clip_cap) {
-    atomicOr(&ctr->overflow, 4u);
-    return 0;
+  if (__ballot(bad) != 0ull) return;
+  const int n_slots = min(n - 2, kMaxSubTris);
+  uint32_t base = 0;
+  if (lane == 0) base = atomicAdd(&ctr->n_clip_slots, (uint32_t)n_slots);
+  base = (uint32_t)__shfl((int)base, 0);
+  if (base + (uint32_t)n_slots > fp.clip_cap) {
+    if (lane == 0) atomicOr(&ctr->overflow, 4u);
+    return;
   }
-  out_base = base;
-  int n_valid = 0;
-  uint32_t valid_mask = 0;
-  for (int i = 1; i <= n_slots; ++i) {
-    ClipSlot s;
+  __builtin_amdgcn_wave_barrier();
+  // fan triangle i = (v0, v_i, v_i+1): lane i - 1
+  bool ok = false;
+  ClipSlot s;
+  if (lane < n_slots) {
+    const int i = lane + 1;
     s.tri.X0 = w.X[0]; s.tri.Y0 = w.Y[0];
     s.tri.X1 = w.X[i]; s.tri.Y1 = w.Y[i];
     s.tri.X2 = w.X[i + 1]; s.tri.Y2 = w.Y[i + 1];
     s.tri.rw0 = w.rw[0]; s.tri.rw1 = w.rw[i]; s.tri.rw2 = w.rw[i + 1];
-    const ClipVert v0 = w.poly[0], v1 = w.poly[i], v2 = w.poly[i + 1];
+    const ClipVert v0 = w.poly[cur][0], v1 = w.poly[cur][i], v2 = w.poly[cur][i + 1];
     for (int c = 0; c < 3; ++c) {
       s.bary[0][c] = v0.b[c];
       s.bary[1][c] = v1.b[c];
       s.bary[2][c] = v2.b[c];
     }
     s.pad[0] = s.pad[1] = 0;
-    bool ok = setup_tri(s.tri, w.z[0], w.z[i], w.z[i + 1]);
+    ok = setup_tri(s.tri, w.z[0], w.z[i], w.z[i + 1]);
     TileRange tr;
     ok = ok && tile_range<TILE_W, TILE_H>(s.tri, fp, tr);
     s.valid = ok ? 1u : 0u;
-    clip_arena[base + i - 1] = s;
+    clip_arena[base + (uint32_t)lane] = s;
+  }
+  const unsigned long long m = __ballot(ok);
+  const int n_valid = (int)__popcll(m);
+  if (lane == owner) {
+    w.base = base;
+    w.n_slots = n_slots;
+  }
+  if (n_valid == 0) return;
+  uint32_t slot = 0;
+  if (lane == 0) slot = atomicAdd(&ctr->n_broad, (uint32_t)n_valid);
+  slot = (uint32_t)__shfl((int)slot, 0);
+  if (slot + (uint32_t)n_valid <= fp.broad_cap) {
     if (ok) {
-      ++n_valid;
-      valid_mask |= 1u << (i - 1);
+      BroadTri b;
+      b.tri = s.tri;
+      b.ref = (w.prim << 3) | (uint32_t)lane;  // the OWNER's primitive (prim is per lane)
+      b.pad[0] = b.pad[1] = b.pad[2] = 0;
+      broad_list[slot + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = b;
     }
+    if (lane == owner) w.n_valid = n_valid;
+  } else if (lane == 0) {
+    atomicOr(&ctr->overflow, 2u);
   }
-  if (n_valid) {
-    uint32_t slot = atomicAdd(&ctr->n_broad, (uint32_t)n_valid);
-    if (slot + n_valid <= fp.broad_cap) {
-      for (int i = 0; i < n_slots; ++i)
-        if (valid_mask & (1u << i)) {
-          BroadTri b;
-          b.tri = clip_arena[base + i].tri;
-          b.ref = (prim << 3) | (uint32_t)i;
-          b.pad[0] = b.pad[1] = b.pad[2] = 0;
-          broad_list[slot++] = b;
-        }
-    } else {
-      atomicOr(&ctr->overflow, 2u);
-    }
-  }
-  RasterTri head;
-  head.X0 = kClippedSentinel;
-  head.Y0 = (int32_t)base;
-  head.X1 = n_slots;
-  head.Y1 = head.X2 = head.Y2 = 0;
-  head.z0 = head.dzdx = head.dzdy = head.l1dx = head.l1dy = head.l2dx = head.l2dy = 0.0f;
-  head.rw0 = head.rw1 = head.rw2 = 0.0f;
-  tris[prim] = head;
-  return n_valid;
 }
 
 // One thread per primitive, all draw calls of the frame in one launch (API order = primitive index order).
@@ -350,9 +390,19 @@ __global__ __launch_bounds__(256) void k_geometry(const DrawDesc *__restrict__ d
                                                   Counters *__restrict__ ctr, uint32_t *__restrict__ tile_count,
                                                   uint32_t *__restrict__ bins, BroadTri *__restrict__ broad_list,
                                                   const MaterialDesc *__restrict__ materials,
-                                                  BlockStats *__restrict__ block_stats) {
+                                                  BlockStats *__restrict__ block_stats,
+                                                  Counters *__restrict__ ctr_next) {
+#ifdef BB_STAMPS
+#define BB_STAMP(i) do { if (threadIdx.x == 0) reinterpret_cast<unsigned long long *>(clip_arena + fp.clip_cap)[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define BB_STAMP(i) do { } while (0)
+#endif
+  BB_STAMP(0);
   __shared__ BlockStats bs;
-  __shared__ ClipWork s_clip[8];  // two per wave
+  // the NEXT frame's counter block is cleared here (three blocks rotate; the one cleared now is idle: its previous
+  // frame left the GPU before this one was submitted) -- saves a memset node per frame
+  if (blockIdx.x == 0 && threadIdx.x < sizeof(Counters) / 4) reinterpret_cast<uint32_t *>(ctr_next)[threadIdx.x] = 0u;
+  __shared__ ClipWork s_clip[4];  // one per wave
   if (threadIdx.x == 0) bs = BlockStats{0u, 0u, 0u};
   __syncthreads();
   const uint32_t prim = blockIdx.x * blockDim.x + threadIdx.x;
@@ -371,6 +421,7 @@ __global__ __launch_bounds__(256) void k_geometry(const DrawDesc *__restrict__ d
     const uint32_t inst = local / draw.tris_per_instance;
     const uint32_t tri = local - inst * draw.tris_per_instance;
 
+    BB_STAMP(1);
     const InstanceBlock &ib = draw.instances[inst];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -438,42 +489,58 @@ __global__ __launch_bounds__(256) void k_geometry(const DrawDesc *__restrict__ d
       }
     }
   }
-  // ---- tile bins: walk each lane's tile range in lock-step, aggregating per tile across the wave ----
+  BB_STAMP(2);
+  // ---- tile bins: walk each lane's tile range in lock-step, aggregating per tile across the wave; four insertions
+  // per lane are reserved back to back, so their returning atomics share one memory round trip ----
   uint32_t refs = 0;
   {
     const int tw = binned ? tr.tx1 - tr.tx0 + 1 : 0;
     const int nt = (binned && !(fp.ablate & 32u)) ? tw * (tr.ty1 - tr.ty0 + 1) : 0;
-    for (int k = 0; __ballot(k < nt) != 0ull; ++k) {
-      bool has = k < nt;
-      int ty = has ? tr.ty0 + k / tw : 0, tx = has ? tr.tx0 + k % tw : 0;
-      if (has && fp.world > 1 && ((ty / fp.band_tiles) % fp.world) != fp.rank) has = false;  // another rank's band
-      uint32_t seg = ((uint32_t)ty * (uint32_t)fp.tiles_x + (uint32_t)tx) * kBinClasses + cls;
-      uint32_t n = wave_bin_insert(has, seg, prim << 3, fp, ctr, tile_count, bins);
-      refs += n;
+    for (int k0 = 0; __ballot(k0 < nt) != 0ull; k0 += 4) {
+      bool has[4];
+      uint32_t seg[4];
+      BinTicket tk[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = k0 + j;
+        has[j] = k < nt;
+        const int ty = has[j] ? tr.ty0 + k / tw : 0, tx = has[j] ? tr.tx0 + k % tw : 0;
+        if (has[j] && fp.world > 1 && ((ty / fp.band_tiles) % fp.world) != fp.rank) has[j] = false;  // another rank's band
+        seg[j] = ((uint32_t)ty * (uint32_t)fp.tiles_x + (uint32_t)tx) * kBinClasses + cls;
+        tk[j] = wave_bin_reserve(has[j], seg[j], tile_count);
+        refs += (uint32_t)__popcll(__ballot(has[j]));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wave_bin_write(has[j], seg[j], prim << 3, tk[j], fp, ctr, bins);
     }
   }
-  // ---- clipper (after the bins, so the other lanes' insertions never wait for it): lanes that need it take
-  // turns, two at a time, on the wave's LDS workspaces ----
-  for (unsigned long long cm = __ballot(needs_clip); cm;) {
-    const int l0 = __ffsll((long long)cm) - 1;
-    cm &= cm - 1ull;
-    const int l1 = cm ? __ffsll((long long)cm) - 1 : -1;
-    if (cm) cm &= cm - 1ull;
-    const int me = (int)(threadIdx.x & 63);
-    if (me == l0 || me == l1) {
+  BB_STAMP(3);
+  // ---- clipper (after the bins, so the other lanes' insertions never wait for it): the wave clips its clipped
+  // primitives one after the other, all lanes on the same polygon ----
+  for (unsigned long long cm = __ballot(needs_clip); cm; cm &= cm - 1ull) {
+    const int owner = __builtin_amdgcn_readfirstlane(__ffsll((long long)cm) - 1);
+    ClipWork &w = s_clip[threadIdx.x >> 6];
+    // the owner's clip-space vertices and primitive index are the wave's input
+    float cv[3][4];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) cv[i][k] = clip[i][k];
+    clip_primitive_wave<TILE_W, TILE_H>(w, owner, cv, prim, fp, clip_arena, ctr, broad_list);
+    __builtin_amdgcn_wave_barrier();
+    if ((int)(threadIdx.x & 63) == owner) {
       n_clipped = 1;
-      ClipWork &w = s_clip[(threadIdx.x >> 6) * 2 + (me == l0 ? 0 : 1)];
-      uint32_t base;
-      int nv = clip_and_route<TILE_W, TILE_H>(w, clip, prim, fp, tris, clip_arena, ctr, broad_list, base);
-      if (nv) {
+      n_raster = (uint32_t)w.n_valid;
+      if (w.n_valid) {
         pa.X0 = pa.Y0 = 0;
         pa.l1dx = pa.l1dy = pa.l2dx = pa.l2dy = pa.rw0 = pa.rw1 = pa.rw2 = 0.0f;
-        pa.clip_base = base;
+        pa.clip_base = w.base;
         recs[prim] = pa;
       }
-      n_raster = (uint32_t)nv;
     }
+    __builtin_amdgcn_wave_barrier();
   }
+  BB_STAMP(4);
   if ((threadIdx.x & 63) == 0 && refs) atomicAdd(&bs.bin_refs, refs);
   if (n_raster) atomicAdd(&bs.raster_tris, n_raster);
   if (n_clipped) atomicAdd(&bs.clipped_prims, n_clipped);
@@ -481,6 +548,7 @@ __global__ __launch_bounds__(256) void k_geometry(const DrawDesc *__restrict__ d
   // statistics leave the kernel as one record per workgroup (summed on the host on demand): a few thousand
   // atomics on ONE counter word would serialise at ~90 per microsecond and dominate this kernel
   if (threadIdx.x == 0) block_stats[blockIdx.x] = bs;
+  BB_STAMP(5);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -563,19 +631,6 @@ struct ShadeParams {
   int32_t enable_normal_map;
   int32_t num_lights;
 };
-
-BB_DEV RasterTri load_tri(const RasterTri *__restrict__ tris, const ClipSlot *__restrict__ clip_arena, uint32_t ref,
-                          bool &clipped, uint32_t &slot_index) {
-  uint32_t prim = ref >> 3, sub = ref & 7u;
-  RasterTri t = tris[prim];
-  clipped = (t.X0 == kClippedSentinel);
-  slot_index = 0;
-  if (clipped) {
-    slot_index = (uint32_t)t.Y0 + sub;
-    t = clip_arena[slot_index].tri;
-  }
-  return t;
-}
 
 // pixel index inside the tile, 8x8-blocked so that 64 consecutive indices form one 8x8 pixel block
 template <int TILE_W>

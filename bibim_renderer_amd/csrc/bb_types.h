@@ -82,11 +82,9 @@ constexpr int kNumVary = 14;  // uv(2) posWorld(3) N(3) T(3) B(3)
 constexpr int kSubpixelBits = 8;
 constexpr int kMaxSubTris = 8;  // visibility key low word = prim*8 + sub + 1
 constexpr uint32_t kMaxPrims = 1u << 29;
-constexpr int32_t kClippedSentinel = INT32_MIN;
 
 // One rasterisable triangle: 24.8 snapped coordinates + planes relative to vertex 0.  64 B.
-// When X0 == kClippedSentinel the primitive went through the clipper: Y0 = first clip-arena slot,
-// X1 = number of slots.
+// (tris[prim] is written for unclipped survivors only; sub-triangles of clipped primitives live in the clip arena.)
 struct RasterTri {
   int32_t X0, Y0, X1, Y1, X2, Y2;
   float z0, dzdx, dzdy;          // NDC depth plane, per sub-pixel unit

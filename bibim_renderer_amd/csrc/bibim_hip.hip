@@ -73,7 +73,7 @@ struct FrameSlot {
   DeviceBuffer<RasterTri> d_tris;
   DeviceBuffer<ShadeRec> d_attrs;
   DeviceBuffer<ClipSlot> d_clip;
-  DeviceBuffer<Counters> d_counters;
+  int ctr_index = 0;                        // which of the context's three counter blocks this slot's frame used
   DeviceBuffer<BlockStats> d_block_stats;  // one record per k_geometry workgroup
   DeviceBuffer<uint32_t> d_tile_count;
   DeviceBuffer<uint32_t> d_bins;
@@ -90,7 +90,7 @@ struct FrameSlot {
     d_tile_count.release(); d_bins.release(); d_frags.release(); d_frag_count.release();
   }
   void release_all() {
-    d_staging.release(); d_tris.release(); d_attrs.release(); d_clip.release(); d_counters.release();
+    d_staging.release(); d_tris.release(); d_attrs.release(); d_clip.release();
     d_block_stats.release();
     release_tile_buffers(); d_broad.release(); d_frame.release();
     if (h_staging) (void)hipHostFree(h_staging);
@@ -122,6 +122,8 @@ struct bbr_context {
   uint32_t n_live_draws = 0;
 
   FrameSlot slots[2];
+  DeviceBuffer<Counters> d_counters;  // three blocks in rotation: each k_geometry clears the next frame's block
+  uint64_t submit_epoch = 0;
   int frames_in_flight = 2;
   uint64_t frame_counter = 0;
   int last_slot = -1;
@@ -218,8 +220,12 @@ int ensure_slot_buffers(bbr_context *c, FrameSlot &s) {
   size_t out_rows = (size_t)std::max(c->height, c->shard_rows());
   HIP_TRY(c, s.d_tris.ensure(std::max<size_t>(c->n_prims, 1)));
   HIP_TRY(c, s.d_attrs.ensure(std::max<size_t>(c->n_prims, 1)));
+#ifdef BB_STAMPS
+  HIP_TRY(c, s.d_clip.ensure(c->clip_cap + 8192));  // diagnostic build: room for per-workgroup time stamps
+#else
   HIP_TRY(c, s.d_clip.ensure(c->clip_cap));
-  HIP_TRY(c, s.d_counters.ensure(1, true));
+#endif
+  HIP_TRY(c, c->d_counters.ensure(3, true));
   HIP_TRY(c, s.d_block_stats.ensure(std::max<size_t>((c->n_prims + 255) / 256, 1), true));
   HIP_TRY(c, s.d_tile_count.ensure(tiles * kBinClasses, true));
   HIP_TRY(c, s.d_bins.ensure(tiles * kBinClasses * c->bin_cap));
@@ -253,11 +259,14 @@ template <int TW, int TH>
 void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const FrameParams &fp, const Mat4 &pv,
                   const ShadeParams &sp, const Light *d_lights, const DrawDesc *d_draws, uint32_t n_draws, float4 *out) {
   hipStream_t sg = c->geom_stream(), ss = c->shade_stream();
+  Counters *ctr = c->d_counters.ptr + s.ctr_index, *ctr_next = c->d_counters.ptr + (s.ctr_index + 1) % 3;
   hipEvent_t *ev = c->timing ? &c->ring[bbr_context::kRingEvents * (c->ring_frames % bbr_context::kRingCap)] : nullptr;
   if (c->n_prims)
     hipLaunchKernelGGL((k_geometry<TW, TH>), dim3((c->n_prims + 255) / 256), dim3(256), 0, sg, d_draws, n_draws,
-                       c->n_prims, pv, fp, s.d_tris.ptr, s.d_attrs.ptr, s.d_clip.ptr, s.d_counters.ptr, s.d_tile_count.ptr,
-                       s.d_bins.ptr, s.d_broad.ptr, c->d_materials.ptr, s.d_block_stats.ptr);
+                       c->n_prims, pv, fp, s.d_tris.ptr, s.d_attrs.ptr, s.d_clip.ptr, ctr, s.d_tile_count.ptr,
+                       s.d_bins.ptr, s.d_broad.ptr, c->d_materials.ptr, s.d_block_stats.ptr, ctr_next);
+  else
+    (void)hipMemsetAsync(ctr_next, 0, sizeof(Counters), sg);
   if (ev) (void)hipEventRecord(ev[1], sg);
   // k_raster writes the background pixels of `out`: if the frame still shading on the other stream writes the
   // same buffer (single external output), raster has to wait for it; geometry above still overlapped
@@ -265,7 +274,7 @@ void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const Fra
   // a rank without bands (more ranks than bands) still launches one row: its blocks fall off tiles_y and exit
   int grid_y = std::max(1, c->world > 1 ? c->local_bands() * fp.band_tiles : fp.tiles_y);
   hipLaunchKernelGGL((k_raster<TW, TH>), dim3(fp.tiles_x, grid_y), dim3(kTileThreads), 0, sg, fp, s.d_tris.ptr,
-                     s.d_clip.ptr, s.d_counters.ptr, s.d_tile_count.ptr, s.d_bins.ptr, s.d_broad.ptr, s.d_frags.ptr,
+                     s.d_clip.ptr, ctr, s.d_tile_count.ptr, s.d_bins.ptr, s.d_broad.ptr, s.d_frags.ptr,
                      s.d_frag_count.ptr, out, c->dump_vis ? c->d_vis_prim.ptr : nullptr,
                      c->dump_vis ? c->d_vis_depth.ptr : nullptr);
   if (ev) (void)hipEventRecord(ev[2], sg);
@@ -347,7 +356,7 @@ int submit_frame_into(bbr_context *c, int slot_index) {
     }
     HIP_TRY(c, hipEventRecord(c->ring[bbr_context::kRingEvents * (c->ring_frames % bbr_context::kRingCap)], sg));
   }
-  HIP_TRY(c, hipMemsetAsync(s.d_counters.ptr, 0, sizeof(Counters), sg));
+  s.ctr_index = (int)(c->submit_epoch++ % 3);
   HIP_TRY(c, hipMemcpyAsync(s.d_staging.ptr, s.h_staging, total, hipMemcpyHostToDevice, sg));
 
   const Light *d_lights = reinterpret_cast<const Light *>(s.d_staging.ptr);
@@ -384,8 +393,8 @@ int sync_and_fix(bbr_context *c, Counters *out_counters) {
     int rc = drain(c);
     if (rc) return rc;
     Counters h = {};
-    if (c->have_frame && c->last_slot >= 0 && c->slots[c->last_slot].d_counters.ptr)
-      HIP_TRY(c, hipMemcpy(&h, c->slots[c->last_slot].d_counters.ptr, sizeof h, hipMemcpyDeviceToHost));
+    if (c->have_frame && c->last_slot >= 0 && c->d_counters.ptr)
+      HIP_TRY(c, hipMemcpy(&h, c->d_counters.ptr + c->slots[c->last_slot].ctr_index, sizeof h, hipMemcpyDeviceToHost));
     if (out_counters) *out_counters = h;
     if (!h.overflow) return BBR_OK;
     if (h.overflow & 1u) {
@@ -482,6 +491,7 @@ int bbr_destroy(bbr_context *c) {
   }
   if (c->d_default_texels) (void)hipFree(c->d_default_texels);
   c->d_materials.release();
+  c->d_counters.release();
   c->d_vis_prim.release();
   c->d_vis_depth.release();
   for (FrameSlot &s : c->slots) {
@@ -937,6 +947,17 @@ int bbr_set_option(bbr_context *c, const char *name, int64_t value) {
   }
   return BBR_OK;
 }
+
+#ifdef BB_STAMPS
+// diagnostic build only: copy out the k_geometry time stamps of the last frame (8 x u64 per workgroup)
+int bbr_debug_stamps(bbr_context *c, unsigned long long *out, uint32_t n_blocks) {
+  if (!c || c->last_slot < 0) return BBR_ERR_INVALID_ARGUMENT;
+  int rc = drain(c);
+  if (rc) return rc;
+  HIP_TRY(c, hipMemcpy(out, c->slots[c->last_slot].d_clip.ptr + c->clip_cap, (size_t)n_blocks * 64, hipMemcpyDeviceToHost));
+  return BBR_OK;
+}
+#endif
 
 int bbr_tone_map(bbr_context *c, int32_t enable, float exposure) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
