@@ -875,6 +875,12 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
   const bool live = tile_row(fp, blockIdx.y, ty, out_tile_row);
   if (!live) return;
   const uint32_t tile = (uint32_t)ty * (uint32_t)fp.tiles_x + (uint32_t)tx;
+#ifdef BB_STAMPS
+#define BB_RSTAMP(i) do { if (tid == 0) reinterpret_cast<unsigned long long *>(frag_count + fp.tiles_x * fp.tiles_y)[tile * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define BB_RSTAMP(i) do { } while (0)
+#endif
+  BB_RSTAMP(0);
   const int tile_x0 = tx * TILE_W, tile_y0 = ty * TILE_H;
   const int out_y0 = out_tile_row * TILE_H;
   const int rx1 = min(tile_x0 + TILE_W, fp.width) - 1, ry1 = min(tile_y0 + TILE_H, fp.height) - 1;
@@ -892,6 +898,7 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
   const uint32_t e1 = n_cls[0], e2 = e1 + n_cls[1], e3 = e2 + n_cls[2], e_end = e3 + n_broad;
   const uint32_t *bin0 = bins + (size_t)(tile * kBinClasses) * fp.bin_cap;
 
+  BB_RSTAMP(1);
   for (uint32_t base = 0; base < e_end; base += kStage) {
     __syncthreads();  // keys initialised / previous chunk consumed
     // ---- stage: every thread fetches one entry (reference -> triangle record), all loads in flight together ----
@@ -928,6 +935,7 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
       st.box[tid] = box;
     }
     __syncthreads();
+    if (base == 0) BB_RSTAMP(2);
     const uint32_t hi = min(base + (uint32_t)kStage, e_end);
     // ---- class 0: one tiny triangle per lane ----
     {
@@ -945,17 +953,16 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
       }
     }
     // ---- class 1: sixteen lanes per small triangle ----
-    {
-      const uint32_t lo = max(base, e1), h1 = min(hi, e2);
-      for (uint32_t e = lo + (uint32_t)(tid >> 4); e < h1; e += kTileThreads / 16) {
-        const int j = (int)(e - base);
-        const uint32_t box = st.box[j];
-        if (box == 0xFFFFFFFFu) continue;
-        const RasterTri t = staged_tri(st, j);
-        raster_triangle_group16<TILE_W, TILE_H>(t, st.ref[j], tile_x0 + (int)(box & 255u), tile_x0 + (int)((box >> 8) & 255u),
-                                                tile_y0 + (int)((box >> 16) & 255u), tile_y0 + (int)(box >> 24), tile_x0,
-                                                tile_y0, keys, tid & 15);
-      }
+    // (one lane per triangle, as for class 0, was measured 2.6x slower here: bounding boxes of up to 64x64 pixels
+    //  make the per-lane loops long and divergent)
+    for (uint32_t e = max(base, e1) + (uint32_t)(tid >> 4); e < min(hi, e2); e += kTileThreads / 16) {
+      const int j = (int)(e - base);
+      const uint32_t box = st.box[j];
+      if (box == 0xFFFFFFFFu) continue;
+      const RasterTri t = staged_tri(st, j);
+      raster_triangle_group16<TILE_W, TILE_H>(t, st.ref[j], tile_x0 + (int)(box & 255u), tile_x0 + (int)((box >> 8) & 255u),
+                                              tile_y0 + (int)((box >> 16) & 255u), tile_y0 + (int)(box >> 24), tile_x0,
+                                              tile_y0, keys, tid & 15);
     }
     // ---- class 2 and the every-tile list: one wave per large triangle ----
     {
@@ -969,6 +976,7 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
     }
   }
   __syncthreads();
+  BB_RSTAMP(3);
 
   // ---- compaction: covered pixels -> fragment list (ballot + popcount prefix); background written here ----
   unsigned long long *my_frags = frags + (size_t)tile * TILE_PIXELS;
@@ -999,6 +1007,14 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
   }
   __syncthreads();
   if (tid == 0) frag_count[tile] = s_count;  // (N_shaded = sum of these, taken on the host on demand)
+  BB_RSTAMP(4);
+  if (tid == 0) {
+    BB_RSTAMP(5);
+#ifdef BB_STAMPS
+    reinterpret_cast<unsigned long long *>(frag_count + fp.tiles_x * fp.tiles_y)[tile * 8 + 6] =
+        ((unsigned long long)e_end << 32) | s_count;
+#endif
+  }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -231,7 +231,11 @@ int ensure_slot_buffers(bbr_context *c, FrameSlot &s) {
   HIP_TRY(c, s.d_bins.ensure(tiles * kBinClasses * c->bin_cap));
   HIP_TRY(c, s.d_broad.ensure(c->broad_cap));
   HIP_TRY(c, s.d_frags.ensure(tiles * (size_t)(c->tile_w() * c->tile_h())));
+#ifdef BB_STAMPS
+  HIP_TRY(c, s.d_frag_count.ensure(tiles * 17, true));  // diagnostic build: 8 x u64 raster stamps per tile behind the counts
+#else
   HIP_TRY(c, s.d_frag_count.ensure(tiles, true));
+#endif
   if (!c->ext_out) HIP_TRY(c, s.d_frame.ensure(out_rows * c->width));
   if (c->dump_vis) {
     HIP_TRY(c, c->d_vis_prim.ensure((size_t)c->width * c->height));
@@ -949,6 +953,14 @@ int bbr_set_option(bbr_context *c, const char *name, int64_t value) {
 }
 
 #ifdef BB_STAMPS
+int bbr_debug_raster_stamps(bbr_context *c, unsigned long long *out) {
+  if (!c || c->last_slot < 0) return BBR_ERR_INVALID_ARGUMENT;
+  int rc = drain(c);
+  if (rc) return rc;
+  size_t tiles = (size_t)c->tiles_x() * c->tiles_y();
+  HIP_TRY(c, hipMemcpy(out, c->slots[c->last_slot].d_frag_count.ptr + tiles, tiles * 64, hipMemcpyDeviceToHost));
+  return BBR_OK;
+}
 // diagnostic build only: copy out the k_geometry time stamps of the last frame (8 x u64 per workgroup)
 int bbr_debug_stamps(bbr_context *c, unsigned long long *out, uint32_t n_blocks) {
   if (!c || c->last_slot < 0) return BBR_ERR_INVALID_ARGUMENT;
