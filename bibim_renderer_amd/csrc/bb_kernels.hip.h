@@ -830,6 +830,57 @@ BB_DEV bool tile_row(const FrameParams &fp, int grid_y, int &ty, int &out_tile_r
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_tile_order: heaviest-first launch order for k_raster.  Tile costs span two orders of magnitude (a sky tile
+// lives ~5 us, a tile of a distant ShaderBall up to ~45 us); in plain row order the heavy tiles of the middle rows
+// start late and the kernel ends in a ~25 us tail with a few dozen workgroups alive (BB_STAMPS build).
+// One thread per launch slot: bucket = log2 of an estimate of the raster rounds the tile's bins need; every wave
+// reserves room in each bucket with one atomic (lanes 0..15 own one bucket each, so a wave pays a single round
+// trip) and writes its slots into order[bucket][...].  k_raster turns its launch index into (bucket, offset) with
+// the sixteen totals.  The order inside a bucket is arbitrary, which cannot change the image: tiles are independent.
+// A single-workgroup counting sort was tried first and cost 25-35 us -- more than the tail it removes.
+// ------------------------------------------------------------------------------------------------
+constexpr int kOrderBuckets = 16;
+constexpr int kOrderThreads = 256;
+
+BB_DEV uint32_t tile_cost_bucket(const uint32_t *__restrict__ tile_count, uint32_t tile, uint32_t bin_cap) {
+  const uint32_t c0 = min(tile_count[tile * kBinClasses + 0], bin_cap), c1 = min(tile_count[tile * kBinClasses + 1], bin_cap),
+                 c2 = min(tile_count[tile * kBinClasses + 2], bin_cap);
+  // class 0 runs 256 triangles at a time, class 1 sixteen, class 2 four
+  const uint32_t cost = c0 + 8u * c1 + 32u * c2 + 1u;
+  const uint32_t lg = 31u - (uint32_t)__clz((int)cost);
+  return (uint32_t)(kOrderBuckets - 1) - min(lg, (uint32_t)(kOrderBuckets - 1));  // heaviest first
+}
+
+__global__ __launch_bounds__(kOrderThreads) void k_tile_order(FrameParams fp, const uint32_t *__restrict__ tile_count,
+                                                               Counters *__restrict__ ctr, uint32_t *__restrict__ order,
+                                                               int grid_x, int grid_y) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t n = (uint32_t)grid_x * (uint32_t)grid_y;
+  const uint32_t lin = blockIdx.x * kOrderThreads + threadIdx.x;
+  const bool live = lin < n;
+  uint32_t bkt = 0xFFu;
+  if (live) {
+    const int gy = (int)(lin / (uint32_t)grid_x), tx = (int)(lin - (uint32_t)gy * (uint32_t)grid_x);
+    int ty, out_tile_row;
+    bkt = tile_row(fp, gy, ty, out_tile_row)
+              ? tile_cost_bucket(tile_count, (uint32_t)ty * (uint32_t)fp.tiles_x + (uint32_t)tx, fp.bin_cap)
+              : (uint32_t)(kOrderBuckets - 1);  // slots past the frame: last, they exit at once
+  }
+  uint32_t my_count = 0u;            // lane b < 16: this wave's slots in bucket b
+  unsigned long long my_peers = 0;  // lanes of my bucket
+#pragma unroll
+  for (uint32_t b = 0; b < (uint32_t)kOrderBuckets; ++b) {
+    const unsigned long long same = __ballot(bkt == b);
+    if ((uint32_t)lane == b) my_count = (uint32_t)__popcll(same);
+    if (bkt == b) my_peers = same;
+  }
+  uint32_t at = 0u;
+  if (my_count) at = atomicAdd(&ctr->order_hist[lane], my_count);
+  const uint32_t base = (uint32_t)__shfl((int)at, (int)(bkt & 15u));
+  if (live) order[(size_t)bkt * n + base + (uint32_t)__popcll(my_peers & ((1ull << lane) - 1ull))] = lin;
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_raster: one workgroup per screen tile.  LDS-resident 64-bit keys (depth bits << 32 | primitive) filled with
 // ds_max_u64 -- depth op GREATER_OR_EQUAL with "later primitive wins ties" falls out of the key order -- then
 // ballot/popcount compaction of the covered pixels into the tile's fragment list.  Background pixels get the
@@ -863,16 +914,28 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
     Counters *__restrict__ ctr, uint32_t *__restrict__ tile_count,
     const uint32_t *__restrict__ bins, const BroadTri *__restrict__ broad_list,
     unsigned long long *__restrict__ frags, uint32_t *__restrict__ frag_count, float4 *__restrict__ out,
-    uint32_t *__restrict__ vis_prim, float *__restrict__ vis_depth) {
+    uint32_t *__restrict__ vis_prim, float *__restrict__ vis_depth, const uint32_t *__restrict__ tile_order) {
   constexpr int TILE_PIXELS = TILE_W * TILE_H;
   __shared__ unsigned long long keys[TILE_PIXELS];
   __shared__ StagedTri st;
   __shared__ uint32_t s_count;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tx = blockIdx.x;
+  // launch slot -> tile: plain row order, or heaviest tiles first (k_tile_order)
+  uint32_t slot = blockIdx.y * gridDim.x + blockIdx.x;
+  if (tile_order) {
+    uint32_t b = 0u, start = 0u;  // (bucket, offset) of this launch index from the bucket totals; uniform
+    for (; b + 1u < (uint32_t)kOrderBuckets; ++b) {
+      const uint32_t h = ctr->order_hist[b];
+      if (slot < start + h) break;
+      start += h;
+    }
+    slot = tile_order[(size_t)b * (gridDim.x * gridDim.y) + (slot - start)];
+  }
+  const int grid_row = (int)(slot / gridDim.x);
+  const int tx = (int)(slot - (uint32_t)grid_row * gridDim.x);
   int ty, out_tile_row;
-  const bool live = tile_row(fp, blockIdx.y, ty, out_tile_row);
+  const bool live = tile_row(fp, grid_row, ty, out_tile_row);
   if (!live) return;
   const uint32_t tile = (uint32_t)ty * (uint32_t)fp.tiles_x + (uint32_t)tx;
 #ifdef BB_STAMPS

@@ -167,8 +167,9 @@ struct Counters {
   uint32_t overflow;  // bit0 bins, bit1 broad list, bit2 clip arena
   uint32_t bin_need;  // largest per-tile reference count seen when a bin overflowed
   uint32_t pad[12];
+  uint32_t order_hist[16];  // k_tile_order: launch slots per cost bucket (heaviest bucket first)
 };
-static_assert(sizeof(Counters) == 64, "Counters");
+static_assert(sizeof(Counters) == 128, "Counters");
 
 // k_geometry statistics of one workgroup
 struct BlockStats {

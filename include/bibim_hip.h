@@ -150,6 +150,15 @@ int bbr_last_frame_time_ms(bbr_context *ctx, float *out_frame_ms, float *out_sha
 int bbr_timing_reset(bbr_context *ctx);
 int bbr_timing_summary(bbr_context *ctx, uint32_t *out_frames, float *out_avg_frame_ms, float *out_avg_geometry_ms,
                        float *out_avg_raster_ms, float *out_avg_shade_ms);
+/* Options (all drain the context first):
+ *   "timing" 0|1             record per-kernel HIP events (bbr_timing_summary)
+ *   "frames_in_flight" 1|2   default 2
+ *   "tile_mode" 0|1          0: 64x64 tiles, 1: 32x32 tiles (default)
+ *   "bin_cap" n              initial references per (tile, raster class); grows by itself on overflow
+ *   "broad_threshold" n      triangles touching more than n x n tiles go to the every-tile list
+ *   "tile_order" 0|1         launch the heaviest raster tiles first (shorter single frame, lower pipelined
+ *                            throughput; default 0)
+ *   "ablate" bits            diagnostics only: skip parts of the pipeline (see bb_kernels.hip.h) */
 int bbr_set_option(bbr_context *ctx, const char *name, int64_t value);
 
 /* next row: hdr_tone_mapping.frag:9-18 on the fp32 frame, in place */

@@ -185,6 +185,14 @@ def test_broad_list_threshold_extremes(maps64):
     check(sc, broad_threshold=100000)  # nothing does: the ground plane is binned into every tile it touches
 
 
+@pytest.mark.parametrize("tile_mode", [0, 1])
+def test_heaviest_first_tile_order_changes_nothing(maps64, tile_mode):
+    """option tile_order: k_raster takes its tiles from the bucketed order of k_tile_order; same image, same bits"""
+    check(scenes.shaderball_scene(configs.C3.scaled(800, 450, 64), bbo.MaterialData(maps64)), tile_mode, tile_order=1)
+    check(scenes.shaderball_scene(configs.C5.scaled(1024, 576, 64), bbo.MaterialData(maps64)), tile_mode, tile_order=1,
+          bin_cap=16)  # with the overflow-and-retry path in between
+
+
 @pytest.mark.parametrize("frames_in_flight", [1, 2])
 def test_frames_in_flight_streams_of_different_frames(maps64, frames_in_flight):
     """two frames in flight on two streams: alternating scenes back to back, no synchronisation in between,

@@ -63,6 +63,7 @@ def test_partitioned_render_reassembles_to_the_single_gpu_frame(maps64, world, b
     for rank in range(world):
         r = Renderer(cfg.width, cfg.height)
         r.set_option("tile_mode", tile_mode)
+        r.set_option("tile_order", rank & 1)  # odd ranks also take the heaviest-first launch order
         r.set_partition(rank, world, band_rows)
         assert r.shard_rows() == P.shard_rows(cfg.height, world, band_rows)
         r.render_scene(sc)

@@ -8,6 +8,8 @@ for name in ('c2', 'c3', 'c5'):
     for fif in (1, 2):
         r = Renderer(cfg.width, cfg.height)
         r.set_option('frames_in_flight', fif)
+        for o in sys.argv[1:]:
+            k, v = o.split('='); r.set_option(k, int(v))
         material = r.upload_material(maps)
         scene, cam, settings = S.config_scene(r, cfg)
         S.draw_frame(r, scene, cam, settings, material); r.synchronize()

@@ -34,3 +34,9 @@ for lo, hi, tag in ((0, 0, 'empty'), (1, 8, '1-8 entries'), (9, 64, '9-64'), (65
 ev = np.concatenate([np.stack([rel[:, 0], np.ones(nt)], 1), np.stack([rel[:, 4], -np.ones(nt)], 1)])
 ev = ev[np.argsort(ev[:, 0])]
 alive = np.cumsum(ev[:, 1]); dt = np.diff(ev[:, 0]); print('avg WGs alive', (alive[:-1] * dt).sum() / dt.sum(), 'start of last WG', rel[:, 0].max())
+# timeline: WGs alive, started and finished per 2-us slice
+edges = np.arange(0, rel[:, 4].max() + 2, 2.0)
+started = np.histogram(rel[:, 0], edges)[0]; finished = np.histogram(rel[:, 4], edges)[0]
+alive_at = [(int(((rel[:, 0] <= t) & (rel[:, 4] > t)).sum())) for t in edges[:-1]]
+print('t_us   alive started finished')
+for t, a, s_, f_ in zip(edges[:-1], alive_at, started, finished): print(f'{t:5.0f} {a:6d} {s_:7d} {f_:8d}')
