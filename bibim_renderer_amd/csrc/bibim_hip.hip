@@ -144,7 +144,7 @@ struct bbr_context {
   // off by default, option "tile_order".
   bool tile_order = false;
   uint32_t ablate = 0;
-  bool timing = false;
+  int timing = 0;  // 0 off, 1 five events per frame, 2 only the two events around k_shade
   // timing ring: (frame start, geometry done, raster done, shade start, shade done) per frame since the last reset
   std::vector<hipEvent_t> ring;
   uint32_t ring_frames = 0;
@@ -278,7 +278,7 @@ void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const Fra
                        s.d_bins.ptr, s.d_broad.ptr, c->d_materials.ptr, s.d_block_stats.ptr, ctr_next);
   else
     (void)hipMemsetAsync(ctr_next, 0, sizeof(Counters), sg);
-  if (ev) (void)hipEventRecord(ev[1], sg);
+  if (ev && c->timing == 1) (void)hipEventRecord(ev[1], sg);
   // k_raster writes the background pixels of `out`: if the frame still shading on the other stream writes the
   // same buffer (single external output), raster has to wait for it; geometry above still overlapped
   if (prev && prev->in_flight && prev->out_used == out && ss != sg) (void)hipStreamWaitEvent(sg, prev->ev_shade_done, 0);
@@ -292,7 +292,7 @@ void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const Fra
                      s.d_clip.ptr, ctr, s.d_tile_count.ptr, s.d_bins.ptr, s.d_broad.ptr, s.d_frags.ptr,
                      s.d_frag_count.ptr, out, c->dump_vis ? c->d_vis_prim.ptr : nullptr,
                      c->dump_vis ? c->d_vis_depth.ptr : nullptr, ordered ? s.d_tile_order.ptr : nullptr);
-  if (ev) (void)hipEventRecord(ev[2], sg);
+  if (ev && c->timing == 1) (void)hipEventRecord(ev[2], sg);
   if (ss != sg) {
     (void)hipEventRecord(s.ev_raster_done, sg);
     (void)hipStreamWaitEvent(ss, s.ev_raster_done, 0);
@@ -369,7 +369,7 @@ int submit_frame_into(bbr_context *c, int slot_index) {
       c->ring.resize(bbr_context::kRingEvents * bbr_context::kRingCap);
       for (auto &e : c->ring) HIP_TRY(c, hipEventCreate(&e));
     }
-    HIP_TRY(c, hipEventRecord(c->ring[bbr_context::kRingEvents * (c->ring_frames % bbr_context::kRingCap)], sg));
+    if (c->timing == 1) HIP_TRY(c, hipEventRecord(c->ring[bbr_context::kRingEvents * (c->ring_frames % bbr_context::kRingCap)], sg));
   }
   s.ctr_index = (int)(c->submit_epoch++ % 3);
   HIP_TRY(c, hipMemcpyAsync(s.d_staging.ptr, s.h_staging, total, hipMemcpyHostToDevice, sg));
@@ -891,7 +891,7 @@ int bbr_last_frame_time_ms(bbr_context *c, float *out_frame_ms, float *out_shade
   if (rc) return rc;
   const hipEvent_t *e = &c->ring[bbr_context::kRingEvents * ((c->ring_frames - 1) % bbr_context::kRingCap)];
   float a = 0.f, b = 0.f;
-  HIP_TRY(c, hipEventElapsedTime(&a, e[0], e[4]));
+  if (c->timing == 1) HIP_TRY(c, hipEventElapsedTime(&a, e[0], e[4]));
   HIP_TRY(c, hipEventElapsedTime(&b, e[3], e[4]));
   if (out_frame_ms) *out_frame_ms = a;
   if (out_shade_ms) *out_shade_ms = b;
@@ -917,9 +917,11 @@ int bbr_timing_summary(bbr_context *c, uint32_t *out_frames, float *out_avg_fram
   for (uint32_t i = 0; i < n; ++i) {
     const hipEvent_t *e = &c->ring[bbr_context::kRingEvents * i];
     float a = 0.f, b = 0.f, d = 0.f, h = 0.f;
-    HIP_TRY(c, hipEventElapsedTime(&a, e[0], e[4]));
-    HIP_TRY(c, hipEventElapsedTime(&b, e[0], e[1]));
-    HIP_TRY(c, hipEventElapsedTime(&d, e[1], e[2]));
+    if (c->timing == 1) {
+      HIP_TRY(c, hipEventElapsedTime(&a, e[0], e[4]));
+      HIP_TRY(c, hipEventElapsedTime(&b, e[0], e[1]));
+      HIP_TRY(c, hipEventElapsedTime(&d, e[1], e[2]));
+    }
     HIP_TRY(c, hipEventElapsedTime(&h, e[3], e[4]));
     f += a; g += b; r += d; t += h;
   }
@@ -937,7 +939,11 @@ int bbr_set_option(bbr_context *c, const char *name, int64_t value) {
   int rc = drain(c);
   if (rc) return rc;
   std::string n(name);
-  if (n == "timing") c->timing = value != 0;
+  if (n == "timing") {
+    if (value < 0 || value > 2) return fail(c, BBR_ERR_INVALID_ARGUMENT, "timing: 0, 1 or 2");
+    c->timing = (int)value;
+    c->ring_frames = 0;
+  }
   else if (n == "frames_in_flight") {
     if (value != 1 && value != 2) return fail(c, BBR_ERR_INVALID_ARGUMENT, "frames_in_flight: 1 or 2");
     c->frames_in_flight = (int)value;
