@@ -44,6 +44,9 @@ BB_DEV f3 cross3(f3 a, f3 b) {
 // GLSL inversesqrt as a fixed sequence (integer seed + three Newton steps, max error 1.1 ulp): the same bits as the
 // oracle's bb_rsqrt, at a third of the instruction count of IEEE sqrt + divide.
 BB_DEV float bb_rsqrt(float x) {
+#ifdef BB_EXPERIMENT_HW_TRANS
+  return __builtin_amdgcn_rsqf(x);
+#endif
   if (!(x >= 1.17549435e-38f && x <= 3.40282347e+38f)) return 1.0f / sqrtf(x);
   float y = __uint_as_float(0x5F375A86u - (__float_as_uint(x) >> 1));
   const float h = 0.5f * x;
@@ -54,6 +57,9 @@ BB_DEV float bb_rsqrt(float x) {
 }
 // Reciprocal as a fixed sequence (integer seed + three fma Newton steps, max error 0.5004 ulp): the oracle's bb_rcp.
 BB_DEV float bb_rcp(float x) {
+#ifdef BB_EXPERIMENT_HW_TRANS
+  return __builtin_amdgcn_rcpf(x);
+#endif
   const float ax = fabsf(x);
   if (!(ax >= 1.17549435e-38f && ax <= 8.5e37f)) return 1.0f / x;
   float r = __uint_as_float(0x7EF311C7u - __float_as_uint(ax));
@@ -399,7 +405,7 @@ __global__ __launch_bounds__(256) void k_geometry(const DrawDesc *__restrict__ d
 #endif
   BB_STAMP(0);
   __shared__ BlockStats bs;
-  // the NEXT frame's counter block is cleared here (three blocks rotate; the one cleared now is idle: its previous
+  // the NEXT frame's counter block is cleared here (frames in flight + 1 blocks rotate; the one cleared now is idle: its previous
   // frame left the GPU before this one was submitted) -- saves a memset node per frame
   if (blockIdx.x == 0 && threadIdx.x < sizeof(Counters) / 4) reinterpret_cast<uint32_t *>(ctr_next)[threadIdx.x] = 0u;
   __shared__ ClipWork s_clip[4];  // one per wave
@@ -423,10 +429,23 @@ __global__ __launch_bounds__(256) void k_geometry(const DrawDesc *__restrict__ d
 
     BB_STAMP(1);
     const InstanceBlock &ib = draw.instances[inst];
+    // The three 44-byte vertices as few, wide loads (a non-indexed triangle is 132 contiguous bytes: nine
+    // dwordx4/x3/x2 loads instead of 33 dword loads).  Lanes are 132 bytes apart, so every load instruction touches
+    // ~64 cache lines and the L1's tag rate, not HBM, bounds this phase: fewer instructions is what counts.
+    Vertex vtx[3];
+    if (draw.indices) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) __builtin_memcpy(&vtx[k], &draw.vertices[draw.indices[3 * tri + k]], sizeof(Vertex));
+    } else {
+      __builtin_memcpy(vtx, &draw.vertices[3 * tri], 3 * sizeof(Vertex));
+    }
+#ifdef BB_STAMPS
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    BB_STAMP(6);
+#endif
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      uint32_t vi = draw.indices ? draw.indices[3 * tri + k] : 3 * tri + k;
-      const Vertex &v = draw.vertices[vi];
+      const Vertex &v = vtx[k];
       // forward_brdf.vert:25,27
       f4 pw = mat4_mul(ib.model, f4{v.pos[0], v.pos[1], v.pos[2], 1.0f});
       f4 c = mat4_mul(pv, pw);
@@ -471,6 +490,9 @@ __global__ __launch_bounds__(256) void k_geometry(const DrawDesc *__restrict__ d
             project_vertex(clip[1], fp.half_w, fp.half_h, t.X1, t.Y1, t.rw1, z1) &&
             project_vertex(clip[2], fp.half_w, fp.half_h, t.X2, t.Y2, t.rw2, z2) && setup_tri(t, z0, z1, z2) &&
             tile_range<TILE_W, TILE_H>(t, fp, tr)) {
+#ifdef BB_STAMPS
+          BB_STAMP(7);
+#endif
           if (!(fp.ablate & 64u)) {
             tris[prim] = t;
             pa.X0 = t.X0; pa.Y0 = t.Y0;

@@ -73,7 +73,7 @@ struct FrameSlot {
   DeviceBuffer<RasterTri> d_tris;
   DeviceBuffer<ShadeRec> d_attrs;
   DeviceBuffer<ClipSlot> d_clip;
-  int ctr_index = 0;                        // which of the context's three counter blocks this slot's frame used
+  int ctr_index = 0;                        // which of the context's counter blocks this slot's frame used
   DeviceBuffer<BlockStats> d_block_stats;  // one record per k_geometry workgroup
   DeviceBuffer<uint32_t> d_tile_count;
   DeviceBuffer<uint32_t> d_bins;
@@ -122,8 +122,10 @@ struct bbr_context {
   uint32_t n_prims = 0;
   uint32_t n_live_draws = 0;
 
-  FrameSlot slots[2];
-  DeviceBuffer<Counters> d_counters;  // three blocks in rotation: each k_geometry clears the next frame's block
+  static constexpr int kMaxSlots = 3;
+  static constexpr int kCounterBlocks = kMaxSlots + 1;
+  FrameSlot slots[kMaxSlots];
+  DeviceBuffer<Counters> d_counters;  // kMaxSlots + 1 blocks in rotation: each k_geometry clears the next frame's block
   uint64_t submit_epoch = 0;
   int frames_in_flight = 2;
   uint64_t frame_counter = 0;
@@ -231,7 +233,7 @@ int ensure_slot_buffers(bbr_context *c, FrameSlot &s) {
 #else
   HIP_TRY(c, s.d_clip.ensure(c->clip_cap));
 #endif
-  HIP_TRY(c, c->d_counters.ensure(3, true));
+  HIP_TRY(c, c->d_counters.ensure(bbr_context::kCounterBlocks, true));
   HIP_TRY(c, s.d_block_stats.ensure(std::max<size_t>((c->n_prims + 255) / 256, 1), true));
   HIP_TRY(c, s.d_tile_count.ensure(tiles * kBinClasses, true));
   HIP_TRY(c, s.d_bins.ensure(tiles * kBinClasses * c->bin_cap));
@@ -270,7 +272,7 @@ template <int TW, int TH>
 void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const FrameParams &fp, const Mat4 &pv,
                   const ShadeParams &sp, const Light *d_lights, const DrawDesc *d_draws, uint32_t n_draws, float4 *out) {
   hipStream_t sg = c->geom_stream(), ss = c->shade_stream();
-  Counters *ctr = c->d_counters.ptr + s.ctr_index, *ctr_next = c->d_counters.ptr + (s.ctr_index + 1) % 3;
+  Counters *ctr = c->d_counters.ptr + s.ctr_index, *ctr_next = c->d_counters.ptr + (s.ctr_index + 1) % bbr_context::kCounterBlocks;
   hipEvent_t *ev = c->timing ? &c->ring[bbr_context::kRingEvents * (c->ring_frames % bbr_context::kRingCap)] : nullptr;
   if (c->n_prims)
     hipLaunchKernelGGL((k_geometry<TW, TH>), dim3((c->n_prims + 255) / 256), dim3(256), 0, sg, d_draws, n_draws,
@@ -371,7 +373,7 @@ int submit_frame_into(bbr_context *c, int slot_index) {
     }
     if (c->timing == 1) HIP_TRY(c, hipEventRecord(c->ring[bbr_context::kRingEvents * (c->ring_frames % bbr_context::kRingCap)], sg));
   }
-  s.ctr_index = (int)(c->submit_epoch++ % 3);
+  s.ctr_index = (int)(c->submit_epoch++ % bbr_context::kCounterBlocks);
   HIP_TRY(c, hipMemcpyAsync(s.d_staging.ptr, s.h_staging, total, hipMemcpyHostToDevice, sg));
 
   const Light *d_lights = reinterpret_cast<const Light *>(s.d_staging.ptr);
@@ -945,7 +947,7 @@ int bbr_set_option(bbr_context *c, const char *name, int64_t value) {
     c->ring_frames = 0;
   }
   else if (n == "frames_in_flight") {
-    if (value != 1 && value != 2) return fail(c, BBR_ERR_INVALID_ARGUMENT, "frames_in_flight: 1 or 2");
+    if (value < 1 || value > bbr_context::kMaxSlots) return fail(c, BBR_ERR_INVALID_ARGUMENT, "frames_in_flight: 1, 2 or 3");
     c->frames_in_flight = (int)value;
     c->frame_counter = 0;
   } else if (n == "tile_mode") {

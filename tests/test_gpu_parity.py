@@ -193,7 +193,7 @@ def test_heaviest_first_tile_order_changes_nothing(maps64, tile_mode):
           bin_cap=16)  # with the overflow-and-retry path in between
 
 
-@pytest.mark.parametrize("frames_in_flight", [1, 2])
+@pytest.mark.parametrize("frames_in_flight", [1, 2, 3])
 def test_frames_in_flight_streams_of_different_frames(maps64, frames_in_flight):
     """two frames in flight on two streams: alternating scenes back to back, no synchronisation in between,
     every frame must still come out exactly as when rendered alone"""

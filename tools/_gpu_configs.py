@@ -5,7 +5,7 @@ from bibim_renderer_amd import scene as S
 maps = textures.make_material(2048)
 for name in ('c2', 'c3', 'c5'):
     cfg = configs.CONFIGS[name]
-    for fif in (1, 2):
+    for fif in (1, 2, 3):
         r = Renderer(cfg.width, cfg.height)
         r.set_option('frames_in_flight', fif)
         for o in sys.argv[1:]:

@@ -24,6 +24,10 @@ print('blocks', nb, 'kernel span us', rel[:, 5].max())
 names = ['start', 'draw found', 'setup done', 'bins done', 'clip done', 'end']
 for b in (0, nb // 2, nb - 2, nb - 1):
     print('block', b, ' '.join(f'{n}={rel[b, i]:.2f}' for i, n in enumerate(names)))
+t8 = buf.astype(np.int64); r8 = (t8 - t0) * 10 / 1e3
+ok = t8[:, 6] > 0
+print('setup split: loads done at +%.2f us after draw found; setup_tri done (thread 0 survivors only) at +%.2f; setup done +%.2f' % (
+    (r8[ok, 6] - r8[ok, 1]).mean(), (r8[t8[:, 7] > 0, 7] - r8[t8[:, 7] > 0, 1]).mean(), (r8[:, 2] - r8[:, 1]).mean()))
 d = np.diff(rel, axis=1)
 print('mean phase us ', d.mean(0).round(2), 'max', d.max(0).round(2))
 print('start spread', rel[:, 0].max(), 'end min/max', rel[:, 5].min(), rel[:, 5].max())
