@@ -73,6 +73,10 @@ SIGNATURES = {
                                      C.POINTER(C.c_float)]),
     "bbr_set_option": (C.c_int, [_P, C.c_char_p, C.c_int64]),
     "bbr_tone_map": (C.c_int, [_P, C.c_int32, C.c_float]),
+    "bbr_present": (C.c_int, [_P, C.c_void_p, C.c_int32]),
+    "bbr_read_presented": (C.c_int, [_P, C.c_void_p]),
+    "bbr_presented_device_ptr": (C.c_int, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
+    "bbr_unpack_gathered_rgba8": (C.c_int, [_P, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 # every symbol include/bibim_scene.h declares (C surface of the C++ Scene/Camera/drawFrame shim)

@@ -1327,18 +1327,99 @@ __global__ void k_unpack_gathered(const float4 *__restrict__ gathered, float4 *_
   frame[i] = gathered[src];
 }
 
-// hdr_tone_mapping.frag:9-18 on the fp32 frame (next row)
+// ------------------------------------------------------------------------------------------------
+// presentation: HDR attachment (binary16) -> hdr_tone_mapping.frag:9-18 -> sRGB UNORM8.
+// Same fixed sequences as the CPU oracle (binary16 rounding, exp, threshold table): byte-exact.
+// ------------------------------------------------------------------------------------------------
+
+// nearest binary16 value (ties to even), as binary32
+BB_DEV float bb_half_round(float x) {
+  const uint32_t u = __float_as_uint(x), sign = u & 0x80000000u, a = u & 0x7FFFFFFFu;
+  if (a >= 0x7F800000u) return x;
+  if (a >= 0x477FF000u) return __uint_as_float(sign | 0x7F800000u);
+  if (a < 0x38800000u) {
+    const float r = (__uint_as_float(a) + 0.5f) - 0.5f;
+    return __uint_as_float(sign | __float_as_uint(r));
+  }
+  const uint32_t r = (a + 0x00000FFFu + ((a >> 13) & 1u)) & 0xFFFFE000u;
+  return __uint_as_float(sign | r);
+}
+
+BB_DEV float bb_exp(float x) {
+  if (!(x >= -104.0f)) return x < -104.0f ? 0.0f : x;
+  if (x > 88.7228317f) return __uint_as_float(0x7F800000u);
+  const float n = __builtin_rintf(x * 1.44269502f);
+  float r = fmaf(n, -0.693145752f, x);
+  r = fmaf(n, -1.42860677e-06f, r);
+  float p = 1.98412701e-04f;
+  p = fmaf(p, r, 1.38888892e-03f);
+  p = fmaf(p, r, 8.33333377e-03f);
+  p = fmaf(p, r, 4.16666679e-02f);
+  p = fmaf(p, r, 1.66666672e-01f);
+  p = fmaf(p, r, 0.5f);
+  p = fmaf(p, r, 1.0f);
+  p = fmaf(p, r, 1.0f);
+  const int ni = (int)n, h = ni / 2;
+  const float s1 = __uint_as_float((uint32_t)(h + 127) << 23), s2 = __uint_as_float((uint32_t)(ni - h + 127) << 23);
+  return (p * s1) * s2;
+}
+
+// hdr_tone_mapping.frag:9-18 on the fp32 frame, in place
 __global__ void k_tone_map(float4 *__restrict__ frame, size_t n, int enable, float exposure) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float4 c = frame[i];
   if (enable) {
-    c.x = 1.0f - expf(-c.x * exposure);
-    c.y = 1.0f - expf(-c.y * exposure);
-    c.z = 1.0f - expf(-c.z * exposure);
+    c.x = 1.0f - bb_exp(-c.x * exposure);
+    c.y = 1.0f - bb_exp(-c.y * exposure);
+    c.z = 1.0f - bb_exp(-c.z * exposure);
   }
   c.w = 1.0f;
   frame[i] = c;
+}
+
+// sRGB byte = number of thresholds <= c (thr[255] = +inf; NaN -> 0): eight LDS probes
+BB_DEV uint32_t srgb8(float c, const float *thr) {
+  uint32_t pos = 0u;
+#pragma unroll
+  for (uint32_t step = 128u; step; step >>= 1)
+    if (thr[pos + step - 1u] <= c) pos += step;
+  return pos;
+}
+
+// One pixel per lane: 16 B read, 4 B written -- 20 algorithmic bytes per pixel, HBM-bound by construction.
+constexpr int kPresentThreads = 256;
+__global__ __launch_bounds__(kPresentThreads) void k_present(const float4 *__restrict__ frame, uint32_t *__restrict__ out_rgba8,
+                                                              size_t n, const float *__restrict__ thresholds, int enable,
+                                                              float exposure, int hdr16) {
+  __shared__ float thr[256];
+  thr[threadIdx.x] = threadIdx.x < 255 ? thresholds[threadIdx.x] : __uint_as_float(0x7F800000u);
+  __syncthreads();
+  const size_t i = (size_t)blockIdx.x * kPresentThreads + threadIdx.x;
+  if (i >= n) return;
+  const float4 c = frame[i];
+  float v[3] = {c.x, c.y, c.z};
+  uint32_t px = 0xFF000000u;  // outColor.a = 1.0
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float x = v[k];
+    if (hdr16) x = bb_half_round(x);
+    if (enable) x = 1.0f - bb_exp(-x * exposure);
+    px |= srgb8(x, thr) << (8 * k);
+  }
+  out_rgba8[i] = px;
+}
+
+// [world][shard_rows][width] RGBA8 -> row-major presented frame (same un-interleave as k_unpack_gathered)
+__global__ void k_unpack_gathered_rgba8(const uint32_t *__restrict__ gathered, uint32_t *__restrict__ frame, int width,
+                                        int height, int world, int band_rows, int shard_rows) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t n = (size_t)width * (size_t)height;
+  if (i >= n) return;
+  int y = (int)(i / (size_t)width), x = (int)(i - (size_t)y * width);
+  int band = y / band_rows, r = y - band * band_rows;
+  int rank = band % world, lb = band / world;
+  frame[i] = gathered[((size_t)rank * shard_rows + (size_t)lb * band_rows + r) * (size_t)width + x];
 }
 
 }  // namespace bbr

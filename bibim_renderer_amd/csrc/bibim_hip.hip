@@ -82,8 +82,17 @@ struct FrameSlot {
   DeviceBuffer<uint32_t> d_frag_count;
   DeviceBuffer<uint32_t> d_tile_order;  // k_raster launch slots, heaviest tiles first
   DeviceBuffer<float4> d_frame;
+  DeviceBuffer<uint32_t> d_present;  // RGBA8 presented image of this slot's frame (bbr_present)
+  struct {
+    bool active = false;  // bbr_present was queued for the frame in this slot (re-queued if the frame is replayed)
+    uint32_t *out = nullptr;
+    int32_t enable = 0, hdr16 = 1;
+    float exposure = 1.f;
+  } present;
   hipEvent_t ev_raster_done = nullptr, ev_shade_done = nullptr;
   bool in_flight = false;
+  int32_t tone_enable = 0;  // FrameUniformBlock.EnableToneMapping / Exposure of the frame in this slot
+  float tone_exposure = 1.f;
   float4 *out_used = nullptr;  // where the frame in this slot wrote its pixels
   uint32_t n_prims = 0;
 
@@ -93,7 +102,7 @@ struct FrameSlot {
   void release_all() {
     d_staging.release(); d_tris.release(); d_attrs.release(); d_clip.release();
     d_block_stats.release();
-    release_tile_buffers(); d_broad.release(); d_frame.release();
+    release_tile_buffers(); d_broad.release(); d_frame.release(); d_present.release();
     if (h_staging) (void)hipHostFree(h_staging);
     h_staging = nullptr;
     staging_cap = 0;
@@ -131,6 +140,7 @@ struct bbr_context {
   uint64_t frame_counter = 0;
   int last_slot = -1;
 
+  DeviceBuffer<float> d_srgb_thresholds;  // 255 floats: linear value at which the sRGB byte becomes k (k = 1..255)
   DeviceBuffer<uint32_t> d_vis_prim;
   DeviceBuffer<float> d_vis_depth;
   void *ext_out = nullptr;
@@ -391,9 +401,34 @@ int submit_frame_into(bbr_context *c, int slot_index) {
   else launch_frame<32, 32>(c, s, prev, fp, pv, sp, d_lights, d_draws, c->n_live_draws, out);
   HIP_TRY(c, hipGetLastError());
   s.in_flight = true;
+  s.present.active = false;
+  s.tone_enable = c->frame_u.enable_tone_mapping;
+  s.tone_exposure = c->frame_u.exposure;
   s.out_used = out;
   s.n_prims = c->n_prims;
   c->last_slot = slot_index;
+  return BBR_OK;
+}
+
+// k_present for the frame in slot `s`, on the shade stream (ordered after the frame's k_shade)
+int queue_present(bbr_context *c, FrameSlot &s) {
+  if (!c->d_srgb_thresholds.ptr) {
+    // t_k = float(decode((k - 0.5) / 255)) (the same table the CPU oracle builds)
+    float h[255];
+    for (int k = 1; k <= 255; ++k) {
+      const double b = ((double)k - 0.5) / 255.0;
+      h[k - 1] = (float)(b <= 0.04045 ? b / 12.92 : std::pow((b + 0.055) / 1.055, 2.4));
+    }
+    HIP_TRY(c, c->d_srgb_thresholds.ensure(255));
+    HIP_TRY(c, hipMemcpy(c->d_srgb_thresholds.ptr, h, sizeof h, hipMemcpyHostToDevice));
+  }
+  const size_t n = (size_t)c->width * (c->world > 1 ? c->shard_rows() : c->height);
+  hipLaunchKernelGGL(k_present, dim3((unsigned)((n + kPresentThreads - 1) / kPresentThreads)), dim3(kPresentThreads), 0,
+                     c->shade_stream(), s.out_used, s.present.out, n, c->d_srgb_thresholds.ptr, s.present.enable,
+                     s.present.exposure, s.present.hdr16);
+  HIP_TRY(c, hipGetLastError());
+  // the slot is busy until the presented image exists
+  HIP_TRY(c, hipEventRecord(s.ev_shade_done, c->shade_stream()));
   return BBR_OK;
 }
 
@@ -426,8 +461,14 @@ int sync_and_fix(bbr_context *c, Counters *out_counters) {
     // tile counters may hold residue of refs that did not fit: clear and replay into the same slot
     FrameSlot &s = c->slots[c->last_slot];
     if (s.d_tile_count.ptr) HIP_TRY(c, hipMemset(s.d_tile_count.ptr, 0, s.d_tile_count.cap * sizeof(uint32_t)));
+    const auto present = s.present;
     rc = submit_frame_into(c, c->last_slot);
     if (rc) return rc;
+    if (present.active) {  // the presented image was made from the overflowed frame: make it again
+      s.present = present;
+      rc = queue_present(c, s);
+      if (rc) return rc;
+    }
   }
   return fail(c, BBR_ERR_CAPACITY, "bin capacity still exceeded after 8 growth steps");
 }
@@ -992,6 +1033,54 @@ int bbr_debug_stamps(bbr_context *c, unsigned long long *out, uint32_t n_blocks)
   return BBR_OK;
 }
 #endif
+
+int bbr_present(bbr_context *c, void *rgba8_device, int32_t hdr16) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  if (!c->have_frame || c->last_slot < 0) return fail(c, BBR_ERR_NOT_IN_FRAME, "present: nothing rendered");
+  FrameSlot &s = c->slots[c->last_slot];
+  const size_t n = (size_t)c->width * (c->world > 1 ? c->shard_rows() : c->height);
+  if (!rgba8_device) HIP_TRY(c, s.d_present.ensure(n));
+  s.present.active = true;
+  s.present.out = rgba8_device ? (uint32_t *)rgba8_device : s.d_present.ptr;
+  s.present.enable = s.tone_enable;
+  s.present.exposure = s.tone_exposure;
+  s.present.hdr16 = hdr16 != 0;
+  return queue_present(c, s);
+}
+
+int bbr_read_presented(bbr_context *c, uint8_t *host) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  if (!host) return fail(c, BBR_ERR_INVALID_ARGUMENT, "read_presented: NULL");
+  if (!c->have_frame || c->last_slot < 0 || !c->slots[c->last_slot].present.active)
+    return fail(c, BBR_ERR_NOT_IN_FRAME, "read_presented: bbr_present was not called for the last frame");
+  int rc = sync_and_fix(c, nullptr);
+  if (rc) return rc;
+  const size_t n = (size_t)c->width * (c->world > 1 ? c->shard_rows() : c->height);
+  HIP_TRY(c, hipMemcpy(host, c->slots[c->last_slot].present.out, n * 4, hipMemcpyDeviceToHost));
+  return BBR_OK;
+}
+
+int bbr_presented_device_ptr(bbr_context *c, void **out_ptr, uint64_t *out_bytes) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  if (!out_ptr) return fail(c, BBR_ERR_INVALID_ARGUMENT, "presented_device_ptr: NULL");
+  if (!c->have_frame || c->last_slot < 0 || !c->slots[c->last_slot].present.active)
+    return fail(c, BBR_ERR_NOT_IN_FRAME, "presented_device_ptr: bbr_present was not called for the last frame");
+  *out_ptr = c->slots[c->last_slot].present.out;
+  if (out_bytes) *out_bytes = (uint64_t)c->width * (c->world > 1 ? c->shard_rows() : c->height) * 4;
+  return BBR_OK;
+}
+
+int bbr_unpack_gathered_rgba8(bbr_context *c, const void *gathered, void *frame, void *stream) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  if (!gathered || !frame) return fail(c, BBR_ERR_INVALID_ARGUMENT, "unpack_gathered_rgba8: NULL");
+  size_t n = (size_t)c->width * c->height;
+  hipStream_t st = stream ? (hipStream_t)stream : c->shade_stream();
+  hipLaunchKernelGGL(k_unpack_gathered_rgba8, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                     (const uint32_t *)gathered, (uint32_t *)frame, c->width, c->height, c->world, c->eff_band_rows(),
+                     c->shard_rows());
+  HIP_TRY(c, hipGetLastError());
+  return BBR_OK;
+}
 
 int bbr_tone_map(bbr_context *c, int32_t enable, float exposure) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;

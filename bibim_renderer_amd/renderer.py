@@ -142,6 +142,26 @@ class Renderer:
     def tone_map(self, enable, exposure):
         self._check(self._L.bbr_tone_map(self._ctx, int(enable), float(exposure)))
 
+    # -- presentation (tone map + sRGB + UNORM8) --
+    def present(self, rgba8_device_ptr=None, hdr16=True):
+        """queue k_present for the last frame; EnableToneMapping / Exposure come from its FrameUniformBlock"""
+        self._check(self._L.bbr_present(self._ctx, C.c_void_p(rgba8_device_ptr) if rgba8_device_ptr else None, int(bool(hdr16))))
+
+    def read_presented(self):
+        rows = self.shard_rows()
+        out = np.empty((rows, self.width, 4), np.uint8)
+        self._check(self._L.bbr_read_presented(self._ctx, _ptr(out)))
+        return out
+
+    def presented_device_ptr(self):
+        p, n = C.c_void_p(), C.c_uint64()
+        self._check(self._L.bbr_presented_device_ptr(self._ctx, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def unpack_gathered_rgba8(self, gathered_ptr, frame_ptr, stream=None):
+        self._check(self._L.bbr_unpack_gathered_rgba8(self._ctx, C.c_void_p(gathered_ptr), C.c_void_p(frame_ptr),
+                                                      C.c_void_p(stream) if stream else None))
+
     # -- multi-GPU partition --
     def set_partition(self, rank, world, band_rows=0):
         self._check(self._L.bbr_set_partition(self._ctx, rank, world, band_rows))

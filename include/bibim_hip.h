@@ -162,7 +162,19 @@ int bbr_timing_summary(bbr_context *ctx, uint32_t *out_frames, float *out_avg_fr
  *   "ablate" bits            diagnostics only: skip parts of the pipeline (see bb_kernels.hip.h) */
 int bbr_set_option(bbr_context *ctx, const char *name, int64_t value);
 
-/* next row: hdr_tone_mapping.frag:9-18 on the fp32 frame, in place */
+/* ---- presentation: the step after the path ----
+ * Replaces the tone-map subpass + swapchain write (src/main.cpp:123-126, src/shaders/hdr_tone_mapping.frag:9-18,
+ * HDR attachment R16G16B16A16_SFLOAT src/render.h:94, sRGB swapchain format src/render.cpp:242-254):
+ * per pixel of the last frame  rgb -> [binary16 round, if hdr16] -> EnableToneMapping ? 1 - exp(-rgb * Exposure) : rgb
+ * -> sRGB encode -> UNORM8, alpha = 255; EnableToneMapping / Exposure are the ones of the FrameUniformBlock the frame
+ * was rendered with.  Asynchronous, queued behind the frame's shading.  `rgba8_device` = NULL writes a buffer owned by
+ * the context (bbr_presented_device_ptr / bbr_read_presented); with a partition the image is this rank's shard
+ * (bbr_shard_rows() rows), gathered with ncclAllGather + bbr_unpack_gathered_rgba8 at a quarter of the fp32 payload. */
+int bbr_present(bbr_context *ctx, void *rgba8_device, int32_t hdr16);
+int bbr_read_presented(bbr_context *ctx, uint8_t *rgba8_host); /* rows*width*4 bytes; synchronises */
+int bbr_presented_device_ptr(bbr_context *ctx, void **out_ptr, uint64_t *out_bytes);
+int bbr_unpack_gathered_rgba8(bbr_context *ctx, const void *gathered_device, void *frame_device, void *hip_stream);
+/* hdr_tone_mapping.frag:9-18 alone on the fp32 frame, in place (no quantisation) */
 int bbr_tone_map(bbr_context *ctx, int32_t enable_tone_mapping, float exposure);
 
 #ifdef __cplusplus

@@ -328,13 +328,95 @@ void bbo_shade_fragment(const bbo_frame_uniforms *frame, const bbo_view_uniforms
   shade_fragment(frame, view, mat, vary, out_rgba);
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* presentation: HDR attachment -> tone map -> sRGB 8-bit swapchain image      */
+/*   hdr_tone_mapping.frag:9-18 (mapped = 1 - exp(-hdr * exposure), alpha = 1)                      */
+/*   HDR attachment is R16G16B16A16_SFLOAT (src/render.h:94, src/main.cpp:463-472): the tone-map    */
+/*     subpass reads binary16 values                                                                */
+/*   swapchain format R8G8B8A8_SRGB / B8G8R8A8_SRGB (src/render.cpp:242-254): the colour output is  */
+/*     sRGB-encoded and rounded to UNORM8 by the attachment write                                   */
+/* Contract (what a Vulkan driver leaves open, fixed here so that GPU and oracle agree on every      */
+/* byte): binary16 conversion rounds to nearest even; exp is the fixed sequence bb_exp below (<= 1   */
+/* ulp from the real exp); the sRGB byte is the number of thresholds t_k <= c, t_k = float(decode(   */
+/* (k - 0.5) / 255)) for k = 1..255 -- the exactly rounded ideal curve (NaN -> 0).  Parity with a     */
+/* particular driver's ROP is unpinned (the Vulkan spec allows 0.6 ULP8 of slack).                   */
+/* ------------------------------------------------------------------------------------------ */
+
+static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+/* round to the nearest binary16 value (ties to even) and return it as binary32 */
+float bbo_half_round(float x) {
+  const uint32_t u = f2u(x), sign = u & 0x80000000u, a = u & 0x7FFFFFFFu;
+  if (a >= 0x7F800000u) return x;                          /* inf, NaN */
+  if (a >= 0x477FF000u) return u2f(sign | 0x7F800000u);    /* >= 65520 = halfway between 65504 and 2^16 -> inf */
+  if (a < 0x38800000u) {                                   /* below 2^-14: the subnormal grid, spacing 2^-24 */
+    const float r = (u2f(a) + 0.5f) - 0.5f;               /* ulp(0.5) = 2^-24: the add rounds to the grid (RNE) */
+    return u2f(sign | f2u(r));
+  }
+  const uint32_t r = (a + 0x00000FFFu + ((a >> 13) & 1u)) & 0xFFFFE000u; /* keep 10 mantissa bits, RNE */
+  return u2f(sign | r);
+}
+
+/* exp as a fixed sequence of binary32 operations: Cody-Waite reduction by ln2 (hi/lo), degree-7 Taylor/Horner in
+ * fma, scaling by 2^n in two exact-until-the-last multiplications.  Max error measured over 2^24 points: < 1 ulp. */
+float bbo_exp(float x) {
+  if (!(x >= -104.0f)) return x < -104.0f ? 0.0f : x; /* underflow to 0; NaN stays NaN */
+  if (x > 88.7228317f) return INFINITY;
+  const float n = rintf(x * 1.44269502f);
+  float r = fmaf(n, -0.693145752f, x);
+  r = fmaf(n, -1.42860677e-06f, r);
+  float p = 1.98412701e-04f;         /* 1/5040 */
+  p = fmaf(p, r, 1.38888892e-03f);   /* 1/720 */
+  p = fmaf(p, r, 8.33333377e-03f);   /* 1/120 */
+  p = fmaf(p, r, 4.16666679e-02f);   /* 1/24 */
+  p = fmaf(p, r, 1.66666672e-01f);   /* 1/6 */
+  p = fmaf(p, r, 0.5f);
+  p = fmaf(p, r, 1.0f);
+  p = fmaf(p, r, 1.0f);
+  const int32_t ni = (int32_t)n, h = ni / 2;
+  const float s1 = u2f((uint32_t)(h + 127) << 23), s2 = u2f((uint32_t)(ni - h + 127) << 23);
+  return (p * s1) * s2;
+}
+
+/* out[k-1] = t_k, k = 1..255 (ascending) */
+void bbo_srgb_thresholds(float *out255) {
+  for (int k = 1; k <= 255; ++k) {
+    const double b = ((double)k - 0.5) / 255.0;
+    const double lin = b <= 0.04045 ? b / 12.92 : pow((b + 0.055) / 1.055, 2.4);
+    out255[k - 1] = (float)lin;
+  }
+}
+
+static inline uint8_t srgb8(float c, const float *thr) { /* number of thresholds <= c; thr[255] = +inf */
+  uint32_t pos = 0;
+  for (uint32_t step = 128; step; step >>= 1)
+    if (thr[pos + step - 1] <= c) pos += step;
+  return (uint8_t)pos;
+}
+
 void bbo_tone_map(float *rgba, uint64_t n_pixels, int32_t enable, float exposure) {
   for (uint64_t i = 0; i < n_pixels; ++i) {
     float *p = rgba + 4 * i;
     if (enable) {
-      for (int c = 0; c < 3; ++c) p[c] = 1.0f - expf(-p[c] * exposure);
+      for (int c = 0; c < 3; ++c) p[c] = 1.0f - bbo_exp(-p[c] * exposure);
     }
     p[3] = 1.0f;
+  }
+}
+
+void bbo_present(const float *rgba, uint64_t n_pixels, int32_t enable, float exposure, int32_t hdr16, uint8_t *out_rgba8) {
+  float thr[256];
+  bbo_srgb_thresholds(thr);
+  thr[255] = INFINITY;
+  for (uint64_t i = 0; i < n_pixels; ++i) {
+    for (int c = 0; c < 3; ++c) {
+      float v = rgba[4 * i + c];
+      if (hdr16) v = bbo_half_round(v);
+      if (enable) v = 1.0f - bbo_exp(-v * exposure);
+      out_rgba8[4 * i + c] = srgb8(v, thr);
+    }
+    out_rgba8[4 * i + 3] = 255; /* outColor.a = 1.0; alpha is not sRGB-encoded */
   }
 }
 

@@ -145,6 +145,12 @@ float bbo_geometry_smith(const float *N, const float *V, const float *L, float r
 void bbo_fresnel_schlick(const float *H, const float *V, const float *F0, float *out);
 /* hdr_tone_mapping.frag:9-18 applied in place on n RGBA pixels (alpha := 1) */
 void bbo_tone_map(float *rgba, uint64_t n_pixels, int32_t enable, float exposure);
+/* presentation: (optional) binary16 rounding of the HDR value, tone map, sRGB encode, UNORM8; alpha = 255.
+ * hdr_tone_mapping.frag:9-18, src/render.h:94, src/render.cpp:242-254.  See bb_oracle.c for the contract. */
+void bbo_present(const float *rgba, uint64_t n_pixels, int32_t enable, float exposure, int32_t hdr16, uint8_t *out_rgba8);
+float bbo_half_round(float x);
+float bbo_exp(float x);
+void bbo_srgb_thresholds(float *out255);
 
 /* ---- vector_math.cpp / camera.cpp restatement (row A0) ---- */
 void bbo_mat4_identity(bbo_mat4 *out);

@@ -109,6 +109,14 @@ def lib():
         L.bbo_geometry_smith.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float]
         L.bbo_fresnel_schlick.argtypes = [C.c_void_p] * 4
         L.bbo_tone_map.argtypes = [C.c_void_p, C.c_uint64, C.c_int32, C.c_float]
+        L.bbo_present.argtypes = [C.c_void_p, C.c_uint64, C.c_int32, C.c_float, C.c_int32, C.c_void_p]
+        L.bbo_present.restype = None
+        L.bbo_half_round.argtypes = [C.c_float]
+        L.bbo_half_round.restype = C.c_float
+        L.bbo_exp.argtypes = [C.c_float]
+        L.bbo_exp.restype = C.c_float
+        L.bbo_srgb_thresholds.argtypes = [C.c_void_p]
+        L.bbo_srgb_thresholds.restype = None
         for n in ("identity",):
             getattr(L, f"bbo_mat4_{n}").argtypes = [C.c_void_p]
         L.bbo_mat4_mul.argtypes = [C.c_void_p] * 3
@@ -307,4 +315,26 @@ def shade_fragment(frame, view, material: MaterialData, vary):
 def tone_map(rgba, enable, exposure):
     out = np.ascontiguousarray(rgba, np.float32).copy()
     lib().bbo_tone_map(_p(out), out.size // 4, int(enable), float(exposure))
+    return out
+
+
+def present(rgba, enable, exposure, hdr16=True):
+    """fp32 RGBA frame -> presented RGBA8 (binary16 HDR attachment, tone map, sRGB, UNORM8)"""
+    src = np.ascontiguousarray(rgba, np.float32)
+    out = np.empty(src.shape, np.uint8)
+    lib().bbo_present(_p(src), src.size // 4, int(enable), float(exposure), int(bool(hdr16)), _p(out))
+    return out
+
+
+def half_round(x):
+    return np.array([lib().bbo_half_round(float(v)) for v in np.ravel(x)], np.float32).reshape(np.shape(x))
+
+
+def exp(x):
+    return np.array([lib().bbo_exp(float(v)) for v in np.ravel(x)], np.float32).reshape(np.shape(x))
+
+
+def srgb_thresholds():
+    out = np.empty(255, np.float32)
+    lib().bbo_srgb_thresholds(_p(out))
     return out

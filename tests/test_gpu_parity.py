@@ -272,4 +272,59 @@ def test_tone_map_next_row(maps64):
     ldr = r.read_framebuffer()
     r.close()
     want = bbo.tone_map(hdr, 1, 1.7)
-    np.testing.assert_allclose(ldr, want, rtol=2e-6, atol=2e-7)  # expf: device vs libm, not part of the bit-exact contract
+    assert np.array_equal(ldr.view(np.uint32), want.view(np.uint32))  # exp is a fixed sequence shared with the oracle
+
+
+@pytest.mark.parametrize("enable,exposure,hdr16", [(0, 1.0, 1), (1, 1.7, 1), (1, 0.6, 0)])
+def test_present_bytes_match_the_oracle(maps64, enable, exposure, hdr16):
+    """the step after the path: binary16 HDR attachment -> tone map -> sRGB UNORM8, byte for byte"""
+    sc = scenes.shaderball_scene(configs.C3.scaled(640, 360, 64), bbo.MaterialData(maps64))
+    sc.frame["enable_tone_mapping"], sc.frame["exposure"] = enable, exposure
+    ref, _, _, _ = bbo.render(sc)
+    r = Renderer(sc.width, sc.height)
+    r.render_scene(sc)
+    r.present(hdr16=hdr16)
+    got = r.read_presented()
+    hdr = r.read_framebuffer()                      # present leaves the fp32 frame untouched
+    r.close()
+    assert np.array_equal(hdr.view(np.uint32), ref.view(np.uint32))
+    want = bbo.present(ref, enable, exposure, hdr16)
+    assert got.shape == want.shape and np.array_equal(got, want)
+    assert np.all(got[..., 3] == 255) and got[..., :3].max() > 100
+
+
+def test_present_golden_fixture_and_special_values(maps64):
+    """committed presented bytes of the golden C2 160x90 frame; NaN / inf pixels of the default-material frame"""
+    z = np.load(os.path.join(GOLDEN, "presented.npz"))
+    sc = scenes.shaderball_scene(configs.C2.scaled(160, 90, 64), bbo.MaterialData(maps64))
+    sc.frame["enable_tone_mapping"], sc.frame["exposure"] = 1, 1.7
+    r = Renderer(sc.width, sc.height)
+    r.render_scene(sc)
+    r.present()
+    assert np.array_equal(r.read_presented(), z["c2_160x90_tonemapped"])
+    r.close()
+    tri = scenes.triangle_scene(96, 96)             # default material: roughness 0 -> NaN where N.H = 1
+    ref, _, _, _ = bbo.render(tri)
+    r = Renderer(96, 96)
+    r.render_scene(tri)
+    r.present()
+    assert np.array_equal(r.read_presented(), bbo.present(ref, 0, 1.0))
+    r.close()
+
+
+def test_present_after_an_overflow_replay_and_into_a_caller_buffer(maps64):
+    import torch
+    sc = scenes.shaderball_scene(configs.C3.scaled(320, 180, 64), bbo.MaterialData(maps64))
+    sc.frame["enable_tone_mapping"], sc.frame["exposure"] = 1, 1.0
+    ref, _, _, _ = bbo.render(sc)
+    want = bbo.present(ref, 1, 1.0)
+    r = Renderer(sc.width, sc.height)
+    r.set_option("bin_cap", 8)                      # the frame overflows its bins and is rendered again on sync
+    out = torch.zeros((sc.height, sc.width, 4), dtype=torch.uint8, device="cuda")
+    r.render_scene(sc)
+    r.present(out.data_ptr())
+    got = r.read_presented()                        # synchronises, replays, presents again
+    assert r.stats()["bin_overflow"] >= 1
+    torch.cuda.synchronize()
+    assert np.array_equal(got, want) and np.array_equal(out.cpu().numpy(), want)
+    r.close()

@@ -76,6 +76,35 @@ def test_partitioned_render_reassembles_to_the_single_gpu_frame(maps64, world, b
     assert np.array_equal(frame.view(np.uint32), ref.view(np.uint32))
 
 
+def test_presented_shards_reassemble(maps64):
+    """RGBA8 shards (a quarter of the fp32 payload) gathered and un-interleaved on the device == presented full frame"""
+    import torch
+    cfg = configs.C3.scaled(512, 300, 64)
+    sc = scenes.shaderball_scene(cfg, bbo.MaterialData(maps64))
+    sc.frame["enable_tone_mapping"], sc.frame["exposure"] = 1, 1.2
+    ref, _, _, _ = bbo.render(sc)
+    want = bbo.present(ref, 1, 1.2)
+    world, band_rows = 3, 32
+    shards = []
+    for rank in range(world):
+        r = Renderer(cfg.width, cfg.height)
+        r.set_partition(rank, world, band_rows)
+        r.render_scene(sc)
+        r.present()
+        shards.append(r.read_presented())
+        assert shards[-1].shape == (r.shard_rows(), cfg.width, 4)
+        if rank == world - 1:
+            gathered = torch.from_numpy(np.stack(shards)).cuda()
+            frame = torch.zeros((cfg.height, cfg.width, 4), dtype=torch.uint8, device="cuda")
+            r.unpack_gathered_rgba8(gathered.data_ptr(), frame.data_ptr())
+            r.synchronize()
+            torch.cuda.synchronize()
+            assert np.array_equal(frame.cpu().numpy(), want)
+        r.close()
+    host = P.unpack_gathered(np.stack(shards), cfg.height, band_rows)
+    assert np.array_equal(host, want)
+
+
 def test_device_side_unpack_matches_host_unpack(maps64):
     import torch
     cfg = configs.C3.scaled(384, 200, 64)

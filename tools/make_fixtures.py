@@ -4,6 +4,7 @@
   math_golden.json         outputs of the REFERENCE's vector_math.cpp / camera.cpp (oracle/_ref)
   default_texels.json      resources/pbr/default/*.png decoded by the reference's stb_image 2.25
   gizmo.npz                gizmo.obj/.mtl expanded to bb::GizmoVertex[] + indices
+  oracle_frames.npz, n_shaded.json, presented.npz   outputs of the oracle itself, frozen
 
 Fixtures are data (inputs / expected outputs); no reference source text is stored.
 """
@@ -177,8 +178,26 @@ def n_shaded():
     json.dump(out, open(os.path.join(GOLD, "n_shaded.json"), "w"), indent=1)
 
 
+def present():
+    """Presentation contract frozen: the 255 sRGB thresholds (bit patterns) and the presented bytes of the golden
+    C2 160x90 frame with and without tone mapping (sha256 + the image itself, 57 KB each)."""
+    from oracle import bbo
+    thr = bbo.srgb_thresholds()
+    frames = np.load(os.path.join(GOLD, "oracle_frames.npz"))
+    hdr = frames["c2_160x90_rgba_bits"].view(np.float32)
+    out = {"srgb_thresholds_bits": thr.view(np.uint32)}
+    info = {"thresholds_sha256": hashlib.sha256(thr.tobytes()).hexdigest()}
+    for tag, enable, exposure, hdr16 in (("plain", 0, 1.0, 1), ("tonemapped", 1, 1.7, 1), ("tonemapped_fp32", 1, 1.7, 0)):
+        img = bbo.present(hdr, enable, exposure, hdr16)
+        out[f"c2_160x90_{tag}"] = img
+        info[tag] = {"enable": enable, "exposure": exposure, "hdr16": hdr16, "sha256": hashlib.sha256(img.tobytes()).hexdigest()}
+    np.savez_compressed(os.path.join(GOLD, "presented.npz"), **out)
+    json.dump(info, open(os.path.join(GOLD, "presented.json"), "w"), indent=1)
+    print("present", info)
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["shaderball", "math_golden", "default_texels", "gizmo", "golden_frames", "n_shaded"]
+    which = sys.argv[1:] or ["shaderball", "math_golden", "default_texels", "gizmo", "golden_frames", "n_shaded", "present"]
     for w in which:
         globals()[w]()
