@@ -116,6 +116,9 @@ def main():
     ap.add_argument("--no-timing-events", action="store_true")
     ap.add_argument("--frames-in-flight", type=int, default=2, choices=[1, 2, 3])
     ap.add_argument("--force-dist", action="store_true", help="exercise the all-gather path with WORLD_SIZE = 1")
+    ap.add_argument("--present", action="store_true",
+                    help="every step also runs the presentation step (tone map + sRGB + RGBA8, SURVEY 8(f) rank 1); "
+                         "for N > 1 the RGBA8 shards are gathered instead of the fp32 ones (a quarter of the payload)")
     args = ap.parse_args()
 
     import torch
@@ -164,6 +167,10 @@ def main():
         shard_t = [torch.empty((shard_rows, W, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
         gathered_t = [torch.empty((world * shard_rows, W, 4), dtype=torch.float32, device="cuda") for _ in range(2)]  # [rank][shard row]
         frame_t = [torch.empty((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
+        if args.present:
+            shard8_t = [torch.empty((shard_rows, W, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
+            gathered8_t = [torch.empty((world * shard_rows, W, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
+            frame8_t = [torch.empty((H, W, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
         ag_stream = torch.cuda.Stream()
         consumed = [torch.cuda.Event(), torch.cuda.Event()]
     step_no = [0]
@@ -173,16 +180,24 @@ def main():
         step_no[0] = n + 1
         if not dist_path:
             S.draw_frame(r, scene, cam, settings, material)  # asynchronous; internal double-buffered framebuffer
+            if args.present:
+                r.present()
             return
         b = n & 1
         if n >= 2:
             r.wait_event(consumed[b].cuda_event)             # shard[b] is free again once gather n-2 has read it
         r.set_output_device_ptr(shard_t[b].data_ptr(), shard_t[b].numel() * 4)
         S.draw_frame(r, scene, cam, settings, material)
+        if args.present:
+            r.present(shard8_t[b].data_ptr())
         r.stream_wait_frame(ag_stream.cuda_stream)
         with torch.cuda.stream(ag_stream):
-            dist.all_gather_into_tensor(gathered_t[b], shard_t[b])
-            r.unpack_gathered(gathered_t[b].data_ptr(), frame_t[b].data_ptr(), ag_stream.cuda_stream)
+            if args.present:
+                dist.all_gather_into_tensor(gathered8_t[b], shard8_t[b])
+                r.unpack_gathered_rgba8(gathered8_t[b].data_ptr(), frame8_t[b].data_ptr(), ag_stream.cuda_stream)
+            else:
+                dist.all_gather_into_tensor(gathered_t[b], shard_t[b])
+                r.unpack_gathered(gathered_t[b].data_ptr(), frame_t[b].data_ptr(), ag_stream.cuda_stream)
             consumed[b].record(ag_stream)
 
     def fence():
@@ -265,6 +280,23 @@ def main():
             "avg_raster_ms": round(ra1, 5), "avg_device_frame_latency_ms": round(f1, 5),
             "achieved": round(shade_bytes / (s1 * 1e-3) / 1e9, 2) if s1 > 0 else 0.0,
             "frac": round(shade_bytes / (s1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if s1 > 0 else 0.0}
+        # the next row of SURVEY 8(f), measured beside the path: k_present alone, 16 B read + 4 B written per pixel
+        import dataclasses
+        settings_tm = dataclasses.replace(settings, enable_tone_mapping=1, exposure=1.0)
+        S.draw_frame(r, scene, cam, settings_tm, material)
+        fence()
+        r.timing_reset()
+        for _ in range(50):
+            r.present()
+        fence()
+        n_p, ms_p = r.present_timing()
+        p_bytes = W * H * 20
+        roofline["next_row_present"] = {
+            "kernel": "k_present", "bound": "hbm", "launches_timed": int(n_p), "avg_kernel_ms": round(ms_p, 5),
+            "algorithmic_bytes_per_launch": p_bytes, "achieved": round(p_bytes / (ms_p * 1e-3) / 1e9, 2) if ms_p > 0 else 0.0,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(p_bytes / (ms_p * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms_p > 0 else 0.0,
+            "what": "binary16 HDR -> tone map (on, exposure 1) -> sRGB UNORM8 of the whole frame"}
         r.set_option("frames_in_flight", args.frames_in_flight)
 
     cpu = None
@@ -284,7 +316,8 @@ def main():
                        "textures": f"{cfg.texture_size}x{cfg.texture_size} RGBA8 x5 (seed 0x5EED)",
                        "partition": "single GPU" if world == 1 else f"interleaved {args.band_rows or r.tile_height()}-row bands, "
                                     f"{world} ranks, ncclAllGather + un-interleave",
-                       "tile": f"{stats['tile_w']}x{stats['tile_h']}"},
+                       "tile": f"{stats['tile_w']}x{stats['tile_h']}",
+                       "output": "RGBA32F frame + presented RGBA8" if args.present else "RGBA32F frame"},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

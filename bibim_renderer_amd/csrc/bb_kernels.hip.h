@@ -1332,18 +1332,10 @@ __global__ void k_unpack_gathered(const float4 *__restrict__ gathered, float4 *_
 // Same fixed sequences as the CPU oracle (binary16 rounding, exp, threshold table): byte-exact.
 // ------------------------------------------------------------------------------------------------
 
-// nearest binary16 value (ties to even), as binary32
-BB_DEV float bb_half_round(float x) {
-  const uint32_t u = __float_as_uint(x), sign = u & 0x80000000u, a = u & 0x7FFFFFFFu;
-  if (a >= 0x7F800000u) return x;
-  if (a >= 0x477FF000u) return __uint_as_float(sign | 0x7F800000u);
-  if (a < 0x38800000u) {
-    const float r = (__uint_as_float(a) + 0.5f) - 0.5f;
-    return __uint_as_float(sign | __float_as_uint(r));
-  }
-  const uint32_t r = (a + 0x00000FFFu + ((a >> 13) & 1u)) & 0xFFFFE000u;
-  return __uint_as_float(sign | r);
-}
+// nearest binary16 value (ties to even), as binary32: v_cvt_f16_f32 / v_cvt_f32_f16 do exactly this on gfx950
+// (round-to-nearest-even, binary16 subnormals kept -- the default float mode of HIP kernels; every binary16
+// midpoint +-3 ulp is checked against the oracle's integer formulation in tests/test_gpu_parity.py)
+BB_DEV float bb_half_round(float x) { return (float)(_Float16)x; }
 
 BB_DEV float bb_exp(float x) {
   if (!(x >= -104.0f)) return x < -104.0f ? 0.0f : x;
@@ -1378,36 +1370,57 @@ __global__ void k_tone_map(float4 *__restrict__ frame, size_t n, int enable, flo
   frame[i] = c;
 }
 
-// sRGB byte = number of thresholds <= c (thr[255] = +inf; NaN -> 0): eight LDS probes
-BB_DEV uint32_t srgb8(float c, const float *thr) {
-  uint32_t pos = 0u;
-#pragma unroll
-  for (uint32_t step = 128u; step; step >>= 1)
-    if (thr[pos + step - 1u] <= c) pos += step;
-  return pos;
+// sRGB byte = number of thresholds t_k <= c (NaN -> 0).  Instead of a binary search (eight dependent LDS probes)
+// the byte is read from a table keyed by the top 16 bits of the float: 256 cells per octave over the 13 octaves
+// [2^-13, 1) that contain all thresholds.  A cell is narrower than the closest pair of thresholds (0.39 % against
+// >= 0.88 %; checked when the table is built), so it holds the count at its lower edge and at most one more
+// threshold, which one compare settles: two LDS reads, same bytes as the search for every float.
+constexpr uint32_t kSrgbLutFirstExp = 114u;             // 2^-13
+constexpr uint32_t kSrgbLutCells = 13u * 256u;          // biased exponents 114..126
+struct SrgbTables {                                      // device copy built by the host
+  float thr[256];                                        // t_1..t_255, then +inf
+  uint8_t lut[kSrgbLutCells];                            // thresholds <= lower edge of the cell
+};
+
+BB_DEV uint32_t srgb8(float c, const SrgbTables &t) {
+  const uint32_t u = __float_as_uint(c);
+  if ((int32_t)u < (int32_t)(kSrgbLutFirstExp << 23)) return 0u;  // below 2^-13, zero, negative, negative NaN
+  if (u >= (127u << 23)) return u <= 0x7F800000u ? 255u : 0u;     // >= 1 (and +inf) -> 255, NaN -> 0
+  const uint32_t k = t.lut[(u >> 15) - (kSrgbLutFirstExp << 8)];
+  return k + (t.thr[k] <= c ? 1u : 0u);
 }
 
-// One pixel per lane: 16 B read, 4 B written -- 20 algorithmic bytes per pixel, HBM-bound by construction.
+// 16 B read + 4 B written per pixel: 20 algorithmic bytes, HBM-bound by construction.  A workgroup loads the 4.3 KB
+// of tables once and converts 2048 pixels (eight coalesced rounds of 256).
 constexpr int kPresentThreads = 256;
+constexpr int kPresentPerThread = 8;
 __global__ __launch_bounds__(kPresentThreads) void k_present(const float4 *__restrict__ frame, uint32_t *__restrict__ out_rgba8,
-                                                              size_t n, const float *__restrict__ thresholds, int enable,
+                                                              size_t n, const SrgbTables *__restrict__ tables, int enable,
                                                               float exposure, int hdr16) {
-  __shared__ float thr[256];
-  thr[threadIdx.x] = threadIdx.x < 255 ? thresholds[threadIdx.x] : __uint_as_float(0x7F800000u);
-  __syncthreads();
-  const size_t i = (size_t)blockIdx.x * kPresentThreads + threadIdx.x;
-  if (i >= n) return;
-  const float4 c = frame[i];
-  float v[3] = {c.x, c.y, c.z};
-  uint32_t px = 0xFF000000u;  // outColor.a = 1.0
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    float x = v[k];
-    if (hdr16) x = bb_half_round(x);
-    if (enable) x = 1.0f - bb_exp(-x * exposure);
-    px |= srgb8(x, thr) << (8 * k);
+  __shared__ SrgbTables t;
+  {
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(tables);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(&t);
+    for (uint32_t w = threadIdx.x; w < sizeof(SrgbTables) / 4; w += kPresentThreads) dst[w] = src[w];
   }
-  out_rgba8[i] = px;
+  __syncthreads();
+  const size_t base = (size_t)blockIdx.x * (kPresentThreads * kPresentPerThread) + threadIdx.x;
+#pragma unroll 2
+  for (int j = 0; j < kPresentPerThread; ++j) {
+    const size_t i = base + (size_t)j * kPresentThreads;
+    if (i >= n) break;
+    const float4 c = frame[i];
+    float v[3] = {c.x, c.y, c.z};
+    uint32_t px = 0xFF000000u;  // outColor.a = 1.0
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      float x = v[k];
+      if (hdr16) x = bb_half_round(x);
+      if (enable) x = 1.0f - bb_exp(-x * exposure);
+      px |= srgb8(x, t) << (8 * k);
+    }
+    out_rgba8[i] = px;
+  }
 }
 
 // [world][shard_rows][width] RGBA8 -> row-major presented frame (same un-interleave as k_unpack_gathered)

@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <limits>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -140,7 +141,7 @@ struct bbr_context {
   uint64_t frame_counter = 0;
   int last_slot = -1;
 
-  DeviceBuffer<float> d_srgb_thresholds;  // 255 floats: linear value at which the sRGB byte becomes k (k = 1..255)
+  DeviceBuffer<SrgbTables> d_srgb_tables;  // thresholds t_k (linear value at which the sRGB byte becomes k) + the keyed table
   DeviceBuffer<uint32_t> d_vis_prim;
   DeviceBuffer<float> d_vis_depth;
   void *ext_out = nullptr;
@@ -160,6 +161,8 @@ struct bbr_context {
   // timing ring: (frame start, geometry done, raster done, shade start, shade done) per frame since the last reset
   std::vector<hipEvent_t> ring;
   uint32_t ring_frames = 0;
+  std::vector<hipEvent_t> present_ring;  // (start, stop) around each k_present while timing is on
+  uint32_t present_launches = 0;
   static constexpr uint32_t kRingCap = 512;
   static constexpr uint32_t kRingEvents = 5;
   int retries = 0;
@@ -410,23 +413,61 @@ int submit_frame_into(bbr_context *c, int slot_index) {
   return BBR_OK;
 }
 
-// k_present for the frame in slot `s`, on the shade stream (ordered after the frame's k_shade)
-int queue_present(bbr_context *c, FrameSlot &s) {
-  if (!c->d_srgb_thresholds.ptr) {
-    // t_k = float(decode((k - 0.5) / 255)) (the same table the CPU oracle builds)
-    float h[255];
+int ensure_srgb_tables(bbr_context *c) {
+  if (!c->d_srgb_tables.ptr) {
+    // t_k = float(decode((k - 0.5) / 255)) (the same table the CPU oracle builds), then the table keyed by the
+    // float's top bits: thresholds <= lower edge of each cell; a cell may contain at most one threshold
+    static SrgbTables h;
     for (int k = 1; k <= 255; ++k) {
       const double b = ((double)k - 0.5) / 255.0;
-      h[k - 1] = (float)(b <= 0.04045 ? b / 12.92 : std::pow((b + 0.055) / 1.055, 2.4));
+      h.thr[k - 1] = (float)(b <= 0.04045 ? b / 12.92 : std::pow((b + 0.055) / 1.055, 2.4));
     }
-    HIP_TRY(c, c->d_srgb_thresholds.ensure(255));
-    HIP_TRY(c, hipMemcpy(c->d_srgb_thresholds.ptr, h, sizeof h, hipMemcpyHostToDevice));
+    h.thr[255] = std::numeric_limits<float>::infinity();
+    for (uint32_t cell = 0; cell < kSrgbLutCells; ++cell) {
+      auto edge = [](uint32_t cl) {
+        uint32_t bits = ((kSrgbLutFirstExp << 8) + cl) << 15;
+        float f;
+        std::memcpy(&f, &bits, 4);
+        return f;
+      };
+      const float lo = edge(cell), hi = edge(cell + 1);
+      uint32_t below = 0, inside = 0;
+      for (int k = 0; k < 255; ++k) {
+        below += h.thr[k] <= lo;
+        inside += h.thr[k] > lo && h.thr[k] < hi;
+      }
+      if (inside > 1) return fail(c, BBR_ERR_HIP, "sRGB table: two thresholds in one cell");
+      h.lut[cell] = (uint8_t)below;
+    }
+    HIP_TRY(c, c->d_srgb_tables.ensure(1));
+    HIP_TRY(c, hipMemcpy(c->d_srgb_tables.ptr, &h, sizeof h, hipMemcpyHostToDevice));
   }
+  return BBR_OK;
+}
+
+// k_present for the frame in slot `s`, on the shade stream (ordered after the frame's k_shade)
+int queue_present(bbr_context *c, FrameSlot &s) {
+  int rc_tables = ensure_srgb_tables(c);
+  if (rc_tables) return rc_tables;
   const size_t n = (size_t)c->width * (c->world > 1 ? c->shard_rows() : c->height);
-  hipLaunchKernelGGL(k_present, dim3((unsigned)((n + kPresentThreads - 1) / kPresentThreads)), dim3(kPresentThreads), 0,
-                     c->shade_stream(), s.out_used, s.present.out, n, c->d_srgb_thresholds.ptr, s.present.enable,
+  hipEvent_t *pe = nullptr;
+  if (c->timing) {
+    if (c->present_ring.empty()) {
+      c->present_ring.resize(2 * bbr_context::kRingCap);
+      for (auto &e : c->present_ring) HIP_TRY(c, hipEventCreate(&e));
+    }
+    pe = &c->present_ring[2 * (c->present_launches % bbr_context::kRingCap)];
+    HIP_TRY(c, hipEventRecord(pe[0], c->shade_stream()));
+  }
+  const size_t per_block = (size_t)kPresentThreads * kPresentPerThread;
+  hipLaunchKernelGGL(k_present, dim3((unsigned)((n + per_block - 1) / per_block)), dim3(kPresentThreads), 0,
+                     c->shade_stream(), s.out_used, s.present.out, n, c->d_srgb_tables.ptr, s.present.enable,
                      s.present.exposure, s.present.hdr16);
   HIP_TRY(c, hipGetLastError());
+  if (pe) {
+    HIP_TRY(c, hipEventRecord(pe[1], c->shade_stream()));
+    ++c->present_launches;
+  }
   // the slot is busy until the presented image exists
   HIP_TRY(c, hipEventRecord(s.ev_shade_done, c->shade_stream()));
   return BBR_OK;
@@ -560,6 +601,9 @@ int bbr_destroy(bbr_context *c) {
   }
   for (auto &e : c->ring)
     if (e) (void)hipEventDestroy(e);
+  for (auto &e : c->present_ring)
+    if (e) (void)hipEventDestroy(e);
+  c->d_srgb_tables.release();
   if (c->s_geom) (void)hipStreamDestroy(c->s_geom);
   if (c->s_shade) (void)hipStreamDestroy(c->s_shade);
   delete c;
@@ -946,6 +990,7 @@ int bbr_timing_reset(bbr_context *c) {
   int rc = drain(c);
   if (rc) return rc;
   c->ring_frames = 0;
+  c->present_launches = 0;
   return BBR_OK;
 }
 
@@ -976,6 +1021,23 @@ int bbr_timing_summary(bbr_context *c, uint32_t *out_frames, float *out_avg_fram
   return BBR_OK;
 }
 
+int bbr_present_timing(bbr_context *c, uint32_t *out_launches, float *out_avg_ms) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  if (!c->timing) return fail(c, BBR_ERR_INVALID_ARGUMENT, "present_timing: enable option \"timing\" first");
+  int rc = drain(c);
+  if (rc) return rc;
+  uint32_t n = std::min(c->present_launches, bbr_context::kRingCap);
+  double t = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    float ms = 0.f;
+    HIP_TRY(c, hipEventElapsedTime(&ms, c->present_ring[2 * i], c->present_ring[2 * i + 1]));
+    t += ms;
+  }
+  if (out_launches) *out_launches = n;
+  if (out_avg_ms) *out_avg_ms = n ? (float)(t / n) : 0.f;
+  return BBR_OK;
+}
+
 int bbr_set_option(bbr_context *c, const char *name, int64_t value) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
   if (!name) return fail(c, BBR_ERR_INVALID_ARGUMENT, "set_option: NULL name");
@@ -986,6 +1048,7 @@ int bbr_set_option(bbr_context *c, const char *name, int64_t value) {
     if (value < 0 || value > 2) return fail(c, BBR_ERR_INVALID_ARGUMENT, "timing: 0, 1 or 2");
     c->timing = (int)value;
     c->ring_frames = 0;
+    c->present_launches = 0;
   }
   else if (n == "frames_in_flight") {
     if (value < 1 || value > bbr_context::kMaxSlots) return fail(c, BBR_ERR_INVALID_ARGUMENT, "frames_in_flight: 1, 2 or 3");
@@ -1046,6 +1109,21 @@ int bbr_present(bbr_context *c, void *rgba8_device, int32_t hdr16) {
   s.present.exposure = s.tone_exposure;
   s.present.hdr16 = hdr16 != 0;
   return queue_present(c, s);
+}
+
+int bbr_present_buffer(bbr_context *c, const void *rgba32f_device, void *rgba8_device, uint64_t n_pixels, int32_t enable,
+                       float exposure, int32_t hdr16, void *stream) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  if (!rgba32f_device || !rgba8_device) return fail(c, BBR_ERR_INVALID_ARGUMENT, "present_buffer: NULL");
+  if (!n_pixels) return BBR_OK;
+  int rc = ensure_srgb_tables(c);
+  if (rc) return rc;
+  const size_t per_block = (size_t)kPresentThreads * kPresentPerThread;
+  hipLaunchKernelGGL(k_present, dim3((unsigned)((n_pixels + per_block - 1) / per_block)), dim3(kPresentThreads), 0,
+                     stream ? (hipStream_t)stream : c->shade_stream(), (const float4 *)rgba32f_device,
+                     (uint32_t *)rgba8_device, (size_t)n_pixels, c->d_srgb_tables.ptr, enable, exposure, hdr16 != 0);
+  HIP_TRY(c, hipGetLastError());
+  return BBR_OK;
 }
 
 int bbr_read_presented(bbr_context *c, uint8_t *host) {

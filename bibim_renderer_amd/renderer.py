@@ -147,11 +147,22 @@ class Renderer:
         """queue k_present for the last frame; EnableToneMapping / Exposure come from its FrameUniformBlock"""
         self._check(self._L.bbr_present(self._ctx, C.c_void_p(rgba8_device_ptr) if rgba8_device_ptr else None, int(bool(hdr16))))
 
+    def present_buffer(self, rgba32f_ptr, rgba8_ptr, n_pixels, enable, exposure, hdr16=True, stream=None):
+        self._check(self._L.bbr_present_buffer(self._ctx, C.c_void_p(rgba32f_ptr), C.c_void_p(rgba8_ptr), int(n_pixels),
+                                               int(enable), float(exposure), int(bool(hdr16)),
+                                               C.c_void_p(stream) if stream else None))
+
     def read_presented(self):
         rows = self.shard_rows()
         out = np.empty((rows, self.width, 4), np.uint8)
         self._check(self._L.bbr_read_presented(self._ctx, _ptr(out)))
         return out
+
+    def present_timing(self):
+        """(launches, average k_present ms) since timing_reset(), option "timing" on"""
+        n, t = C.c_uint32(), C.c_float()
+        self._check(self._L.bbr_present_timing(self._ctx, C.byref(n), C.byref(t)))
+        return n.value, t.value
 
     def presented_device_ptr(self):
         p, n = C.c_void_p(), C.c_uint64()

@@ -172,8 +172,14 @@ int bbr_set_option(bbr_context *ctx, const char *name, int64_t value);
  * (bbr_shard_rows() rows), gathered with ncclAllGather + bbr_unpack_gathered_rgba8 at a quarter of the fp32 payload. */
 int bbr_present(bbr_context *ctx, void *rgba8_device, int32_t hdr16);
 int bbr_read_presented(bbr_context *ctx, uint8_t *rgba8_host); /* rows*width*4 bytes; synchronises */
+/* the same conversion on any device buffer of n_pixels RGBA32F pixels (e.g. an all-gathered frame), queued on
+ * `hip_stream` (NULL = the context's shading stream) */
+int bbr_present_buffer(bbr_context *ctx, const void *rgba32f_device, void *rgba8_device, uint64_t n_pixels,
+                       int32_t enable_tone_mapping, float exposure, int32_t hdr16, void *hip_stream);
 int bbr_presented_device_ptr(bbr_context *ctx, void **out_ptr, uint64_t *out_bytes);
 int bbr_unpack_gathered_rgba8(bbr_context *ctx, const void *gathered_device, void *frame_device, void *hip_stream);
+/* with option "timing" on: launches of k_present since bbr_timing_reset and their average duration (HIP events) */
+int bbr_present_timing(bbr_context *ctx, uint32_t *out_launches, float *out_avg_ms);
 /* hdr_tone_mapping.frag:9-18 alone on the fp32 frame, in place (no quantisation) */
 int bbr_tone_map(bbr_context *ctx, int32_t enable_tone_mapping, float exposure);
 

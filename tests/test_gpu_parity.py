@@ -312,6 +312,37 @@ def test_present_golden_fixture_and_special_values(maps64):
     r.close()
 
 
+def test_present_buffer_on_every_rounding_boundary():
+    """k_present reads the sRGB byte from a table keyed by the float's top bits instead of searching the thresholds:
+    same byte for every float -- all thresholds and all table cell edges +-3 ulp, the binary16 rounding boundaries,
+    specials, and 4M random bit patterns; with and without the binary16 stage and the tone map"""
+    import torch
+    thr = bbo.srgb_thresholds().view(np.uint32).astype(np.int64)
+    cells = ((np.arange(13 * 256 + 1, dtype=np.int64) + (114 << 8)) << 15)
+    halves = np.arange(0, 0x7C00, dtype=np.uint16).view(np.float16).astype(np.float32)   # every non-negative binary16
+    mids = ((halves[:-1].astype(np.float64) + halves[1:].astype(np.float64)) / 2).astype(np.float32).view(np.uint32).astype(np.int64)
+    near = np.concatenate([b + d for b in (thr, cells, mids) for d in range(-3, 4)])
+    rng = np.random.default_rng(11)
+    specials = np.array([0, 0x80000000, 0x7F800000, 0xFF800000, 0x7FC00000, 0xFFC00000, 0x7F800001, 1, 0x007FFFFF, 0x00800000,
+                         0x3F800000, 0x3F7FFFFF, 0x3F800001, 0x477FE000, 0x477FF000, 0x477FEFFF, 0x38800000, 0x387FFFFF], np.int64)
+    bits = np.concatenate([near, specials, rng.integers(0, 1 << 32, 1 << 22, dtype=np.int64),
+                           rng.integers(0x38000000, 0x40000000, 1 << 21, dtype=np.int64)]).astype(np.uint32)
+    bits = np.resize(bits, (bits.size + 3) // 4 * 4)
+    src = bits.view(np.float32).reshape(-1, 4).copy()
+    d_src = torch.from_numpy(src).cuda()
+    d_out = torch.zeros(src.shape, dtype=torch.uint8, device="cuda")
+    r = Renderer(64, 64)
+    for enable, exposure, hdr16 in ((0, 1.0, 0), (0, 1.0, 1), (1, 0.9, 1), (1, 2.5, 0)):
+        r.present_buffer(d_src.data_ptr(), d_out.data_ptr(), src.shape[0], enable, exposure, hdr16)
+        r.synchronize()
+        torch.cuda.synchronize()
+        got = d_out.cpu().numpy()
+        want = bbo.present(src, enable, exposure, hdr16)
+        bad = np.nonzero((got != want).any(axis=1))[0]
+        assert bad.size == 0, (enable, exposure, hdr16, src[bad[:4]], got[bad[:4]], want[bad[:4]])
+    r.close()
+
+
 def test_present_after_an_overflow_replay_and_into_a_caller_buffer(maps64):
     import torch
     sc = scenes.shaderball_scene(configs.C3.scaled(320, 180, 64), bbo.MaterialData(maps64))
