@@ -68,6 +68,11 @@ BB_DEV float bb_rcp(float x) {
   r = fmaf(r, fmaf(-ax, r, 1.0f), r);
   return copysignf(r, x);
 }
+// nearest binary16 value (ties to even), as binary32: v_cvt_f16_f32 / v_cvt_f32_f16 do exactly this on gfx950
+// (round-to-nearest-even, binary16 subnormals kept -- the default float mode of HIP kernels; every binary16
+// midpoint +-3 ulp is checked against the oracle's integer formulation in tests/test_gpu_parity.py)
+BB_DEV float bb_half_round(float x) { return (float)(_Float16)x; }
+
 BB_DEV f3 normalize3(f3 a) { return scale3(a, bb_rsqrt(dot3(a, a))); }
 BB_DEV float max0(float a) { return a > 0.0f ? a : 0.0f; }
 
@@ -391,7 +396,7 @@ BB_DEV void clip_primitive_wave(ClipWork &w, int owner, const float (*clip)[4], 
 // One thread per primitive, all draw calls of the frame in one launch (API order = primitive index order).
 template <int TILE_W, int TILE_H>
 __global__ __launch_bounds__(256) void k_geometry(const DrawDesc *__restrict__ draws, uint32_t n_draws, uint32_t n_prims,
-                                                  Mat4 pv, FrameParams fp, RasterTri *__restrict__ tris,
+                                                  Mat4 pv, Mat4 view, FrameParams fp, RasterTri *__restrict__ tris,
                                                   ShadeRec *__restrict__ recs, ClipSlot *__restrict__ clip_arena,
                                                   Counters *__restrict__ ctr, uint32_t *__restrict__ tile_count,
                                                   uint32_t *__restrict__ bins, BroadTri *__restrict__ broad_list,
@@ -448,7 +453,8 @@ __global__ __launch_bounds__(256) void k_geometry(const DrawDesc *__restrict__ d
       const Vertex &v = vtx[k];
       // forward_brdf.vert:25,27
       f4 pw = mat4_mul(ib.model, f4{v.pos[0], v.pos[1], v.pos[2], 1.0f});
-      f4 c = mat4_mul(pv, pw);
+      // forward_brdf.vert:27 multiplies (P*V) * posWorld (pv = P*V); gbuffer.vert:19-22 P * (V * posWorld) (pv = P)
+      f4 c = fp.deferred ? mat4_mul(pv, mat4_mul(view, pw)) : mat4_mul(pv, pw);
       clip[k][0] = c.x; clip[k][1] = c.y; clip[k][2] = c.z; clip[k][3] = c.w;
       // :31-36  normalMat = transpose(mat3(aInvModel))
       f3 n = ld3(v.normal), t = ld3(v.tangent);
@@ -936,7 +942,8 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
     Counters *__restrict__ ctr, uint32_t *__restrict__ tile_count,
     const uint32_t *__restrict__ bins, const BroadTri *__restrict__ broad_list,
     unsigned long long *__restrict__ frags, uint32_t *__restrict__ frag_count, float4 *__restrict__ out,
-    uint32_t *__restrict__ vis_prim, float *__restrict__ vis_depth, const uint32_t *__restrict__ tile_order) {
+    uint32_t *__restrict__ vis_prim, float *__restrict__ vis_depth, const uint32_t *__restrict__ tile_order,
+    const float4 *__restrict__ background) {
   constexpr int TILE_PIXELS = TILE_W * TILE_H;
   __shared__ unsigned long long keys[TILE_PIXELS];
   __shared__ StagedTri st;
@@ -1082,7 +1089,8 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
       my_frags[wave_base + rank_in_wave] = ((unsigned long long)(uint32_t)p << 32) | (unsigned long long)((uint32_t)key - 1u);
     } else if (in_frame) {
       size_t o = (size_t)(out_y0 + y) * (size_t)fp.width + (size_t)gx;
-      out[o] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // clear colour, src/main.cpp:84
+      // forward: the clear colour (src/main.cpp:84); deferred: brdf.frag on the cleared G-buffer texel (k_deferred_background)
+      out[o] = background ? background[0] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
     if (vis_prim && in_frame) {
       size_t o = (size_t)gy * (size_t)fp.width + (size_t)gx;
@@ -1100,6 +1108,76 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
         ((unsigned long long)e_end << 32) | s_count;
 #endif
   }
+}
+
+// The light loop and the ambient term: forward_brdf.frag:27-75 == brdf.frag:26-72 (same statements), on a surface
+// point given by position, (unnormalised) normal, albedo, metallic, roughness, ao.
+BB_DEV float4 light_surface(const ShadeParams &sp, const Light *__restrict__ lights, f3 P, f3 normal, f3 albedo, float metallic,
+                            float roughness, float ao) {
+  // loop invariants of forward_brdf.frag:51-52 hoisted (bit-identical: same inputs, same operations)
+  const f3 V = normalize3(sub3(ld3(sp.view_pos), P));
+  const f3 N = normalize3(normal);
+  const float NdotV = max0(dot3(V, N));
+  const float rr = roughness + 1.0f;
+  const float kk = (rr * rr) * 0.125f;
+  const float G_V = geometry_schlick_ggx(NdotV, kk);
+  const f3 F0 = mk3(mixf(0.04f, albedo.x, metallic), mixf(0.04f, albedo.y, metallic), mixf(0.04f, albedo.z, metallic));
+  const float om = 1.0f - metallic;
+
+  f3 Lo = mk3(0.0f, 0.0f, 0.0f);
+  for (int li = 0; li < sp.num_lights; ++li) {
+    const Light &light = lights[li];
+    f3 L;
+    float att;
+    if (light.type == 0 || light.type == 1) {
+      f3 Lv = sub3(ld3(light.pos), P);
+      float inv_d = bb_rsqrt(dot3(Lv, Lv));
+      att = inv_d * inv_d;
+      L = scale3(Lv, inv_d);
+      if (light.type == 1) {
+        float theta = dot3(L, normalize3(neg3(ld3(light.dir))));
+        float epsilon = light.inner_cutoff - light.outer_cutoff;
+        att *= clamp01((theta - light.outer_cutoff) * bb_rcp(epsilon));
+      }
+    } else if (light.type == 2) {
+      L = neg3(normalize3(ld3(light.dir)));
+      att = 1.0f;
+    } else {
+      continue;
+    }
+    f3 H = normalize3(add3(L, V));
+    float D = distribution_ggx(dot3(N, H), roughness);
+    float x = 1.0f - max0(dot3(H, V));
+    float x2 = x * x;
+    float p5 = (x2 * x2) * x;
+    f3 F = mk3(fmaf(1.0f - F0.x, p5, F0.x), fmaf(1.0f - F0.y, p5, F0.y), fmaf(1.0f - F0.z, p5, F0.z));
+    float NdotL = max0(dot3(N, L));
+    float G = G_V * geometry_schlick_ggx(NdotL, kk);
+    f3 radiance = mk3((att * light.color[0]) * light.intensity, (att * light.color[1]) * light.intensity,
+                      (att * light.color[2]) * light.intensity);
+    float sden = (4.0f * NdotV) * NdotL;
+    if (!(sden > 0.001f)) sden = 0.001f;
+    float rden = bb_rcp(sden);
+    f3 spec = mk3(((D * F.x) * G) * rden, ((D * F.y) * G) * rden, ((D * F.z) * G) * rden);
+    f3 kD = mk3((1.0f - F.x) * om, (1.0f - F.y) * om, (1.0f - F.z) * om);
+    Lo.x = fmaf(fmaf(kD.x * albedo.x, kInvPi, spec.x) * radiance.x, NdotL, Lo.x);
+    Lo.y = fmaf(fmaf(kD.y * albedo.y, kInvPi, spec.y) * radiance.y, NdotL, Lo.y);
+    Lo.z = fmaf(fmaf(kD.z * albedo.z, kInvPi, spec.z) * radiance.z, NdotL, Lo.z);
+  }
+  float4 color;
+  color.x = fmaf(0.03f * albedo.x, ao, Lo.x);
+  color.y = fmaf(0.03f * albedo.y, ao, Lo.y);
+  color.z = fmaf(0.03f * albedo.z, ao, Lo.z);
+  color.w = 1.0f;
+  return color;
+}
+
+// Deferred path: brdf.frag runs on every pixel of its full-screen triangle (src/main.cpp:101-104), also where the
+// G-buffer still holds its clear value 0; that colour is the same for all such pixels (it depends on the lights and
+// the camera only -- and is not always 0: a light at the world origin makes it NaN), so it is evaluated once.
+__global__ void k_deferred_background(ShadeParams sp, const Light *__restrict__ lights, float4 *__restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0)
+    out[0] = light_surface(sp, lights, mk3(0.f, 0.f, 0.f), mk3(0.f, 0.f, 0.f), mk3(0.f, 0.f, 0.f), 0.f, 0.f, 0.f);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1120,7 +1198,8 @@ template <int TILE_W, int TILE_H>
 __global__ __launch_bounds__(kShadeThreads) void k_shade(
     FrameParams fp, ShadeParams sp, const Light *__restrict__ lights, const ShadeRec *__restrict__ recs,
     const ClipSlot *__restrict__ clip_arena, const unsigned long long *__restrict__ frags,
-    const uint32_t *__restrict__ frag_count, const MaterialDesc *__restrict__ materials, float4 *__restrict__ out) {
+    const uint32_t *__restrict__ frag_count, const MaterialDesc *__restrict__ materials, float4 *__restrict__ out,
+    uint2 *__restrict__ gbuffer) {
   constexpr int TILE_PIXELS = TILE_W * TILE_H;
   constexpr int CHUNKS = TILE_PIXELS / kShadeThreads;
   const int tx = blockIdx.x / CHUNKS, chunk = blockIdx.x - tx * CHUNKS;
@@ -1202,7 +1281,7 @@ __global__ __launch_bounds__(kShadeThreads) void k_shade(
         normal.y = fmaf(a[6], nt.z, fmaf(a[12], nt.y, a[9] * nt.x));
         normal.z = fmaf(a[7], nt.z, fmaf(a[13], nt.y, a[10] * nt.x));
       } else {
-        normal = normalize3(mk3(a[5], a[6], a[7]));
+        normal = fp.deferred ? mk3(a[5], a[6], a[7]) : normalize3(mk3(a[5], a[6], a[7]));  // gbuffer.frag:29 / forward :24
       }
     } else {
       // maps of different sizes: one set of taps per map
@@ -1246,66 +1325,39 @@ __global__ __launch_bounds__(kShadeThreads) void k_shade(
         normal.y = fmaf(a[6], nt.z, fmaf(a[12], nt.y, a[9] * nt.x));
         normal.z = fmaf(a[7], nt.z, fmaf(a[13], nt.y, a[10] * nt.x));
       } else {
-        normal = normalize3(mk3(a[5], a[6], a[7]));
+        normal = fp.deferred ? mk3(a[5], a[6], a[7]) : normalize3(mk3(a[5], a[6], a[7]));
       }
     }
 
-    // loop invariants of forward_brdf.frag:51-52 hoisted (bit-identical: same inputs, same operations)
-    const f3 P = mk3(a[2], a[3], a[4]);
-    const f3 V = normalize3(sub3(ld3(sp.view_pos), P));
-    const f3 N = normalize3(normal);
-    const float NdotV = max0(dot3(V, N));
-    const float rr = roughness + 1.0f;
-    const float kk = (rr * rr) * 0.125f;
-    const float G_V = geometry_schlick_ggx(NdotV, kk);
-    const f3 F0 = mk3(mixf(0.04f, albedo.x, metallic), mixf(0.04f, albedo.y, metallic), mixf(0.04f, albedo.z, metallic));
-    const float om = 1.0f - metallic;
-
-    f3 Lo = mk3(0.0f, 0.0f, 0.0f);
-    for (int li = 0; li < sp.num_lights; ++li) {
-      const Light &light = lights[li];
-      f3 L;
-      float att;
-      if (light.type == 0 || light.type == 1) {
-        f3 Lv = sub3(ld3(light.pos), P);
-        float inv_d = bb_rsqrt(dot3(Lv, Lv));
-        att = inv_d * inv_d;
-        L = scale3(Lv, inv_d);
-        if (light.type == 1) {
-          float theta = dot3(L, normalize3(neg3(ld3(light.dir))));
-          float epsilon = light.inner_cutoff - light.outer_cutoff;
-          att *= clamp01((theta - light.outer_cutoff) * bb_rcp(epsilon));
-        }
-      } else if (light.type == 2) {
-        L = neg3(normalize3(ld3(light.dir)));
-        att = 1.0f;
-      } else {
-        continue;
-      }
-      f3 H = normalize3(add3(L, V));
-      float D = distribution_ggx(dot3(N, H), roughness);
-      float x = 1.0f - max0(dot3(H, V));
-      float x2 = x * x;
-      float p5 = (x2 * x2) * x;
-      f3 F = mk3(fmaf(1.0f - F0.x, p5, F0.x), fmaf(1.0f - F0.y, p5, F0.y), fmaf(1.0f - F0.z, p5, F0.z));
-      float NdotL = max0(dot3(N, L));
-      float G = G_V * geometry_schlick_ggx(NdotL, kk);
-      f3 radiance = mk3((att * light.color[0]) * light.intensity, (att * light.color[1]) * light.intensity,
-                        (att * light.color[2]) * light.intensity);
-      float sden = (4.0f * NdotV) * NdotL;
-      if (!(sden > 0.001f)) sden = 0.001f;
-      float rden = bb_rcp(sden);
-      f3 spec = mk3(((D * F.x) * G) * rden, ((D * F.y) * G) * rden, ((D * F.z) * G) * rden);
-      f3 kD = mk3((1.0f - F.x) * om, (1.0f - F.y) * om, (1.0f - F.z) * om);
-      Lo.x = fmaf(fmaf(kD.x * albedo.x, kInvPi, spec.x) * radiance.x, NdotL, Lo.x);
-      Lo.y = fmaf(fmaf(kD.y * albedo.y, kInvPi, spec.y) * radiance.y, NdotL, Lo.y);
-      Lo.z = fmaf(fmaf(kD.z * albedo.z, kInvPi, spec.z) * radiance.z, NdotL, Lo.z);
-    }
     float4 color;
-    color.x = fmaf(0.03f * albedo.x, ao, Lo.x);
-    color.y = fmaf(0.03f * albedo.y, ao, Lo.y);
-    color.z = fmaf(0.03f * albedo.z, ao, Lo.z);
-    color.w = 1.0f;
+    if (fp.deferred) {
+      // gbuffer.frag:24-32 into four RGBA16F attachments (binary16, round to nearest even), then brdf.frag:12-73 on
+      // the pixel's own texel: fused, the texel only goes to memory when somebody asked to see it
+      f3 P = mk3(bb_half_round(a[2]), bb_half_round(a[3]), bb_half_round(a[4]));
+      normal = mk3(bb_half_round(normal.x), bb_half_round(normal.y), bb_half_round(normal.z));
+      albedo = mk3(bb_half_round(albedo.x), bb_half_round(albedo.y), bb_half_round(albedo.z));
+      metallic = bb_half_round(metallic); roughness = bb_half_round(roughness); ao = bb_half_round(ao);
+      if (gbuffer) {
+        const MaterialDesc &md = materials[pa.material];
+        const TexDesc &td = md.maps[kMapHeight];
+        BilinearTaps tp = bilinear_taps(u, v, td.w, td.h);
+        const uint32_t *tx32 = reinterpret_cast<const uint32_t *>(td.texels);
+        const float height = bb_half_round(filter_channel(tx32[tp.o00], tx32[tp.o10], tx32[tp.o01], tx32[tp.o11], 0, tp.fx, tp.fy));
+        _Float16 g[16] = {(_Float16)P.x, (_Float16)P.y, (_Float16)P.z, (_Float16)1.0f,
+                          (_Float16)normal.x, (_Float16)normal.y, (_Float16)normal.z, (_Float16)0.0f,
+                          (_Float16)albedo.x, (_Float16)albedo.y, (_Float16)albedo.z, (_Float16)0.0f,
+                          (_Float16)metallic, (_Float16)roughness, (_Float16)ao, (_Float16)height};
+        uint4 *dst = reinterpret_cast<uint4 *>(gbuffer) + 2 * ((size_t)gy * (size_t)fp.width + (size_t)gx);
+        uint4 lo, hi;
+        __builtin_memcpy(&lo, g, 16);
+        __builtin_memcpy(&hi, g + 8, 16);
+        dst[0] = lo;
+        dst[1] = hi;
+      }
+      color = light_surface(sp, lights, P, normal, albedo, metallic, roughness, ao);
+    } else {
+      color = light_surface(sp, lights, mk3(a[2], a[3], a[4]), normal, albedo, metallic, roughness, ao);
+    }
     out[o] = color;
   }
 }
@@ -1331,11 +1383,6 @@ __global__ void k_unpack_gathered(const float4 *__restrict__ gathered, float4 *_
 // presentation: HDR attachment (binary16) -> hdr_tone_mapping.frag:9-18 -> sRGB UNORM8.
 // Same fixed sequences as the CPU oracle (binary16 rounding, exp, threshold table): byte-exact.
 // ------------------------------------------------------------------------------------------------
-
-// nearest binary16 value (ties to even), as binary32: v_cvt_f16_f32 / v_cvt_f32_f16 do exactly this on gfx950
-// (round-to-nearest-even, binary16 subnormals kept -- the default float mode of HIP kernels; every binary16
-// midpoint +-3 ulp is checked against the oracle's integer formulation in tests/test_gpu_parity.py)
-BB_DEV float bb_half_round(float x) { return (float)(_Float16)x; }
 
 BB_DEV float bb_exp(float x) {
   if (!(x >= -104.0f)) return x < -104.0f ? 0.0f : x;

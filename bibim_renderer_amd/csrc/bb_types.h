@@ -186,6 +186,7 @@ struct FrameParams {
   int32_t rank, world, band_tiles;
   int32_t shard_rows;                // rows of the compact output when world > 1
   uint32_t ablate;                   // diagnostics only: bit0 skip raster, bit1 skip shading, bit2 skip broad list
+  int32_t deferred;                  // 1: the reference's deferred path (gbuffer.vert/.frag + brdf.frag), 0: forward
 };
 
 }  // namespace bbr

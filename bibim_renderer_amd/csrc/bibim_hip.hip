@@ -83,6 +83,7 @@ struct FrameSlot {
   DeviceBuffer<uint32_t> d_frag_count;
   DeviceBuffer<uint32_t> d_tile_order;  // k_raster launch slots, heaviest tiles first
   DeviceBuffer<float4> d_frame;
+  DeviceBuffer<float4> d_background;  // deferred path: colour of the pixels no geometry covers
   DeviceBuffer<uint32_t> d_present;  // RGBA8 presented image of this slot's frame (bbr_present)
   struct {
     bool active = false;  // bbr_present was queued for the frame in this slot (re-queued if the frame is replayed)
@@ -103,7 +104,7 @@ struct FrameSlot {
   void release_all() {
     d_staging.release(); d_tris.release(); d_attrs.release(); d_clip.release();
     d_block_stats.release();
-    release_tile_buffers(); d_broad.release(); d_frame.release(); d_present.release();
+    release_tile_buffers(); d_broad.release(); d_frame.release(); d_present.release(); d_background.release();
     if (h_staging) (void)hipHostFree(h_staging);
     h_staging = nullptr;
     staging_cap = 0;
@@ -156,6 +157,9 @@ struct bbr_context {
   // k_shade and the extra kernel plus the co-scheduled heavy tiles cost throughput (C3 184 -> 190 us, C5 +2 %):
   // off by default, option "tile_order".
   bool tile_order = false;
+  bool deferred = false;  // option "render_pass": the reference's deferred path (its default) instead of the forward one
+  bool dump_gbuffer = false;
+  DeviceBuffer<uint2> d_gbuffer;  // width*height*4 (four RGBA16F texels per pixel), only while bbr_read_gbuffer runs
   uint32_t ablate = 0;
   int timing = 0;  // 0 off, 1 five events per frame, 2 only the two events around k_shade
   // timing ring: (frame start, geometry done, raster done, shade start, shade done) per frame since the last reset
@@ -225,6 +229,7 @@ FrameParams make_params(const bbr_context *c) {
   fp.band_tiles = c->eff_band_rows() / c->tile_h();
   fp.shard_rows = c->shard_rows();
   fp.ablate = c->ablate;
+  fp.deferred = c->deferred ? 1 : 0;
   return fp;
 }
 
@@ -258,6 +263,8 @@ int ensure_slot_buffers(bbr_context *c, FrameSlot &s) {
   HIP_TRY(c, s.d_frag_count.ensure(tiles, true));
 #endif
   HIP_TRY(c, s.d_tile_order.ensure(tiles * kOrderBuckets));
+  if (c->deferred) HIP_TRY(c, s.d_background.ensure(1));
+  if (c->dump_gbuffer) HIP_TRY(c, c->d_gbuffer.ensure((size_t)c->width * c->height * 4, true));
   if (!c->ext_out) HIP_TRY(c, s.d_frame.ensure(out_rows * c->width));
   if (c->dump_vis) {
     HIP_TRY(c, c->d_vis_prim.ensure((size_t)c->width * c->height));
@@ -283,13 +290,13 @@ int upload_material_table(bbr_context *c) {
 
 template <int TW, int TH>
 void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const FrameParams &fp, const Mat4 &pv,
-                  const ShadeParams &sp, const Light *d_lights, const DrawDesc *d_draws, uint32_t n_draws, float4 *out) {
+                  const Mat4 &view, const ShadeParams &sp, const Light *d_lights, const DrawDesc *d_draws, uint32_t n_draws, float4 *out) {
   hipStream_t sg = c->geom_stream(), ss = c->shade_stream();
   Counters *ctr = c->d_counters.ptr + s.ctr_index, *ctr_next = c->d_counters.ptr + (s.ctr_index + 1) % bbr_context::kCounterBlocks;
   hipEvent_t *ev = c->timing ? &c->ring[bbr_context::kRingEvents * (c->ring_frames % bbr_context::kRingCap)] : nullptr;
   if (c->n_prims)
     hipLaunchKernelGGL((k_geometry<TW, TH>), dim3((c->n_prims + 255) / 256), dim3(256), 0, sg, d_draws, n_draws,
-                       c->n_prims, pv, fp, s.d_tris.ptr, s.d_attrs.ptr, s.d_clip.ptr, ctr, s.d_tile_count.ptr,
+                       c->n_prims, pv, view, fp, s.d_tris.ptr, s.d_attrs.ptr, s.d_clip.ptr, ctr, s.d_tile_count.ptr,
                        s.d_bins.ptr, s.d_broad.ptr, c->d_materials.ptr, s.d_block_stats.ptr, ctr_next);
   else
     (void)hipMemsetAsync(ctr_next, 0, sizeof(Counters), sg);
@@ -299,6 +306,7 @@ void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const Fra
   if (prev && prev->in_flight && prev->out_used == out && ss != sg) (void)hipStreamWaitEvent(sg, prev->ev_shade_done, 0);
   // a rank without bands (more ranks than bands) still launches one row: its blocks fall off tiles_y and exit
   int grid_y = std::max(1, c->world > 1 ? c->local_bands() * fp.band_tiles : fp.tiles_y);
+  if (fp.deferred) hipLaunchKernelGGL(k_deferred_background, dim3(1), dim3(64), 0, sg, sp, d_lights, s.d_background.ptr);
   const bool ordered = c->tile_order && c->n_prims;
   if (ordered)
     hipLaunchKernelGGL(k_tile_order, dim3((fp.tiles_x * grid_y + kOrderThreads - 1) / kOrderThreads), dim3(kOrderThreads),
@@ -306,7 +314,8 @@ void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const Fra
   hipLaunchKernelGGL((k_raster<TW, TH>), dim3(fp.tiles_x, grid_y), dim3(kTileThreads), 0, sg, fp, s.d_tris.ptr,
                      s.d_clip.ptr, ctr, s.d_tile_count.ptr, s.d_bins.ptr, s.d_broad.ptr, s.d_frags.ptr,
                      s.d_frag_count.ptr, out, c->dump_vis ? c->d_vis_prim.ptr : nullptr,
-                     c->dump_vis ? c->d_vis_depth.ptr : nullptr, ordered ? s.d_tile_order.ptr : nullptr);
+                     c->dump_vis ? c->d_vis_depth.ptr : nullptr, ordered ? s.d_tile_order.ptr : nullptr,
+                     fp.deferred ? s.d_background.ptr : nullptr);
   if (ev && c->timing == 1) (void)hipEventRecord(ev[2], sg);
   if (ss != sg) {
     (void)hipEventRecord(s.ev_raster_done, sg);
@@ -320,7 +329,8 @@ void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const Fra
   // save (FETCH_SIZE -20 %) does not matter to kernels that are issue- and latency-bound, not L2-bandwidth-bound.
   constexpr int kChunks = TW * TH / kShadeThreads;
   hipLaunchKernelGGL((k_shade<TW, TH>), dim3(fp.tiles_x * kChunks, grid_y), dim3(kShadeThreads), 0, ss, fp, sp, d_lights,
-                     s.d_attrs.ptr, s.d_clip.ptr, s.d_frags.ptr, s.d_frag_count.ptr, c->d_materials.ptr, out);
+                     s.d_attrs.ptr, s.d_clip.ptr, s.d_frags.ptr, s.d_frag_count.ptr, c->d_materials.ptr, out,
+                     (fp.deferred && c->dump_gbuffer) ? c->d_gbuffer.ptr : nullptr);
   (void)hipEventRecord(s.ev_shade_done, ss);
   if (ev) {
     (void)hipEventRecord(ev[4], ss);
@@ -392,7 +402,9 @@ int submit_frame_into(bbr_context *c, int slot_index) {
   const Light *d_lights = reinterpret_cast<const Light *>(s.d_staging.ptr);
   const DrawDesc *d_draws = reinterpret_cast<const DrawDesc *>(s.d_staging.ptr + lights_bytes);
   FrameParams fp = make_params(c);
-  Mat4 pv = proj_view(c->view_u);
+  // forward: gl_Position = (P*V) * posWorld; deferred: P * (V * posWorld) -- the kernel gets P and V separately
+  Mat4 pv = c->deferred ? c->view_u.proj : proj_view(c->view_u);
+  const Mat4 view = c->view_u.view;
   ShadeParams sp;
   std::memcpy(sp.view_pos, c->view_u.view_pos, sizeof sp.view_pos);
   sp.enable_normal_map = c->view_u.enable_normal_map;
@@ -400,8 +412,8 @@ int submit_frame_into(bbr_context *c, int slot_index) {
   float4 *out = c->ext_out ? reinterpret_cast<float4 *>(c->ext_out) : s.d_frame.ptr;
   const FrameSlot *prev = (c->last_slot >= 0 && c->last_slot != slot_index) ? &c->slots[c->last_slot] : nullptr;
 
-  if (c->tile_mode == 0) launch_frame<64, 64>(c, s, prev, fp, pv, sp, d_lights, d_draws, c->n_live_draws, out);
-  else launch_frame<32, 32>(c, s, prev, fp, pv, sp, d_lights, d_draws, c->n_live_draws, out);
+  if (c->tile_mode == 0) launch_frame<64, 64>(c, s, prev, fp, pv, view, sp, d_lights, d_draws, c->n_live_draws, out);
+  else launch_frame<32, 32>(c, s, prev, fp, pv, view, sp, d_lights, d_draws, c->n_live_draws, out);
   HIP_TRY(c, hipGetLastError());
   s.in_flight = true;
   s.present.active = false;
@@ -970,6 +982,28 @@ int bbr_read_visibility(bbr_context *c, uint32_t *prim_host, float *depth_host) 
   return BBR_OK;
 }
 
+int bbr_read_gbuffer(bbr_context *c, float *host) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  if (!host) return fail(c, BBR_ERR_INVALID_ARGUMENT, "read_gbuffer: NULL");
+  if (!c->have_frame || c->last_slot < 0) return fail(c, BBR_ERR_NOT_IN_FRAME, "read_gbuffer: nothing rendered");
+  if (!c->deferred) return fail(c, BBR_ERR_INVALID_ARGUMENT, "read_gbuffer: option render_pass is not 1 (deferred)");
+  if (c->world > 1) return fail(c, BBR_ERR_INVALID_ARGUMENT, "read_gbuffer: not available with a partition");
+  int rc = sync_and_fix(c, nullptr);
+  if (rc) return rc;
+  // the fused deferred kernel keeps the G-buffer in registers; render the frame once more with the dump enabled
+  c->dump_gbuffer = true;
+  rc = submit_frame_into(c, c->last_slot);
+  if (rc == BBR_OK) rc = sync_and_fix(c, nullptr);
+  c->dump_gbuffer = false;
+  if (rc) return rc;
+  const size_t n = (size_t)c->width * c->height * 16;
+  std::vector<_Float16> h(n);
+  HIP_TRY(c, hipMemcpy(h.data(), c->d_gbuffer.ptr, n * 2, hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < n; ++i) host[i] = (float)h[i];
+  c->d_gbuffer.release();
+  return BBR_OK;
+}
+
 int bbr_last_frame_time_ms(bbr_context *c, float *out_frame_ms, float *out_shade_ms) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
   if (!c->timing) return fail(c, BBR_ERR_INVALID_ARGUMENT, "last_frame_time_ms: enable option \"timing\" first");
@@ -1067,6 +1101,9 @@ int bbr_set_option(bbr_context *c, const char *name, int64_t value) {
     for (FrameSlot &s : c->slots) s.d_bins.release();
   } else if (n == "ablate") {
     c->ablate = (uint32_t)value;
+  } else if (n == "render_pass") {
+    if (value != 0 && value != 1) return fail(c, BBR_ERR_INVALID_ARGUMENT, "render_pass: 0 (forward) or 1 (deferred)");
+    c->deferred = value == 1;
   } else if (n == "tile_order") {
     c->tile_order = value != 0;
   } else if (n == "broad_threshold") {

@@ -142,6 +142,12 @@ class Renderer:
     def tone_map(self, enable, exposure):
         self._check(self._L.bbr_tone_map(self._ctx, int(enable), float(exposure)))
 
+    def read_gbuffer(self):
+        """deferred path only: [h, w, 4 attachments, 4] float32 (binary16 values)"""
+        out = np.empty((self.height, self.width, 4, 4), np.float32)
+        self._check(self._L.bbr_read_gbuffer(self._ctx, _ptr(out)))
+        return out
+
     # -- presentation (tone map + sRGB + UNORM8; SURVEY 8(f) rank 1) --
     def present(self, rgba8_device_ptr=None, hdr16=True):
         """queue k_present for the last frame; EnableToneMapping / Exposure come from its FrameUniformBlock"""

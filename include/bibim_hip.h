@@ -157,10 +157,20 @@ int bbr_timing_summary(bbr_context *ctx, uint32_t *out_frames, float *out_avg_fr
  *   "tile_mode" 0|1          0: 64x64 tiles, 1: 32x32 tiles (default)
  *   "bin_cap" n              initial references per (tile, raster class); grows by itself on overflow
  *   "broad_threshold" n      triangles touching more than n x n tiles go to the every-tile list
+ *   "render_pass" 0|1        0: forward path (default, the path BASELINE measures), 1: deferred path
  *   "tile_order" 0|1         launch the heaviest raster tiles first (shorter single frame, lower pipelined
  *                            throughput; default 0)
  *   "ablate" bits            diagnostics only: skip parts of the pipeline (see bb_kernels.hip.h) */
 int bbr_set_option(bbr_context *ctx, const char *name, int64_t value);
+
+/* ---- deferred variant ----
+ * bbr_set_option(ctx, "render_pass", 1) renders with the reference's deferred path, its default
+ * (SceneBase::SceneRenderPassType, src/scene.h:77; recordCommand src/main.cpp:89-104): gbuffer.vert/.frag into four
+ * R16G16B16A16_SFLOAT attachments (src/main.cpp:443), then brdf.frag on every pixel.  The two subpasses are fused
+ * (the G-buffer texel of a pixel is only read by the same pixel), so the G-buffer is not stored unless asked for:
+ * bbr_read_gbuffer re-renders the last frame and returns width*height*16 floats, per pixel
+ * position.xyz 1 | normal.xyz 0 | albedo.rgb 0 | metallic roughness ao height (binary16 values widened); synchronises. */
+int bbr_read_gbuffer(bbr_context *ctx, float *gbuffer_host);
 
 /* ---- presentation: the step after the path ----
  * Replaces the tone-map subpass + swapchain write (src/main.cpp:123-126, src/shaders/hdr_tone_mapping.frag:9-18,

@@ -109,11 +109,14 @@ void bbo_proj_view(const bbo_view_uniforms *view, bbo_mat4 *out) {
   }
 }
 
-static void vertex_stage(const bbo_mat4 *pv, const bbo_instance *inst, const bbo_vertex *v, float *clip,
-                         float *vary) {
+/* view == NULL: forward_brdf.vert (gl_Position = (P*V) * posWorld, `pv` = P*V).
+ * view != NULL: gbuffer.vert:19-22 (posView = V * posWorld; gl_Position = P * posView), `pv` = P.  The other
+ * outputs are the same in both shaders (gbuffer.vert:25-35 == forward_brdf.vert:31-36). */
+static void vertex_stage(const bbo_mat4 *pv, const bbo_mat4 *view, const bbo_instance *inst, const bbo_vertex *v,
+                         float *clip, float *vary) {
   v4 p = {v->pos[0], v->pos[1], v->pos[2], 1.0f};
   v4 pw = mat4_mul_v4(&inst->model, p);   /* :25 */
-  v4 c = mat4_mul_v4(pv, pw);             /* :27 */
+  v4 c = view ? mat4_mul_v4(pv, mat4_mul_v4(view, pw)) : mat4_mul_v4(pv, pw); /* :27 */
   clip[0] = c.x; clip[1] = c.y; clip[2] = c.z; clip[3] = c.w;
   /* normalMat = transpose(mat3(aInvModel)) (:31): (normalMat*n)_i = dot(InvModel column i, n) */
   const bbo_mat4 *im = &inst->inv_model;
@@ -132,7 +135,7 @@ void bbo_vertex_stage(const bbo_view_uniforms *view, const bbo_instance *inst, c
                       float *out_clip, float *out_vary) {
   bbo_mat4 pv;
   bbo_proj_view(view, &pv);
-  vertex_stage(&pv, inst, v, out_clip, out_vary);
+  vertex_stage(&pv, NULL, inst, v, out_clip, out_vary);
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -237,32 +240,47 @@ void bbo_fresnel_schlick(const float *H, const float *V, const float *F0, float 
 static inline float mixf(float a, float b, float t) { return fmaf(b, t, a * (1.0f - t)); }
 static inline float clamp01(float x) { return x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x); }
 
-static void shade_fragment(const bbo_frame_uniforms *fu, const bbo_view_uniforms *vu, const bbo_material *mat,
-                           const float *vary, float *out) {
+typedef struct {
+  v3 P, normal, albedo;
+  float metallic, roughness, ao, height;
+} surface;
+
+/* texture fetches + normal selection.  forward_brdf.frag:16-25 (gbuffer = 0: the unmapped normal is normalised, :24)
+ * or gbuffer.frag:19-32 (gbuffer = 1: the unmapped normal is written as interpolated, :29; height is fetched, :22) */
+static void surface_inputs(const bbo_view_uniforms *vu, const bbo_material *mat, const float *vary, int gbuffer, surface *s) {
   float u = vary[0], v = vary[1];
-  v3 P = v3_ld(vary + 2);
+  s->P = v3_ld(vary + 2);
   float tex[4];
   sample_bilinear(&mat->maps[BBO_MAP_ALBEDO], BBO_MAP_ALBEDO, u, v, tex);       /* :16 */
-  v3 albedo = v3_make(tex[0], tex[1], tex[2]);
+  s->albedo = v3_make(tex[0], tex[1], tex[2]);
   sample_bilinear(&mat->maps[BBO_MAP_METALLIC], BBO_MAP_METALLIC, u, v, tex);   /* :17 */
-  float metallic = tex[0];
+  s->metallic = tex[0];
   sample_bilinear(&mat->maps[BBO_MAP_ROUGHNESS], BBO_MAP_ROUGHNESS, u, v, tex); /* :18 */
-  float roughness = tex[0];
+  s->roughness = tex[0];
   sample_bilinear(&mat->maps[BBO_MAP_AO], BBO_MAP_AO, u, v, tex);               /* :19 */
-  float ao = tex[0];
-  v3 normal;
+  s->ao = tex[0];
+  s->height = 0.0f;
+  if (gbuffer) {
+    sample_bilinear(&mat->maps[BBO_MAP_HEIGHT], BBO_MAP_HEIGHT, u, v, tex);     /* gbuffer.frag:22 */
+    s->height = tex[0];
+  }
   if (vu->enable_normal_map != 0) {                                             /* :21-22 */
     sample_bilinear(&mat->maps[BBO_MAP_NORMAL], BBO_MAP_NORMAL, u, v, tex);
     v3 nt = v3_make(fmaf(tex[0], 2.0f, -1.0f), fmaf(tex[1], 2.0f, -1.0f), fmaf(tex[2], 2.0f, -1.0f));
     v3 N = v3_ld(vary + 5), T = v3_ld(vary + 8), B = v3_ld(vary + 11);
     /* vTBN = mat3(T,B,N); vTBN * nt */
-    normal.x = fmaf(N.x, nt.z, fmaf(B.x, nt.y, T.x * nt.x));
-    normal.y = fmaf(N.y, nt.z, fmaf(B.y, nt.y, T.y * nt.x));
-    normal.z = fmaf(N.z, nt.z, fmaf(B.z, nt.y, T.z * nt.x));
+    s->normal.x = fmaf(N.x, nt.z, fmaf(B.x, nt.y, T.x * nt.x));
+    s->normal.y = fmaf(N.y, nt.z, fmaf(B.y, nt.y, T.y * nt.x));
+    s->normal.z = fmaf(N.z, nt.z, fmaf(B.z, nt.y, T.z * nt.x));
   } else {
-    normal = normalize3(v3_ld(vary + 5));                                       /* :24 */
+    s->normal = gbuffer ? v3_ld(vary + 5) : normalize3(v3_ld(vary + 5));        /* :24 / gbuffer.frag:29 */
   }
+}
 
+/* the light loop and the ambient term: forward_brdf.frag:27-75 == brdf.frag:26-72 (same statements) */
+static void light_surface(const bbo_frame_uniforms *fu, const bbo_view_uniforms *vu, const surface *s, float *out) {
+  const v3 P = s->P, normal = s->normal, albedo = s->albedo;
+  const float metallic = s->metallic, roughness = s->roughness, ao = s->ao;
   v3 Lo = v3_make(0.0f, 0.0f, 0.0f);
   int n_lights = fu->num_lights;
   if (n_lights > BBO_MAX_LIGHTS) n_lights = BBO_MAX_LIGHTS;
@@ -321,6 +339,35 @@ static void shade_fragment(const bbo_frame_uniforms *fu, const bbo_view_uniforms
   out[1] = fmaf(0.03f * albedo.y, ao, Lo.y);
   out[2] = fmaf(0.03f * albedo.z, ao, Lo.z);
   out[3] = 1.0f;
+}
+
+static void shade_fragment(const bbo_frame_uniforms *fu, const bbo_view_uniforms *vu, const bbo_material *mat,
+                           const float *vary, float *out) {
+  surface s;
+  surface_inputs(vu, mat, vary, 0, &s);
+  light_surface(fu, vu, &s, out);
+}
+
+/* One G-buffer texel: four R16G16B16A16_SFLOAT attachments (src/main.cpp:443, 453-459) as 16 binary32 values that
+ * are exactly representable in binary16: position.xyz 1 | normal.xyz 0 | albedo.rgb 0 | metallic roughness ao height.
+ * (vPosWorld.w interpolates the constant 1 and rounds to 1; the alpha of the vec3 outputs is undefined in Vulkan, 0
+ * here; outMaterialIndex, gbuffer.frag:33, is a constant nobody reads.) */
+static void gbuffer_fragment(const bbo_view_uniforms *vu, const bbo_material *mat, const float *vary, float *g) {
+  surface s;
+  surface_inputs(vu, mat, vary, 1, &s);
+  g[0] = bbo_half_round(s.P.x); g[1] = bbo_half_round(s.P.y); g[2] = bbo_half_round(s.P.z); g[3] = 1.0f;
+  g[4] = bbo_half_round(s.normal.x); g[5] = bbo_half_round(s.normal.y); g[6] = bbo_half_round(s.normal.z); g[7] = 0.0f;
+  g[8] = bbo_half_round(s.albedo.x); g[9] = bbo_half_round(s.albedo.y); g[10] = bbo_half_round(s.albedo.z); g[11] = 0.0f;
+  g[12] = bbo_half_round(s.metallic); g[13] = bbo_half_round(s.roughness); g[14] = bbo_half_round(s.ao);
+  g[15] = bbo_half_round(s.height);
+}
+
+/* brdf.frag:12-73 on one G-buffer texel (nearest fetch of the pixel's own texel) */
+static void brdf_pixel(const bbo_frame_uniforms *fu, const bbo_view_uniforms *vu, const float *g, float *out) {
+  surface s;
+  s.P = v3_ld(g); s.normal = v3_ld(g + 4); s.albedo = v3_ld(g + 8);
+  s.metallic = g[12]; s.roughness = g[13]; s.ao = g[14]; s.height = g[15];
+  light_surface(fu, vu, &s, out);
 }
 
 void bbo_shade_fragment(const bbo_frame_uniforms *frame, const bbo_view_uniforms *view, const bbo_material *mat,
@@ -639,6 +686,7 @@ typedef struct {
   const bbo_frame_uniforms *fu;
   const bbo_view_uniforms *vu;
   bbo_mat4 pv;
+  int deferred; /* gbuffer.vert: clip = P * (V * posWorld) */
   const draw_info *draws;
   uint32_t n_draws;
 } pbr_ctx;
@@ -652,7 +700,10 @@ static void pbr_fetch(const void *vctx, uint32_t prim, float clip[3][4], float v
   uint32_t inst = local / di->tris_per_instance, tri = local % di->tris_per_instance;
   for (int k = 0; k < 3; ++k) {
     uint32_t vi = di->draw->indices ? di->draw->indices[3 * tri + k] : 3 * tri + k;
-    vertex_stage(&c->pv, &di->draw->instances[inst], &di->draw->vertices[vi], clip[k], vary[k]);
+    if (c->deferred)
+      vertex_stage(&c->vu->proj, &c->vu->view, &di->draw->instances[inst], &di->draw->vertices[vi], clip[k], vary[k]);
+    else
+      vertex_stage(&c->pv, NULL, &di->draw->instances[inst], &di->draw->vertices[vi], clip[k], vary[k]);
   }
   *mat = di->draw->material;
 }
@@ -690,11 +741,13 @@ static void gizmo_shade(const float *vary, float *out) {
 }
 
 typedef struct {
-  int program; /* 0 = forward PBR, 1 = gizmo */
+  int program; /* 0 = forward PBR, 1 = gizmo, 2 = deferred PBR (G-buffer write + brdf.frag) */
   const void *ctx;
   prim_fetch_fn fetch;
   const bbo_frame_uniforms *fu;
   const bbo_view_uniforms *vu;
+  float *gbuffer; /* program 2, optional: width*height*16 floats */
+  int32_t width;
 } pipeline;
 
 static void shade_pixel(const pipeline *pl, const raster_tri *t, const float vary[3][NVARY], const void *mat,
@@ -704,6 +757,12 @@ static void shade_pixel(const pipeline *pl, const raster_tri *t, const float var
   if (pl->program == 0) {
     interpolate(beta, vary, NVARY, attr);
     shade_fragment(pl->fu, pl->vu, (const bbo_material *)mat, attr, out);
+  } else if (pl->program == 2) {
+    float g[16];
+    interpolate(beta, vary, NVARY, attr);
+    gbuffer_fragment(pl->vu, (const bbo_material *)mat, attr, g);
+    if (pl->gbuffer) memcpy(pl->gbuffer + 16 * ((size_t)py * (size_t)pl->width + (size_t)px), g, sizeof g);
+    brdf_pixel(pl->fu, pl->vu, g, out);
   } else {
     interpolate(beta, vary, 6, attr);
     gizmo_shade(attr, out);
@@ -728,7 +787,9 @@ static int render_core(const pipeline *pl, uint32_t n_prims, int32_t width, int3
   bbo_stats st;
   memset(&st, 0, sizeof st);
   st.n_prims = n_prims;
+  if (pl->program == 2) flags &= ~(uint32_t)BBO_FLAG_FORWARD_SHADE; /* the G-buffer keeps the depth-test winner */
   for (int32_t y = y0; y < y1; ++y) {
+    if (pl->gbuffer) memset(pl->gbuffer + 16 * (size_t)y * width, 0, sizeof(float) * 16 * (size_t)width); /* src/main.cpp:84 */
     memset(out_rgba + 4 * (size_t)y * width, 0, sizeof(float) * 4 * (size_t)width);   /* clear colour 0 */
     memset(out_depth + (size_t)y * width, 0, sizeof(float) * (size_t)width);            /* clear depth 0  */
     memset(key + (size_t)y * width, 0, sizeof(uint32_t) * (size_t)width);
@@ -790,6 +851,11 @@ static int render_core(const pipeline *pl, uint32_t n_prims, int32_t width, int3
       size_t o = (size_t)py * width + px;
       uint32_t k = key[o];
       if (out_prim) out_prim[o] = k ? (k - 1u) >> 3 : BBO_NO_PRIM;
+      if (!k && pl->program == 2) {
+        /* brdf.frag runs on every pixel of its full-screen triangle (src/main.cpp:101-104): the cleared texel too */
+        static const float cleared[16] = {0};
+        brdf_pixel(pl->fu, pl->vu, cleared, out_rgba + 4 * o);
+      }
       if (!k) continue;
       ++st.n_shaded;
       if (flags & BBO_FLAG_FORWARD_SHADE) continue;
@@ -810,9 +876,9 @@ static int render_core(const pipeline *pl, uint32_t n_prims, int32_t width, int3
   return 0;
 }
 
-int bbo_render(const bbo_frame_uniforms *frame, const bbo_view_uniforms *view, const bbo_draw *draws, uint32_t n_draws,
-               int32_t width, int32_t height, int32_t y0, int32_t y1, uint32_t flags, float *out_rgba,
-               uint32_t *out_prim, float *out_depth, bbo_stats *stats) {
+static int render_pbr(const bbo_frame_uniforms *frame, const bbo_view_uniforms *view, const bbo_draw *draws, uint32_t n_draws,
+                      int32_t width, int32_t height, int32_t y0, int32_t y1, uint32_t flags, float *out_rgba,
+                      float *out_gbuffer, uint32_t *out_prim, float *out_depth, bbo_stats *stats) {
   if (!frame || !view || (!draws && n_draws)) return -1;
   draw_info *di = (draw_info *)calloc(n_draws ? n_draws : 1, sizeof(draw_info));
   if (!di) return -3;
@@ -834,11 +900,25 @@ int bbo_render(const bbo_frame_uniforms *frame, const bbo_view_uniforms *view, c
     if (di[d].tris_per_instance && draws[d].n_instances) di[m++] = di[d];
   pbr_ctx ctx;
   ctx.fu = frame; ctx.vu = view; ctx.draws = di; ctx.n_draws = m;
+  ctx.deferred = (flags & BBO_FLAG_DEFERRED) != 0;
   bbo_proj_view(view, &ctx.pv);
-  pipeline pl = {0, &ctx, pbr_fetch, frame, view};
+  pipeline pl = {ctx.deferred ? 2 : 0, &ctx, pbr_fetch, frame, view, ctx.deferred ? out_gbuffer : NULL, width};
   int rc = render_core(&pl, (uint32_t)total, width, height, y0, y1, flags, out_rgba, out_prim, out_depth, stats);
   free(di);
   return rc;
+}
+
+int bbo_render(const bbo_frame_uniforms *frame, const bbo_view_uniforms *view, const bbo_draw *draws, uint32_t n_draws,
+               int32_t width, int32_t height, int32_t y0, int32_t y1, uint32_t flags, float *out_rgba,
+               uint32_t *out_prim, float *out_depth, bbo_stats *stats) {
+  return render_pbr(frame, view, draws, n_draws, width, height, y0, y1, flags, out_rgba, NULL, out_prim, out_depth, stats);
+}
+
+int bbo_render_deferred(const bbo_frame_uniforms *frame, const bbo_view_uniforms *view, const bbo_draw *draws,
+                        uint32_t n_draws, int32_t width, int32_t height, int32_t y0, int32_t y1, float *out_rgba,
+                        float *out_gbuffer, uint32_t *out_prim, float *out_depth, bbo_stats *stats) {
+  return render_pbr(frame, view, draws, n_draws, width, height, y0, y1, BBO_FLAG_DEFERRED, out_rgba, out_gbuffer, out_prim,
+                    out_depth, stats);
 }
 
 int bbo_render_gizmo(const bbo_view_uniforms *view, const bbo_gizmo_vertex *vertices, uint32_t n_vertices,
@@ -867,7 +947,7 @@ int bbo_render_gizmo(const bbo_view_uniforms *view, const bbo_gizmo_vertex *vert
   gv.proj.M[0][0] = d;
   gv.proj.M[1][1] = -d;
   bbo_proj_view(&gv, &ctx.pv);
-  pipeline pl = {1, &ctx, gizmo_fetch, NULL, view};
+  pipeline pl = {1, &ctx, gizmo_fetch, NULL, view, NULL, width};
   return render_core(&pl, n / 3, width, height, 0, height, 0, out_rgba, out_prim, out_depth, stats);
 }
 

@@ -103,6 +103,9 @@ typedef struct {
 #define BBO_FLAG_FORWARD_SHADE 1 /* shade every fragment that passes the depth test, in API order
                                     (literal forward pipeline) instead of shading the winner once */
 
+#define BBO_FLAG_DEFERRED 2      /* the reference's deferred path (its default, src/scene.h:77): gbuffer.vert/.frag into
+                                    four RGBA16F attachments, then brdf.frag on every pixel */
+
 typedef struct {
   uint64_t n_prims;         /* triangles submitted */
   uint64_t n_raster_tris;   /* sub-triangles that survived clip + cull */
@@ -120,6 +123,15 @@ typedef struct {
 int bbo_render(const bbo_frame_uniforms *frame, const bbo_view_uniforms *view, const bbo_draw *draws,
                uint32_t n_draws, int32_t width, int32_t height, int32_t y0, int32_t y1, uint32_t flags,
                float *out_rgba, uint32_t *out_prim, float *out_depth, bbo_stats *stats);
+
+/* Deferred path: src/main.cpp:89-104 (G-buffer subpass, then brdf.frag over a full-screen triangle),
+ * src/shaders/gbuffer.vert:17-36, gbuffer.frag:17-33, brdf.frag:11-73, attachments R16G16B16A16_SFLOAT
+ * (src/main.cpp:443) cleared to 0.  out_rgba: the HDR colour of every pixel (alpha 1 everywhere: brdf.frag also runs
+ * on cleared texels).  out_gbuffer (optional): width*height*16 floats, per pixel position.xyz 1 | normal.xyz 0 |
+ * albedo.rgb 0 | metallic roughness ao height, each value exactly representable in binary16 (RNE, as bbo_present). */
+int bbo_render_deferred(const bbo_frame_uniforms *frame, const bbo_view_uniforms *view, const bbo_draw *draws,
+                        uint32_t n_draws, int32_t width, int32_t height, int32_t y0, int32_t y1, float *out_rgba,
+                        float *out_gbuffer, uint32_t *out_prim, float *out_depth, bbo_stats *stats);
 
 /* BASELINE config #1: gizmo.vert/.frag (src/shaders/gizmo.vert:12-28, gizmo.frag:10-17) rasterised
  * with the same fixed-function rules into a width x height target (viewport = whole target). */

@@ -273,6 +273,28 @@ def render(scene: Scene, y0=0, y1=None, flags=0, want_prim=True, want_depth=True
     return rgba, prim, depth, st.as_dict()
 
 
+def render_deferred(scene: Scene, y0=0, y1=None, want_gbuffer=True):
+    """The reference's deferred path (gbuffer.vert/.frag + brdf.frag).  Returns (rgba[h,w,4], gbuffer[h,w,4,4]|None,
+    prim, depth, stats); gbuffer[..., a, :] = attachment a (position, normal, albedo, MRAH), binary16-representable."""
+    W, H = scene.width, scene.height
+    if y1 is None:
+        y1 = H
+    rgba = np.zeros((H, W, 4), np.float32)
+    gbuf = np.zeros((H, W, 4, 4), np.float32) if want_gbuffer else None
+    prim = np.full((H, W), NO_PRIM, np.uint32)
+    depth = np.zeros((H, W), np.float32)
+    arr = (Draw * max(1, len(scene.draws)))(*[d.c_struct() for d in scene.draws])
+    st = Stats()
+    L = lib()
+    L.bbo_render_deferred.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, C.c_int32, C.c_int32,
+                                      C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    rc = L.bbo_render_deferred(_p(scene.frame), _p(scene.view), arr, len(scene.draws), W, H, y0, y1, _p(rgba), _p(gbuf),
+                               _p(prim), _p(depth), C.byref(st))
+    if rc != 0:
+        raise RuntimeError(f"bbo_render_deferred failed: {rc}")
+    return rgba, gbuf, prim, depth, st.as_dict()
+
+
 def render_gizmo(view, vertices, indices, width, height):
     rgba = np.zeros((height, width, 4), np.float32)
     prim = np.full((height, width), NO_PRIM, np.uint32)

@@ -1,0 +1,125 @@
+"""Deferred variant on the GPU against the oracle's bbo_render_deferred: colour bits, winning
+primitive, depth bits, G-buffer texels -- all exact."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from bibim_renderer_amd import Renderer, configs, partition as P
+from oracle import bbo, scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_deferred(sc, tile_mode=None, gbuffer=True, **opts):
+    r = Renderer(sc.width, sc.height)
+    if tile_mode is not None:
+        r.set_option("tile_mode", tile_mode)
+    r.set_option("render_pass", 1)
+    for k, v in opts.items():
+        r.set_option(k, v)
+    r.render_scene(sc)
+    img = r.read_framebuffer()
+    prim, depth = r.read_visibility()
+    g = r.read_gbuffer() if gbuffer else None
+    img2 = r.read_framebuffer()           # the G-buffer dump re-renders the frame: same bits
+    st = r.stats()
+    r.close()
+    assert np.array_equal(img.view(np.uint32), img2.view(np.uint32))
+    return img, g, prim, depth, st
+
+
+def check(sc, tile_mode=None, **opts):
+    ref, rg, rprim, rdepth, rst = bbo.render_deferred(sc)
+    img, g, prim, depth, st = gpu_deferred(sc, tile_mode, **opts)
+    assert np.array_equal(prim, rprim), f"{int((prim != rprim).sum())} pixels pick another primitive"
+    assert np.array_equal(depth.view(np.uint32), rdepth.view(np.uint32))
+    assert st["n_shaded"] == rst["n_shaded"] and st["n_clipped_prims"] == rst["n_clipped_prims"]
+    assert np.array_equal(g.view(np.uint32), rg.view(np.uint32)), "G-buffer texels differ"
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32)), "colour bits differ"
+    return img, ref
+
+
+@pytest.mark.parametrize("tile_mode", [0, 1])
+def test_c2_and_c3_small(maps64, tile_mode):
+    check(scenes.shaderball_scene(configs.C2.scaled(320, 180, 64), bbo.MaterialData(maps64)), tile_mode)
+    check(scenes.shaderball_scene(configs.C3.scaled(640, 360, 64), bbo.MaterialData(maps64)), tile_mode)
+
+
+def test_golden_fixture(maps64):
+    z = np.load(os.path.join(GOLDEN, "deferred.npz"))
+    sc = scenes.shaderball_scene(configs.C2.scaled(160, 90, 64), bbo.MaterialData(maps64))
+    img, g, prim, depth, _ = gpu_deferred(sc)
+    assert np.array_equal(img.view(np.uint32), z["c2_160x90_rgba_bits"])
+    assert np.array_equal(g, z["c2_160x90_gbuffer_f16"].astype(np.float32))
+    assert np.array_equal(prim, z["c2_160x90_prim"])
+
+
+def test_unmapped_normal_default_material_and_nan_background(maps64):
+    sc = scenes.shaderball_scene(configs.C2.scaled(256, 144, 64), bbo.MaterialData(maps64))
+    sc.view["enable_normal_map"] = 0
+    check(sc)
+    sc.frame["lights"][0]["pos"] = (0, 0, 0)          # brdf.frag on the cleared texel: 1/d^2 = inf -> NaN background
+    img, ref = check(sc)
+    assert np.isnan(img[..., 0]).any()
+    check(scenes.triangle_scene(96, 96))              # default material (1x1 maps, roughness 0), directional light
+
+
+def test_mixed_map_sizes_with_a_height_map():
+    rng = np.random.default_rng(5)
+    maps = {"albedo": rng.integers(0, 256, (24, 40, 4), dtype=np.uint8), "roughness": rng.integers(40, 256, (16, 16, 4), dtype=np.uint8),
+            "height": rng.integers(0, 256, (12, 20, 4), dtype=np.uint8), "normal": rng.integers(100, 156, (32, 32, 4), dtype=np.uint8)}
+    sc = scenes.shaderball_scene(configs.C2.scaled(200, 120, 64), bbo.MaterialData(maps))
+    _, rg, _, _, _ = bbo.render_deferred(sc)
+    assert rg[..., 3, 3].max() > 0                    # the height channel is live
+    check(sc)
+
+
+def test_heavy_clipping_overflow_replay_and_frames_in_flight(maps64):
+    cfg = configs.C3.scaled(384, 216, 64)
+    sc = scenes.shaderball_scene(cfg, bbo.MaterialData(maps64))
+    check(sc, bin_cap=8, frames_in_flight=3, tile_order=1)
+    sc.view = scenes.view_uniforms((-1.0, -0.55, 1.6), 35.0, -5.0, cfg.width, cfg.height, 1, near=0.05)  # camera between the balls
+    check(sc)
+
+
+def test_partition_and_present_on_the_deferred_image(maps64):
+    cfg = configs.C3.scaled(512, 300, 64)
+    sc = scenes.shaderball_scene(cfg, bbo.MaterialData(maps64))
+    sc.frame["enable_tone_mapping"], sc.frame["exposure"] = 1, 1.4
+    ref, _, _, _, rst = bbo.render_deferred(sc)
+    world, band_rows = 4, 32
+    shards, shards8, n = [], [], 0
+    for rank in range(world):
+        r = Renderer(cfg.width, cfg.height)
+        r.set_option("render_pass", 1)
+        r.set_partition(rank, world, band_rows)
+        r.render_scene(sc)
+        r.present()
+        shards.append(r.read_shard())
+        shards8.append(r.read_presented())
+        n += r.stats()["n_shaded"]
+        r.close()
+    assert n == rst["n_shaded"]
+    frame = P.unpack_gathered(np.stack(shards), cfg.height, band_rows)
+    assert np.array_equal(frame.view(np.uint32), ref.view(np.uint32))
+    assert np.array_equal(P.unpack_gathered(np.stack(shards8), cfg.height, band_rows), bbo.present(ref, 1, 1.4))
+
+
+def test_switching_render_pass_between_frames(maps64):
+    sc = scenes.shaderball_scene(configs.C2.scaled(192, 108, 64), bbo.MaterialData(maps64))
+    fwd, _, _, _ = bbo.render(sc)
+    dfr, _, _, _, _ = bbo.render_deferred(sc)
+    r = Renderer(sc.width, sc.height)
+    h = r.render_scene(sc)
+    assert np.array_equal(r.read_framebuffer().view(np.uint32), fwd.view(np.uint32))
+    r.set_option("render_pass", 1)
+    h = r.render_scene(sc, h)
+    assert np.array_equal(r.read_framebuffer().view(np.uint32), dfr.view(np.uint32))
+    r.set_option("render_pass", 0)
+    r.render_scene(sc, h)
+    assert np.array_equal(r.read_framebuffer().view(np.uint32), fwd.view(np.uint32))
+    with pytest.raises(Exception):
+        r.read_gbuffer()                              # forward path has no G-buffer
+    r.close()

@@ -196,8 +196,24 @@ def present():
     print("present", info)
 
 
+def deferred():
+    """Deferred path of the oracle frozen: colour bits, G-buffer (as binary16) and coverage of the golden C2 160x90 scene."""
+    from bibim_renderer_amd import configs, textures
+    from oracle import bbo, scenes
+    mat = bbo.MaterialData(textures.make_material(64))
+    rgba, gbuf, prim, depth, st = bbo.render_deferred(scenes.shaderball_scene(configs.C2.scaled(160, 90, 64), mat))
+    g16 = gbuf.astype(np.float16)
+    assert np.array_equal(g16.astype(np.float32), gbuf)
+    np.savez_compressed(os.path.join(GOLD, "deferred.npz"), c2_160x90_rgba_bits=rgba.view(np.uint32), c2_160x90_gbuffer_f16=g16,
+                        c2_160x90_prim=prim, c2_160x90_depth_bits=depth.view(np.uint32))
+    info = {"c2_160x90": st, "rgba_sha256": hashlib.sha256(rgba.tobytes()).hexdigest(),
+            "gbuffer_sha256": hashlib.sha256(g16.tobytes()).hexdigest()}
+    json.dump(info, open(os.path.join(GOLD, "deferred.json"), "w"), indent=1)
+    print("deferred", info)
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["shaderball", "math_golden", "default_texels", "gizmo", "golden_frames", "n_shaded", "present"]
+    which = sys.argv[1:] or ["shaderball", "math_golden", "default_texels", "gizmo", "golden_frames", "n_shaded", "present", "deferred"]
     for w in which:
         globals()[w]()
