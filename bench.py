@@ -116,6 +116,8 @@ def main():
     ap.add_argument("--no-timing-events", action="store_true")
     ap.add_argument("--frames-in-flight", type=int, default=2, choices=[1, 2, 3])
     ap.add_argument("--force-dist", action="store_true", help="exercise the all-gather path with WORLD_SIZE = 1")
+    ap.add_argument("--render-pass", default="forward", choices=["forward", "deferred"],
+                    help="forward_brdf.* (the path BASELINE measures) or the reference's deferred path, gbuffer.* + brdf.*")
     ap.add_argument("--present", action="store_true",
                     help="every step also runs the presentation step (tone map + sRGB + RGBA8, SURVEY 8(f) rank 1); "
                          "for N > 1 the RGBA8 shards are gathered instead of the fp32 ones (a quarter of the payload)")
@@ -152,6 +154,7 @@ def main():
     if args.tile_mode is not None:
         r.set_option("tile_mode", args.tile_mode)
     r.set_option("frames_in_flight", args.frames_in_flight)
+    r.set_option("render_pass", 1 if args.render_pass == "deferred" else 0)
     material = r.upload_material(maps)
     scene, cam, settings = S.config_scene(r, cfg, ball)
 
@@ -317,7 +320,8 @@ def main():
                        "partition": "single GPU" if world == 1 else f"interleaved {args.band_rows or r.tile_height()}-row bands, "
                                     f"{world} ranks, ncclAllGather + un-interleave",
                        "tile": f"{stats['tile_w']}x{stats['tile_h']}",
-                       "output": "RGBA32F frame + presented RGBA8" if args.present else "RGBA32F frame"},
+                       "output": "RGBA32F frame + presented RGBA8" if args.present else "RGBA32F frame",
+                       "render_pass": args.render_pass},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

@@ -71,7 +71,13 @@ BB_DEV float bb_rcp(float x) {
 // nearest binary16 value (ties to even), as binary32: v_cvt_f16_f32 / v_cvt_f32_f16 do exactly this on gfx950
 // (round-to-nearest-even, binary16 subnormals kept -- the default float mode of HIP kernels; every binary16
 // midpoint +-3 ulp is checked against the oracle's integer formulation in tests/test_gpu_parity.py)
-BB_DEV float bb_half_round(float x) { return (float)(_Float16)x; }
+// The empty asm pins the binary32 value: without it the compiler folds a producing fma and the conversion into one
+// v_fma_mix*_f16, which rounds the exact fma result ONCE to binary16 -- different from rounding the binary32 result
+// (what an attachment write does) exactly when that result sits on a binary16 tie.
+BB_DEV float bb_half_round(float x) {
+  asm("" : "+v"(x));
+  return (float)(_Float16)x;
+}
 
 BB_DEV f3 normalize3(f3 a) { return scale3(a, bb_rsqrt(dot3(a, a))); }
 BB_DEV float max0(float a) { return a > 0.0f ? a : 0.0f; }
@@ -1194,7 +1200,7 @@ __global__ void k_deferred_background(ShadeParams sp, const Light *__restrict__ 
 #endif
 constexpr int kShadeThreads = BB_SHADE_THREADS;
 
-template <int TILE_W, int TILE_H>
+template <int TILE_W, int TILE_H, bool DEFERRED>
 __global__ __launch_bounds__(kShadeThreads) void k_shade(
     FrameParams fp, ShadeParams sp, const Light *__restrict__ lights, const ShadeRec *__restrict__ recs,
     const ClipSlot *__restrict__ clip_arena, const unsigned long long *__restrict__ frags,
@@ -1281,7 +1287,7 @@ __global__ __launch_bounds__(kShadeThreads) void k_shade(
         normal.y = fmaf(a[6], nt.z, fmaf(a[12], nt.y, a[9] * nt.x));
         normal.z = fmaf(a[7], nt.z, fmaf(a[13], nt.y, a[10] * nt.x));
       } else {
-        normal = fp.deferred ? mk3(a[5], a[6], a[7]) : normalize3(mk3(a[5], a[6], a[7]));  // gbuffer.frag:29 / forward :24
+        normal = DEFERRED ? mk3(a[5], a[6], a[7]) : normalize3(mk3(a[5], a[6], a[7]));  // gbuffer.frag:29 / forward :24
       }
     } else {
       // maps of different sizes: one set of taps per map
@@ -1325,12 +1331,12 @@ __global__ __launch_bounds__(kShadeThreads) void k_shade(
         normal.y = fmaf(a[6], nt.z, fmaf(a[12], nt.y, a[9] * nt.x));
         normal.z = fmaf(a[7], nt.z, fmaf(a[13], nt.y, a[10] * nt.x));
       } else {
-        normal = fp.deferred ? mk3(a[5], a[6], a[7]) : normalize3(mk3(a[5], a[6], a[7]));
+        normal = DEFERRED ? mk3(a[5], a[6], a[7]) : normalize3(mk3(a[5], a[6], a[7]));
       }
     }
 
     float4 color;
-    if (fp.deferred) {
+    if (DEFERRED) {
       // gbuffer.frag:24-32 into four RGBA16F attachments (binary16, round to nearest even), then brdf.frag:12-73 on
       // the pixel's own texel: fused, the texel only goes to memory when somebody asked to see it
       f3 P = mk3(bb_half_round(a[2]), bb_half_round(a[3]), bb_half_round(a[4]));

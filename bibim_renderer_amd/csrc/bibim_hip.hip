@@ -328,9 +328,14 @@ void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const Fra
   // (k_shade 102 -> 169 us), interleaved 2-row bands still leave a 3:2 imbalance (132 us); the L2-miss traffic they
   // save (FETCH_SIZE -20 %) does not matter to kernels that are issue- and latency-bound, not L2-bandwidth-bound.
   constexpr int kChunks = TW * TH / kShadeThreads;
-  hipLaunchKernelGGL((k_shade<TW, TH>), dim3(fp.tiles_x * kChunks, grid_y), dim3(kShadeThreads), 0, ss, fp, sp, d_lights,
-                     s.d_attrs.ptr, s.d_clip.ptr, s.d_frags.ptr, s.d_frag_count.ptr, c->d_materials.ptr, out,
-                     (fp.deferred && c->dump_gbuffer) ? c->d_gbuffer.ptr : nullptr);
+  if (fp.deferred)
+    hipLaunchKernelGGL((k_shade<TW, TH, true>), dim3(fp.tiles_x * kChunks, grid_y), dim3(kShadeThreads), 0, ss, fp, sp, d_lights,
+                       s.d_attrs.ptr, s.d_clip.ptr, s.d_frags.ptr, s.d_frag_count.ptr, c->d_materials.ptr, out,
+                       c->dump_gbuffer ? c->d_gbuffer.ptr : nullptr);
+  else
+    hipLaunchKernelGGL((k_shade<TW, TH, false>), dim3(fp.tiles_x * kChunks, grid_y), dim3(kShadeThreads), 0, ss, fp, sp, d_lights,
+                       s.d_attrs.ptr, s.d_clip.ptr, s.d_frags.ptr, s.d_frag_count.ptr, c->d_materials.ptr, out,
+                       (uint2 *)nullptr);
   (void)hipEventRecord(s.ev_shade_done, ss);
   if (ev) {
     (void)hipEventRecord(ev[4], ss);
