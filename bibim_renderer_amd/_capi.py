@@ -99,6 +99,7 @@ SCENE_SIGNATURES = {
     "bbs_triangle_scene_create": (_P, [_P]),
     "bbs_scene_destroy": (None, [_P]),
     "bbs_scene_set_lights": (C.c_int, [_P, _P, C.c_uint32]),
+    "bbs_scene_set_render_pass": (C.c_int, [_P, C.c_int32]),
     "bbs_scene_num_lights": (C.c_uint32, [_P]),
     "bbs_scene_get_lights": (C.c_int, [_P, _P]),
     "bbs_scene_instances": (C.c_int, [_P, C.c_int32, _P, C.c_uint32, C.POINTER(C.c_uint32)]),

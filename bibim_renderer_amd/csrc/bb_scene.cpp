@@ -278,6 +278,8 @@ int drawFrame(bbr_context *ctx, SceneBase &scene, const FreeLookCamera &cam, con
   if (rc != BBR_OK) return rc;
   rc = bbr_set_view_uniforms(ctx, &vb);
   if (rc != BBR_OK) return rc;
+  rc = bbr_set_option(ctx, "render_pass", scene.SceneRenderPassType == RenderPassType::Deferred ? 1 : 0);
+  if (rc != BBR_OK) return rc;
   rc = bbr_begin_frame(ctx);
   if (rc != BBR_OK) return rc;
   Frame frame;
@@ -369,6 +371,12 @@ bbs_scene *bbs_triangle_scene_create(bbr_context *ctx) {
   return s;
 }
 void bbs_scene_destroy(bbs_scene *scene) { delete scene; }
+
+int bbs_scene_set_render_pass(bbs_scene *scene, int32_t render_pass) {
+  if (!scene || !scene->scene || (render_pass != 0 && render_pass != 1)) return BBR_ERR_INVALID_ARGUMENT;
+  scene->scene->SceneRenderPassType = render_pass ? bb::RenderPassType::Deferred : bb::RenderPassType::Forward;
+  return BBR_OK;
+}
 
 int bbs_scene_set_lights(bbs_scene *scene, const void *lights, uint32_t n) {
   if (!scene || (!lights && n) || n >= (uint32_t)bb::MaxNumLights) return BBR_ERR_INVALID_ARGUMENT;

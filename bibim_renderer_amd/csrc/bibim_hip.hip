@@ -1080,9 +1080,14 @@ int bbr_present_timing(bbr_context *c, uint32_t *out_launches, float *out_avg_ms
 int bbr_set_option(bbr_context *c, const char *name, int64_t value) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
   if (!name) return fail(c, BBR_ERR_INVALID_ARGUMENT, "set_option: NULL name");
+  std::string n(name);
+  if (n == "render_pass") {  // takes effect with the next submitted frame; no need to wait for the ones in flight
+    if (value != 0 && value != 1) return fail(c, BBR_ERR_INVALID_ARGUMENT, "render_pass: 0 (forward) or 1 (deferred)");
+    c->deferred = value == 1;
+    return BBR_OK;
+  }
   int rc = drain(c);
   if (rc) return rc;
-  std::string n(name);
   if (n == "timing") {
     if (value < 0 || value > 2) return fail(c, BBR_ERR_INVALID_ARGUMENT, "timing: 0, 1 or 2");
     c->timing = (int)value;
@@ -1106,9 +1111,6 @@ int bbr_set_option(bbr_context *c, const char *name, int64_t value) {
     for (FrameSlot &s : c->slots) s.d_bins.release();
   } else if (n == "ablate") {
     c->ablate = (uint32_t)value;
-  } else if (n == "render_pass") {
-    if (value != 0 && value != 1) return fail(c, BBR_ERR_INVALID_ARGUMENT, "render_pass: 0 (forward) or 1 (deferred)");
-    c->deferred = value == 1;
   } else if (n == "tile_order") {
     c->tile_order = value != 0;
   } else if (n == "broad_threshold") {

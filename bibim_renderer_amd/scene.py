@@ -83,6 +83,12 @@ class _Scene:
         if rc:
             raise BibimError(rc, "set_lights")
 
+    def set_render_pass(self, deferred):
+        """SceneBase::SceneRenderPassType: False = forward (this shim's default), True = deferred (the reference's)"""
+        rc = lib().bbs_scene_set_render_pass(self._h, 1 if deferred else 0)
+        if rc:
+            raise BibimError(rc, "set_render_pass")
+
     def set_point_lights(self, point_lights):
         a = np.zeros(len(point_lights), LIGHT_DTYPE)
         for i, l in enumerate(point_lights):

@@ -150,7 +150,7 @@ int bbr_last_frame_time_ms(bbr_context *ctx, float *out_frame_ms, float *out_sha
 int bbr_timing_reset(bbr_context *ctx);
 int bbr_timing_summary(bbr_context *ctx, uint32_t *out_frames, float *out_avg_frame_ms, float *out_avg_geometry_ms,
                        float *out_avg_raster_ms, float *out_avg_shade_ms);
-/* Options (all drain the context first):
+/* Options (all but "render_pass" drain the context first):
  *   "timing" 0|1|2           1: five HIP events per frame (frame start, geometry, raster, shade start, shade done);
  *                            2: only the two around k_shade (frame/geometry/raster averages read 0); restarts the ring
  *   "frames_in_flight" 1|2   default 2

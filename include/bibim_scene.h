@@ -130,7 +130,13 @@ struct Frame {
   int32_t Material = -1;
 };
 
+enum class RenderPassType : int32_t { Forward = 0, Deferred = 1 };  // src/scene.h:76 (enum), :77 (member)
+
 struct SceneBase {
+  // The reference defaults to Deferred (src/scene.h:77); this shim defaults to the forward path, the one BASELINE
+  // measures.  drawFrame selects forward_brdf.* or gbuffer.* + brdf.* with it, as recordCommand does
+  // (src/main.cpp:89-112).
+  RenderPassType SceneRenderPassType = RenderPassType::Forward;
   std::vector<Light> Lights;
   virtual ~SceneBase() = default;
   virtual void updateScene(float dt) = 0;
@@ -212,6 +218,8 @@ bbs_scene *bbs_triangle_scene_create(bbr_context *ctx);
 void bbs_scene_destroy(bbs_scene *scene);
 /* replace the scene's lights with n Light records (64 B each) */
 int bbs_scene_set_lights(bbs_scene *scene, const void *lights, uint32_t n);
+/* SceneBase::SceneRenderPassType: 0 forward, 1 deferred */
+int bbs_scene_set_render_pass(bbs_scene *scene, int32_t render_pass);
 uint32_t bbs_scene_num_lights(const bbs_scene *scene);
 int bbs_scene_get_lights(const bbs_scene *scene, void *out_lights);
 /* run updateScene and copy out the instance data of draw `draw_index` (0 ball, 1 plane) */

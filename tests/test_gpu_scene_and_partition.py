@@ -29,6 +29,26 @@ def test_draw_frame_through_the_shim_matches_oracle(maps256):
     scene.close(); r.close()
 
 
+def test_scene_render_pass_type_selects_the_deferred_path(maps256):
+    """SceneBase::SceneRenderPassType (src/scene.h:77) drives drawFrame as it drives recordCommand (src/main.cpp:89-112)"""
+    cfg = configs.C3.scaled(480, 270, 256)
+    r = Renderer(cfg.width, cfg.height)
+    material = r.upload_material(maps256)
+    scene, cam, settings = S.config_scene(r, cfg)
+    sc = scenes.shaderball_scene(cfg, bbo.MaterialData(maps256))
+    fwd, _, _, _ = bbo.render(sc)
+    dfr, _, _, _, _ = bbo.render_deferred(sc)
+    S.draw_frame(r, scene, cam, settings, material)
+    assert np.array_equal(r.read_framebuffer().view(np.uint32), fwd.view(np.uint32))
+    scene.set_render_pass(True)
+    S.draw_frame(r, scene, cam, settings, material)
+    assert np.array_equal(r.read_framebuffer().view(np.uint32), dfr.view(np.uint32))
+    scene.set_render_pass(False)
+    S.draw_frame(r, scene, cam, settings, material)
+    assert np.array_equal(r.read_framebuffer().view(np.uint32), fwd.view(np.uint32))
+    scene.close(); r.close()
+
+
 def test_reference_default_scene_through_the_shim(maps64):
     """ShaderBallScene as the reference constructs it: 1 instance, its 3 lights, normal map off, 1280x720 window"""
     r = Renderer(1280, 720)
