@@ -73,6 +73,7 @@ SIGNATURES = {
                                      C.POINTER(C.c_float)]),
     "bbr_set_option": (C.c_int, [_P, C.c_char_p, C.c_int64]),
     "bbr_tone_map": (C.c_int, [_P, C.c_int32, C.c_float]),
+    "bbr_selftest_rcp": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]),
     "bbr_read_gbuffer": (C.c_int, [_P, C.c_void_p]),
     "bbr_present": (C.c_int, [_P, C.c_void_p, C.c_int32]),
     "bbr_read_presented": (C.c_int, [_P, C.c_void_p]),

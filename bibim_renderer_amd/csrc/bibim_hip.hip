@@ -1204,6 +1204,22 @@ int bbr_unpack_gathered_rgba8(bbr_context *c, const void *gathered, void *frame,
   return BBR_OK;
 }
 
+int bbr_selftest_rcp(bbr_context *c, uint32_t lo_bits, uint32_t hi_bits, uint64_t *out_mismatches) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  if (!out_mismatches || hi_bits < lo_bits) return fail(c, BBR_ERR_INVALID_ARGUMENT, "selftest_rcp: bad arguments");
+  int rc = drain(c);
+  if (rc) return rc;
+  unsigned long long *d = nullptr, h = 0;
+  HIP_TRY(c, hipMalloc(&d, sizeof h));
+  HIP_TRY(c, hipMemset(d, 0, sizeof h));
+  hipLaunchKernelGGL(k_selftest_rcp, dim3(4096), dim3(256), 0, c->geom_stream(), d, lo_bits, hi_bits);
+  hipError_t e = hipMemcpy(&h, d, sizeof h, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  HIP_TRY(c, e);
+  *out_mismatches = h;
+  return BBR_OK;
+}
+
 int bbr_tone_map(bbr_context *c, int32_t enable, float exposure) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
   if (!c->have_frame || c->last_slot < 0) return fail(c, BBR_ERR_NOT_IN_FRAME, "tone_map: nothing rendered");

@@ -139,6 +139,11 @@ class Renderer:
         self._check(self._L.bbr_timing_summary(self._ctx, C.byref(n), C.byref(f), C.byref(g), C.byref(r), C.byref(t)))
         return n.value, f.value, g.value, r.value, t.value
 
+    def selftest_rcp(self, lo_bits=0, hi_bits=0x7FFFFFFF):
+        n = C.c_uint64()
+        self._check(self._L.bbr_selftest_rcp(self._ctx, lo_bits, hi_bits, C.byref(n)))
+        return n.value
+
     def tone_map(self, enable, exposure):
         self._check(self._L.bbr_tone_map(self._ctx, int(enable), float(exposure)))
 

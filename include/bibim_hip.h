@@ -162,6 +162,10 @@ int bbr_timing_summary(bbr_context *ctx, uint32_t *out_frames, float *out_avg_fr
  *                            throughput; default 0)
  *   "ablate" bits            diagnostics only: skip parts of the pipeline (see bb_kernels.hip.h) */
 int bbr_set_option(bbr_context *ctx, const char *name, int64_t value);
+/* Self-test of the arithmetic contract on this device: the shader's reciprocal (v_rcp_f32 + one Newton step) against
+ * the IEEE division for +x and -x of every float with bit pattern in [lo_bits, hi_bits); 0 mismatches expected.
+ * The whole positive range 0 .. 0x7FFFFFFF takes about half a second. */
+int bbr_selftest_rcp(bbr_context *ctx, uint32_t lo_bits, uint32_t hi_bits, uint64_t *out_mismatches);
 
 /* ---- deferred variant ----
  * bbr_set_option(ctx, "render_pass", 1) renders with the reference's deferred path, its default

@@ -70,18 +70,10 @@ static inline float bb_rsqrt(float x) {
   y = y * fmaf(-(h * y), y, 1.5f);
   return y;
 }
-static inline float bb_rcp(float x) {
-  const float ax = fabsf(x);
-  if (!(ax >= 1.17549435e-38f && ax <= 8.5e37f)) return 1.0f / x;
-  union { float f; uint32_t u; } c;
-  c.f = ax;
-  c.u = 0x7EF311C7u - c.u;
-  float r = c.f;
-  r = fmaf(r, fmaf(-ax, r, 1.0f), r);
-  r = fmaf(r, fmaf(-ax, r, 1.0f), r);
-  r = fmaf(r, fmaf(-ax, r, 1.0f), r);
-  return copysignf(r, x);
-}
+/* Reciprocal: the correctly rounded 1/x (IEEE division).  The GPU reaches the same bits for every input with
+ * v_rcp_f32 plus ONE Newton step -- verified exhaustively over all 2 113 929 216 normal inputs with a normal result
+ * (tools/microbench/exact_rcp.hip, and bbr_selftest_rcp in the library) -- and IEEE division outside that range. */
+static inline float bb_rcp(float x) { return 1.0f / x; }
 static inline v3 normalize3(v3 a) { return scale3(a, bb_rsqrt(dot3(a, a))); }
 static inline float max0(float a) { return a > 0.0f ? a : 0.0f; } /* GLSL max(a,0): NaN -> 0 */
 

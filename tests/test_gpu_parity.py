@@ -263,6 +263,15 @@ def test_error_codes():
         Renderer(0, 10)
 
 
+def test_reciprocal_of_the_contract_is_the_ieee_division_for_every_float():
+    """bb_rcp = v_rcp_f32 + one Newton step on the GPU, 1.0f / x in the oracle: identical for all 2^31 magnitudes and
+    both signs (denormals, zero, inf and NaN take the IEEE path on both sides)"""
+    r = Renderer(64, 64)
+    assert r.selftest_rcp(0x00000000, 0x7FFFFFFF) == 0
+    assert r.selftest_rcp(0x7F800000, 0x7F800010) == 0 and r.selftest_rcp(0, 0x00800010) == 0
+    r.close()
+
+
 def test_tone_map_next_row(maps64):
     sc = scenes.shaderball_scene(configs.C2.scaled(160, 90, 64), bbo.MaterialData(maps64))
     r = Renderer(sc.width, sc.height)
