@@ -114,7 +114,8 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--band-rows", type=int, default=0, help="screen band height for N > 1 (0 = tile height)")
     ap.add_argument("--no-timing-events", action="store_true")
-    ap.add_argument("--frames-in-flight", type=int, default=2, choices=[1, 2, 3])
+    ap.add_argument("--frames-in-flight", type=int, default=3, choices=[1, 2, 3],
+                    help="frames queued on the GPU at once (the reference keeps 2; 3 keeps the host off the critical path: +2 %%)")
     ap.add_argument("--force-dist", action="store_true", help="exercise the all-gather path with WORLD_SIZE = 1")
     ap.add_argument("--render-pass", default="forward", choices=["forward", "deferred"],
                     help="forward_brdf.* (the path BASELINE measures) or the reference's deferred path, gbuffer.* + brdf.*")

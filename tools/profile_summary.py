@@ -67,7 +67,10 @@ elif mode == "phases":
         for k, v in sorted(per.items()):
             if not k.startswith("k_"):
                 continue
-            timed, tail = v[skip:skip + steps], v[skip + steps + 5:]
+            if len(v) < skip + steps:  # not a per-frame kernel (k_present: only the next-row measurement launches it)
+                f.write(f"{k:12s} launches {len(v):4d}  all: mean={sum(v) / len(v) / 1e3:8.2f} us\n")
+                continue
+            timed, tail = v[skip:skip + steps], v[skip + steps + 5:skip + steps + 55]
             f.write(f"{k:12s} launches {len(v):4d}  timed region: n={len(timed)} mean={sum(timed) / max(len(timed), 1) / 1e3:8.2f} us"
                     f"   one frame in flight: n={len(tail)} mean={sum(tail) / max(len(tail), 1) / 1e3:8.2f} us\n")
 elif mode == "counters":
