@@ -97,6 +97,7 @@ SCENE_SIGNATURES = {
     "bbs_camera_view": (None, [_P, _F, _F, _P]),
     "bbs_plane_mesh": (None, [_P, _P]),
     "bbs_shaderball_scene_create": (_P, [_P, _P, C.c_uint32, C.c_int32]),
+    "bbs_shaderball_scene_create_from_file": (_P, [_P, C.c_char_p, C.c_int32]),
     "bbs_triangle_scene_create": (_P, [_P]),
     "bbs_scene_destroy": (None, [_P]),
     "bbs_scene_set_lights": (C.c_int, [_P, _P, C.c_uint32]),

@@ -5,6 +5,7 @@
 // vector_math.cpp / camera.cpp (tests/golden/math_golden.json, minted from oracle/_ref) -- which fixes the
 // evaluation order: plain left-to-right mul/add, no fused operations (this file is built -ffp-contract=off).
 #include "../../include/bibim_scene.h"
+#include "../../include/bibim_assets.h"
 
 #include <cmath>
 #include <cstring>
@@ -362,6 +363,16 @@ bbs_scene *bbs_shaderball_scene_create(bbr_context *ctx, const void *ball_vertic
   bbs_scene *s = new bbs_scene();
   s->scene.reset(new bb::ShaderBallScene(ctx, static_cast<const bb::Vertex *>(ball_vertices), n_vertices, grid));
   s->kind = 0;
+  return s;
+}
+bbs_scene *bbs_shaderball_scene_create_from_file(bbr_context *ctx, const char *fbx_path, int32_t grid) {
+  // what the reference's constructor does itself: import ShaderBall.fbx and expand it to a triangle list
+  // (src/scene.cpp:57-86), here with the in-repo FBX reader instead of assimp
+  void *v = nullptr;
+  uint32_t n = 0;
+  if (bba_load_fbx_vertices(fbx_path, &v, &n) != BBA_OK) return nullptr;  // bba_last_error() has the reason
+  bbs_scene *s = bbs_shaderball_scene_create(ctx, v, n, grid);
+  bba_free(v);
   return s;
 }
 bbs_scene *bbs_triangle_scene_create(bbr_context *ctx) {

@@ -125,9 +125,12 @@ class _Scene:
 
 
 class ShaderBallScene(_Scene):
-    def __init__(self, renderer: Renderer | None, ball_vertices=None, grid=1):
-        v = load_shaderball_vertices() if ball_vertices is None else np.ascontiguousarray(ball_vertices)
+    def __init__(self, renderer: Renderer | None, ball_vertices=None, grid=1, fbx_path=None):
         ctx = renderer._ctx if renderer is not None else None
+        if fbx_path is not None:  # import the ball like the reference's constructor does (src/scene.cpp:57-86)
+            super().__init__(lib().bbs_shaderball_scene_create_from_file(ctx, str(fbx_path).encode(), grid), renderer)
+            return
+        v = load_shaderball_vertices() if ball_vertices is None else np.ascontiguousarray(ball_vertices)
         super().__init__(lib().bbs_shaderball_scene_create(ctx, _p(v), v.shape[0], grid), renderer)
 
 

@@ -214,6 +214,9 @@ void bbs_camera_view(const float *pos, float yaw, float pitch, float *out);
 void bbs_plane_mesh(void *out_vertices4, uint32_t *out_indices6);
 
 bbs_scene *bbs_shaderball_scene_create(bbr_context *ctx, const void *ball_vertices, uint32_t n_vertices, int32_t grid);
+/* the same, importing the ball from a binary FBX file like the reference's constructor (src/scene.cpp:57-86) with
+ * bba_load_fbx_vertices (include/bibim_assets.h); NULL on failure, reason in bba_last_error() */
+bbs_scene *bbs_shaderball_scene_create_from_file(bbr_context *ctx, const char *fbx_path, int32_t grid);
 bbs_scene *bbs_triangle_scene_create(bbr_context *ctx);
 void bbs_scene_destroy(bbs_scene *scene);
 /* replace the scene's lights with n Light records (64 B each) */

@@ -194,3 +194,48 @@ def test_light_superposition_property_at_full_hd(maps256):
     r.close()
     amb, a, b, ab = outs
     np.testing.assert_allclose((a - amb) + (b - amb), ab - amb, rtol=2e-5, atol=2e-5)
+
+
+def test_material_directories_load_like_create_pbr_material_set(maps64, tmp_path):
+    """pbr/<name>/{albedo,metallic,roughness,ao,normal,height}.png -> materials in the reference's order
+    (src/render.cpp:1243-1316): directories by name, "default" swapped with the last and dropped, missing maps fall
+    back to the default maps; the loaded material renders exactly like the same maps handed over directly"""
+    from test_assets import encode_png
+    from bibim_renderer_amd import assets
+
+    def write_dir(name, maps):
+        d = tmp_path / "pbr" / name
+        d.mkdir(parents=True)
+        for k, img in maps.items():
+            a = np.asarray(img)
+            if k in ("metallic", "roughness", "ao"):      # as most reference maps: grey files, expanded on load
+                (d / f"{k}.png").write_bytes(encode_png(a[..., :1].astype(int), 0, 8))
+            else:
+                (d / f"{k}.png").write_bytes(encode_png(a[..., :3].astype(int), 2, 8))
+    grey = {k: np.repeat(v[..., :1], 4, axis=2) for k, v in maps64.items() if k in ("metallic", "roughness", "ao")}
+    for k in grey:
+        grey[k][..., 3] = 255
+    full = {**{k: np.concatenate([v[..., :3], np.full(v.shape[:2] + (1,), 255, np.uint8)], axis=2) for k, v in maps64.items()}, **grey}
+    write_dir("zinc", {k: full[k] for k in ("albedo", "normal")})            # partial: the rest falls back to default
+    write_dir("bark1", full)
+    write_dir("default", {"albedo": np.full((4, 4, 4), 255, np.uint8)})
+    write_dir("alder", {k: full[k] for k in ("roughness", "metallic")})
+    (tmp_path / "pbr" / "notes.txt").write_text("not a directory")
+    cfg = configs.C2.scaled(256, 144, 64)
+    r = Renderer(cfg.width, cfg.height)
+    loaded = assets.load_material_set(r, tmp_path / "pbr")
+    assert [n for _, n in loaded] == ["alder", "bark1", "zinc"]             # [alder bark1 default zinc] -> default<->zinc, pop
+    for (mid, name), maps in zip(loaded, ({k: full[k] for k in ("roughness", "metallic")}, full, {k: full[k] for k in ("albedo", "normal")})):
+        sc = scenes.shaderball_scene(cfg, bbo.MaterialData(maps))
+        ref, _, _, _ = bbo.render(sc)
+        r.set_frame_uniforms(sc.frame); r.set_view_uniforms(sc.view)
+        r.begin_frame()
+        for d in sc.draws:
+            r.draw(r.upload_mesh(d.vertices, d.indices), mid, d.instances)
+        r.end_frame()
+        assert np.array_equal(r.read_framebuffer().view(np.uint32), ref.view(np.uint32)), name
+    single = assets.load_material_dir(r, tmp_path / "pbr" / "bark1")
+    assert single not in [m for m, _ in loaded]
+    with pytest.raises(assets.AssetError):
+        assets.load_material_set(r, tmp_path / "nope")
+    r.close()

@@ -178,6 +178,28 @@ def n_shaded():
     json.dump(out, open(os.path.join(GOLD, "n_shaded.json"), "w"), indent=1)
 
 
+def reference_pngs():
+    """Every PNG the reference ships, decoded with the reference's own stb_image 2.25 (oracle/_ref/libstb_ref.so,
+    STBI_rgb_alpha): size + sha256 of the RGBA8 bytes.  Pins the in-repo PNG decoder (bba_load_png)."""
+    import glob
+    stb = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libstb_ref.so"))
+    stb.stbi_load.restype = C.POINTER(C.c_ubyte)
+    stb.stbi_load.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]
+    stb.stbi_image_free.argtypes = [C.c_void_p]
+    out = {}
+    for path in sorted(glob.glob(os.path.join(REF, "resources", "**", "*.png"), recursive=True)):
+        w, h, ch = C.c_int(), C.c_int(), C.c_int()
+        px = stb.stbi_load(path.encode(), C.byref(w), C.byref(h), C.byref(ch), 4)
+        if not px:
+            continue
+        a = np.ctypeslib.as_array(px, shape=(h.value, w.value, 4))
+        out[os.path.relpath(path, os.path.join(REF, "resources"))] = {
+            "w": w.value, "h": h.value, "file_channels": ch.value, "sha256_rgba8": hashlib.sha256(a.tobytes()).hexdigest()}
+        stb.stbi_image_free(px)
+    json.dump(out, open(os.path.join(GOLD, "reference_png_sha256.json"), "w"), indent=1)
+    print("reference_pngs", len(out), "files")
+
+
 def present():
     """Presentation contract frozen: the 255 sRGB thresholds (bit patterns) and the presented bytes of the golden
     C2 160x90 frame with and without tone mapping (sha256 + the image itself, 57 KB each)."""
@@ -214,6 +236,6 @@ def deferred():
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["shaderball", "math_golden", "default_texels", "gizmo", "golden_frames", "n_shaded", "present", "deferred"]
+    which = sys.argv[1:] or ["shaderball", "math_golden", "default_texels", "gizmo", "golden_frames", "n_shaded", "present", "deferred", "reference_pngs"]
     for w in which:
         globals()[w]()
