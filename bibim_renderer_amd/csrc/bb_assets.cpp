@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <map>
 #include <string>
 #include <vector>
@@ -42,6 +43,9 @@ bool read_file(const char *path, std::vector<uint8_t> &out) {
 }
 
 bool inflate_all(const uint8_t *src, size_t n, std::vector<uint8_t> &out, size_t expected) {
+  // deflate cannot expand by more than ~1032:1: a declared size beyond that is a corrupt (or hostile) header, not a
+  // reason to allocate gigabytes
+  if (expected > n * 1100 + 4096) return false;
   out.resize(expected);
   z_stream zs;
   std::memset(&zs, 0, sizeof zs);
@@ -300,7 +304,7 @@ int decode_png(const uint8_t *bytes, size_t n, uint8_t **out_rgba, int32_t *out_
       if (len != 13) return fail(BBA_ERR_FORMAT, "bad IHDR");
       w = be32(data); h = be32(data + 4);
       depth = data[8]; color = data[9]; interlace = data[12];
-      if (!w || !h || w > (1u << 24) || h > (1u << 24)) return fail(BBA_ERR_FORMAT, "bad PNG size");
+      if (!w || !h || w > (1u << 24) || h > (1u << 24) || (uint64_t)w * h > (1ull << 28)) return fail(BBA_ERR_FORMAT, "bad PNG size");
       if (data[10] != 0 || data[11] != 0 || interlace > 1) return fail(BBA_ERR_FORMAT, "bad PNG compression/filter/interlace method");
       const bool ok = (color == 0 && (depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16)) ||
                       (color == 3 && (depth == 1 || depth == 2 || depth == 4 || depth == 8)) ||
@@ -451,214 +455,238 @@ const char *bba_last_error(void) { return g_error.c_str(); }
 void bba_free(void *p) { std::free(p); }
 
 int bba_load_fbx_vertices(const char *path, void **out_vertices, uint32_t *out_n) {
-  if (!path || !out_vertices || !out_n) return fail(BBA_ERR_ARGUMENT, "load_fbx_vertices: NULL argument");
-  *out_vertices = nullptr;
-  *out_n = 0;
-  std::vector<uint8_t> file;
-  if (!read_file(path, file)) return fail(BBA_ERR_IO, std::string("cannot read ") + path);
-  if (file.size() < 27 || std::memcmp(file.data(), "Kaydara FBX Binary  ", 20) != 0) return fail(BBA_ERR_FORMAT, "not a binary FBX file");
-  const uint32_t version = rd<uint32_t>(file.data() + 23);
-  if (version >= 7500) return fail(BBA_ERR_UNSUPPORTED, "FBX >= 7500 (64-bit records) not supported");
-  FbxReader r{file.data(), file.size(), {}};
-  FbxNode root;
-  size_t pos = 27;
-  while (pos < file.size()) {
-    FbxNode nd;
-    bool null_rec = false;
-    if (!r.node(pos, nd, null_rec, 0)) return fail(BBA_ERR_FORMAT, r.err);
-    if (null_rec) break;
-    root.children.push_back(std::move(nd));
-  }
-  const FbxNode *objects = root.find("Objects");
-  const FbxNode *geom = objects ? objects->find("Geometry") : nullptr;
-  if (!geom) return fail(BBA_ERR_FORMAT, "FBX: no Objects/Geometry");
-  const FbxNode *vn = geom->find("Vertices"), *pn = geom->find("PolygonVertexIndex");
-  if (!vn || !pn || vn->props.empty() || pn->props.empty()) return fail(BBA_ERR_FORMAT, "FBX geometry without Vertices / PolygonVertexIndex");
-  const std::vector<double> &ctrl = vn->props[0].f64;
-  const std::vector<int64_t> &pvi = pn->props[0].i64;
-  const size_t n = pvi.size(), n_ctrl = ctrl.size() / 3;
-  if (n == 0 || n % 3) return fail(BBA_ERR_UNSUPPORTED, "FBX: polygon-vertex count is not a multiple of three");
-  for (size_t k = 0; k < n; ++k)
-    if ((pvi[k] < 0) != (k % 3 == 2)) return fail(BBA_ERR_UNSUPPORTED, "FBX: non-triangle polygons (triangulation not implemented)");
-  std::string err;
-  Layer ln, lt, lu;
-  if (!get_layer(*geom, "LayerElementNormal", "Normals", "NormalsIndex", ln, err) ||
-      !get_layer(*geom, "LayerElementTangent", "Tangents", "TangentsIndex", lt, err) ||
-      !get_layer(*geom, "LayerElementUV", "UV", "UVIndex", lu, err))
-    return fail(BBA_ERR_UNSUPPORTED, err);
-  auto fetch = [&](const Layer &l, size_t k, int width, float *dst) -> bool {
-    size_t e = k;
-    if (l.index) {
-      if (k >= l.index->size() || (*l.index)[k] < 0) return false;
-      e = (size_t)(*l.index)[k];
+  try {
+    if (!path || !out_vertices || !out_n) return fail(BBA_ERR_ARGUMENT, "load_fbx_vertices: NULL argument");
+    *out_vertices = nullptr;
+    *out_n = 0;
+    std::vector<uint8_t> file;
+    if (!read_file(path, file)) return fail(BBA_ERR_IO, std::string("cannot read ") + path);
+    if (file.size() < 27 || std::memcmp(file.data(), "Kaydara FBX Binary  ", 20) != 0) return fail(BBA_ERR_FORMAT, "not a binary FBX file");
+    const uint32_t version = rd<uint32_t>(file.data() + 23);
+    if (version >= 7500) return fail(BBA_ERR_UNSUPPORTED, "FBX >= 7500 (64-bit records) not supported");
+    FbxReader r{file.data(), file.size(), {}};
+    FbxNode root;
+    size_t pos = 27;
+    while (pos < file.size()) {
+      FbxNode nd;
+      bool null_rec = false;
+      if (!r.node(pos, nd, null_rec, 0)) return fail(BBA_ERR_FORMAT, r.err);
+      if (null_rec) break;
+      root.children.push_back(std::move(nd));
     }
-    if ((e + 1) * width > l.data->size()) return false;
-    for (int c = 0; c < width; ++c) dst[c] = (float)(*l.data)[e * width + c];
-    return true;
-  };
-  float *v = (float *)std::malloc(n * 11 * sizeof(float));
-  if (!v) return fail(BBA_ERR_IO, "out of memory");
-  for (size_t k = 0; k < n; ++k) {
-    const int64_t raw = pvi[k];
-    const size_t ci = (size_t)(raw < 0 ? ~raw : raw);
-    float *o = v + 11 * k;
-    if (ci >= n_ctrl || !fetch(lu, k, 2, o + 3) || !fetch(ln, k, 3, o + 5) || !fetch(lt, k, 3, o + 8)) {
-      std::free(v);
-      return fail(BBA_ERR_FORMAT, "FBX: index out of range");
+    const FbxNode *objects = root.find("Objects");
+    const FbxNode *geom = objects ? objects->find("Geometry") : nullptr;
+    if (!geom) return fail(BBA_ERR_FORMAT, "FBX: no Objects/Geometry");
+    const FbxNode *vn = geom->find("Vertices"), *pn = geom->find("PolygonVertexIndex");
+    if (!vn || !pn || vn->props.empty() || pn->props.empty()) return fail(BBA_ERR_FORMAT, "FBX geometry without Vertices / PolygonVertexIndex");
+    const std::vector<double> &ctrl = vn->props[0].f64;
+    const std::vector<int64_t> &pvi = pn->props[0].i64;
+    const size_t n = pvi.size(), n_ctrl = ctrl.size() / 3;
+    if (n == 0 || n % 3) return fail(BBA_ERR_UNSUPPORTED, "FBX: polygon-vertex count is not a multiple of three");
+    for (size_t k = 0; k < n; ++k)
+      if ((pvi[k] < 0) != (k % 3 == 2)) return fail(BBA_ERR_UNSUPPORTED, "FBX: non-triangle polygons (triangulation not implemented)");
+    std::string err;
+    Layer ln, lt, lu;
+    if (!get_layer(*geom, "LayerElementNormal", "Normals", "NormalsIndex", ln, err) ||
+        !get_layer(*geom, "LayerElementTangent", "Tangents", "TangentsIndex", lt, err) ||
+        !get_layer(*geom, "LayerElementUV", "UV", "UVIndex", lu, err))
+      return fail(BBA_ERR_UNSUPPORTED, err);
+    auto fetch = [&](const Layer &l, size_t k, int width, float *dst) -> bool {
+      size_t e = k;
+      if (l.index) {
+        if (k >= l.index->size() || (*l.index)[k] < 0) return false;
+        e = (size_t)(*l.index)[k];
+      }
+      if ((e + 1) * width > l.data->size()) return false;
+      for (int c = 0; c < width; ++c) dst[c] = (float)(*l.data)[e * width + c];
+      return true;
+    };
+    float *v = (float *)std::malloc(n * 11 * sizeof(float));
+    if (!v) return fail(BBA_ERR_IO, "out of memory");
+    for (size_t k = 0; k < n; ++k) {
+      const int64_t raw = pvi[k];
+      const size_t ci = (size_t)(raw < 0 ? ~raw : raw);
+      float *o = v + 11 * k;
+      if (ci >= n_ctrl || !fetch(lu, k, 2, o + 3) || !fetch(ln, k, 3, o + 5) || !fetch(lt, k, 3, o + 8)) {
+        std::free(v);
+        return fail(BBA_ERR_FORMAT, "FBX: index out of range");
+      }
+      o[0] = (float)ctrl[3 * ci]; o[1] = (float)ctrl[3 * ci + 1]; o[2] = (float)ctrl[3 * ci + 2];
     }
-    o[0] = (float)ctrl[3 * ci]; o[1] = (float)ctrl[3 * ci + 1]; o[2] = (float)ctrl[3 * ci + 2];
+    *out_vertices = v;
+    *out_n = (uint32_t)n;
+    return BBA_OK;
+  } catch (const std::exception &e) {
+    return fail(BBA_ERR_IO, std::string("bba_load_fbx_vertices: ")+e.what());
   }
-  *out_vertices = v;
-  *out_n = (uint32_t)n;
-  return BBA_OK;
 }
 
 int bba_load_obj_gizmo(const char *path, void **out_vertices, uint32_t *out_nv, uint32_t **out_indices, uint32_t *out_ni) {
-  if (!path || !out_vertices || !out_nv || !out_indices || !out_ni) return fail(BBA_ERR_ARGUMENT, "load_obj_gizmo: NULL argument");
-  std::vector<uint8_t> file;
-  if (!read_file(path, file)) return fail(BBA_ERR_IO, std::string("cannot read ") + path);
-  std::string dir(path);
-  size_t slash = dir.find_last_of('/');
-  dir = slash == std::string::npos ? std::string(".") : dir.substr(0, slash);
-  std::vector<float> pos, nrm, verts;
-  std::vector<uint32_t> idx;
-  std::map<std::string, std::array<float, 3>> mats;
-  std::array<float, 3> color = {1.f, 1.f, 1.f};
-  for (const std::string &line : lines_of(file)) {
-    std::vector<std::string> t = split_ws(line);
-    if (t.empty() || t[0][0] == '#') continue;
-    if (t[0] == "mtllib" && t.size() > 1) {
-      std::vector<uint8_t> mtl;
-      if (!read_file((dir + "/" + t[1]).c_str(), mtl)) return fail(BBA_ERR_IO, "cannot read material library " + t[1]);
-      std::string cur;
-      for (const std::string &ml : lines_of(mtl)) {
-        std::vector<std::string> m = split_ws(ml);
-        if (m.empty()) continue;
-        if (m[0] == "newmtl" && m.size() > 1) {
-          cur = m[1];
-          mats[cur] = {1.f, 1.f, 1.f};
-        } else if (m[0] == "Kd" && m.size() > 3 && !cur.empty()) {
-          mats[cur] = {(float)std::atof(m[1].c_str()), (float)std::atof(m[2].c_str()), (float)std::atof(m[3].c_str())};
+  try {
+    if (!path || !out_vertices || !out_nv || !out_indices || !out_ni) return fail(BBA_ERR_ARGUMENT, "load_obj_gizmo: NULL argument");
+    std::vector<uint8_t> file;
+    if (!read_file(path, file)) return fail(BBA_ERR_IO, std::string("cannot read ") + path);
+    std::string dir(path);
+    size_t slash = dir.find_last_of('/');
+    dir = slash == std::string::npos ? std::string(".") : dir.substr(0, slash);
+    std::vector<float> pos, nrm, verts;
+    std::vector<uint32_t> idx;
+    std::map<std::string, std::array<float, 3>> mats;
+    std::array<float, 3> color = {1.f, 1.f, 1.f};
+    for (const std::string &line : lines_of(file)) {
+      std::vector<std::string> t = split_ws(line);
+      if (t.empty() || t[0][0] == '#') continue;
+      if (t[0] == "mtllib" && t.size() > 1) {
+        std::vector<uint8_t> mtl;
+        if (!read_file((dir + "/" + t[1]).c_str(), mtl)) return fail(BBA_ERR_IO, "cannot read material library " + t[1]);
+        std::string cur;
+        for (const std::string &ml : lines_of(mtl)) {
+          std::vector<std::string> m = split_ws(ml);
+          if (m.empty()) continue;
+          if (m[0] == "newmtl" && m.size() > 1) {
+            cur = m[1];
+            mats[cur] = {1.f, 1.f, 1.f};
+          } else if (m[0] == "Kd" && m.size() > 3 && !cur.empty()) {
+            mats[cur] = {(float)std::atof(m[1].c_str()), (float)std::atof(m[2].c_str()), (float)std::atof(m[3].c_str())};
+          }
+        }
+      } else if (t[0] == "v" && t.size() > 3) {
+        for (int k = 1; k <= 3; ++k) pos.push_back((float)std::atof(t[k].c_str()));
+      } else if (t[0] == "vn" && t.size() > 3) {
+        for (int k = 1; k <= 3; ++k) nrm.push_back((float)std::atof(t[k].c_str()));
+      } else if (t[0] == "usemtl" && t.size() > 1) {
+        auto it = mats.find(t[1]);
+        if (it == mats.end()) return fail(BBA_ERR_FORMAT, "usemtl of an unknown material: " + t[1]);
+        color = it->second;
+      } else if (t[0] == "f") {
+        std::vector<uint32_t> corners;
+        for (size_t k = 1; k < t.size(); ++k) {
+          // v, v/vt, v//vn, v/vt/vn
+          long vi = std::atol(t[k].c_str()), ni = 0;
+          size_t s1 = t[k].find('/'), s2 = s1 == std::string::npos ? s1 : t[k].find('/', s1 + 1);
+          if (s2 != std::string::npos && s2 + 1 < t[k].size()) ni = std::atol(t[k].c_str() + s2 + 1);
+          const long np = (long)pos.size() / 3, nn = (long)nrm.size() / 3;
+          vi = vi > 0 ? vi - 1 : np + vi;
+          ni = ni > 0 ? ni - 1 : nn + ni;
+          if (vi < 0 || vi >= np || (nn && (ni < 0 || ni >= nn))) return fail(BBA_ERR_FORMAT, "OBJ face index out of range");
+          corners.push_back((uint32_t)(verts.size() / 9));
+          for (int c = 0; c < 3; ++c) verts.push_back(pos[3 * vi + c]);
+          for (int c = 0; c < 3; ++c) verts.push_back(color[c]);
+          for (int c = 0; c < 3; ++c) verts.push_back(nn ? nrm[3 * ni + c] : 0.f);
+        }
+        for (size_t k = 1; k + 1 < corners.size(); ++k) {
+          idx.push_back(corners[0]);
+          idx.push_back(corners[k]);
+          idx.push_back(corners[k + 1]);
         }
       }
-    } else if (t[0] == "v" && t.size() > 3) {
-      for (int k = 1; k <= 3; ++k) pos.push_back((float)std::atof(t[k].c_str()));
-    } else if (t[0] == "vn" && t.size() > 3) {
-      for (int k = 1; k <= 3; ++k) nrm.push_back((float)std::atof(t[k].c_str()));
-    } else if (t[0] == "usemtl" && t.size() > 1) {
-      auto it = mats.find(t[1]);
-      if (it == mats.end()) return fail(BBA_ERR_FORMAT, "usemtl of an unknown material: " + t[1]);
-      color = it->second;
-    } else if (t[0] == "f") {
-      std::vector<uint32_t> corners;
-      for (size_t k = 1; k < t.size(); ++k) {
-        // v, v/vt, v//vn, v/vt/vn
-        long vi = std::atol(t[k].c_str()), ni = 0;
-        size_t s1 = t[k].find('/'), s2 = s1 == std::string::npos ? s1 : t[k].find('/', s1 + 1);
-        if (s2 != std::string::npos && s2 + 1 < t[k].size()) ni = std::atol(t[k].c_str() + s2 + 1);
-        const long np = (long)pos.size() / 3, nn = (long)nrm.size() / 3;
-        vi = vi > 0 ? vi - 1 : np + vi;
-        ni = ni > 0 ? ni - 1 : nn + ni;
-        if (vi < 0 || vi >= np || (nn && (ni < 0 || ni >= nn))) return fail(BBA_ERR_FORMAT, "OBJ face index out of range");
-        corners.push_back((uint32_t)(verts.size() / 9));
-        for (int c = 0; c < 3; ++c) verts.push_back(pos[3 * vi + c]);
-        for (int c = 0; c < 3; ++c) verts.push_back(color[c]);
-        for (int c = 0; c < 3; ++c) verts.push_back(nn ? nrm[3 * ni + c] : 0.f);
-      }
-      for (size_t k = 1; k + 1 < corners.size(); ++k) {
-        idx.push_back(corners[0]);
-        idx.push_back(corners[k]);
-        idx.push_back(corners[k + 1]);
-      }
     }
+    float *v = (float *)std::malloc(std::max<size_t>(verts.size(), 1) * sizeof(float));
+    uint32_t *ix = (uint32_t *)std::malloc(std::max<size_t>(idx.size(), 1) * sizeof(uint32_t));
+    if (!v || !ix) {
+      std::free(v);
+      std::free(ix);
+      return fail(BBA_ERR_IO, "out of memory");
+    }
+    if (!verts.empty()) std::memcpy(v, verts.data(), verts.size() * sizeof(float));
+    if (!idx.empty()) std::memcpy(ix, idx.data(), idx.size() * sizeof(uint32_t));
+    *out_vertices = v;
+    *out_nv = (uint32_t)(verts.size() / 9);
+    *out_indices = ix;
+    *out_ni = (uint32_t)idx.size();
+    return BBA_OK;
+  } catch (const std::exception &e) {
+    return fail(BBA_ERR_IO, std::string("bba_load_obj_gizmo: ")+e.what());
   }
-  float *v = (float *)std::malloc(std::max<size_t>(verts.size(), 1) * sizeof(float));
-  uint32_t *ix = (uint32_t *)std::malloc(std::max<size_t>(idx.size(), 1) * sizeof(uint32_t));
-  if (!v || !ix) {
-    std::free(v);
-    std::free(ix);
-    return fail(BBA_ERR_IO, "out of memory");
-  }
-  std::memcpy(v, verts.data(), verts.size() * sizeof(float));
-  std::memcpy(ix, idx.data(), idx.size() * sizeof(uint32_t));
-  *out_vertices = v;
-  *out_nv = (uint32_t)(verts.size() / 9);
-  *out_indices = ix;
-  *out_ni = (uint32_t)idx.size();
-  return BBA_OK;
 }
 
 int bba_decode_png(const uint8_t *bytes, uint64_t n, uint8_t **out_rgba, int32_t *out_w, int32_t *out_h) {
-  if (!bytes || !out_rgba || !out_w || !out_h) return fail(BBA_ERR_ARGUMENT, "decode_png: NULL argument");
-  *out_rgba = nullptr;
-  return decode_png(bytes, (size_t)n, out_rgba, out_w, out_h);
+  try {
+    if (!bytes || !out_rgba || !out_w || !out_h) return fail(BBA_ERR_ARGUMENT, "decode_png: NULL argument");
+    *out_rgba = nullptr;
+    return decode_png(bytes, (size_t)n, out_rgba, out_w, out_h);
+  } catch (const std::exception &e) {
+    return fail(BBA_ERR_IO, std::string("bba_decode_png: ")+e.what());
+  }
 }
 
 int bba_load_png(const char *path, uint8_t **out_rgba, int32_t *out_w, int32_t *out_h) {
-  if (!path || !out_rgba || !out_w || !out_h) return fail(BBA_ERR_ARGUMENT, "load_png: NULL argument");
-  *out_rgba = nullptr;
-  std::vector<uint8_t> file;
-  if (!read_file(path, file)) return fail(BBA_ERR_IO, std::string("cannot read ") + path);
-  return decode_png(file.data(), file.size(), out_rgba, out_w, out_h);
+  try {
+    if (!path || !out_rgba || !out_w || !out_h) return fail(BBA_ERR_ARGUMENT, "load_png: NULL argument");
+    *out_rgba = nullptr;
+    std::vector<uint8_t> file;
+    if (!read_file(path, file)) return fail(BBA_ERR_IO, std::string("cannot read ") + path);
+    return decode_png(file.data(), file.size(), out_rgba, out_w, out_h);
+  } catch (const std::exception &e) {
+    return fail(BBA_ERR_IO, std::string("bba_load_png: ")+e.what());
+  }
 }
 
 int bba_load_material_dir(bbr_context *ctx, const char *dir, int32_t *out_material) {
-  if (!ctx || !dir || !out_material) return fail(BBA_ERR_ARGUMENT, "load_material_dir: NULL argument");
-  // PBRMapType order: src/render.h:235-243
-  static const char *names[BBR_MAP_COUNT] = {"albedo.png", "metallic.png", "roughness.png", "ao.png", "normal.png", "height.png"};
-  bbr_image maps[BBR_MAP_COUNT];
-  uint8_t *owned[BBR_MAP_COUNT] = {};
-  int rc = BBA_OK;
-  for (int i = 0; i < BBR_MAP_COUNT && rc == BBA_OK; ++i) {
-    maps[i].rgba = nullptr;
-    maps[i].width = maps[i].height = 0;
-    const std::string p = std::string(dir) + "/" + names[i];
-    if (!is_file(p)) continue;  // missing map: the default material's map (src/render.cpp:1328-1336)
-    rc = bba_load_png(p.c_str(), &owned[i], &maps[i].width, &maps[i].height);
-    maps[i].rgba = owned[i];
+  try {
+    if (!ctx || !dir || !out_material) return fail(BBA_ERR_ARGUMENT, "load_material_dir: NULL argument");
+    // PBRMapType order: src/render.h:235-243
+    static const char *names[BBR_MAP_COUNT] = {"albedo.png", "metallic.png", "roughness.png", "ao.png", "normal.png", "height.png"};
+    bbr_image maps[BBR_MAP_COUNT];
+    uint8_t *owned[BBR_MAP_COUNT] = {};
+    int rc = BBA_OK;
+    for (int i = 0; i < BBR_MAP_COUNT && rc == BBA_OK; ++i) {
+      maps[i].rgba = nullptr;
+      maps[i].width = maps[i].height = 0;
+      const std::string p = std::string(dir) + "/" + names[i];
+      if (!is_file(p)) continue;  // missing map: the default material's map (src/render.cpp:1328-1336)
+      rc = bba_load_png(p.c_str(), &owned[i], &maps[i].width, &maps[i].height);
+      maps[i].rgba = owned[i];
+    }
+    if (rc == BBA_OK) {
+      int brc = bbr_upload_material(ctx, maps, out_material);
+      if (brc != BBR_OK) rc = fail(BBA_ERR_IO, std::string("bbr_upload_material: ") + bbr_last_error(ctx));
+    }
+    for (uint8_t *p : owned) std::free(p);
+    return rc;
+  } catch (const std::exception &e) {
+    return fail(BBA_ERR_IO, std::string("bba_load_material_dir: ")+e.what());
   }
-  if (rc == BBA_OK) {
-    int brc = bbr_upload_material(ctx, maps, out_material);
-    if (brc != BBR_OK) rc = fail(BBA_ERR_IO, std::string("bbr_upload_material: ") + bbr_last_error(ctx));
-  }
-  for (uint8_t *p : owned) std::free(p);
-  return rc;
 }
 
 int bba_load_material_set(bbr_context *ctx, const char *root, int32_t *out_materials, char (*out_names)[64], uint32_t capacity,
                           uint32_t *out_n) {
-  if (!ctx || !root || !out_n) return fail(BBA_ERR_ARGUMENT, "load_material_set: NULL argument");
-  *out_n = 0;
-  DIR *d = opendir(root);
-  if (!d) return fail(BBA_ERR_IO, std::string("cannot open directory ") + root);
-  std::vector<std::string> dirs;
-  while (dirent *e = readdir(d)) {
-    const std::string name = e->d_name;
-    if (name == "." || name == "..") continue;
-    if (is_dir(std::string(root) + "/" + name)) dirs.push_back(name);
-  }
-  closedir(d);
-  std::sort(dirs.begin(), dirs.end());  // FindFirstFile order on NTFS
-  // "default" is swapped with the last entry and popped (src/render.cpp:1297-1306)
-  for (size_t i = 0; i < dirs.size(); ++i)
-    if (dirs[i] == "default") {
-      std::swap(dirs[i], dirs.back());
-      dirs.pop_back();
-      break;
+  try {
+    if (!ctx || !root || !out_n) return fail(BBA_ERR_ARGUMENT, "load_material_set: NULL argument");
+    *out_n = 0;
+    DIR *d = opendir(root);
+    if (!d) return fail(BBA_ERR_IO, std::string("cannot open directory ") + root);
+    std::vector<std::string> dirs;
+    while (dirent *e = readdir(d)) {
+      const std::string name = e->d_name;
+      if (name == "." || name == "..") continue;
+      if (is_dir(std::string(root) + "/" + name)) dirs.push_back(name);
     }
-  for (size_t i = 0; i < dirs.size(); ++i) {
-    if (i >= capacity) break;
-    int32_t id = -1;
-    int rc = bba_load_material_dir(ctx, (std::string(root) + "/" + dirs[i]).c_str(), &id);
-    if (rc != BBA_OK) return rc;
-    if (out_materials) out_materials[i] = id;
-    if (out_names) {
-      std::memset(out_names[i], 0, 64);
-      std::strncpy(out_names[i], dirs[i].c_str(), 63);
+    closedir(d);
+    std::sort(dirs.begin(), dirs.end());  // FindFirstFile order on NTFS
+    // "default" is swapped with the last entry and popped (src/render.cpp:1297-1306)
+    for (size_t i = 0; i < dirs.size(); ++i)
+      if (dirs[i] == "default") {
+        std::swap(dirs[i], dirs.back());
+        dirs.pop_back();
+        break;
+      }
+    for (size_t i = 0; i < dirs.size(); ++i) {
+      if (i >= capacity) break;
+      int32_t id = -1;
+      int rc = bba_load_material_dir(ctx, (std::string(root) + "/" + dirs[i]).c_str(), &id);
+      if (rc != BBA_OK) return rc;
+      if (out_materials) out_materials[i] = id;
+      if (out_names) {
+        std::memset(out_names[i], 0, 64);
+        std::strncpy(out_names[i], dirs[i].c_str(), 63);
+      }
+      ++*out_n;
     }
-    ++*out_n;
+    return BBA_OK;
+  } catch (const std::exception &e) {
+    return fail(BBA_ERR_IO, std::string("bba_load_material_set: ")+e.what());
   }
-  return BBA_OK;
 }
 
 }  // extern "C"
