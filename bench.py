@@ -119,6 +119,9 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="exercise the all-gather path with WORLD_SIZE = 1")
     ap.add_argument("--render-pass", default="forward", choices=["forward", "deferred"],
                     help="forward_brdf.* (the path BASELINE measures) or the reference's deferred path, gbuffer.* + brdf.*")
+    ap.add_argument("--verify", action="store_true",
+                    help="after the timed region, compare the last gathered frame with the same frame rendered unpartitioned "
+                         "on this rank's GPU (bit for bit)")
     ap.add_argument("--present", action="store_true",
                     help="every step also runs the presentation step (tone map + sRGB + RGBA8, SURVEY 8(f) rank 1); "
                          "for N > 1 the RGBA8 shards are gathered instead of the fp32 ones (a quarter of the payload)")
@@ -136,13 +139,22 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback exists)")
+    # Rehearsal hooks (not used by the driver): BBR_BENCH_BACKEND=gloo gathers through host memory, and
+    # BBR_BENCH_SINGLE_DEVICE=1 puts every rank on cuda:0, so that the N > 1 code path (partition, shard buffers,
+    # events, un-interleave) can be run as real separate processes on a one-GPU box, where RCCL refuses two ranks per GPU.
+    backend = os.environ.get("BBR_BENCH_BACKEND", "nccl")
+    if os.environ.get("BBR_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from bibim_renderer_amd import Renderer, configs, textures
     from bibim_renderer_amd import scene as S
@@ -196,11 +208,17 @@ def main():
             r.present(shard8_t[b].data_ptr())
         r.stream_wait_frame(ag_stream.cuda_stream)
         with torch.cuda.stream(ag_stream):
+            src, dst = (shard8_t[b], gathered8_t[b]) if args.present else (shard_t[b], gathered_t[b])
+            if backend == "nccl":
+                dist.all_gather_into_tensor(dst, src)
+            else:  # rehearsal: through host memory
+                h_src = src.cpu()
+                h_dst = torch.empty(dst.shape, dtype=dst.dtype)
+                dist.all_gather_into_tensor(h_dst, h_src)
+                dst.copy_(h_dst)
             if args.present:
-                dist.all_gather_into_tensor(gathered8_t[b], shard8_t[b])
                 r.unpack_gathered_rgba8(gathered8_t[b].data_ptr(), frame8_t[b].data_ptr(), ag_stream.cuda_stream)
             else:
-                dist.all_gather_into_tensor(gathered_t[b], shard_t[b])
                 r.unpack_gathered(gathered_t[b].data_ptr(), frame_t[b].data_ptr(), ag_stream.cuda_stream)
             consumed[b].record(ag_stream)
 
@@ -303,6 +321,46 @@ def main():
             "what": "binary16 HDR -> tone map (on, exposure 1) -> sRGB UNORM8 of the whole frame"}
         r.set_option("frames_in_flight", args.frames_in_flight)
 
+    verified = None
+    if args.verify and dist_path:
+        last = (step_no[0] - 1) & 1
+        torch.cuda.synchronize()
+        got = (frame8_t[last] if args.present else frame_t[last]).cpu().numpy()
+        r2 = Renderer(cfg.width, cfg.height, device=local_rank)
+        r2.set_option("render_pass", 1 if args.render_pass == "deferred" else 0)
+        m2 = r2.upload_material(maps)
+        scene2, cam2, settings2 = S.config_scene(r2, cfg, ball)
+        S.draw_frame(r2, scene2, cam2, settings2, m2)
+        if args.present:
+            r2.present()
+            want = r2.read_presented()
+        else:
+            want = r2.read_framebuffer()
+        verified = bool(np.array_equal(got.view(np.uint8), want.view(np.uint8)))
+        if not verified and os.environ.get("BBR_BENCH_DEBUG"):
+            S.draw_frame(r2, scene2, cam2, settings2, m2)
+            if args.present:
+                r2.present()
+                want2 = r2.read_presented()
+            else:
+                want2 = r2.read_framebuffer()
+            bad = (got.view(np.uint8) != want.view(np.uint8)).reshape(H, W, -1).any(axis=2)
+            ys, xs = np.nonzero(bad)
+            print(f"[debug rank {rank}] want == want2: {np.array_equal(want2.view(np.uint8), want.view(np.uint8))}; "
+                  f"got == want2: {np.array_equal(got.view(np.uint8), want2.view(np.uint8))}; differing pixels {bad.sum()} "
+                  f"x {xs.min()}..{xs.max()} y {ys.min()}..{ys.max()}; sample got {got[ys[0], xs[0]]} want {want[ys[0], xs[0]]} "
+                  f"want2 {want2[ys[0], xs[0]]}", flush=True)
+        scene2.close(); r2.close()
+        if not verified:
+            bad = (got.view(np.uint8) != want.view(np.uint8)).reshape(H, -1).any(axis=1)
+            rows = np.nonzero(bad)[0]
+            extra = ""
+            if not args.present:
+                d = np.abs(got.astype(np.float64) - want.astype(np.float64))
+                extra = f"; max |diff| {np.nanmax(d):.3g}, differing values {int((got.view(np.uint32) != want.view(np.uint32)).sum())}"
+            raise SystemExit(f"rank {rank}: gathered frame differs from the unpartitioned render in {rows.size} rows "
+                             f"(first {rows[:8].tolist()}, last {rows[-3:].tolist()}){extra}")
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(cfg, maps, args.cpu_budget)
@@ -325,6 +383,8 @@ def main():
                        "render_pass": args.render_pass},
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        if verified is not None:
+            out["verified_against_unpartitioned_render"] = verified
         print(json.dumps(out), flush=True)
 
     scene.close()

@@ -984,14 +984,22 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
   const int out_y0 = out_tile_row * TILE_H;
   const int rx1 = min(tile_x0 + TILE_W, fp.width) - 1, ry1 = min(tile_y0 + TILE_H, fp.height) - 1;
 
-  uint32_t n_cls[kBinClasses];
-#pragma unroll
-  for (uint32_t c = 0; c < kBinClasses; ++c)
-    n_cls[c] = (fp.ablate & (1u | (256u << c))) ? 0u : min(tile_count[tile * kBinClasses + c], fp.bin_cap);
+  // The tile's bin counts are read ONCE per workgroup, published through LDS, and only cleared (for the slot's next
+  // frame) after the barrier.  When every thread read them from global memory and threads 0..2 cleared them right
+  // away, a wave that started late -- other processes sharing the GPU are enough -- could read the cleared value:
+  // its loop bounds then disagreed with the other waves' and a handful of triangles of the tile went missing (seen as
+  // ~100 wrong pixels in one tile of one frame in a few hundred, never on an otherwise idle GPU).
+  __shared__ uint32_t s_n_cls[kBinClasses];
+  if (tid < (int)kBinClasses)
+    s_n_cls[tid] = (fp.ablate & (1u | (256u << tid))) ? 0u : min(tile_count[tile * kBinClasses + tid], fp.bin_cap);
   const uint32_t n_broad = (fp.ablate & 5u) ? 0u : min(ctr->n_broad, fp.broad_cap);
   for (int p = tid; p < TILE_PIXELS; p += kTileThreads) keys[p] = 0ull;
   if (tid == 0) s_count = 0;
-  if (tid < (int)kBinClasses && n_cls[tid]) tile_count[tile * kBinClasses + tid] = 0;  // ready for the next frame
+  __syncthreads();  // counts published, keys cleared
+  uint32_t n_cls[kBinClasses];
+#pragma unroll
+  for (uint32_t c = 0; c < kBinClasses; ++c) n_cls[c] = s_n_cls[c];
+  if (tid < (int)kBinClasses && n_cls[tid]) tile_count[tile * kBinClasses + tid] = 0;  // ready for the slot's next frame
 
   // entry order: class 0 | class 1 | class 2 | every-tile list
   const uint32_t e1 = n_cls[0], e2 = e1 + n_cls[1], e3 = e2 + n_cls[2], e_end = e3 + n_broad;
@@ -999,7 +1007,7 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
 
   BB_RSTAMP(1);
   for (uint32_t base = 0; base < e_end; base += kStage) {
-    __syncthreads();  // keys initialised / previous chunk consumed
+    if (base) __syncthreads();  // previous chunk consumed
     // ---- stage: every thread fetches one entry (reference -> triangle record), all loads in flight together ----
     {
       const uint32_t e = base + (uint32_t)tid;

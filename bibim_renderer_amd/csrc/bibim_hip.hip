@@ -42,6 +42,24 @@ struct RecordedDraw {
   uint32_t n_instances, first_instance, first_prim, tris_per_instance;
 };
 
+// hipMemset runs on the NULL stream and may return before the fill has happened; the context's streams are created
+// hipStreamNonBlocking, i.e. they do NOT order themselves after the NULL stream.  A kernel launched right after an
+// allocation could therefore run BEFORE the zero fill and have its counters / fragment counts wiped afterwards
+// (seen as an empty first frame when several processes share the GPU).  Every zero fill is completed here.
+inline hipError_t zero_fill_sync(void *ptr, size_t bytes) {
+  hipError_t e = hipMemset(ptr, 0, bytes);
+  if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+  return e;
+}
+
+// Host -> device copies that kernels on the (non-blocking) context streams read right afterwards: completed on the
+// NULL stream before returning, for the same reason.
+inline hipError_t upload_sync(void *dst, const void *src, size_t bytes) {
+  hipError_t e = hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+  return e;
+}
+
 template <typename T>
 struct DeviceBuffer {
   T *ptr = nullptr;
@@ -54,7 +72,7 @@ struct DeviceBuffer {
     hipError_t e = hipMalloc(&ptr, n * sizeof(T));
     if (e != hipSuccess) return e;
     cap = n;
-    if (zero) e = hipMemset(ptr, 0, n * sizeof(T));
+    if (zero) e = zero_fill_sync(ptr, n * sizeof(T));
     return e;
   }
   void release() {
@@ -283,7 +301,7 @@ int upload_material_table(bbr_context *c) {
   int rc = drain(c);
   if (rc) return rc;
   HIP_TRY(c, c->d_materials.ensure(n));
-  HIP_TRY(c, hipMemcpy(c->d_materials.ptr, h.data(), n * sizeof(MaterialDesc), hipMemcpyHostToDevice));
+  HIP_TRY(c, upload_sync(c->d_materials.ptr, h.data(), n * sizeof(MaterialDesc)));
   c->materials_dirty = false;
   return BBR_OK;
 }
@@ -457,7 +475,7 @@ int ensure_srgb_tables(bbr_context *c) {
       h.lut[cell] = (uint8_t)below;
     }
     HIP_TRY(c, c->d_srgb_tables.ensure(1));
-    HIP_TRY(c, hipMemcpy(c->d_srgb_tables.ptr, &h, sizeof h, hipMemcpyHostToDevice));
+    HIP_TRY(c, upload_sync(c->d_srgb_tables.ptr, &h, sizeof h));
   }
   return BBR_OK;
 }
@@ -518,7 +536,7 @@ int sync_and_fix(bbr_context *c, Counters *out_counters) {
     ++c->retries;
     // tile counters may hold residue of refs that did not fit: clear and replay into the same slot
     FrameSlot &s = c->slots[c->last_slot];
-    if (s.d_tile_count.ptr) HIP_TRY(c, hipMemset(s.d_tile_count.ptr, 0, s.d_tile_count.cap * sizeof(uint32_t)));
+    if (s.d_tile_count.ptr) HIP_TRY(c, zero_fill_sync(s.d_tile_count.ptr, s.d_tile_count.cap * sizeof(uint32_t)));
     const auto present = s.present;
     rc = submit_frame_into(c, c->last_slot);
     if (rc) return rc;
@@ -587,7 +605,7 @@ int bbr_create(int32_t width, int32_t height, int32_t device, bbr_context **out_
   static const uint8_t k_default[kMapCount][4] = {{255, 255, 255, 255}, {0, 0, 0, 255},       {0, 0, 0, 255},
                                                   {255, 255, 255, 255}, {127, 127, 255, 255}, {0, 0, 0, 255}};
   CREATE_TRY(hipMalloc(&c->d_default_texels, sizeof k_default));
-  CREATE_TRY(hipMemcpy(c->d_default_texels, k_default, sizeof k_default, hipMemcpyHostToDevice));
+  CREATE_TRY(upload_sync(c->d_default_texels, k_default, sizeof k_default));
 #undef CREATE_TRY
   *out_ctx = c;
   return BBR_OK;
@@ -642,10 +660,10 @@ int bbr_upload_mesh(bbr_context *c, const void *vertices, uint32_t n_vertices, c
   m.n_vertices = n_vertices;
   m.n_indices = indices ? n_indices : 0;
   HIP_TRY(c, hipMalloc(&m.d_vertices, (size_t)n_vertices * sizeof(Vertex)));
-  HIP_TRY(c, hipMemcpy(m.d_vertices, vertices, (size_t)n_vertices * sizeof(Vertex), hipMemcpyHostToDevice));
+  HIP_TRY(c, upload_sync(m.d_vertices, vertices, (size_t)n_vertices * sizeof(Vertex)));
   if (m.n_indices) {
     HIP_TRY(c, hipMalloc(&m.d_indices, (size_t)n_indices * sizeof(uint32_t)));
-    HIP_TRY(c, hipMemcpy(m.d_indices, indices, (size_t)n_indices * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(c, upload_sync(m.d_indices, indices, (size_t)n_indices * sizeof(uint32_t)));
   }
   m.alive = true;
   c->meshes.push_back(m);
@@ -678,7 +696,7 @@ int bbr_upload_material(bbr_context *c, const bbr_image maps[BBR_MAP_COUNT], int
       if (im.width > 16384 || im.height > 16384) return fail(c, BBR_ERR_INVALID_ARGUMENT, "upload_material: map too large");
       size_t bytes = (size_t)im.width * im.height * 4;
       HIP_TRY(c, hipMalloc(&m.d_texels[i], bytes));
-      HIP_TRY(c, hipMemcpy(m.d_texels[i], im.rgba, bytes, hipMemcpyHostToDevice));
+      HIP_TRY(c, upload_sync(m.d_texels[i], im.rgba, bytes));
       m.desc.maps[i] = TexDesc{m.d_texels[i], im.width, im.height};
     } else {
       // missing map => the `default` material's map (src/render.cpp:1328-1336)
@@ -720,7 +738,7 @@ int bbr_upload_material(bbr_context *c, const bbr_image maps[BBR_MAP_COUNT], int
         host[i] = t;
       }
       HIP_TRY(c, hipMalloc(&m.d_packed, host.size() * sizeof(PackedTexel)));
-      HIP_TRY(c, hipMemcpy(m.d_packed, host.data(), host.size() * sizeof(PackedTexel), hipMemcpyHostToDevice));
+      HIP_TRY(c, upload_sync(m.d_packed, host.data(), host.size() * sizeof(PackedTexel)));
       m.desc.packed = m.d_packed;
       m.desc.pw = pw;
       m.desc.ph = ph;
@@ -1211,7 +1229,7 @@ int bbr_selftest_rcp(bbr_context *c, uint32_t lo_bits, uint32_t hi_bits, uint64_
   if (rc) return rc;
   unsigned long long *d = nullptr, h = 0;
   HIP_TRY(c, hipMalloc(&d, sizeof h));
-  HIP_TRY(c, hipMemset(d, 0, sizeof h));
+  HIP_TRY(c, zero_fill_sync(d, sizeof h));
   hipLaunchKernelGGL(k_selftest_rcp, dim3(4096), dim3(256), 0, c->geom_stream(), d, lo_bits, hi_bits);
   hipError_t e = hipMemcpy(&h, d, sizeof h, hipMemcpyDeviceToHost);
   (void)hipFree(d);
