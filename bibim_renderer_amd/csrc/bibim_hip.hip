@@ -9,6 +9,8 @@
 #include <algorithm>
 #include <cmath>
 #include <limits>
+#include <mutex>
+#include <unordered_set>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -128,6 +130,18 @@ struct FrameSlot {
     staging_cap = 0;
   }
 };
+
+// Live contexts: a scene object (bb::SceneBase, bbs_scene) frees its meshes through the context it was created on; if
+// the host destroys the context first (garbage collectors do), those late calls must fail cleanly instead of touching
+// freed memory.
+namespace {
+std::mutex g_live_mutex;
+std::unordered_set<const bbr_context *> g_live;
+bool is_live(const bbr_context *c) {
+  std::lock_guard<std::mutex> lock(g_live_mutex);
+  return g_live.count(c) != 0;
+}
+}  // namespace
 
 struct bbr_context {
   int device = 0;
@@ -607,12 +621,20 @@ int bbr_create(int32_t width, int32_t height, int32_t device, bbr_context **out_
   CREATE_TRY(hipMalloc(&c->d_default_texels, sizeof k_default));
   CREATE_TRY(upload_sync(c->d_default_texels, k_default, sizeof k_default));
 #undef CREATE_TRY
+  {
+    std::lock_guard<std::mutex> lock(g_live_mutex);
+    g_live.insert(c);
+  }
   *out_ctx = c;
   return BBR_OK;
 }
 
 int bbr_destroy(bbr_context *c) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  {
+    std::lock_guard<std::mutex> lock(g_live_mutex);
+    if (!g_live.erase(c)) return BBR_ERR_BAD_HANDLE;  // never created, or destroyed already
+  }
   (void)hipSetDevice(c->device);
   (void)drain(c);
   for (Mesh &m : c->meshes) {
@@ -673,6 +695,7 @@ int bbr_upload_mesh(bbr_context *c, const void *vertices, uint32_t n_vertices, c
 
 int bbr_free_mesh(bbr_context *c, int32_t mesh) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  if (!is_live(c)) return BBR_ERR_BAD_HANDLE;  // the context is gone and took the mesh with it
   if (mesh < 0 || mesh >= (int32_t)c->meshes.size() || !c->meshes[mesh].alive)
     return fail(c, BBR_ERR_BAD_HANDLE, "free_mesh: bad handle");
   int rc = drain(c);
@@ -753,6 +776,7 @@ int bbr_upload_material(bbr_context *c, const bbr_image maps[BBR_MAP_COUNT], int
 
 int bbr_free_material(bbr_context *c, int32_t material) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  if (!is_live(c)) return BBR_ERR_BAD_HANDLE;  // the context is gone and took the material with it
   if (material < 0 || material >= (int32_t)c->materials.size() || !c->materials[material].alive)
     return fail(c, BBR_ERR_BAD_HANDLE, "free_material: bad handle");
   int rc = drain(c);

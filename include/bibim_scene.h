@@ -199,7 +199,9 @@ extern "C" {
 #endif /* __cplusplus */
 
 /* ---- C surface over the shim (used by the Python harness and by non-C++ hosts) ---- */
-/* A scene owns meshes of the context it was created on: destroy scenes BEFORE bbr_destroy(ctx). */
+/* A scene owns meshes of the context it was created on: destroy scenes before bbr_destroy(ctx).  (If the order is
+ * reversed -- garbage-collected hosts -- bbr_free_mesh on the dead context returns BBR_ERR_BAD_HANDLE and touches
+ * nothing.) */
 typedef struct bbs_scene bbs_scene;
 
 void bbs_mat4_mul(const float *a, const float *b, float *out);

@@ -272,6 +272,21 @@ def test_reciprocal_of_the_contract_is_the_ieee_division_for_every_float():
     r.close()
 
 
+def test_destroying_the_context_before_its_scene_is_harmless():
+    """garbage-collected hosts may drop the context first: the scene's late bbr_free_mesh calls must fail cleanly"""
+    import ctypes as C
+    from bibim_renderer_amd import _capi
+    L = _capi.lib()
+    ctx = C.c_void_p()
+    assert L.bbr_create(64, 64, 0, C.byref(ctx)) == 0
+    scene = L.bbs_triangle_scene_create(ctx)
+    assert scene
+    assert L.bbr_destroy(ctx) == 0
+    assert L.bbr_destroy(ctx) != 0            # already gone: BBR_ERR_BAD_HANDLE, not a double free
+    assert L.bbr_free_mesh(ctx, 0) != 0
+    L.bbs_scene_destroy(C.c_void_p(scene))    # frees its mesh through the dead context: must not crash
+
+
 def test_tone_map_next_row(maps64):
     sc = scenes.shaderball_scene(configs.C2.scaled(160, 90, 64), bbo.MaterialData(maps64))
     r = Renderer(sc.width, sc.height)

@@ -239,3 +239,56 @@ def test_material_directories_load_like_create_pbr_material_set(maps64, tmp_path
     with pytest.raises(assets.AssetError):
         assets.load_material_set(r, tmp_path / "nope")
     r.close()
+
+
+def test_frames_stay_identical_while_other_processes_share_the_gpu(maps64):
+    """Regression for two races that only showed with other processes on the GPU (waves of a workgroup starting far
+    apart): k_raster reading a tile's bin counts after another wave had cleared them, and zero fills on the NULL stream
+    landing after the first kernels.  Two contender processes render in a loop; this one renders 300 partitioned frames
+    into two alternating caller buffers (bench.py's N > 1 pattern) and every frame must have the same bits."""
+    import subprocess, sys, time, torch
+    contender = ("import sys; sys.path.insert(0, '.');\n"
+                 "from bibim_renderer_amd import configs, textures, Renderer; from bibim_renderer_amd import scene as S\n"
+                 "cfg = configs.C3.scaled(1920, 1080, 256); r = Renderer(cfg.width, cfg.height)\n"
+                 "m = r.upload_material(textures.make_material(256)); sc, cam, st = S.config_scene(r, cfg)\n"
+                 "import time; t = time.time()\n"
+                 "while time.time() - t < 12: [S.draw_frame(r, sc, cam, st, m) for _ in range(50)]; r.synchronize()\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = [subprocess.Popen([sys.executable, "-c", contender], cwd=root, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+             for _ in range(2)]
+    try:
+        time.sleep(4.0)  # let the contenders get going (their first import of torch-free modules is quick)
+        cfg = configs.C3.scaled(1920, 1080, 64)
+        for fif in (1, 3):
+            r = Renderer(cfg.width, cfg.height)
+            r.set_option("frames_in_flight", fif)
+            material = r.upload_material(maps64)
+            scene, cam, settings = S.config_scene(r, cfg)
+            r.set_partition(1, 4, r.tile_height())
+            S.draw_frame(r, scene, cam, settings, material)
+            r.synchronize()          # first frame sizes the bins (an overflowed frame is re-rendered here)
+            rows, W, steps = r.shard_rows(), cfg.width, 300
+            # zeros: the rows of a band that hang over the bottom of the frame are padding nobody writes
+            shard = [torch.zeros((rows, W, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
+            keep = torch.empty((steps, rows, W, 4), dtype=torch.float32, device="cuda")
+            side = torch.cuda.Stream()
+            consumed = [torch.cuda.Event(), torch.cuda.Event()]
+            for n in range(steps):
+                b = n & 1
+                if n >= 2:
+                    r.wait_event(consumed[b].cuda_event)
+                r.set_output_device_ptr(shard[b].data_ptr(), shard[b].numel() * 4)
+                S.draw_frame(r, scene, cam, settings, material)
+                r.stream_wait_frame(side.cuda_stream)
+                with torch.cuda.stream(side):
+                    keep[n].copy_(shard[b], non_blocking=True)
+                    consumed[b].record(side)
+            r.synchronize()
+            torch.cuda.synchronize()
+            k = keep.view(torch.int32)
+            bad = [n for n in range(steps) if not torch.equal(k[n], k[0])]
+            assert not bad, (fif, bad[:10])
+            scene.close(); r.close()
+    finally:
+        for p in procs:
+            p.wait(timeout=60)
