@@ -282,7 +282,10 @@ def main():
                     "frame_algorithmic_bytes": int(balg["total"]),
                     "frame_achieved_gbs": round(balg["total"] / (ms_per_step * 1e-3) / 1e9, 2),
                     "frame_frac": round(balg["total"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                    "n_shaded": int(n_shaded_total)}
+                    "n_shaded": int(n_shaded_total),
+                    # what actually limits the kernel (profiles/*_pmc_sq.txt): vector-ALU issue, not HBM.  fp32 flops per
+                    # shaded pixel from the committed counters (2*fma + mul + add wave-instructions x 64 lanes / N_shaded)
+                    "limiter": "vector ALU issue (see DESIGN.md, k_shade)"}
 
     if roofline is not None and not dist_path:
         # Outside the timed region: the same kernels with one frame in flight, i.e. without the other frame's
