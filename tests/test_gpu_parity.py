@@ -165,6 +165,56 @@ def test_camera_inside_geometry_heavy_clipping(maps64):
     assert st["n_clipped_prims"] >= 8
 
 
+def hostile_scene(W=160, H=120, seed=0):
+    """NaN, +-inf, huge, denormal and zero coordinates, uv, normals and instance matrices mixed into valid geometry"""
+    rng = np.random.default_rng(seed)
+    n_tri = 96
+    v = np.zeros(n_tri * 3, bbo.VERTEX_DTYPE)
+    pos = rng.uniform(-2, 2, (n_tri * 3, 3)).astype(np.float32)
+    pos[:, 2] = rng.uniform(0.5, 8, n_tri * 3)
+    bad = [np.nan, np.inf, -np.inf, 3e38, -3e38, 1e-42, 0.0]
+    for t in range(0, n_tri, 3):
+        pos[3 * t + rng.integers(0, 3), rng.integers(0, 3)] = bad[(t // 3) % len(bad)]
+    v["pos"] = pos
+    v["uv"] = rng.uniform(-3, 3, (n_tri * 3, 2))
+    v["uv"][5] = (np.nan, np.inf)
+    nrm = rng.standard_normal((n_tri * 3, 3)).astype(np.float32)
+    nrm[7] = 0
+    nrm[11] = np.nan
+    v["normal"] = nrm
+    v["tangent"] = rng.standard_normal((n_tri * 3, 3)).astype(np.float32)
+    inst = np.zeros(3, bbo.INSTANCE_DTYPE)
+    inst[0]["model"] = inst[0]["inv_model"] = np.eye(4, dtype=np.float32)
+    m = np.eye(4, dtype=np.float32)
+    m[3, :3] = (0.5, 0.2, 1.0)
+    inst[1]["model"], inst[1]["inv_model"] = m, np.linalg.inv(m).astype(np.float32)
+    m2 = np.eye(4, dtype=np.float32)
+    m2[0, 0], m2[3, 2] = np.nan, np.inf
+    inst[2]["model"] = inst[2]["inv_model"] = m2
+    mat = bbo.MaterialData(textures.make_material(16))
+    fu = scenes.frame_uniforms([scenes.light(0, pos=(0, 2, 0), color=(1, .8, .8), intensity=50.0),
+                                scenes.light(2, dir=(0, 0, 0), color=(1, 1, 1), intensity=1.0)])   # normalize(0): NaN light
+    vu = scenes.view_uniforms((0, 0, 0), 0.0, 0.0, W, H, 1)
+    return bbo.Scene(fu, vu, [bbo.DrawData(v, None, inst, mat)], W, H, "hostile")
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_hostile_inputs_neither_hang_nor_differ(seed):
+    """garbage in the vertex / instance streams must come out exactly as the oracle says (mostly: culled or clipped),
+    on both render passes -- and must never fault or spin"""
+    sc = hostile_scene(seed=seed)
+    _, ref, st = check(sc)
+    assert st["n_clipped_prims"] > 20
+    dref, dg, dprim, ddepth, _ = bbo.render_deferred(sc)
+    r = Renderer(sc.width, sc.height)
+    r.set_option("render_pass", 1)
+    r.render_scene(sc)
+    img = r.read_framebuffer()
+    g = r.read_gbuffer()
+    r.close()
+    assert np.array_equal(img.view(np.uint32), dref.view(np.uint32)) and np.array_equal(g.view(np.uint32), dg.view(np.uint32))
+
+
 def test_depth_ties_follow_api_order():
     from test_oracle_kat import quad_scene
     for order in ("ab", "ba"):
