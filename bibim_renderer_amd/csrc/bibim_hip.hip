@@ -89,6 +89,8 @@ struct DeviceBuffer {
 // Everything one frame in flight owns.
 struct FrameSlot {
   void *h_staging = nullptr;  // pinned: lights, draw descriptors, instances
+  uint32_t *h_flags = nullptr;  // pinned {overflow bits, bin_need} of the frame last rendered in this slot (copied back
+                                // behind its k_shade): lets a host that never synchronises still grow the capacities
   size_t staging_cap = 0;
   DeviceBuffer<uint8_t> d_staging;
   DeviceBuffer<RasterTri> d_tris;
@@ -127,6 +129,8 @@ struct FrameSlot {
     release_tile_buffers(); d_broad.release(); d_frame.release(); d_present.release(); d_background.release();
     if (h_staging) (void)hipHostFree(h_staging);
     h_staging = nullptr;
+    if (h_flags) (void)hipHostFree(h_flags);
+    h_flags = nullptr;
     staging_cap = 0;
   }
 };
@@ -302,6 +306,10 @@ int ensure_slot_buffers(bbr_context *c, FrameSlot &s) {
     HIP_TRY(c, c->d_vis_prim.ensure((size_t)c->width * c->height));
     HIP_TRY(c, c->d_vis_depth.ensure((size_t)c->width * c->height));
   }
+  if (!s.h_flags) {
+    HIP_TRY(c, hipHostMalloc((void **)&s.h_flags, 2 * sizeof(uint32_t), hipHostMallocDefault));
+    s.h_flags[0] = s.h_flags[1] = 0u;
+  }
   if (!s.ev_raster_done) HIP_TRY(c, hipEventCreateWithFlags(&s.ev_raster_done, hipEventDisableTiming));
   if (!s.ev_shade_done) HIP_TRY(c, hipEventCreateWithFlags(&s.ev_shade_done, hipEventDisableTiming));
   return BBR_OK;
@@ -368,11 +376,32 @@ void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const Fra
     hipLaunchKernelGGL((k_shade<TW, TH, false>), dim3(fp.tiles_x * kChunks, grid_y), dim3(kShadeThreads), 0, ss, fp, sp, d_lights,
                        s.d_attrs.ptr, s.d_clip.ptr, s.d_frags.ptr, s.d_frag_count.ptr, c->d_materials.ptr, out,
                        (uint2 *)nullptr);
+  // {overflow, bin_need} of this frame, for submit_frame_into's self-healing check when this slot comes round again
+  (void)hipMemcpyAsync(s.h_flags, &ctr->overflow, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ss);
   (void)hipEventRecord(s.ev_shade_done, ss);
   if (ev) {
     (void)hipEventRecord(ev[4], ss);
     ++c->ring_frames;
   }
+}
+
+// A capacity overflowed (bit0 bins, bit1 every-tile list, bit2 clip arena): grow it.  Everything must have left the GPU.
+int apply_growth(bbr_context *c, uint32_t overflow, uint32_t bin_need) {
+  if (overflow & 1u) {
+    // bin_need is exact for the frame that overflowed; round up with headroom so small scene changes do not re-trigger
+    uint32_t need = std::max(bin_need + bin_need / 4u, c->bin_cap * 2u);
+    c->bin_cap = (need + 255u) & ~255u;
+    for (FrameSlot &s : c->slots) s.d_bins.release();
+  }
+  if (overflow & 2u) c->broad_cap *= 2;
+  if (overflow & 4u) c->clip_cap *= 2;
+  ++c->retries;
+  for (FrameSlot &s : c->slots) {
+    if (s.h_flags) s.h_flags[0] = s.h_flags[1] = 0u;  // they describe frames rendered with the old capacities
+    // tile counters may hold residue of references that did not fit
+    if (s.d_tile_count.ptr) HIP_TRY(c, zero_fill_sync(s.d_tile_count.ptr, s.d_tile_count.cap * sizeof(uint32_t)));
+  }
+  return BBR_OK;
 }
 
 // Queue the recorded frame into slot `slot_index`.  Asynchronous.
@@ -385,6 +414,16 @@ int submit_frame_into(bbr_context *c, int slot_index) {
   if (s.in_flight) {
     HIP_TRY(c, hipEventSynchronize(s.ev_shade_done));
     s.in_flight = false;
+  }
+  // Self-healing for hosts that only stream frames: the frame that last used this slot reported an overflow.  Its
+  // pixels (and those of the frames queued since) are incomplete and already handed out; from this frame on the
+  // capacities fit.  (Synchronising calls do better: they re-render the overflowed frame, sync_and_fix.)
+  if (s.h_flags && s.h_flags[0]) {
+    const uint32_t overflow = s.h_flags[0], bin_need = s.h_flags[1];
+    rc = drain(c);
+    if (rc) return rc;
+    rc = apply_growth(c, overflow, bin_need);
+    if (rc) return rc;
   }
   rc = ensure_slot_buffers(c, s);
   if (rc) return rc;
@@ -539,18 +578,9 @@ int sync_and_fix(bbr_context *c, Counters *out_counters) {
       HIP_TRY(c, hipMemcpy(&h, c->d_counters.ptr + c->slots[c->last_slot].ctr_index, sizeof h, hipMemcpyDeviceToHost));
     if (out_counters) *out_counters = h;
     if (!h.overflow) return BBR_OK;
-    if (h.overflow & 1u) {
-      // bin_need is exact for this frame; round up with headroom so small scene changes do not re-trigger
-      uint32_t need = std::max(h.bin_need + h.bin_need / 4u, c->bin_cap * 2u);
-      c->bin_cap = (need + 255u) & ~255u;
-      for (FrameSlot &s : c->slots) s.d_bins.release();
-    }
-    if (h.overflow & 2u) c->broad_cap *= 2;
-    if (h.overflow & 4u) c->clip_cap *= 2;
-    ++c->retries;
-    // tile counters may hold residue of refs that did not fit: clear and replay into the same slot
+    rc = apply_growth(c, h.overflow, h.bin_need);
+    if (rc) return rc;
     FrameSlot &s = c->slots[c->last_slot];
-    if (s.d_tile_count.ptr) HIP_TRY(c, zero_fill_sync(s.d_tile_count.ptr, s.d_tile_count.cap * sizeof(uint32_t)));
     const auto present = s.present;
     rc = submit_frame_into(c, c->last_slot);
     if (rc) return rc;

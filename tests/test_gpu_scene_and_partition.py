@@ -292,3 +292,40 @@ def test_frames_stay_identical_while_other_processes_share_the_gpu(maps64):
     finally:
         for p in procs:
             p.wait(timeout=60)
+
+
+def test_a_host_that_never_synchronises_still_outgrows_an_overflow(maps64):
+    """bins far too small, frames only streamed into a caller buffer: the first frames are incomplete (and stay so),
+    but within a few frames the capacities have grown by themselves and every later frame is exact"""
+    import torch
+    cfg = configs.C3.scaled(640, 360, 64)
+    sc = scenes.shaderball_scene(cfg, bbo.MaterialData(maps64))
+    ref, _, _, _ = bbo.render(sc)
+    for fif in (1, 2, 3):
+        r = Renderer(cfg.width, cfg.height)
+        r.set_option("frames_in_flight", fif)
+        r.set_option("bin_cap", 4)
+        steps = 16
+        out = torch.zeros((cfg.height, cfg.width, 4), dtype=torch.float32, device="cuda")
+        keep = torch.empty((steps,) + tuple(out.shape), dtype=torch.float32, device="cuda")
+        side = torch.cuda.Stream()
+        r.set_output_device_ptr(out.data_ptr(), out.numel() * 4)
+        h = None
+        done = torch.cuda.Event()
+        for n in range(steps):
+            if n:
+                r.wait_event(done.cuda_event)
+            h = r.render_scene(sc, h)                 # asynchronous; nothing here synchronises the context
+            r.stream_wait_frame(side.cuda_stream)
+            with torch.cuda.stream(side):
+                keep[n].copy_(out, non_blocking=True)
+                done.record(side)
+        torch.cuda.synchronize()
+        frames = keep.cpu().numpy()
+        exact = [bool(np.array_equal(f.view(np.uint32), ref.view(np.uint32))) for f in frames]
+        assert not exact[0]                           # 4 references per bin cannot hold this scene
+        first_good = exact.index(True)
+        assert first_good <= 3 * (fif + 1), exact     # a growth step or two, each a few frames after the overflow
+        assert all(exact[first_good:]), exact         # and it stays right
+        assert r.stats()["bin_overflow"] >= 1
+        r.close()
