@@ -100,7 +100,7 @@ def cpu_baseline(cfg, maps, budget_s=20.0):
     return {"value": round(mpix * reps / t_multi, 3), "unit": "Mpixels/s", "cores": cores, "kind": "port",
             "sample": f"{reps} full {cfg.name} frame(s) ({W}x{H}), oracle/bb_oracle.c, {cores} threads over 32-row bands; "
                       f"single-thread whole-frame run: {mpix / t_single:.3f} Mpixels/s",
-            "single_thread_value": round(mpix / t_single, 3), "n_shaded": int(n1)}
+            "single_thread_value": round(mpix / t_single, 3), "n_shaded": int(n1)}, rgba
 
 
 def main():
@@ -364,11 +364,22 @@ def main():
             raise SystemExit(f"rank {rank}: gathered frame differs from the unpartitioned render in {rows.size} rows "
                              f"(first {rows[:8].tolist()}, last {rows[-3:].tolist()}){extra}")
 
-    cpu = None
+    cpu, parity = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(cfg, maps, args.cpu_budget)
+        cpu, oracle_frame = cpu_baseline(cfg, maps, args.cpu_budget)
         if cpu["n_shaded"] != n_shaded_total:
             raise SystemExit(f"GPU shaded {n_shaded_total} pixels, oracle {cpu['n_shaded']}: parity broken")
+        # the frame the bench has been rendering, against the frame the oracle just rendered (forward pass only: the
+        # CPU baseline is the forward oracle)
+        if args.render_pass == "forward" and not dist_path:
+            gpu_frame = r.read_framebuffer()
+            tol = 1e-4 * np.maximum(1.0, np.abs(oracle_frame))
+            d = np.abs(gpu_frame - oracle_frame)
+            parity = {"bit_exact": bool(np.array_equal(gpu_frame.view(np.uint32), oracle_frame.view(np.uint32))),
+                      "within_1e-4_times_max_1_ref": bool((d <= tol).all()), "max_abs_diff": float(np.nanmax(d)),
+                      "pixels": int(W * H)}
+            if not parity["within_1e-4_times_max_1_ref"]:
+                raise SystemExit(f"GPU frame outside the 1e-4 tolerance of the oracle: {parity}")
 
     if rank == 0:
         out = {
@@ -388,6 +399,8 @@ def main():
         }
         if verified is not None:
             out["verified_against_unpartitioned_render"] = verified
+        if parity is not None:
+            out["parity_vs_oracle"] = parity
         print(json.dumps(out), flush=True)
 
     scene.close()
