@@ -433,3 +433,64 @@ def test_present_after_an_overflow_replay_and_into_a_caller_buffer(maps64):
     torch.cuda.synchronize()
     assert np.array_equal(got, want) and np.array_equal(out.cpu().numpy(), want)
     r.close()
+
+
+def test_api_lifecycle_user_stream_frees_and_timing(maps64):
+    """the less-travelled entry points: rendering on the caller's stream, freeing meshes / materials between frames
+    (and the stale-handle errors afterwards), timing queries, re-creating a context at another size"""
+    import torch
+    sc = scenes.shaderball_scene(configs.C2.scaled(256, 144, 64), bbo.MaterialData(maps64))
+    ref, _, _, _ = bbo.render(sc)
+    r = Renderer(sc.width, sc.height)
+    # (1) everything on a caller-owned stream, ordered with the caller's own work on it
+    stream = torch.cuda.Stream()
+    out = torch.full((sc.height, sc.width, 4), 7.0, dtype=torch.float32, device="cuda")
+    stream.wait_stream(torch.cuda.current_stream())   # the fill above ran on torch's current stream
+    r.set_stream(stream.cuda_stream)
+    r.set_output_device_ptr(out.data_ptr(), out.numel() * 4)
+    h = r.render_scene(sc)
+    r.synchronize()                             # first frame of a scene: sizes the bins (re-renders on overflow)
+    with torch.cuda.stream(stream):
+        out.fill_(7.0)
+        h = r.render_scene(sc, h)
+        doubled = out * 2                       # queued behind the frame on the same stream
+    stream.synchronize()
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), ref.view(np.uint32))
+    assert np.array_equal(doubled.cpu().numpy(), ref * 2)
+    r.set_stream(None)
+    r.set_output_device_ptr(None, 0)
+    # (2) timing queries
+    r.set_option("timing", 1)
+    r.timing_reset()
+    h = r.render_scene(sc, h)
+    frame_ms, shade_ms = r.last_frame_time_ms()
+    n, f, g, ra, s = r.timing_summary()
+    assert n == 1 and 0 < shade_ms <= frame_ms and f > 0 and g > 0 and ra > 0 and s > 0
+    r.set_option("timing", 0)
+    assert np.array_equal(r.read_framebuffer().view(np.uint32), ref.view(np.uint32))
+    # (3) freeing resources: handles die, other resources keep working, slots are not recycled into live handles
+    meshes, mats = list(h["mesh"].values()), list(h["mat"].values())
+    r.free_mesh(meshes[0])
+    with pytest.raises(BibimError):
+        r.free_mesh(meshes[0])
+    r.begin_frame()
+    with pytest.raises(BibimError):
+        r.draw(meshes[0], mats[0], sc.draws[0].instances)
+    r.draw(meshes[1], mats[0], sc.draws[1].instances)   # the plane alone still renders
+    r.end_frame()
+    plane_only = bbo.Scene(sc.frame, sc.view, [sc.draws[1]], sc.width, sc.height, "plane")
+    pref, _, _, _ = bbo.render(plane_only)
+    assert np.array_equal(r.read_framebuffer().view(np.uint32), pref.view(np.uint32))
+    r.free_material(mats[0])
+    r.begin_frame()
+    with pytest.raises(BibimError):
+        r.draw(meshes[1], mats[0], sc.draws[1].instances)
+    r.end_frame()
+    r.close()
+    # (4) "resize" = destroy + create (src/main.cpp:1042-1070 recreates the swapchain-dependent objects)
+    sc2 = scenes.shaderball_scene(configs.C2.scaled(200, 300, 64), bbo.MaterialData(maps64))
+    r2 = Renderer(sc2.width, sc2.height)
+    r2.render_scene(sc2)
+    ref2, _, _, _ = bbo.render(sc2)
+    assert np.array_equal(r2.read_framebuffer().view(np.uint32), ref2.view(np.uint32))
+    r2.close()
