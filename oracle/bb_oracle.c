@@ -527,12 +527,18 @@ static int clip_polygon(clip_vert *poly, int n) {
 }
 
 /* project + snap one clip-space vertex; returns 0 if it cannot be represented */
-static int project_vertex(const float *c, float half_w, float half_h, int32_t *X, int32_t *Y, float *rw, float *zndc) {
+/* Viewport transform xf = (px / 2) * xd + (x + px / 2), Vulkan 1.2 sec. 26.9: half extents and centre in pixels.  The
+ * main passes use the whole target (centre = half extent); the gizmo overlay uses a 100 x 100 corner (src/main.cpp:760-772). */
+typedef struct {
+  float half_w, half_h, cx, cy;
+} viewport;
+
+static int project_vertex(const float *c, const viewport *vp, int32_t *X, int32_t *Y, float *rw, float *zndc) {
   float w = c[3];
   if (!(w > 0.0f)) return 0;
   float r = 1.0f / w;
-  float xs = fmaf(c[0] * r, half_w, half_w);
-  float ys = fmaf(c[1] * r, half_h, half_h);
+  float xs = fmaf(c[0] * r, vp->half_w, vp->cx);
+  float ys = fmaf(c[1] * r, vp->half_h, vp->cy);
   if (!(fabsf(xs) <= 4194304.0f) || !(fabsf(ys) <= 4194304.0f)) return 0;
   *X = (int32_t)rintf(xs * 256.0f);
   *Y = (int32_t)rintf(ys * 256.0f);
@@ -561,7 +567,7 @@ static int setup_tri(raster_tri *t, const float *z) {
 }
 
 /* Build the raster triangles of one primitive from its three clip-space vertices. */
-static int build_prim(const float clip[3][4], float half_w, float half_h, raster_tri *out, int *was_clipped) {
+static int build_prim(const float clip[3][4], const viewport *vp, raster_tri *out, int *was_clipped) {
   *was_clipped = 0;
   /* trivial reject against the true frustum planes (cannot change any pixel: the viewport scissor
    * removes everything outside anyway) */
@@ -584,7 +590,7 @@ static int build_prim(const float clip[3][4], float half_w, float half_h, raster
     raster_tri *t = &out[0];
     float z[3];
     for (int i = 0; i < 3; ++i)
-      if (!project_vertex(clip[i], half_w, half_h, &t->X[i], &t->Y[i], &t->rw[i], &z[i])) return 0;
+      if (!project_vertex(clip[i], vp, &t->X[i], &t->Y[i], &t->rw[i], &z[i])) return 0;
     t->clipped = 0;
     memset(t->bary, 0, sizeof t->bary);
     t->bary[0][0] = t->bary[1][1] = t->bary[2][2] = 1.0f;
@@ -603,7 +609,7 @@ static int build_prim(const float clip[3][4], float half_w, float half_h, raster
   int32_t X[MAX_CLIP_VERTS], Y[MAX_CLIP_VERTS];
   float rw[MAX_CLIP_VERTS], z[MAX_CLIP_VERTS];
   for (int i = 0; i < n; ++i)
-    if (!project_vertex(poly[i].c, half_w, half_h, &X[i], &Y[i], &rw[i], &z[i])) return 0;
+    if (!project_vertex(poly[i].c, vp, &X[i], &Y[i], &rw[i], &z[i])) return 0;
   /* fan (0, i, i+1); slot index = i-1 is kept even when a fan triangle is culled so that the sub-triangle
    * number is a pure function of the clipped polygon */
   int count = 0;
@@ -786,7 +792,7 @@ static int render_core(const pipeline *pl, uint32_t n_prims, int32_t width, int3
     memset(out_depth + (size_t)y * width, 0, sizeof(float) * (size_t)width);            /* clear depth 0  */
     memset(key + (size_t)y * width, 0, sizeof(uint32_t) * (size_t)width);
   }
-  float half_w = 0.5f * (float)width, half_h = 0.5f * (float)height;
+  const viewport whole = {0.5f * (float)width, 0.5f * (float)height, 0.5f * (float)width, 0.5f * (float)height};
 
   /* ---- pass 1: visibility in API order, depth op GREATER_OR_EQUAL (src/render.cpp:1121) ---- */
   for (uint32_t prim = 0; prim < n_prims; ++prim) {
@@ -795,7 +801,7 @@ static int render_core(const pipeline *pl, uint32_t n_prims, int32_t width, int3
     pl->fetch(pl->ctx, prim, clip, vary, &mat);
     raster_tri tris[MAX_SUBTRIS];
     int was_clipped;
-    int n = build_prim(clip, half_w, half_h, tris, &was_clipped);
+    int n = build_prim(clip, &whole, tris, &was_clipped);
     st.n_clipped_prims += (uint64_t)was_clipped;
     for (int s = 0; s < n; ++s) {
       const raster_tri *t = &tris[s];
@@ -855,7 +861,7 @@ static int render_core(const pipeline *pl, uint32_t n_prims, int32_t width, int3
       if (prim != cached_prim) {
         int wc;
         pl->fetch(pl->ctx, prim, clip, vary, &mat);
-        n_tris = build_prim(clip, half_w, half_h, tris, &wc);
+        n_tris = build_prim(clip, &whole, tris, &wc);
         cached_prim = prim;
       }
       if ((int)sub >= n_tris) { free(key); if (own_depth) free(out_depth); return -4; }
@@ -913,6 +919,202 @@ int bbo_render_deferred(const bbo_frame_uniforms *frame, const bbo_view_uniforms
                     out_depth, stats);
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* overlay subpass: light markers and the corner gizmo, drawn into the      */
+/* presented image after tone mapping, depth-tested against the scene's depth                    */
+/*   recordCommand src/main.cpp:128-171; light.vert:10-16, light.frag; marker mesh               */
+/*   generateUVSphereMesh(0.1, 16, 16) src/main.cpp:953-957, src/render.cpp:1774-1833;           */
+/*   pipelines src/main.cpp:746-784 (gizmo: 100 x 100 viewport + scissor in the top-right        */
+/*   corner), :825-861 (markers: whole target); both cull BACK, depth test + write,              */
+/*   GREATER_OR_EQUAL; depth of the gizmo rectangle cleared to 0 in between (:150-160)           */
+/* ------------------------------------------------------------------------------------------ */
+
+#define BB_PI32 3.141592f              /* src/vector_math.h:6 */
+#define BB_HALF_PI32 (BB_PI32 * 0.5f) /* src/vector_math.h:7 */
+#define BB_TWO_PI32 (BB_PI32 * 2.f)   /* :8 */
+
+/* Positions and indices of generateUVSphereMesh (the markers only keep Pos, src/main.cpp:956): (h+1)*(v+1) vertices,
+ * 6*h*(v-1) indices.  sphericalToCartesian: src/vector_math.cpp:284-292. */
+void bbo_uv_sphere(float radius, int32_t hdiv, int32_t vdiv, float *out_pos3, uint32_t *out_indices, uint32_t *out_n_vertices,
+                   uint32_t *out_n_indices) {
+  uint32_t nv = 0, ni = 0;
+  for (int v = 0; v <= vdiv; ++v) {
+    float theta = -BB_HALF_PI32 + BB_PI32 * ((float)v / (float)vdiv);
+    for (int h = 0; h <= hdiv; ++h) {
+      float phi = BB_TWO_PI32 * ((float)h / (float)hdiv);
+      float cos_theta = cosf(theta);
+      if (out_pos3) {
+        out_pos3[3 * nv + 0] = radius * cos_theta * cosf(phi);
+        out_pos3[3 * nv + 1] = radius * sinf(theta);
+        out_pos3[3 * nv + 2] = radius * cos_theta * sinf(phi);
+      }
+      ++nv;
+    }
+  }
+  for (int v = 0; v < vdiv; ++v)
+    for (int h = 0; h < hdiv; ++h) {
+      uint32_t base = (uint32_t)((hdiv + 1) * v + h);
+      if (v < vdiv - 1) {
+        if (out_indices) { out_indices[ni] = base; out_indices[ni + 1] = base + hdiv + 1; out_indices[ni + 2] = base + hdiv + 2; }
+        ni += 3;
+      }
+      if (v > 0) {
+        if (out_indices) { out_indices[ni] = base + hdiv + 2; out_indices[ni + 1] = base + 1; out_indices[ni + 2] = base; }
+        ni += 3;
+      }
+    }
+  if (out_n_vertices) *out_n_vertices = nv;
+  if (out_n_indices) *out_n_indices = ni;
+}
+
+/* the gizmo's own matrices, gizmo.vert:13-24 */
+static void gizmo_matrices(const bbo_view_uniforms *view, bbo_mat4 *gview, bbo_mat4 *gpv) {
+  const bbo_mat4 *uv = &view->view;
+  v3 right = v3_make(uv->M[0][0], uv->M[1][0], uv->M[2][0]);
+  v3 up = v3_make(uv->M[0][1], uv->M[1][1], uv->M[2][1]);
+  v3 look = v3_make(uv->M[0][2], uv->M[1][2], uv->M[2][2]);
+  v3 view_pos = scale3(look, -27.0f);
+  *gview = *uv;
+  gview->M[3][0] = -dot3(view_pos, right);
+  gview->M[3][1] = -dot3(view_pos, up);
+  gview->M[3][2] = -dot3(view_pos, look);
+  bbo_view_uniforms gv = *view;
+  gv.view = *gview;
+  float d = 1.0f / tanf(0.261799f);
+  gv.proj.M[0][0] = d;
+  gv.proj.M[1][1] = -d;
+  bbo_proj_view(&gv, gpv);
+}
+
+/* one overlay triangle: clip, set up, rasterise inside the scissor rectangle with depth test GREATER_OR_EQUAL and
+ * depth write; the colour is flat (markers) or gizmo.frag on the interpolated colour + normal */
+static void overlay_triangle(const float clip[3][4], const float vary[3][NVARY], int n_vary, const viewport *vp, const int32_t *sc,
+                             int32_t width, float *depth, uint8_t *rgba8, const float *thr, bbo_stats *st) {
+  raster_tri tris[MAX_SUBTRIS];
+  int was_clipped;
+  int n = build_prim(clip, vp, tris, &was_clipped);
+  st->n_clipped_prims += (uint64_t)was_clipped;
+  for (int s = 0; s < n; ++s) {
+    const raster_tri *t = &tris[s];
+    if (t->clipped < 0) continue;
+    ++st->n_raster_tris;
+    int32_t minX = t->X[0], maxX = t->X[0], minY = t->Y[0], maxY = t->Y[0];
+    for (int k = 1; k < 3; ++k) {
+      if (t->X[k] < minX) minX = t->X[k];
+      if (t->X[k] > maxX) maxX = t->X[k];
+      if (t->Y[k] < minY) minY = t->Y[k];
+      if (t->Y[k] > maxY) maxY = t->Y[k];
+    }
+    int32_t px0 = (minX - 128 + 255) >> 8, px1 = (maxX - 128) >> 8;
+    int32_t py0 = (minY - 128 + 255) >> 8, py1 = (maxY - 128) >> 8;
+    if (px0 < sc[0]) px0 = sc[0];
+    if (py0 < sc[1]) py0 = sc[1];
+    if (px1 > sc[2] - 1) px1 = sc[2] - 1;
+    if (py1 > sc[3] - 1) py1 = sc[3] - 1;
+    for (int32_t py = py0; py <= py1; ++py)
+      for (int32_t px = px0; px <= px1; ++px) {
+        int32_t Xc = px * SUBPIXEL_ONE + 128, Yc = py * SUBPIXEL_ONE + 128;
+        if (!covers(t, Xc, Yc)) continue;
+        ++st->n_fragments;
+        float z = tri_depth(t, Xc, Yc);
+        size_t o = (size_t)py * width + px;
+        if (!(z >= depth[o])) continue;
+        depth[o] = z;
+        float beta[3], attr[NVARY], col[4];
+        tri_bary(t, Xc, Yc, beta);
+        interpolate(beta, vary, n_vary, attr);
+        if (n_vary == 3) { col[0] = attr[0]; col[1] = attr[1]; col[2] = attr[2]; } /* light.frag: outColor = vec4(vColor, 1) */
+        else gizmo_shade(attr, col);
+        for (int c = 0; c < 3; ++c) rgba8[4 * o + c] = srgb8(col[c], thr);
+        rgba8[4 * o + 3] = 255;
+      }
+  }
+}
+
+int bbo_overlay(const bbo_frame_uniforms *frame, const bbo_view_uniforms *view, int32_t width, int32_t height,
+                const float *scene_depth, uint8_t *rgba8, const bbo_gizmo_vertex *gizmo_vertices, uint32_t n_gizmo_vertices,
+                const uint32_t *gizmo_indices, uint32_t n_gizmo_indices, int32_t gizmo_extent, bbo_stats *stats) {
+  if (!frame || !view || !scene_depth || !rgba8 || width <= 0 || height <= 0) return -1;
+  size_t npx = (size_t)width * (size_t)height;
+  float *depth = (float *)malloc(npx * sizeof(float));
+  if (!depth) return -3;
+  memcpy(depth, scene_depth, npx * sizeof(float));
+  float thr[256];
+  bbo_srgb_thresholds(thr);
+  thr[255] = INFINITY;
+  bbo_stats st;
+  memset(&st, 0, sizeof st);
+  const viewport whole = {0.5f * (float)width, 0.5f * (float)height, 0.5f * (float)width, 0.5f * (float)height};
+  const int32_t sc_whole[4] = {0, 0, width, height};
+
+  /* ---- light markers: instance i sits at uLights[i].pos and has its colour (light.vert:11-15) ---- */
+  {
+    enum { HD = 16, VD = 16 };
+    float pos[(HD + 1) * (VD + 1) * 3];
+    uint32_t idx[6 * HD * (VD - 1)], nv, ni;
+    bbo_uv_sphere(0.1f, HD, VD, pos, idx, &nv, &ni);
+    bbo_mat4 pv;
+    bbo_proj_view(view, &pv); /* uProjMat * uViewMat */
+    int n_lights = frame->num_lights;
+    if (n_lights < 0) n_lights = 0;
+    if (n_lights > BBO_MAX_LIGHTS) n_lights = BBO_MAX_LIGHTS;
+    for (int li = 0; li < n_lights; ++li) {
+      const bbo_light *light = &frame->lights[li];
+      /* (P*V) * modelMat, modelMat = identity with column 3 = (pos, 1): columns 0..2 are those of P*V */
+      bbo_mat4 pvm = pv;
+      v4 t = {light->pos[0], light->pos[1], light->pos[2], 1.0f};
+      v4 c3 = mat4_mul_v4(&pv, t);
+      pvm.M[3][0] = c3.x; pvm.M[3][1] = c3.y; pvm.M[3][2] = c3.z; pvm.M[3][3] = c3.w;
+      for (uint32_t k = 0; k + 2 < ni; k += 3) {
+        float clip[3][4], vary[3][NVARY];
+        for (int j = 0; j < 3; ++j) {
+          const float *p = pos + 3 * idx[k + j];
+          v4 pc = mat4_mul_v4(&pvm, (v4){p[0], p[1], p[2], 1.0f});
+          clip[j][0] = pc.x; clip[j][1] = pc.y; clip[j][2] = pc.z; clip[j][3] = pc.w;
+          memset(vary[j], 0, sizeof vary[j]);
+          vary[j][0] = light->color[0]; vary[j][1] = light->color[1]; vary[j][2] = light->color[2];
+        }
+        ++st.n_prims;
+        overlay_triangle(clip, vary, 3, &whole, sc_whole, width, depth, rgba8, thr, &st);
+      }
+    }
+  }
+
+  /* ---- gizmo: depth of its rectangle cleared, own viewport and scissor (src/main.cpp:150-160, 760-772) ---- */
+  if (gizmo_vertices && n_gizmo_vertices && gizmo_extent > 0) {
+    int32_t x0 = width - gizmo_extent, y0 = 0;
+    int32_t sc[4] = {x0 < 0 ? 0 : x0, y0, width, gizmo_extent < height ? gizmo_extent : height};
+    for (int32_t y = sc[1]; y < sc[3]; ++y)
+      for (int32_t x = sc[0]; x < sc[2]; ++x) depth[(size_t)y * width + x] = 0.0f;
+    const float half = 0.5f * (float)gizmo_extent;
+    const viewport vp = {half, half, (float)x0 + half, (float)y0 + half};
+    bbo_mat4 gview, gpv;
+    gizmo_matrices(view, &gview, &gpv);
+    uint32_t n = gizmo_indices ? n_gizmo_indices : n_gizmo_vertices;
+    for (uint32_t k = 0; k + 2 < n; k += 3) {
+      float clip[3][4], vary[3][NVARY];
+      for (int j = 0; j < 3; ++j) {
+        uint32_t vi = gizmo_indices ? gizmo_indices[k + j] : k + j;
+        if (vi >= n_gizmo_vertices) { free(depth); return -5; }
+        const bbo_gizmo_vertex *gv = &gizmo_vertices[vi];
+        v4 pc = mat4_mul_v4(&gpv, (v4){gv->pos[0], gv->pos[1], gv->pos[2], 1.0f});
+        clip[j][0] = pc.x; clip[j][1] = pc.y; clip[j][2] = pc.z; clip[j][3] = pc.w;
+        memset(vary[j], 0, sizeof vary[j]);
+        vary[j][0] = gv->color[0]; vary[j][1] = gv->color[1]; vary[j][2] = gv->color[2];
+        v3 nn = v3_ld(gv->normal);
+        vary[j][3] = fmaf(gview.M[2][0], nn.z, fmaf(gview.M[1][0], nn.y, gview.M[0][0] * nn.x));
+        vary[j][4] = fmaf(gview.M[2][1], nn.z, fmaf(gview.M[1][1], nn.y, gview.M[0][1] * nn.x));
+        vary[j][5] = fmaf(gview.M[2][2], nn.z, fmaf(gview.M[1][2], nn.y, gview.M[0][2] * nn.x));
+      }
+      ++st.n_prims;
+      overlay_triangle(clip, vary, 6, &vp, sc, width, depth, rgba8, thr, &st);
+    }
+  }
+  free(depth);
+  if (stats) *stats = st;
+  return 0;
+}
+
 int bbo_render_gizmo(const bbo_view_uniforms *view, const bbo_gizmo_vertex *vertices, uint32_t n_vertices,
                      const uint32_t *indices, uint32_t n_indices, int32_t width, int32_t height, float *out_rgba,
                      uint32_t *out_prim, float *out_depth, bbo_stats *stats) {
@@ -948,7 +1150,6 @@ int bbo_render_gizmo(const bbo_view_uniforms *view, const bbo_gizmo_vertex *vert
 /* plain mul/add order of the reference, no fused ops                                          */
 /* ------------------------------------------------------------------------------------------ */
 
-#define BB_PI32 3.141592f /* src/vector_math.h:6 */
 static inline float deg_to_rad(float d) { return d * BB_PI32 / 180.f; }
 
 void bbo_mat4_identity(bbo_mat4 *out) {

@@ -139,6 +139,19 @@ int bbo_render_gizmo(const bbo_view_uniforms *view, const bbo_gizmo_vertex *vert
                      const uint32_t *indices, uint32_t n_indices, int32_t width, int32_t height,
                      float *out_rgba, uint32_t *out_prim, float *out_depth, bbo_stats *stats);
 
+/* Overlay subpass (src/main.cpp:128-171): the light markers (light.vert/.frag on generateUVSphereMesh(0.1, 16, 16),
+ * one instance per light) and the corner gizmo (gizmo.vert/.frag in a gizmo_extent^2 viewport at the top-right, depth of
+ * that rectangle cleared first), drawn over the presented RGBA8 image `rgba8` (in/out) and depth-tested against
+ * `scene_depth` (width*height floats as bbo_render returns them; not modified).  Colours are sRGB-encoded like
+ * bbo_present does.  gizmo_vertices may be NULL (markers only). */
+int bbo_overlay(const bbo_frame_uniforms *frame, const bbo_view_uniforms *view, int32_t width, int32_t height,
+                const float *scene_depth, uint8_t *rgba8, const bbo_gizmo_vertex *gizmo_vertices, uint32_t n_gizmo_vertices,
+                const uint32_t *gizmo_indices, uint32_t n_gizmo_indices, int32_t gizmo_extent, bbo_stats *stats);
+/* generateUVSphereMesh (src/render.cpp:1774-1833): positions (3 floats each) and triangle indices; either output may be
+ * NULL to query the counts */
+void bbo_uv_sphere(float radius, int32_t hdiv, int32_t vdiv, float *out_pos3, uint32_t *out_indices, uint32_t *out_n_vertices,
+                   uint32_t *out_n_indices);
+
 /* ---- stage-level entry points (known-answer tests, stage parity) ---- */
 
 /* forward_brdf.vert: out_clip[4], out_vary[14] = uv(2) posWorld(3) N(3) T(3) B(3) */

@@ -295,6 +295,40 @@ def render_deferred(scene: Scene, y0=0, y1=None, want_gbuffer=True):
     return rgba, gbuf, prim, depth, st.as_dict()
 
 
+def uv_sphere(radius=0.1, hdiv=16, vdiv=16):
+    """generateUVSphereMesh positions [n, 3] f32 and indices [m] u32 (the light-marker mesh)"""
+    L = lib()
+    L.bbo_uv_sphere.argtypes = [C.c_float, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.bbo_uv_sphere.restype = None
+    nv, ni = C.c_uint32(), C.c_uint32()
+    L.bbo_uv_sphere(radius, hdiv, vdiv, None, None, C.byref(nv), C.byref(ni))
+    pos = np.zeros((nv.value, 3), np.float32)
+    idx = np.zeros(ni.value, np.uint32)
+    L.bbo_uv_sphere(radius, hdiv, vdiv, _p(pos), _p(idx), None, None)
+    return pos, idx
+
+
+def overlay(frame, view, scene_depth, rgba8, gizmo_vertices=None, gizmo_indices=None, gizmo_extent=100):
+    """light markers + corner gizmo over a presented RGBA8 image (returns a new array), depth-tested against scene_depth"""
+    L = lib()
+    L.bbo_overlay.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                              C.c_void_p, C.c_uint32, C.c_int32, C.c_void_p]
+    out = np.ascontiguousarray(rgba8, np.uint8).copy()
+    H, W = out.shape[:2]
+    depth = np.ascontiguousarray(scene_depth, np.float32)
+    assert depth.shape == (H, W)
+    gv = None if gizmo_vertices is None else np.ascontiguousarray(gizmo_vertices)
+    gi = None if gizmo_indices is None else np.ascontiguousarray(gizmo_indices, np.uint32)
+    if gv is not None:
+        assert gv.dtype == GIZMO_VERTEX_DTYPE
+    st = Stats()
+    rc = L.bbo_overlay(_p(frame), _p(view), W, H, _p(depth), _p(out), _p(gv), 0 if gv is None else len(gv), _p(gi),
+                       0 if gi is None else len(gi), gizmo_extent, C.byref(st))
+    if rc != 0:
+        raise RuntimeError(f"bbo_overlay failed: {rc}")
+    return out, st.as_dict()
+
+
 def render_gizmo(view, vertices, indices, width, height):
     rgba = np.zeros((height, width, 4), np.float32)
     prim = np.full((height, width), NO_PRIM, np.uint32)
