@@ -75,6 +75,8 @@ SIGNATURES = {
     "bbr_tone_map": (C.c_int, [_P, C.c_int32, C.c_float]),
     "bbr_selftest_rcp": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]),
     "bbr_read_gbuffer": (C.c_int, [_P, C.c_void_p]),
+    "bbr_upload_gizmo": (C.c_int, [_P, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]),
+    "bbr_draw_overlays": (C.c_int, [_P, C.c_int32]),
     "bbr_present": (C.c_int, [_P, C.c_void_p, C.c_int32]),
     "bbr_read_presented": (C.c_int, [_P, C.c_void_p]),
     "bbr_present_buffer": (C.c_int, [_P, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_float, C.c_int32, C.c_void_p]),

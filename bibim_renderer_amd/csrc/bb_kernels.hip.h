@@ -174,13 +174,17 @@ BB_DEV int clip_polygon_wave(ClipWork &w, int &n) {
   return cur;
 }
 
-BB_DEV bool project_vertex(const float *c, float half_w, float half_h, int32_t &X, int32_t &Y, float &rw,
-                           float &zndc) {
+// viewport transform: half extents and centre in pixels (the main passes cover the whole target: centre = half extent)
+struct Viewport {
+  float half_w, half_h, cx, cy;
+};
+
+BB_DEV bool project_vertex(const float *c, const Viewport &vp, int32_t &X, int32_t &Y, float &rw, float &zndc) {
   float w = c[3];
   if (!(w > 0.0f)) return false;
   float r = 1.0f / w;
-  float xs = fmaf(c[0] * r, half_w, half_w);
-  float ys = fmaf(c[1] * r, half_h, half_h);
+  float xs = fmaf(c[0] * r, vp.half_w, vp.cx);
+  float ys = fmaf(c[1] * r, vp.half_h, vp.cy);
   if (!(fabsf(xs) <= 4194304.0f) || !(fabsf(ys) <= 4194304.0f)) return false;
   X = (int32_t)rintf(xs * 256.0f);
   Y = (int32_t)rintf(ys * 256.0f);
@@ -315,7 +319,7 @@ BB_DEV void wave_bin_write(bool has, uint32_t seg, uint32_t ref, const BinTicket
 // the bins.  One atomic reserves the arena slots, one the list entries.  Results in w.n_valid / w.base.
 template <int TILE_W, int TILE_H>
 BB_DEV void clip_primitive_wave(ClipWork &w, int owner, const float (*clip)[4], uint32_t prim, const FrameParams &fp,
-                                ClipSlot *clip_arena, Counters *ctr, BroadTri *broad_list) {
+                                const Viewport &vp, ClipSlot *clip_arena, Counters *ctr, BroadTri *broad_list) {
   const int lane = threadIdx.x & 63;
   if (lane == owner) {
     w.prim = prim;
@@ -341,7 +345,7 @@ BB_DEV void clip_primitive_wave(ClipWork &w, int owner, const float (*clip)[4], 
     const ClipVert v = w.poly[cur][lane];
     int32_t X = 0, Y = 0;
     float rw = 0.0f, z = 0.0f;
-    bad = !project_vertex(v.c, fp.half_w, fp.half_h, X, Y, rw, z);
+    bad = !project_vertex(v.c, vp, X, Y, rw, z);
     w.X[lane] = X; w.Y[lane] = Y; w.rw[lane] = rw; w.z[lane] = z;
   }
   if (__ballot(bad) != 0ull) return;
@@ -401,7 +405,9 @@ BB_DEV void clip_primitive_wave(ClipWork &w, int owner, const float (*clip)[4], 
 }
 
 // One thread per primitive, all draw calls of the frame in one launch (API order = primitive index order).
-template <int TILE_W, int TILE_H>
+// OVERLAY = true is the overlay subpass (light markers, corner gizmo): other vertex programs and a
+// per-primitive viewport, everything downstream of the vertex stage shared.
+template <int TILE_W, int TILE_H, bool OVERLAY = false>
 __global__ __launch_bounds__(256) void k_geometry(const DrawDesc *__restrict__ draws, uint32_t n_draws, uint32_t n_prims,
                                                   Mat4 pv, Mat4 view, FrameParams fp, RasterTri *__restrict__ tris,
                                                   ShadeRec *__restrict__ recs, ClipSlot *__restrict__ clip_arena,
@@ -431,6 +437,7 @@ __global__ __launch_bounds__(256) void k_geometry(const DrawDesc *__restrict__ d
   uint32_t cls = 0;     // raster class of the triangle: bin segment (kBinClasses per tile)
   TileRange tr = {0, -1, 0, -1};
   uint32_t n_raster = 0, n_clipped = 0;
+  Viewport vp = {fp.half_w, fp.half_h, fp.half_w, fp.half_h};
   if (prim < n_prims) {
     uint32_t d = 0;
     while (d + 1 < n_draws && prim >= draws[d + 1].first_prim) ++d;
@@ -455,28 +462,58 @@ __global__ __launch_bounds__(256) void k_geometry(const DrawDesc *__restrict__ d
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     BB_STAMP(6);
 #endif
+    if (OVERLAY) {
+      // The host folds the matrices: ib.model = (P*V)*modelMat of the light (light.vert:11-14) or the gizmo's own
+      // projMat*viewMat (gizmo.vert:13-24); ib.inv_model row 0 = the light's colour, or the gizmo's viewMat whose
+      // upper 3x3 turns the normals (gizmo.vert:27).  draw.material is the program: 1 marker, 2 gizmo.
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const Vertex &v = vtx[k];
-      // forward_brdf.vert:25,27
-      f4 pw = mat4_mul(ib.model, f4{v.pos[0], v.pos[1], v.pos[2], 1.0f});
-      // forward_brdf.vert:27 multiplies (P*V) * posWorld (pv = P*V); gbuffer.vert:19-22 P * (V * posWorld) (pv = P)
-      f4 c = fp.deferred ? mat4_mul(pv, mat4_mul(view, pw)) : mat4_mul(pv, pw);
-      clip[k][0] = c.x; clip[k][1] = c.y; clip[k][2] = c.z; clip[k][3] = c.w;
-      // :31-36  normalMat = transpose(mat3(aInvModel))
-      f3 n = ld3(v.normal), t = ld3(v.tangent);
-      const Mat4 &im = ib.inv_model;
-      f3 N = normalize3(mk3(dot3(ld3(im.M[0]), n), dot3(ld3(im.M[1]), n), dot3(ld3(im.M[2]), n)));
-      f3 T = normalize3(mk3(dot3(ld3(im.M[0]), t), dot3(ld3(im.M[1]), t), dot3(ld3(im.M[2]), t)));
-      f3 B = cross3(N, T);
-      float *o = pa.vary[k];
-      o[0] = v.uv[0]; o[1] = v.uv[1];
-      o[2] = pw.x; o[3] = pw.y; o[4] = pw.z;
-      o[5] = N.x; o[6] = N.y; o[7] = N.z;
-      o[8] = T.x; o[9] = T.y; o[10] = T.z;
-      o[11] = B.x; o[12] = B.y; o[13] = B.z;
+      for (int k = 0; k < 3; ++k) {
+        const Vertex &v = vtx[k];
+        f4 c = mat4_mul(ib.model, f4{v.pos[0], v.pos[1], v.pos[2], 1.0f});
+        clip[k][0] = c.x; clip[k][1] = c.y; clip[k][2] = c.z; clip[k][3] = c.w;
+        float *o = pa.vary[k];
+#pragma unroll
+        for (int j = 0; j < kNumVary; ++j) o[j] = 0.0f;
+        if (draw.material == 1u) {
+          o[0] = ib.inv_model.M[0][0]; o[1] = ib.inv_model.M[0][1]; o[2] = ib.inv_model.M[0][2];
+        } else {
+          const Mat4 &gv = ib.inv_model;
+          f3 n = ld3(v.normal);
+          o[0] = v.tangent[0]; o[1] = v.tangent[1]; o[2] = v.tangent[2];  // the gizmo mesh keeps its colour there
+          o[3] = fmaf(gv.M[2][0], n.z, fmaf(gv.M[1][0], n.y, gv.M[0][0] * n.x));
+          o[4] = fmaf(gv.M[2][1], n.z, fmaf(gv.M[1][1], n.y, gv.M[0][1] * n.x));
+          o[5] = fmaf(gv.M[2][2], n.z, fmaf(gv.M[1][2], n.y, gv.M[0][2] * n.x));
+        }
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const Vertex &v = vtx[k];
+        // forward_brdf.vert:25,27
+        f4 pw = mat4_mul(ib.model, f4{v.pos[0], v.pos[1], v.pos[2], 1.0f});
+        // forward_brdf.vert:27 multiplies (P*V) * posWorld (pv = P*V); gbuffer.vert:19-22 P * (V * posWorld) (pv = P)
+        f4 c = fp.deferred ? mat4_mul(pv, mat4_mul(view, pw)) : mat4_mul(pv, pw);
+        clip[k][0] = c.x; clip[k][1] = c.y; clip[k][2] = c.z; clip[k][3] = c.w;
+        // :31-36  normalMat = transpose(mat3(aInvModel))
+        f3 n = ld3(v.normal), t = ld3(v.tangent);
+        const Mat4 &im = ib.inv_model;
+        f3 N = normalize3(mk3(dot3(ld3(im.M[0]), n), dot3(ld3(im.M[1]), n), dot3(ld3(im.M[2]), n)));
+        f3 T = normalize3(mk3(dot3(ld3(im.M[0]), t), dot3(ld3(im.M[1]), t), dot3(ld3(im.M[2]), t)));
+        f3 B = cross3(N, T);
+        float *o = pa.vary[k];
+        o[0] = v.uv[0]; o[1] = v.uv[1];
+        o[2] = pw.x; o[3] = pw.y; o[4] = pw.z;
+        o[5] = N.x; o[6] = N.y; o[7] = N.z;
+        o[8] = T.x; o[9] = T.y; o[10] = T.z;
+        o[11] = B.x; o[12] = B.y; o[13] = B.z;
+      }
     }
-    {
+    if (OVERLAY) {  // draw.material is the overlay program here, not an index into the material table
+      pa.material = draw.material;
+      pa.packed = nullptr;
+      pa.packed_dims = 0u;
+      pa.clip_base = kNotClipped;
+    } else {
       const MaterialDesc &md = materials[draw.material];
       pa.material = draw.material;
       pa.packed = md.packed;
@@ -484,6 +521,7 @@ __global__ __launch_bounds__(256) void k_geometry(const DrawDesc *__restrict__ d
       pa.clip_base = kNotClipped;
     }
 
+    if (OVERLAY && prim >= fp.ov_first_gizmo_prim) vp = Viewport{fp.ov_half, fp.ov_half, fp.ov_cx, fp.ov_cy};
     // trivial reject against the true frustum (cannot change any pixel)
     bool o_l = true, o_r = true, o_t = true, o_b = true, o_n = true, o_f = true, all_in = true;
 #pragma unroll
@@ -499,9 +537,8 @@ __global__ __launch_bounds__(256) void k_geometry(const DrawDesc *__restrict__ d
       if (all_in) {
         RasterTri t;
         float z0, z1, z2;
-        if (project_vertex(clip[0], fp.half_w, fp.half_h, t.X0, t.Y0, t.rw0, z0) &&
-            project_vertex(clip[1], fp.half_w, fp.half_h, t.X1, t.Y1, t.rw1, z1) &&
-            project_vertex(clip[2], fp.half_w, fp.half_h, t.X2, t.Y2, t.rw2, z2) && setup_tri(t, z0, z1, z2) &&
+        if (project_vertex(clip[0], vp, t.X0, t.Y0, t.rw0, z0) && project_vertex(clip[1], vp, t.X1, t.Y1, t.rw1, z1) &&
+            project_vertex(clip[2], vp, t.X2, t.Y2, t.rw2, z2) && setup_tri(t, z0, z1, z2) &&
             tile_range<TILE_W, TILE_H>(t, fp, tr)) {
 #ifdef BB_STAMPS
           BB_STAMP(7);
@@ -561,7 +598,12 @@ __global__ __launch_bounds__(256) void k_geometry(const DrawDesc *__restrict__ d
     for (int i = 0; i < 3; ++i)
 #pragma unroll
       for (int k = 0; k < 4; ++k) cv[i][k] = clip[i][k];
-    clip_primitive_wave<TILE_W, TILE_H>(w, owner, cv, prim, fp, clip_arena, ctr, broad_list);
+    Viewport ovp = vp;  // the owner's viewport for the whole wave
+    if (OVERLAY) {
+      ovp.half_w = __shfl(vp.half_w, owner); ovp.half_h = __shfl(vp.half_h, owner);
+      ovp.cx = __shfl(vp.cx, owner); ovp.cy = __shfl(vp.cy, owner);
+    }
+    clip_primitive_wave<TILE_W, TILE_H>(w, owner, cv, prim, fp, ovp, clip_arena, ctr, broad_list);
     __builtin_amdgcn_wave_barrier();
     if ((int)(threadIdx.x & 63) == owner) {
       n_clipped = 1;
@@ -718,13 +760,17 @@ BB_DEV int classify_rect(const EdgeSetup &e, int x0, int x1, int y0, int y1) {
   return all_in ? 2 : 1;
 }
 
-BB_DEV void depth_max(const RasterTri &t, int px, int py, uint32_t ref, unsigned long long *keys, int key_index) {
+// zbias (overlay pass only): added to the depth BITS of the key, order-preserving -- 0x40000000 lifts the gizmo's
+// fragments above every depth in [0, 1] drawn before (the reference clears the rectangle's depth before the gizmo)
+// while they still compete among themselves by depth.
+BB_DEV void depth_max(const RasterTri &t, int px, int py, uint32_t ref, unsigned long long *keys, int key_index,
+                      uint32_t zbias = 0u) {
   int Xc = px * 256 + 128, Yc = py * 256 + 128;
   float dxp = (float)(Xc - t.X0), dyp = (float)(Yc - t.Y0);
   float z = fmaf(t.dzdx, dxp, fmaf(t.dzdy, dyp, t.z0));
   if (!(z >= 0.0f)) z = 0.0f;
   if (z > 1.0f) z = 1.0f;
-  unsigned long long key = ((unsigned long long)__float_as_uint(z) << 32) | (unsigned long long)(ref + 1u);
+  unsigned long long key = ((unsigned long long)(__float_as_uint(z) + zbias) << 32) | (unsigned long long)(ref + 1u);
   atomicMax(&keys[key_index], key);
 }
 
@@ -733,13 +779,14 @@ BB_DEV void depth_max(const RasterTri &t, int px, int py, uint32_t ref, unsigned
 // 32-bit edge functions stepped with 24-bit multiply-adds (exact: every term < 2^30); larger ones use 64-bit products.
 template <int TILE_W, int TILE_H>
 BB_DEV void raster_triangle_wave(const RasterTri &t, uint32_t ref, int tile_x0, int tile_y0, const FrameParams &fp,
-                                 unsigned long long *keys, int lane) {
+                                 unsigned long long *keys, int lane, uint32_t zbias = 0u, int sx0 = 0, int sy0 = 0,
+                                 int sx1 = 1 << 30, int sy1 = 1 << 30) {
   int32_t minX = min(t.X0, min(t.X1, t.X2)), maxX = max(t.X0, max(t.X1, t.X2));
   int32_t minY = min(t.Y0, min(t.Y1, t.Y2)), maxY = max(t.Y0, max(t.Y1, t.Y2));
-  int px0 = max(max((minX - 128 + 255) >> 8, 0), tile_x0);
-  int px1 = min(min((maxX - 128) >> 8, fp.width - 1), tile_x0 + TILE_W - 1);
-  int py0 = max(max((minY - 128 + 255) >> 8, 0), tile_y0);
-  int py1 = min(min((maxY - 128) >> 8, fp.height - 1), tile_y0 + TILE_H - 1);
+  int px0 = max(max((minX - 128 + 255) >> 8, sx0), tile_x0);
+  int px1 = min(min((maxX - 128) >> 8, min(fp.width, sx1) - 1), tile_x0 + TILE_W - 1);
+  int py0 = max(max((minY - 128 + 255) >> 8, sy0), tile_y0);
+  int py1 = min(min((maxY - 128) >> 8, min(fp.height, sy1) - 1), tile_y0 + TILE_H - 1);
   if (px0 > px1 || py0 > py1) return;
   const EdgeSetup e = edge_setup(t);
   const int w = px1 - px0 + 1, h = py1 - py0 + 1;
@@ -769,7 +816,7 @@ BB_DEV void raster_triangle_wave(const RasterTri &t, uint32_t ref, int tile_x0, 
           int e2 = __mul24(x, sx[2]) + __mul24(y, sy[2]) + o[2];
           in = (e0 | e1 | e2) >= 0;
         }
-        if (in) depth_max(t, px0 + x, py0 + y, ref, keys, tile_index<TILE_W>(px0 + x - tile_x0, py0 + y - tile_y0));
+        if (in) depth_max(t, px0 + x, py0 + y, ref, keys, tile_index<TILE_W>(px0 + x - tile_x0, py0 + y - tile_y0), zbias);
       }
     }
     return;
@@ -781,7 +828,7 @@ BB_DEV void raster_triangle_wave(const RasterTri &t, uint32_t ref, int tile_x0, 
       int px = px0 + bx + lx, py = py0 + by + ly;
       bool in = px <= px1 && py <= py1;
       if (in && cls == 1) in = (edge_eval(e, 0, px, py) | edge_eval(e, 1, px, py) | edge_eval(e, 2, px, py)) >= 0;
-      if (in) depth_max(t, px, py, ref, keys, tile_index<TILE_W>(px - tile_x0, py - tile_y0));
+      if (in) depth_max(t, px, py, ref, keys, tile_index<TILE_W>(px - tile_x0, py - tile_y0), zbias);
     }
   }
 }
@@ -793,7 +840,7 @@ constexpr int kTileWaves = kTileThreads / 64;
 // => every edge-function term fits 32 bits and steps are plain adds.
 template <int TILE_W, int TILE_H>
 BB_DEV void raster_triangle_lane(const RasterTri &t, uint32_t ref, int px0, int px1, int py0, int py1, int tile_x0,
-                                 int tile_y0, unsigned long long *keys) {
+                                 int tile_y0, unsigned long long *keys, uint32_t zbias = 0u) {
   const int dx0 = t.X1 - t.X0, dy0 = t.Y1 - t.Y0;
   const int dx1 = t.X2 - t.X1, dy1 = t.Y2 - t.Y1;
   const int dx2 = t.X0 - t.X2, dy2 = t.Y0 - t.Y2;
@@ -809,7 +856,7 @@ BB_DEV void raster_triangle_lane(const RasterTri &t, uint32_t ref, int px0, int 
   for (int i = 0; i < n; ++i) {
     if ((e0 | e1 | e2) >= 0) {
       int px = px0 + x;
-      depth_max(t, px, py, ref, keys, tile_index<TILE_W>(px - tile_x0, py - tile_y0));
+      depth_max(t, px, py, ref, keys, tile_index<TILE_W>(px - tile_x0, py - tile_y0), zbias);
     }
     ++x;
     e0 -= sx0; e1 -= sx1; e2 -= sx2;
@@ -826,7 +873,7 @@ BB_DEV void raster_triangle_lane(const RasterTri &t, uint32_t ref, int px0, int 
 // per lane, 32-bit edge functions evaluated with 24-bit multiply-adds (exact: |step| < 2^23, offsets < 64).
 template <int TILE_W, int TILE_H>
 BB_DEV void raster_triangle_group16(const RasterTri &t, uint32_t ref, int px0, int px1, int py0, int py1, int tile_x0,
-                                    int tile_y0, unsigned long long *keys, int gl) {
+                                    int tile_y0, unsigned long long *keys, int gl, uint32_t zbias = 0u) {
   const EdgeSetup e = edge_setup(t);
   const int Xc0 = px0 * 256 + 128, Yc0 = py0 * 256 + 128;
   const int w = px1 - px0 + 1, h = py1 - py0 + 1;
@@ -846,7 +893,7 @@ BB_DEV void raster_triangle_group16(const RasterTri &t, uint32_t ref, int px0, i
         int e1 = __mul24(x, sx[1]) + __mul24(y, sy[1]) + o[1];
         int e2 = __mul24(x, sx[2]) + __mul24(y, sy[2]) + o[2];
         if ((e0 | e1 | e2) >= 0)
-          depth_max(t, px0 + x, py0 + y, ref, keys, tile_index<TILE_W>(px0 + x - tile_x0, py0 + y - tile_y0));
+          depth_max(t, px0 + x, py0 + y, ref, keys, tile_index<TILE_W>(px0 + x - tile_x0, py0 + y - tile_y0), zbias);
       }
     }
   }
@@ -943,14 +990,17 @@ BB_DEV RasterTri staged_tri(const StagedTri &st, int j) {
   return t;
 }
 
-template <int TILE_W, int TILE_H>
+// OVERLAY = true (overlay subpass): the keys start from the scene's resolved depth (`depth_io`, read) instead of 0,
+// gizmo primitives are scissored to their rectangle and biased above everything else, pixels no overlay primitive
+// wins are left alone (no background fill).  OVERLAY = false with depth_io != nullptr stores the resolved depth.
+template <int TILE_W, int TILE_H, bool OVERLAY = false>
 __global__ __launch_bounds__(kTileThreads) void k_raster(
     FrameParams fp, const RasterTri *__restrict__ tris, const ClipSlot *__restrict__ clip_arena,
     Counters *__restrict__ ctr, uint32_t *__restrict__ tile_count,
     const uint32_t *__restrict__ bins, const BroadTri *__restrict__ broad_list,
     unsigned long long *__restrict__ frags, uint32_t *__restrict__ frag_count, float4 *__restrict__ out,
     uint32_t *__restrict__ vis_prim, float *__restrict__ vis_depth, const uint32_t *__restrict__ tile_order,
-    const float4 *__restrict__ background) {
+    const float4 *__restrict__ background, float *__restrict__ depth_io) {
   constexpr int TILE_PIXELS = TILE_W * TILE_H;
   __shared__ unsigned long long keys[TILE_PIXELS];
   __shared__ StagedTri st;
@@ -993,7 +1043,17 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
   if (tid < (int)kBinClasses)
     s_n_cls[tid] = (fp.ablate & (1u | (256u << tid))) ? 0u : min(tile_count[tile * kBinClasses + tid], fp.bin_cap);
   const uint32_t n_broad = (fp.ablate & 5u) ? 0u : min(ctr->n_broad, fp.broad_cap);
-  for (int p = tid; p < TILE_PIXELS; p += kTileThreads) keys[p] = 0ull;
+  for (int p = tid; p < TILE_PIXELS; p += kTileThreads) {
+    unsigned long long k0 = 0ull;
+    if (OVERLAY) {  // depth test against what the scene left behind; low word 0 = "no overlay primitive here"
+      int x, y;
+      tile_pixel<TILE_W>(p, x, y);
+      const int gx = tile_x0 + x, gy = tile_y0 + y;
+      if (gx < fp.width && gy < fp.height)
+        k0 = (unsigned long long)__float_as_uint(depth_io[(size_t)gy * (size_t)fp.width + (size_t)gx]) << 32;
+    }
+    keys[p] = k0;
+  }
   if (tid == 0) s_count = 0;
   __syncthreads();  // counts published, keys cleared
   uint32_t n_cls[kBinClasses];
@@ -1005,6 +1065,10 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
   const uint32_t e1 = n_cls[0], e2 = e1 + n_cls[1], e3 = e2 + n_cls[2], e_end = e3 + n_broad;
   const uint32_t *bin0 = bins + (size_t)(tile * kBinClasses) * fp.bin_cap;
 
+  // overlay pass: the gizmo's fragments are lifted above every other depth (see depth_max); 0 everywhere else
+  auto zbias_of = [&](uint32_t ref) -> uint32_t {
+    return (OVERLAY && (ref >> 3) >= fp.ov_first_gizmo_prim) ? 0x40000000u : 0u;
+  };
   BB_RSTAMP(1);
   for (uint32_t base = 0; base < e_end; base += kStage) {
     if (base) __syncthreads();  // previous chunk consumed
@@ -1029,6 +1093,10 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
         int32_t minY = min(t.Y0, min(t.Y1, t.Y2)), maxY = max(t.Y0, max(t.Y1, t.Y2));
         int px0 = max((minX - 128 + 255) >> 8, tile_x0), px1 = min((maxX - 128) >> 8, rx1);
         int py0 = max((minY - 128 + 255) >> 8, tile_y0), py1 = min((maxY - 128) >> 8, ry1);
+        if (OVERLAY && (ref >> 3) >= fp.ov_first_gizmo_prim) {  // the gizmo's scissor rectangle (src/main.cpp:767-772)
+          px0 = max(px0, fp.ov_x0); px1 = min(px1, fp.ov_x1 - 1);
+          py0 = max(py0, fp.ov_y0); py1 = min(py1, fp.ov_y1 - 1);
+        }
         bool ok = px0 <= px1 && py0 <= py1;
         if (ok && e >= e3) ok = classify_rect(edge_setup(t), px0, px1, py0, py1) != 0;  // every-tile list: accept / reject
         if (ok) {
@@ -1055,7 +1123,7 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
           const RasterTri t = staged_tri(st, j);
           raster_triangle_lane<TILE_W, TILE_H>(t, st.ref[j], tile_x0 + (int)(box & 255u), tile_x0 + (int)((box >> 8) & 255u),
                                                tile_y0 + (int)((box >> 16) & 255u), tile_y0 + (int)(box >> 24), tile_x0,
-                                               tile_y0, keys);
+                                               tile_y0, keys, zbias_of(st.ref[j]));
         }
       }
     }
@@ -1069,7 +1137,7 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
       const RasterTri t = staged_tri(st, j);
       raster_triangle_group16<TILE_W, TILE_H>(t, st.ref[j], tile_x0 + (int)(box & 255u), tile_x0 + (int)((box >> 8) & 255u),
                                               tile_y0 + (int)((box >> 16) & 255u), tile_y0 + (int)(box >> 24), tile_x0,
-                                              tile_y0, keys, tid & 15);
+                                              tile_y0, keys, tid & 15, zbias_of(st.ref[j]));
     }
     // ---- class 2 and the every-tile list: one wave per large triangle ----
     {
@@ -1078,7 +1146,11 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
         const int j = __builtin_amdgcn_readfirstlane((int)(e - base));
         if (st.box[j] == 0xFFFFFFFFu) continue;
         const RasterTri t = staged_tri(st, j);
-        raster_triangle_wave<TILE_W, TILE_H>(t, st.ref[j], tile_x0, tile_y0, fp, keys, lane);
+        if (OVERLAY && (st.ref[j] >> 3) >= fp.ov_first_gizmo_prim)
+          raster_triangle_wave<TILE_W, TILE_H>(t, st.ref[j], tile_x0, tile_y0, fp, keys, lane, zbias_of(st.ref[j]), fp.ov_x0,
+                                               fp.ov_y0, fp.ov_x1, fp.ov_y1);
+        else
+          raster_triangle_wave<TILE_W, TILE_H>(t, st.ref[j], tile_x0, tile_y0, fp, keys, lane);
       }
     }
   }
@@ -1094,7 +1166,8 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
     int gx = tile_x0 + x, gy = tile_y0 + y;
     bool in_frame = gx < fp.width && gy < fp.height;
     unsigned long long key = keys[p];
-    bool covered = in_frame && key != 0ull;
+    // main passes: any key; overlay pass: only pixels an overlay primitive won (low word = reference + 1)
+    bool covered = in_frame && (OVERLAY ? (uint32_t)key != 0u : key != 0ull);
     unsigned long long mask = __ballot(covered);
     uint32_t wave_base = 0;
     if (lane == 0 && mask) wave_base = atomicAdd(&s_count, (uint32_t)__popcll(mask));
@@ -1102,7 +1175,7 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
     if (covered) {
       uint32_t rank_in_wave = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
       my_frags[wave_base + rank_in_wave] = ((unsigned long long)(uint32_t)p << 32) | (unsigned long long)((uint32_t)key - 1u);
-    } else if (in_frame) {
+    } else if (in_frame && !OVERLAY) {
       size_t o = (size_t)(out_y0 + y) * (size_t)fp.width + (size_t)gx;
       // forward: the clear colour (src/main.cpp:84); deferred: brdf.frag on the cleared G-buffer texel (k_deferred_background)
       out[o] = background ? background[0] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -1112,6 +1185,8 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
       vis_prim[o] = key ? (((uint32_t)key - 1u) >> 3) : 0xFFFFFFFFu;
       vis_depth[o] = __uint_as_float((uint32_t)(key >> 32));
     }
+    // the resolved depth, kept for the overlay subpass (option "overlays")
+    if (!OVERLAY && depth_io && in_frame) depth_io[(size_t)gy * (size_t)fp.width + (size_t)gx] = __uint_as_float((uint32_t)(key >> 32));
   }
   __syncthreads();
   if (tid == 0) frag_count[tile] = s_count;  // (N_shaded = sum of these, taken on the host on demand)
@@ -1507,6 +1582,69 @@ __global__ void k_unpack_gathered_rgba8(const uint32_t *__restrict__ gathered, u
   int band = y / band_rows, r = y - band * band_rows;
   int rank = band % world, lb = band / world;
   frame[i] = gathered[((size_t)rank * shard_rows + (size_t)lb * band_rows + r) * (size_t)width + x];
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_shade_overlay: light.frag / gizmo.frag on the fragments of the overlay pass, written sRGB-encoded into the
+// presented RGBA8 image (the overlay subpass draws into the swapchain image, src/main.cpp:128-171).
+// ------------------------------------------------------------------------------------------------
+template <int TILE_W, int TILE_H>
+__global__ __launch_bounds__(kShadeThreads) void k_shade_overlay(
+    FrameParams fp, const ShadeRec *__restrict__ recs, const ClipSlot *__restrict__ clip_arena,
+    const unsigned long long *__restrict__ frags, const uint32_t *__restrict__ frag_count,
+    const SrgbTables *__restrict__ tables, uint32_t *__restrict__ out_rgba8) {
+  constexpr int TILE_PIXELS = TILE_W * TILE_H;
+  constexpr int CHUNKS = TILE_PIXELS / kShadeThreads;
+  const int tx = blockIdx.x / CHUNKS, chunk = blockIdx.x - tx * CHUNKS;
+  const int ty = blockIdx.y;
+  if (ty >= fp.tiles_y) return;
+  const uint32_t tile = (uint32_t)ty * (uint32_t)fp.tiles_x + (uint32_t)tx;
+  const uint32_t i = (uint32_t)chunk * kShadeThreads + threadIdx.x;
+  const uint32_t n_frag = frag_count[tile];
+  if (i >= n_frag) return;
+  const unsigned long long frag = frags[(size_t)tile * TILE_PIXELS + i];
+  const uint32_t ref = (uint32_t)frag, prim = ref >> 3;
+  int x, y;
+  tile_pixel<TILE_W>((int)(frag >> 32) & (TILE_PIXELS - 1), x, y);
+  const int gx = tx * TILE_W + x, gy = ty * TILE_H + y;
+  const ShadeRec pa = recs[prim];
+  // perspective-correct barycentrics: the same statements as k_shade
+  const bool clipped = pa.clip_base != kNotClipped;
+  const ClipSlot *cs = clipped ? &clip_arena[pa.clip_base + (ref & 7u)] : nullptr;
+  int X0 = pa.X0, Y0 = pa.Y0;
+  float l1dx = pa.l1dx, l1dy = pa.l1dy, l2dx = pa.l2dx, l2dy = pa.l2dy, rw0 = pa.rw0, rw1 = pa.rw1, rw2 = pa.rw2;
+  if (clipped) {
+    X0 = cs->tri.X0; Y0 = cs->tri.Y0;
+    l1dx = cs->tri.l1dx; l1dy = cs->tri.l1dy; l2dx = cs->tri.l2dx; l2dy = cs->tri.l2dy;
+    rw0 = cs->tri.rw0; rw1 = cs->tri.rw1; rw2 = cs->tri.rw2;
+  }
+  const int Xc = gx * 256 + 128, Yc = gy * 256 + 128;
+  const float dxp = (float)(Xc - X0), dyp = (float)(Yc - Y0);
+  const float l1 = fmaf(l1dx, dxp, l1dy * dyp);
+  const float l2 = fmaf(l2dx, dxp, l2dy * dyp);
+  const float l0 = (1.0f - l1) - l2;
+  const float u0 = l0 * rw0, u1 = l1 * rw1, u2 = l2 * rw2;
+  const float r = bb_rcp((u0 + u1) + u2);
+  float b0 = u0 * r, b1 = u1 * r, b2 = u2 * r;
+  if (clipped) {
+    const float c0 = fmaf(b2, cs->bary[2][0], fmaf(b1, cs->bary[1][0], b0 * cs->bary[0][0]));
+    const float c1 = fmaf(b2, cs->bary[2][1], fmaf(b1, cs->bary[1][1], b0 * cs->bary[0][1]));
+    const float c2 = fmaf(b2, cs->bary[2][2], fmaf(b1, cs->bary[1][2], b0 * cs->bary[0][2]));
+    b0 = c0; b1 = c1; b2 = c2;
+  }
+  float a[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) a[k] = fmaf(b2, pa.vary[2][k], fmaf(b1, pa.vary[1][k], b0 * pa.vary[0][k]));
+  float col[3] = {a[0], a[1], a[2]};  // light.frag: outColor = vec4(vColor, 1)
+  if (pa.material == 2u) {             // gizmo.frag:10-17: L = -(0,0,1); diff = max(dot(L, normalize(vNormal)), 0)
+    const f3 N = normalize3(mk3(a[3], a[4], a[5]));
+    const float diff = max0(dot3(mk3(-0.0f, -0.0f, -1.0f), N));
+    col[0] = a[0] * diff; col[1] = a[1] * diff; col[2] = a[2] * diff;
+  }
+  uint32_t px = 0xFF000000u;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) px |= srgb8(col[k], *tables) << (8 * k);
+  out_rgba8[(size_t)gy * (size_t)fp.width + (size_t)gx] = px;
 }
 
 }  // namespace bbr

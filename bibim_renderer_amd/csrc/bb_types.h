@@ -187,6 +187,12 @@ struct FrameParams {
   int32_t shard_rows;                // rows of the compact output when world > 1
   uint32_t ablate;                   // diagnostics only: bit0 skip raster, bit1 skip shading, bit2 skip broad list
   int32_t deferred;                  // 1: the reference's deferred path (gbuffer.vert/.frag + brdf.frag), 0: forward
+  // overlay pass only (k_*<..., OVERLAY>): primitives >= ov_first_gizmo_prim are the gizmo -- own viewport (centre
+  // ov_cx/ov_cy, half extent ov_half), scissor rectangle [ov_x0, ov_x1) x [ov_y0, ov_y1), and a depth bias that lets
+  // them win over everything drawn before (the reference clears the rectangle's depth first, src/main.cpp:150-160)
+  uint32_t ov_first_gizmo_prim;
+  float ov_half, ov_cx, ov_cy;
+  int32_t ov_x0, ov_y0, ov_x1, ov_y1;
 };
 
 }  // namespace bbr

@@ -106,6 +106,10 @@ struct FrameSlot {
   DeviceBuffer<uint32_t> d_tile_order;  // k_raster launch slots, heaviest tiles first
   DeviceBuffer<float4> d_frame;
   DeviceBuffer<float4> d_background;  // deferred path: colour of the pixels no geometry covers
+  DeviceBuffer<float> d_depth;        // option "overlays": the frame's resolved depth, for bbr_draw_overlays
+  bool has_depth = false;
+  FrameUniformBlock frame_u = {};     // the uniforms the frame in this slot was rendered with (overlays need them)
+  ViewUniformBlock view_u = {};
   DeviceBuffer<uint32_t> d_present;  // RGBA8 presented image of this slot's frame (bbr_present)
   struct {
     bool active = false;  // bbr_present was queued for the frame in this slot (re-queued if the frame is replayed)
@@ -126,7 +130,7 @@ struct FrameSlot {
   void release_all() {
     d_staging.release(); d_tris.release(); d_attrs.release(); d_clip.release();
     d_block_stats.release();
-    release_tile_buffers(); d_broad.release(); d_frame.release(); d_present.release(); d_background.release();
+    release_tile_buffers(); d_broad.release(); d_frame.release(); d_present.release(); d_background.release(); d_depth.release();
     if (h_staging) (void)hipHostFree(h_staging);
     h_staging = nullptr;
     if (h_flags) (void)hipHostFree(h_flags);
@@ -170,7 +174,7 @@ struct bbr_context {
   uint32_t n_live_draws = 0;
 
   static constexpr int kMaxSlots = 3;
-  static constexpr int kCounterBlocks = kMaxSlots + 1;
+  static constexpr int kCounterBlocks = kMaxSlots + 1;  // (the overlay pass runs on a drained context: any block is idle)
   FrameSlot slots[kMaxSlots];
   DeviceBuffer<Counters> d_counters;  // kMaxSlots + 1 blocks in rotation: each k_geometry clears the next frame's block
   uint64_t submit_epoch = 0;
@@ -193,6 +197,9 @@ struct bbr_context {
   // k_shade and the extra kernel plus the co-scheduled heavy tiles cost throughput (C3 184 -> 190 us, C5 +2 %):
   // off by default, option "tile_order".
   bool tile_order = false;
+  bool overlays = false;  // option "overlays": frames keep their depth so that bbr_draw_overlays can test against it
+  Mesh marker_mesh, gizmo_mesh;  // generateUVSphereMesh(0.1, 16, 16) and the caller's gizmo, both as Vertex meshes
+  FrameSlot ov;           // buffers of the overlay pass (its own little frame)
   bool deferred = false;  // option "render_pass": the reference's deferred path (its default) instead of the forward one
   bool dump_gbuffer = false;
   DeviceBuffer<uint2> d_gbuffer;  // width*height*4 (four RGBA16F texels per pixel), only while bbr_read_gbuffer runs
@@ -300,6 +307,7 @@ int ensure_slot_buffers(bbr_context *c, FrameSlot &s) {
 #endif
   HIP_TRY(c, s.d_tile_order.ensure(tiles * kOrderBuckets));
   if (c->deferred) HIP_TRY(c, s.d_background.ensure(1));
+  if (c->overlays && &s != &c->ov) HIP_TRY(c, s.d_depth.ensure((size_t)c->width * c->height));
   if (c->dump_gbuffer) HIP_TRY(c, c->d_gbuffer.ensure((size_t)c->width * c->height * 4, true));
   if (!c->ext_out) HIP_TRY(c, s.d_frame.ensure(out_rows * c->width));
   if (c->dump_vis) {
@@ -355,7 +363,8 @@ void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const Fra
                      s.d_clip.ptr, ctr, s.d_tile_count.ptr, s.d_bins.ptr, s.d_broad.ptr, s.d_frags.ptr,
                      s.d_frag_count.ptr, out, c->dump_vis ? c->d_vis_prim.ptr : nullptr,
                      c->dump_vis ? c->d_vis_depth.ptr : nullptr, ordered ? s.d_tile_order.ptr : nullptr,
-                     fp.deferred ? s.d_background.ptr : nullptr);
+                     fp.deferred ? s.d_background.ptr : nullptr, (c->overlays && c->world == 1) ? s.d_depth.ptr : nullptr);
+  s.has_depth = c->overlays && c->world == 1;
   if (ev && c->timing == 1) (void)hipEventRecord(ev[2], sg);
   if (ss != sg) {
     (void)hipEventRecord(s.ev_raster_done, sg);
@@ -493,6 +502,8 @@ int submit_frame_into(bbr_context *c, int slot_index) {
   HIP_TRY(c, hipGetLastError());
   s.in_flight = true;
   s.present.active = false;
+  s.frame_u = c->frame_u;
+  s.view_u = c->view_u;
   s.tone_enable = c->frame_u.enable_tone_mapping;
   s.tone_exposure = c->frame_u.exposure;
   s.out_used = out;
@@ -600,6 +611,216 @@ const void *last_output(const bbr_context *c) {
 }  // namespace
 
 // ================================================================================================
+// overlay subpass: light markers + corner gizmo over the presented image
+// ================================================================================================
+namespace {
+
+int upload_internal_mesh(bbr_context *c, Mesh &m, const std::vector<Vertex> &v, const std::vector<uint32_t> &idx) {
+  if (m.d_vertices) (void)hipFree(m.d_vertices);
+  if (m.d_indices) (void)hipFree(m.d_indices);
+  m = Mesh();
+  HIP_TRY(c, hipMalloc(&m.d_vertices, v.size() * sizeof(Vertex)));
+  HIP_TRY(c, upload_sync(m.d_vertices, v.data(), v.size() * sizeof(Vertex)));
+  HIP_TRY(c, hipMalloc(&m.d_indices, idx.size() * sizeof(uint32_t)));
+  HIP_TRY(c, upload_sync(m.d_indices, idx.data(), idx.size() * sizeof(uint32_t)));
+  m.n_vertices = (uint32_t)v.size();
+  m.n_indices = (uint32_t)idx.size();
+  m.alive = true;
+  return BBR_OK;
+}
+
+// generateUVSphereMesh(0.1f, 16, 16) as the light markers use it: positions only (src/main.cpp:953-957,
+// src/render.cpp:1774-1833; sphericalToCartesian src/vector_math.cpp:284-292; pi32 = 3.141592f)
+int ensure_marker_mesh(bbr_context *c) {
+  if (c->marker_mesh.alive) return BBR_OK;
+  constexpr float pi32 = 3.141592f, half_pi32 = pi32 * 0.5f, two_pi32 = pi32 * 2.f, radius = 0.1f;
+  constexpr int hdiv = 16, vdiv = 16;
+  std::vector<Vertex> v;
+  std::vector<uint32_t> idx;
+  for (int iv = 0; iv <= vdiv; ++iv) {
+    const float theta = -half_pi32 + pi32 * ((float)iv / (float)vdiv);
+    for (int ih = 0; ih <= hdiv; ++ih) {
+      const float phi = two_pi32 * ((float)ih / (float)hdiv);
+      const float cos_theta = cosf(theta);
+      Vertex vx = {};
+      vx.pos[0] = radius * cos_theta * cosf(phi);
+      vx.pos[1] = radius * sinf(theta);
+      vx.pos[2] = radius * cos_theta * sinf(phi);
+      v.push_back(vx);
+    }
+  }
+  for (int iv = 0; iv < vdiv; ++iv)
+    for (int ih = 0; ih < hdiv; ++ih) {
+      const uint32_t base = (uint32_t)((hdiv + 1) * iv + ih);
+      if (iv < vdiv - 1) { idx.push_back(base); idx.push_back(base + hdiv + 1); idx.push_back(base + hdiv + 2); }
+      if (iv > 0) { idx.push_back(base + hdiv + 2); idx.push_back(base + 1); idx.push_back(base); }
+    }
+  return upload_internal_mesh(c, c->marker_mesh, v, idx);
+}
+
+inline float dot3_fma(const float *a, const float *b) { return std::fmaf(a[2], b[2], std::fmaf(a[1], b[1], a[0] * b[0])); }
+
+// column-major M * v with the vertex stage's fma chain
+inline void mat_vec(const Mat4 &m, const float *v, float *out) {
+  for (int i = 0; i < 4; ++i)
+    out[i] = std::fmaf(m.M[3][i], v[3], std::fmaf(m.M[2][i], v[2], std::fmaf(m.M[1][i], v[1], m.M[0][i] * v[0])));
+}
+
+}  // namespace
+
+extern "C" int bbr_upload_gizmo(bbr_context *c, const void *gizmo_vertices, uint32_t n_vertices, const uint32_t *indices,
+                                uint32_t n_indices) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  if (!gizmo_vertices || !n_vertices) return fail(c, BBR_ERR_INVALID_ARGUMENT, "upload_gizmo: null/empty input");
+  HIP_TRY(c, hipSetDevice(c->device));
+  int rc = drain(c);
+  if (rc) return rc;
+  // bb::GizmoVertex {Pos, Color, Normal} (src/render.h:122-126) -> Vertex {pos, uv, normal, tangent := colour}
+  const float *g = static_cast<const float *>(gizmo_vertices);
+  std::vector<Vertex> v(n_vertices);
+  for (uint32_t i = 0; i < n_vertices; ++i) {
+    Vertex vx = {};
+    for (int k = 0; k < 3; ++k) {
+      vx.pos[k] = g[9 * i + k];
+      vx.tangent[k] = g[9 * i + 3 + k];
+      vx.normal[k] = g[9 * i + 6 + k];
+    }
+    v[i] = vx;
+  }
+  std::vector<uint32_t> idx;
+  if (indices) {
+    for (uint32_t i = 0; i < n_indices; ++i)
+      if (indices[i] >= n_vertices) return fail(c, BBR_ERR_INVALID_ARGUMENT, "upload_gizmo: index out of range");
+    idx.assign(indices, indices + n_indices / 3 * 3);
+  } else {
+    for (uint32_t i = 0; i < n_vertices / 3 * 3; ++i) idx.push_back(i);
+  }
+  return upload_internal_mesh(c, c->gizmo_mesh, v, idx);
+}
+
+extern "C" int bbr_draw_overlays(bbr_context *c, int32_t gizmo_extent) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  if (!c->have_frame || c->last_slot < 0) return fail(c, BBR_ERR_NOT_IN_FRAME, "draw_overlays: nothing rendered");
+  if (c->world > 1) return fail(c, BBR_ERR_INVALID_ARGUMENT, "draw_overlays: not available with a partition");
+  int rc = sync_and_fix(c, nullptr);  // the overlay pass is synchronous: it is a debugging aid, not part of the hot path
+  if (rc) return rc;
+  FrameSlot &fs = c->slots[c->last_slot];
+  if (!fs.has_depth) return fail(c, BBR_ERR_INVALID_ARGUMENT, "draw_overlays: the frame was rendered without option \"overlays\"");
+  if (!fs.present.active) return fail(c, BBR_ERR_NOT_IN_FRAME, "draw_overlays: call bbr_present first (overlays go into the presented image)");
+  rc = ensure_marker_mesh(c);
+  if (rc) return rc;
+  rc = ensure_srgb_tables(c);
+  if (rc) return rc;
+
+  // ---- the pass's draw list: instanced markers, then the gizmo (src/main.cpp:138-171) ----
+  const int n_lights = std::max(0, std::min(fs.frame_u.num_lights, kMaxNumLights));
+  const bool gizmo = gizmo_extent > 0 && c->gizmo_mesh.alive;
+  const Mat4 pv = proj_view(fs.view_u);  // uProjMat * uViewMat
+  std::vector<InstanceBlock> inst((size_t)n_lights + (gizmo ? 1 : 0));
+  for (int i = 0; i < n_lights; ++i) {
+    const Light &l = fs.frame_u.lights[i];
+    InstanceBlock ib = {};
+    ib.model = pv;  // (P*V) * modelMat, modelMat = identity with column 3 = (pos, 1): light.vert:11-14
+    const float p[4] = {l.pos[0], l.pos[1], l.pos[2], 1.0f};
+    mat_vec(pv, p, ib.model.M[3]);
+    ib.inv_model.M[0][0] = l.color[0]; ib.inv_model.M[0][1] = l.color[1]; ib.inv_model.M[0][2] = l.color[2];
+    inst[i] = ib;
+  }
+  if (gizmo) {  // gizmo.vert:13-24
+    const Mat4 &uv = fs.view_u.view;
+    const float right[3] = {uv.M[0][0], uv.M[1][0], uv.M[2][0]}, up[3] = {uv.M[0][1], uv.M[1][1], uv.M[2][1]};
+    const float look[3] = {uv.M[0][2], uv.M[1][2], uv.M[2][2]};
+    const float view_pos[3] = {look[0] * -27.0f, look[1] * -27.0f, look[2] * -27.0f};
+    ViewUniformBlock gv = fs.view_u;
+    gv.view.M[3][0] = -dot3_fma(view_pos, right);
+    gv.view.M[3][1] = -dot3_fma(view_pos, up);
+    gv.view.M[3][2] = -dot3_fma(view_pos, look);
+    const float d = 1.0f / tanf(0.261799f);
+    gv.proj.M[0][0] = d;
+    gv.proj.M[1][1] = -d;
+    InstanceBlock ib = {};
+    ib.model = proj_view(gv);
+    ib.inv_model = gv.view;
+    inst[(size_t)n_lights] = ib;
+  }
+  const uint32_t marker_tris = c->marker_mesh.n_indices / 3, gizmo_tris = gizmo ? c->gizmo_mesh.n_indices / 3 : 0;
+  const uint32_t n_prims = marker_tris * (uint32_t)n_lights + gizmo_tris;
+  if (!n_prims) return BBR_OK;
+  std::vector<DrawDesc> draws;
+  FrameSlot &s = c->ov;
+  const size_t draws_bytes = 2 * sizeof(DrawDesc), inst_bytes = inst.size() * sizeof(InstanceBlock);
+  HIP_TRY(c, s.d_staging.ensure(draws_bytes + inst_bytes));
+  const InstanceBlock *d_inst = reinterpret_cast<const InstanceBlock *>(s.d_staging.ptr + draws_bytes);
+  if (n_lights) {
+    DrawDesc d = {};
+    d.vertices = c->marker_mesh.d_vertices; d.indices = c->marker_mesh.d_indices; d.instances = d_inst;
+    d.n_instances = (uint32_t)n_lights; d.tris_per_instance = marker_tris; d.first_prim = 0; d.material = 1u;  // program: marker
+    draws.push_back(d);
+  }
+  if (gizmo) {
+    DrawDesc d = {};
+    d.vertices = c->gizmo_mesh.d_vertices; d.indices = c->gizmo_mesh.d_indices; d.instances = d_inst + n_lights;
+    d.n_instances = 1; d.tris_per_instance = gizmo_tris; d.first_prim = marker_tris * (uint32_t)n_lights; d.material = 2u;  // program: gizmo
+    draws.push_back(d);
+  }
+  HIP_TRY(c, upload_sync(s.d_staging.ptr, draws.data(), draws.size() * sizeof(DrawDesc)));
+  HIP_TRY(c, upload_sync(s.d_staging.ptr + draws_bytes, inst.data(), inst_bytes));
+  const DrawDesc *d_draws = reinterpret_cast<const DrawDesc *>(s.d_staging.ptr);
+
+  for (int attempt = 0; attempt < 8; ++attempt) {
+    const size_t tiles = (size_t)c->tiles_x() * c->tiles_y();
+    HIP_TRY(c, s.d_tris.ensure(n_prims));
+    HIP_TRY(c, s.d_attrs.ensure(n_prims));
+    HIP_TRY(c, s.d_clip.ensure(c->clip_cap));
+    HIP_TRY(c, c->d_counters.ensure(bbr_context::kCounterBlocks, true));
+    HIP_TRY(c, s.d_block_stats.ensure((n_prims + 255) / 256, true));
+    HIP_TRY(c, s.d_tile_count.ensure(tiles * kBinClasses, true));
+    HIP_TRY(c, s.d_bins.ensure(tiles * kBinClasses * c->bin_cap));
+    HIP_TRY(c, s.d_broad.ensure(c->broad_cap));
+    HIP_TRY(c, s.d_frags.ensure(tiles * (size_t)(c->tile_w() * c->tile_h())));
+    HIP_TRY(c, s.d_frag_count.ensure(tiles, true));
+    FrameParams fp = make_params(c);
+    fp.deferred = 0;
+    fp.ov_first_gizmo_prim = gizmo ? marker_tris * (uint32_t)n_lights : 0xFFFFFFFFu;
+    const int x0 = c->width - gizmo_extent;
+    fp.ov_half = 0.5f * (float)gizmo_extent;
+    fp.ov_cx = (float)x0 + fp.ov_half;
+    fp.ov_cy = fp.ov_half;
+    fp.ov_x0 = std::max(x0, 0); fp.ov_y0 = 0; fp.ov_x1 = c->width; fp.ov_y1 = std::min(gizmo_extent, c->height);
+    s.ctr_index = (int)(c->submit_epoch++ % bbr_context::kCounterBlocks);
+    Counters *ctr = c->d_counters.ptr + s.ctr_index, *ctr_next = c->d_counters.ptr + (s.ctr_index + 1) % bbr_context::kCounterBlocks;
+    hipStream_t st = c->shade_stream();
+    const Mat4 ident = {};
+    auto launch = [&](auto tw, auto th) {
+      constexpr int TW = decltype(tw)::value, TH = decltype(th)::value;
+      hipLaunchKernelGGL((k_geometry<TW, TH, true>), dim3((n_prims + 255) / 256), dim3(256), 0, st, d_draws, (uint32_t)draws.size(),
+                         n_prims, ident, ident, fp, s.d_tris.ptr, s.d_attrs.ptr, s.d_clip.ptr, ctr, s.d_tile_count.ptr,
+                         s.d_bins.ptr, s.d_broad.ptr, c->d_materials.ptr, s.d_block_stats.ptr, ctr_next);
+      hipLaunchKernelGGL((k_raster<TW, TH, true>), dim3(fp.tiles_x, fp.tiles_y), dim3(kTileThreads), 0, st, fp, s.d_tris.ptr,
+                         s.d_clip.ptr, ctr, s.d_tile_count.ptr, s.d_bins.ptr, s.d_broad.ptr, s.d_frags.ptr, s.d_frag_count.ptr,
+                         (float4 *)nullptr, (uint32_t *)nullptr, (float *)nullptr, (const uint32_t *)nullptr,
+                         (const float4 *)nullptr, fs.d_depth.ptr);
+      constexpr int kChunks = TW * TH / kShadeThreads;
+      hipLaunchKernelGGL((k_shade_overlay<TW, TH>), dim3(fp.tiles_x * kChunks, fp.tiles_y), dim3(kShadeThreads), 0, st, fp,
+                         s.d_attrs.ptr, s.d_clip.ptr, s.d_frags.ptr, s.d_frag_count.ptr, c->d_srgb_tables.ptr, fs.present.out);
+    };
+    if (c->tile_mode == 0) launch(std::integral_constant<int, 64>{}, std::integral_constant<int, 64>{});
+    else launch(std::integral_constant<int, 32>{}, std::integral_constant<int, 32>{});
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(st));
+    Counters h = {};
+    HIP_TRY(c, hipMemcpy(&h, ctr, sizeof h, hipMemcpyDeviceToHost));
+    if (!h.overflow) return BBR_OK;
+    // an overlay triangle did not fit: the presented pixels it already wrote are a subset of the right ones (same
+    // colours), so growing and drawing again on top is correct
+    rc = apply_growth(c, h.overflow, h.bin_need);
+    if (rc) return rc;
+    if (s.d_tile_count.ptr) HIP_TRY(c, zero_fill_sync(s.d_tile_count.ptr, s.d_tile_count.cap * sizeof(uint32_t)));
+  }
+  return fail(c, BBR_ERR_CAPACITY, "draw_overlays: capacity still exceeded after 8 growth steps");
+}
+
+// ================================================================================================
 // C ABI
 // ================================================================================================
 
@@ -686,6 +907,13 @@ int bbr_destroy(bbr_context *c) {
     if (s.ev_raster_done) (void)hipEventDestroy(s.ev_raster_done);
     if (s.ev_shade_done) (void)hipEventDestroy(s.ev_shade_done);
   }
+  for (Mesh *m : {&c->marker_mesh, &c->gizmo_mesh}) {
+    if (m->d_vertices) (void)hipFree(m->d_vertices);
+    if (m->d_indices) (void)hipFree(m->d_indices);
+  }
+  c->ov.release_all();
+  if (c->ov.ev_raster_done) (void)hipEventDestroy(c->ov.ev_raster_done);
+  if (c->ov.ev_shade_done) (void)hipEventDestroy(c->ov.ev_shade_done);
   for (auto &e : c->ring)
     if (e) (void)hipEventDestroy(e);
   for (auto &e : c->present_ring)
@@ -1183,6 +1411,8 @@ int bbr_set_option(bbr_context *c, const char *name, int64_t value) {
     for (FrameSlot &s : c->slots) s.d_bins.release();
   } else if (n == "ablate") {
     c->ablate = (uint32_t)value;
+  } else if (n == "overlays") {
+    c->overlays = value != 0;
   } else if (n == "tile_order") {
     c->tile_order = value != 0;
   } else if (n == "broad_threshold") {

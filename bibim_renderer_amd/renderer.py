@@ -153,6 +153,16 @@ class Renderer:
         self._check(self._L.bbr_read_gbuffer(self._ctx, _ptr(out)))
         return out
 
+    # -- overlay subpass (light markers + corner gizmo over the presented image) --
+    def upload_gizmo(self, vertices, indices=None):
+        """vertices: float32 [n, 9] = pos, colour, normal (bb::GizmoVertex); indices: uint32 [m] or None"""
+        v = np.ascontiguousarray(vertices, np.float32).reshape(-1, 9)
+        i = None if indices is None else np.ascontiguousarray(indices, np.uint32)
+        self._check(self._L.bbr_upload_gizmo(self._ctx, _ptr(v), v.shape[0], None if i is None else _ptr(i), 0 if i is None else i.size))
+
+    def draw_overlays(self, gizmo_extent=100):
+        self._check(self._L.bbr_draw_overlays(self._ctx, int(gizmo_extent)))
+
     # -- presentation (tone map + sRGB + UNORM8; SURVEY 8(f) rank 1) --
     def present(self, rgba8_device_ptr=None, hdr16=True):
         """queue k_present for the last frame; EnableToneMapping / Exposure come from its FrameUniformBlock"""

@@ -163,6 +163,7 @@ int bbr_timing_summary(bbr_context *ctx, uint32_t *out_frames, float *out_avg_fr
  *   "bin_cap" n              initial references per (tile, raster class); grows by itself on overflow
  *   "broad_threshold" n      triangles touching more than n x n tiles go to the every-tile list
  *   "render_pass" 0|1        0: forward path (default, the path BASELINE measures), 1: deferred path
+ *   "overlays" 0|1           keep every frame's resolved depth for bbr_draw_overlays (default 0)
  *   "tile_order" 0|1         launch the heaviest raster tiles first (shorter single frame, lower pipelined
  *                            throughput; default 0)
  *   "ablate" bits            diagnostics only: skip parts of the pipeline (see bb_kernels.hip.h) */
@@ -180,6 +181,21 @@ int bbr_selftest_rcp(bbr_context *ctx, uint32_t lo_bits, uint32_t hi_bits, uint6
  * bbr_read_gbuffer re-renders the last frame and returns width*height*16 floats, per pixel
  * position.xyz 1 | normal.xyz 0 | albedo.rgb 0 | metallic roughness ao height (binary16 values widened); synchronises. */
 int bbr_read_gbuffer(bbr_context *ctx, float *gbuffer_host);
+
+/* ---- overlay subpass ----
+ * The reference draws its light markers and the corner gizmo into the swapchain image after tone mapping, depth-tested
+ * against the scene (recordCommand, src/main.cpp:128-171; light.vert/.frag on generateUVSphereMesh(0.1, 16, 16), one
+ * instance per light; gizmo.vert/.frag in a gizmo_extent^2 viewport at the top-right whose depth is cleared first).
+ *   bbr_set_option(ctx, "overlays", 1)   frames keep their resolved depth (4 bytes per pixel) from now on
+ *   bbr_upload_gizmo                     the gizmo mesh: 36-byte bb::GizmoVertex records (Pos, Color, Normal,
+ *                                        src/render.h:122-126), optional uint32 indices (see bba_load_obj_gizmo)
+ *   bbr_draw_overlays                    after bbr_present of the last frame: draws markers (the frame's own lights) and,
+ *                                        if gizmo_extent > 0 and a gizmo was uploaded, the gizmo (the reference uses
+ *                                        100) over the presented image.  Synchronous: a debugging aid, not part of the
+ *                                        hot path.  Not available with a partition. */
+int bbr_upload_gizmo(bbr_context *ctx, const void *gizmo_vertices, uint32_t n_vertices, const uint32_t *indices,
+                     uint32_t n_indices);
+int bbr_draw_overlays(bbr_context *ctx, int32_t gizmo_extent);
 
 /* ---- presentation: the step after the path ----
  * Replaces the tone-map subpass + swapchain write (src/main.cpp:123-126, src/shaders/hdr_tone_mapping.frag:9-18,
