@@ -38,3 +38,9 @@ void ref_camera_view(const float *pos, float yaw, float pitch, float *out) {
 }
 unsigned ref_sizeof_mat4() { return (unsigned)sizeof(Mat4); }
 }
+
+// sphericalToCartesian (src/vector_math.cpp:284-292): pins the light-marker sphere of the overlay oracle
+extern "C" void ref_spherical_to_cartesian(float r, float theta, float phi, float *out3) {
+  Float3 c = sphericalToCartesian({r, theta, phi});
+  out3[0] = c.X; out3[1] = c.Y; out3[2] = c.Z;
+}

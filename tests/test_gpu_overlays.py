@@ -121,3 +121,20 @@ def test_error_paths(maps64):
     with pytest.raises(BibimError):
         r.upload_gizmo(np.zeros((3, 9), np.float32), np.array([0, 1, 7], np.uint32))   # index out of range
     r.close()
+
+
+def test_frozen_fixture(maps64):
+    """the committed overlaid image (reference default lights incl. a directional one, 48-pixel gizmo corner)"""
+    z = np.load(os.path.join(GOLDEN, "overlays.npz"))
+    raw, gi, gv = gizmo()
+    sc = scenes.shaderball_scene(configs.C2.scaled(160, 90, 64), bbo.MaterialData(maps64))
+    sc.frame = scenes.frame_uniforms(scenes.reference_default_lights(), 1, 1.7)
+    r = Renderer(sc.width, sc.height)
+    r.set_option("overlays", 1)
+    r.upload_gizmo(raw, gi)
+    r.render_scene(sc)
+    r.present()
+    assert np.array_equal(r.read_presented(), z["c2_160x90_base"])
+    r.draw_overlays(48)
+    assert np.array_equal(r.read_presented(), z["c2_160x90_overlaid"])
+    r.close()

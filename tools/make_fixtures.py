@@ -200,6 +200,58 @@ def reference_pngs():
     print("reference_pngs", len(out), "files")
 
 
+def uv_sphere():
+    """The light-marker sphere (generateUVSphereMesh(0.1, 16, 16), src/main.cpp:953-957): every position computed by the
+    REFERENCE's own sphericalToCartesian (oracle/_ref/libbb_ref.so) from the angles of src/render.cpp:1805-1812, plus the
+    index pattern of :1825-1838 restated here.  Pins bbo_uv_sphere and the library's marker mesh."""
+    ref = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libbb_ref.so"))
+    ref.ref_spherical_to_cartesian.argtypes = [C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float)]
+    f32 = np.float32
+    pi32 = f32(3.141592)
+    half_pi, two_pi = pi32 * f32(0.5), pi32 * f32(2.0)
+    H = V = 16
+    pos = np.zeros(((H + 1) * (V + 1), 3), np.float32)
+    k = 0
+    for v in range(V + 1):
+        theta = f32(-half_pi + pi32 * (f32(v) / f32(V)))
+        for h in range(H + 1):
+            phi = f32(two_pi * (f32(h) / f32(H)))
+            out = (C.c_float * 3)()
+            ref.ref_spherical_to_cartesian(f32(0.1), theta, phi, out)
+            pos[k] = out[:]
+            k += 1
+    idx = []
+    for v in range(V):
+        for h in range(H):
+            base = (H + 1) * v + h
+            if v < V - 1:
+                idx += [base, base + H + 1, base + H + 2]
+            if v > 0:
+                idx += [base + H + 2, base + 1, base]
+    idx = np.array(idx, np.uint32)
+    np.savez_compressed(os.path.join(GOLD, "uv_sphere.npz"), pos_bits=pos.view(np.uint32), indices=idx)
+    print("uv_sphere", pos.shape, idx.shape, hashlib.sha256(pos.tobytes()).hexdigest()[:16])
+
+
+def overlays():
+    """Overlay subpass of the oracle frozen: markers + gizmo over the presented golden C2 160x90 frame."""
+    from bibim_renderer_amd import configs, textures
+    from oracle import bbo, scenes
+    mat = bbo.MaterialData(textures.make_material(64))
+    sc = scenes.shaderball_scene(configs.C2.scaled(160, 90, 64), mat)
+    sc.frame = scenes.frame_uniforms(scenes.reference_default_lights(), 1, 1.7)
+    hdr, _, depth, _ = bbo.render(sc)
+    base = bbo.present(hdr, 1, 1.7)
+    g = np.load(os.path.join(GOLD, "gizmo.npz"))
+    gv = np.zeros(len(g["vertices"]), bbo.GIZMO_VERTEX_DTYPE)
+    gv["pos"], gv["color"], gv["normal"] = g["vertices"][:, 0:3], g["vertices"][:, 3:6], g["vertices"][:, 6:9]
+    img, st = bbo.overlay(sc.frame, sc.view, depth, base, gv, g["indices"], 48)
+    np.savez_compressed(os.path.join(GOLD, "overlays.npz"), c2_160x90_base=base, c2_160x90_overlaid=img)
+    json.dump({"stats": st, "gizmo_extent": 48, "sha256": hashlib.sha256(img.tobytes()).hexdigest()},
+              open(os.path.join(GOLD, "overlays.json"), "w"), indent=1)
+    print("overlays", st)
+
+
 def present():
     """Presentation contract frozen: the 255 sRGB thresholds (bit patterns) and the presented bytes of the golden
     C2 160x90 frame with and without tone mapping (sha256 + the image itself, 57 KB each)."""
@@ -236,6 +288,6 @@ def deferred():
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["shaderball", "math_golden", "default_texels", "gizmo", "golden_frames", "n_shaded", "present", "deferred", "reference_pngs"]
+    which = sys.argv[1:] or ["shaderball", "math_golden", "default_texels", "gizmo", "golden_frames", "n_shaded", "present", "deferred", "reference_pngs", "uv_sphere", "overlays"]
     for w in which:
         globals()[w]()
