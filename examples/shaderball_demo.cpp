@@ -4,7 +4,8 @@
 //
 //   g++ -std=c++17 -O2 -Iinclude examples/shaderball_demo.cpp -Lbibim_renderer_amd -lbibim_hip -Wl,-rpath,$PWD/bibim_renderer_amd -o demo
 //   ./demo --fbx resources/ShaderBall.fbx            (or --vertices-bin file: raw bb::Vertex records)
-//          [--size 1920 1080] [--grid 4] [--frames 100] [--deferred] [--tone-map 1.0] [--pbr-dir resources/pbr/bark1] [--out frame.ppm]
+//          [--size 1920 1080] [--grid 4] [--frames 100] [--deferred] [--tone-map 1.0] [--pbr-dir resources/pbr/bark1]
+//          [--gizmo resources/gizmo.obj] [--out frame.ppm]        (--gizmo also turns the light markers on)
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -24,7 +25,7 @@ int main(int argc, char **argv) {
   int width = 1920, height = 1080, grid = 1, frames = 100;
   bool deferred = false, tone = false;
   float exposure = 1.f;
-  std::string fbx, vbin, out = "frame.ppm", pbr;
+  std::string fbx, vbin, out = "frame.ppm", pbr, gizmo;
   for (int i = 1; i < argc; ++i) {
     std::string a = argv[i];
     if (a == "--fbx" && i + 1 < argc) fbx = argv[++i];
@@ -35,6 +36,7 @@ int main(int argc, char **argv) {
     else if (a == "--deferred") deferred = true;
     else if (a == "--tone-map" && i + 1 < argc) { tone = true; exposure = (float)std::atof(argv[++i]); }
     else if (a == "--pbr-dir" && i + 1 < argc) pbr = argv[++i];
+    else if (a == "--gizmo" && i + 1 < argc) gizmo = argv[++i];
     else if (a == "--out" && i + 1 < argc) out = argv[++i];
     else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
   }
@@ -74,6 +76,16 @@ int main(int argc, char **argv) {
       if (bbr_upload_material(ctx, none, &material) != BBR_OK) return die("bbr_upload_material", ctx);
     }
 
+    // --- overlay subpass (src/main.cpp:128-171): the gizmo mesh, and frames that keep their depth
+    if (!gizmo.empty()) {
+      void *gv = nullptr;
+      uint32_t *gi = nullptr, ngv = 0, ngi = 0;
+      if (bba_load_obj_gizmo(gizmo.c_str(), &gv, &ngv, &gi, &ngi) != BBA_OK) return die("bba_load_obj_gizmo");
+      if (bbr_set_option(ctx, "overlays", 1) != BBR_OK || bbr_upload_gizmo(ctx, gv, ngv, gi, ngi) != BBR_OK) return die("bbr_upload_gizmo", ctx);
+      bba_free(gv);
+      bba_free(gi);
+    }
+
     bb::ShaderBallScene scene(ctx, ball.data(), (uint32_t)ball.size(), grid);
     scene.SceneRenderPassType = deferred ? bb::RenderPassType::Deferred : bb::RenderPassType::Forward;
     bb::FreeLookCamera cam;  // reference default: origin, yaw = pitch = 0 (src/main.cpp:1123)
@@ -99,7 +111,9 @@ int main(int argc, char **argv) {
 
     // --- present (tone map + sRGB + RGBA8) and write it out
     std::vector<uint8_t> rgba((size_t)width * height * 4);
-    if (bbr_present(ctx, nullptr, 1) != BBR_OK || bbr_read_presented(ctx, rgba.data()) != BBR_OK) return die("bbr_present", ctx);
+    if (bbr_present(ctx, nullptr, 1) != BBR_OK) return die("bbr_present", ctx);
+    if (!gizmo.empty() && bbr_draw_overlays(ctx, 100) != BBR_OK) return die("bbr_draw_overlays", ctx);
+    if (bbr_read_presented(ctx, rgba.data()) != BBR_OK) return die("bbr_read_presented", ctx);
     FILE *f = std::fopen(out.c_str(), "wb");
     if (!f) { std::perror(out.c_str()); rc = 1; }
     else {

@@ -22,8 +22,22 @@ def test_native_demo_writes_the_oracles_image(tmp_path, deferred):
     ball = S.load_shaderball_vertices()
     (tmp_path / "ball.bin").write_bytes(np.ascontiguousarray(ball).tobytes())
     W, H = 480, 270
+    # a gizmo.obj written from the committed fixture (one triangle per face, one material per colour)
+    g = np.load(os.path.join(ROOT, "tests", "golden", "gizmo.npz"))
+    gvx, gix = g["vertices"], g["indices"]
+    colours = sorted({tuple(c) for c in gvx[:, 3:6].tolist()})
+    with open(tmp_path / "g.mtl", "w") as f:
+        for k, c in enumerate(colours):
+            f.write(f"newmtl m{k}\nKd {c[0]!r} {c[1]!r} {c[2]!r}\n")
+    with open(tmp_path / "g.obj", "w") as f:
+        f.write("mtllib g.mtl\n")
+        for v in gvx:
+            f.write(f"v {float(v[0])!r} {float(v[1])!r} {float(v[2])!r}\nvn {float(v[6])!r} {float(v[7])!r} {float(v[8])!r}\n")
+        for t in gix.reshape(-1, 3):
+            f.write(f"usemtl m{colours.index(tuple(gvx[t[0], 3:6].tolist()))}\n")
+            f.write("f " + " ".join(f"{i + 1}//{i + 1}" for i in t) + "\n")
     cmd = [str(exe), "--vertices-bin", str(tmp_path / "ball.bin"), "--size", str(W), str(H), "--frames", "5", "--tone-map", "1.5",
-           "--out", str(tmp_path / "f.ppm")] + (["--deferred"] if deferred else [])
+           "--gizmo", str(tmp_path / "g.obj"), "--out", str(tmp_path / "f.ppm")] + (["--deferred"] if deferred else [])
     out = subprocess.run(cmd, check=True, capture_output=True, text=True).stdout
     assert "Mpixels/s" in out and ("deferred" if deferred else "forward") in out
     raw = (tmp_path / "f.ppm").read_bytes()
@@ -35,6 +49,12 @@ def test_native_demo_writes_the_oracles_image(tmp_path, deferred):
     osc = scenes.shaderball_scene(configs.C2.scaled(W, H, 64), bbo.MaterialData())
     osc.frame = scenes.frame_uniforms(scenes.reference_default_lights(), 1, 1.5)
     osc.view["enable_normal_map"] = 1
-    hdr = bbo.render_deferred(osc)[0] if deferred else bbo.render(osc)[0]
-    want = bbo.present(hdr, 1, 1.5)[..., :3]
-    assert np.array_equal(got, want)
+    if deferred:
+        hdr, _, _, depth, _ = bbo.render_deferred(osc)
+    else:
+        hdr, _, depth, _ = bbo.render(osc)
+    gv = np.zeros(len(gvx), bbo.GIZMO_VERTEX_DTYPE)
+    gv["pos"], gv["color"], gv["normal"] = gvx[:, 0:3], gvx[:, 3:6], gvx[:, 6:9]
+    # the OBJ round trip expands to one vertex per corner, which draws the same triangles
+    want, _ = bbo.overlay(osc.frame, osc.view, depth, bbo.present(hdr, 1, 1.5), gv, gix, 100)
+    assert np.array_equal(got, want[..., :3])
