@@ -1000,13 +1000,19 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
     const uint32_t *__restrict__ bins, const BroadTri *__restrict__ broad_list,
     unsigned long long *__restrict__ frags, uint32_t *__restrict__ frag_count, float4 *__restrict__ out,
     uint32_t *__restrict__ vis_prim, float *__restrict__ vis_depth, const uint32_t *__restrict__ tile_order,
-    const float4 *__restrict__ background, float *__restrict__ depth_io) {
+    const float4 *__restrict__ background, float *__restrict__ depth_io, uint32_t *__restrict__ host_flags) {
   constexpr int TILE_PIXELS = TILE_W * TILE_H;
   __shared__ unsigned long long keys[TILE_PIXELS];
   __shared__ StagedTri st;
   __shared__ uint32_t s_count;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // {overflow bits, bin_need} of this frame straight into pinned host memory (final since k_geometry ended): the host
+  // looks at them when it reuses the frame's slot -- two stores instead of a copy kernel on the stream
+  if (host_flags && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
+    host_flags[0] = ctr->overflow;
+    host_flags[1] = ctr->bin_need;
+  }
   // launch slot -> tile: plain row order, or heaviest tiles first (k_tile_order)
   uint32_t slot = blockIdx.y * gridDim.x + blockIdx.x;
   if (tile_order) {

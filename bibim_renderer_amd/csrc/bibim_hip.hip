@@ -89,8 +89,8 @@ struct DeviceBuffer {
 // Everything one frame in flight owns.
 struct FrameSlot {
   void *h_staging = nullptr;  // pinned: lights, draw descriptors, instances
-  uint32_t *h_flags = nullptr;  // pinned {overflow bits, bin_need} of the frame last rendered in this slot (copied back
-                                // behind its k_shade): lets a host that never synchronises still grow the capacities
+  uint32_t *h_flags = nullptr;  // pinned, device-visible {overflow bits, bin_need} of the frame last rendered in this
+                                // slot (stored by its k_raster): lets a host that never synchronises still grow capacities
   size_t staging_cap = 0;
   DeviceBuffer<uint8_t> d_staging;
   DeviceBuffer<RasterTri> d_tris;
@@ -363,7 +363,8 @@ void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const Fra
                      s.d_clip.ptr, ctr, s.d_tile_count.ptr, s.d_bins.ptr, s.d_broad.ptr, s.d_frags.ptr,
                      s.d_frag_count.ptr, out, c->dump_vis ? c->d_vis_prim.ptr : nullptr,
                      c->dump_vis ? c->d_vis_depth.ptr : nullptr, ordered ? s.d_tile_order.ptr : nullptr,
-                     fp.deferred ? s.d_background.ptr : nullptr, (c->overlays && c->world == 1) ? s.d_depth.ptr : nullptr);
+                     fp.deferred ? s.d_background.ptr : nullptr, (c->overlays && c->world == 1) ? s.d_depth.ptr : nullptr,
+                     s.h_flags);
   s.has_depth = c->overlays && c->world == 1;
   if (ev && c->timing == 1) (void)hipEventRecord(ev[2], sg);
   if (ss != sg) {
@@ -385,8 +386,6 @@ void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const Fra
     hipLaunchKernelGGL((k_shade<TW, TH, false>), dim3(fp.tiles_x * kChunks, grid_y), dim3(kShadeThreads), 0, ss, fp, sp, d_lights,
                        s.d_attrs.ptr, s.d_clip.ptr, s.d_frags.ptr, s.d_frag_count.ptr, c->d_materials.ptr, out,
                        (uint2 *)nullptr);
-  // {overflow, bin_need} of this frame, for submit_frame_into's self-healing check when this slot comes round again
-  (void)hipMemcpyAsync(s.h_flags, &ctr->overflow, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ss);
   (void)hipEventRecord(s.ev_shade_done, ss);
   if (ev) {
     (void)hipEventRecord(ev[4], ss);
@@ -799,7 +798,7 @@ extern "C" int bbr_draw_overlays(bbr_context *c, int32_t gizmo_extent) {
       hipLaunchKernelGGL((k_raster<TW, TH, true>), dim3(fp.tiles_x, fp.tiles_y), dim3(kTileThreads), 0, st, fp, s.d_tris.ptr,
                          s.d_clip.ptr, ctr, s.d_tile_count.ptr, s.d_bins.ptr, s.d_broad.ptr, s.d_frags.ptr, s.d_frag_count.ptr,
                          (float4 *)nullptr, (uint32_t *)nullptr, (float *)nullptr, (const uint32_t *)nullptr,
-                         (const float4 *)nullptr, fs.d_depth.ptr);
+                         (const float4 *)nullptr, fs.d_depth.ptr, (uint32_t *)nullptr);
       constexpr int kChunks = TW * TH / kShadeThreads;
       hipLaunchKernelGGL((k_shade_overlay<TW, TH>), dim3(fp.tiles_x * kChunks, fp.tiles_y), dim3(kShadeThreads), 0, st, fp,
                          s.d_attrs.ptr, s.d_clip.ptr, s.d_frags.ptr, s.d_frag_count.ptr, c->d_srgb_tables.ptr, fs.present.out);

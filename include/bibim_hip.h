@@ -101,8 +101,9 @@ int bbr_begin_frame(bbr_context *ctx);
 int bbr_draw(bbr_context *ctx, int32_t mesh, int32_t material, const void *instance_blocks, uint32_t n_instances);
 /* Capacities that depend on the scene (tile bins, every-tile list, clip arena) grow by themselves.  A synchronising
  * call (bbr_synchronize, bbr_get_stats, any read-back) that finds the last frame overflowed re-renders it with larger
- * buffers before returning.  A host that only streams frames is covered too: every frame reports its overflow bits
- * back (8 bytes, asynchronously) and the next frame that reuses its slot grows the capacities first -- the overflowed
+ * buffers before returning.  A host that only streams frames is covered too: every frame stores its overflow bits
+ * into pinned host memory (two words, from the raster kernel) and the next frame that reuses its slot grows the
+ * capacities first -- the overflowed
  * frames themselves (at most frames_in_flight + 1 of them) are incomplete and stay so. */
 int bbr_end_frame(bbr_context *ctx);   /* queues the kernels; asynchronous */
 int bbr_replay_frame(bbr_context *ctx); /* re-submit the last recorded frame (same draws and uniforms) */
