@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cmath>
 #include <limits>
+#include <memory>
 #include <mutex>
 #include <unordered_set>
 #include <cstdio>
@@ -515,7 +516,8 @@ int ensure_srgb_tables(bbr_context *c) {
   if (!c->d_srgb_tables.ptr) {
     // t_k = float(decode((k - 0.5) / 255)) (the same table the CPU oracle builds), then the table keyed by the
     // float's top bits: thresholds <= lower edge of each cell; a cell may contain at most one threshold
-    static SrgbTables h;
+    auto hp = std::make_unique<SrgbTables>();  // 4.3 KB: not on the stack, not shared between contexts
+    SrgbTables &h = *hp;
     for (int k = 1; k <= 255; ++k) {
       const double b = ((double)k - 0.5) / 255.0;
       h.thr[k - 1] = (float)(b <= 0.04045 ? b / 12.92 : std::pow((b + 0.055) / 1.055, 2.4));
@@ -970,6 +972,15 @@ int bbr_upload_material(bbr_context *c, const bbr_image maps[BBR_MAP_COUNT], int
   if (!maps || !out_material) return fail(c, BBR_ERR_INVALID_ARGUMENT, "upload_material: null input");
   HIP_TRY(c, hipSetDevice(c->device));
   Material m;
+  struct Guard {  // frees what a failed upload had already allocated
+    Material *m;
+    ~Guard() {
+      if (!m) return;
+      for (auto &p : m->d_texels)
+        if (p) (void)hipFree(p);
+      if (m->d_packed) (void)hipFree(m->d_packed);
+    }
+  } guard{&m};
   for (int i = 0; i < kMapCount; ++i) {
     const bbr_image &im = maps[i];
     if (im.rgba && im.width > 0 && im.height > 0) {
@@ -1025,6 +1036,7 @@ int bbr_upload_material(bbr_context *c, const bbr_image maps[BBR_MAP_COUNT], int
     }
   }
   m.alive = true;
+  guard.m = nullptr;  // ownership passes to the context
   c->materials.push_back(m);
   c->materials_dirty = true;
   *out_material = (int32_t)c->materials.size() - 1;
