@@ -335,3 +335,27 @@ def test_a_host_that_never_synchronises_still_outgrows_an_overflow(maps64):
         assert all(exact[first_good:]), exact         # and it stays right
         assert r.stats()["bin_overflow"] >= 1
         r.close()
+
+
+def test_two_and_a_half_million_triangles_at_4k(maps256):
+    """256 ShaderBalls (2 502 658 triangles, most of them sub-pixel) on a 4K frame: the whole image against the oracle,
+    bit for bit (band-parallel oracle), with the first-frame bin overflow on the way"""
+    from concurrent.futures import ThreadPoolExecutor
+    from dataclasses import replace
+    cfg = replace(configs.C5, width=3840, height=2160, grid=16, cam_pos=(0.0, 8.0, -10.0), cam_pitch=-25.0, texture_size=256,
+                  name="big")
+    sc = scenes.shaderball_scene(cfg, bbo.MaterialData(maps256))
+    r = Renderer(cfg.width, cfg.height)
+    r.render_scene(sc)
+    a = r.read_framebuffer()
+    st = r.stats()
+    assert st["n_prims"] == 256 * 9776 + 2 and st["n_raster_tris"] > 1_000_000
+
+    def band(y0):
+        ref, _, _, _ = bbo.render(sc, y0, min(y0 + 24, cfg.height), want_prim=False, want_depth=False)
+        return y0, bool(np.array_equal(ref[y0:y0 + 24].view(np.uint32), a[y0:y0 + 24].view(np.uint32)))
+
+    with ThreadPoolExecutor(min(16, os.cpu_count() or 1)) as ex:
+        wrong = [y0 for y0, ok in ex.map(band, range(0, cfg.height, 24)) if not ok]
+    assert not wrong, wrong[:8]
+    r.close()
