@@ -1046,6 +1046,7 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
   // its loop bounds then disagreed with the other waves' and a handful of triangles of the tile went missing (seen as
   // ~100 wrong pixels in one tile of one frame in a few hundred, never on an otherwise idle GPU).
   __shared__ uint32_t s_n_cls[kBinClasses];
+  __shared__ uint32_t s_n_valid, s_full_ref;  // staged entries that touch the tile; (reference + 1) of one that covers all of it
   if (tid < (int)kBinClasses)
     s_n_cls[tid] = (fp.ablate & (1u | (256u << tid))) ? 0u : min(tile_count[tile * kBinClasses + tid], fp.bin_cap);
   const uint32_t n_broad = (fp.ablate & 5u) ? 0u : min(ctr->n_broad, fp.broad_cap);
@@ -1060,7 +1061,11 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
     }
     keys[p] = k0;
   }
-  if (tid == 0) s_count = 0;
+  if (tid == 0) {
+    s_count = 0;
+    s_n_valid = 0;
+    s_full_ref = 0;
+  }
   __syncthreads();  // counts published, keys cleared
   uint32_t n_cls[kBinClasses];
 #pragma unroll
@@ -1076,6 +1081,7 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
     return (OVERLAY && (ref >> 3) >= fp.ov_first_gizmo_prim) ? 0x40000000u : 0u;
   };
   BB_RSTAMP(1);
+  bool fast_full = false;  // uniform over the workgroup
   for (uint32_t base = 0; base < e_end; base += kStage) {
     if (base) __syncthreads();  // previous chunk consumed
     // ---- stage: every thread fetches one entry (reference -> triangle record), all loads in flight together ----
@@ -1104,8 +1110,14 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
           py0 = max(py0, fp.ov_y0); py1 = min(py1, fp.ov_y1 - 1);
         }
         bool ok = px0 <= px1 && py0 <= py1;
-        if (ok && e >= e3) ok = classify_rect(edge_setup(t), px0, px1, py0, py1) != 0;  // every-tile list: accept / reject
+        int cls_rect = 1;
+        if (ok && e >= e3) {  // every-tile list: accept / reject
+          cls_rect = classify_rect(edge_setup(t), px0, px1, py0, py1);
+          ok = cls_rect != 0;
+        }
         if (ok) {
+          atomicAdd(&s_n_valid, 1u);
+          if (cls_rect == 2 && px1 - px0 + 1 == TILE_W && py1 - py0 + 1 == TILE_H) s_full_ref = ref + 1u;  // covers every pixel of the tile
           box = (uint32_t)(px0 - tile_x0) | ((uint32_t)(px1 - tile_x0) << 8) | ((uint32_t)(py0 - tile_y0) << 16) |
                 ((uint32_t)(py1 - tile_y0) << 24);
           st.X0[tid] = t.X0; st.Y0[tid] = t.Y0; st.X1[tid] = t.X1; st.Y1[tid] = t.Y1; st.X2[tid] = t.X2; st.Y2[tid] = t.Y2;
@@ -1117,6 +1129,13 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
     }
     __syncthreads();
     if (base == 0) BB_RSTAMP(2);
+    // One triangle covers the whole tile and nothing else touches it (most ground-plane tiles): every pixel's winner is
+    // known without a single depth atomic -- the fragment list is the pixel list.  (Same set of fragments as the general
+    // path; their order inside a tile's list is arbitrary there too.)
+    if (!OVERLAY && e_end <= (uint32_t)kStage && s_n_valid == 1u && s_full_ref != 0u && !vis_prim && !depth_io) {
+      fast_full = true;
+      break;
+    }
     const uint32_t hi = min(base + (uint32_t)kStage, e_end);
     // ---- class 0: one tiny triangle per lane ----
     {
@@ -1165,6 +1184,12 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
 
   // ---- compaction: covered pixels -> fragment list (ballot + popcount prefix); background written here ----
   unsigned long long *my_frags = frags + (size_t)tile * TILE_PIXELS;
+  if (fast_full) {
+    const unsigned long long ref = (unsigned long long)(s_full_ref - 1u);
+    for (int p = tid; p < TILE_PIXELS; p += kTileThreads) my_frags[p] = ((unsigned long long)(uint32_t)p << 32) | ref;
+    if (tid == 0) frag_count[tile] = (uint32_t)TILE_PIXELS;
+    return;
+  }
   for (int base = 0; base < TILE_PIXELS; base += kTileThreads) {
     int p = base + tid;
     int x, y;
