@@ -155,7 +155,7 @@ bool is_live(const bbr_context *c) {
 struct bbr_context {
   int device = 0;
   int32_t width = 0, height = 0;
-  hipStream_t s_geom = nullptr, s_shade = nullptr;  // context-owned streams
+  hipStream_t s_geom = nullptr, s_shade = nullptr, s_present = nullptr;  // context-owned streams
   hipStream_t user_stream = nullptr;                 // bbr_set_stream: everything on the caller's stream, 1 frame in flight
   std::string last_error;
 
@@ -217,6 +217,9 @@ struct bbr_context {
 
   hipStream_t geom_stream() const { return user_stream ? user_stream : s_geom; }
   hipStream_t shade_stream() const { return user_stream ? user_stream : (frames_in_flight > 1 ? s_shade : s_geom); }
+  // k_present is bandwidth-bound, k_shade issue-bound: on its own stream the presentation of frame N overlaps the
+  // shading of frame N+1 instead of delaying it
+  hipStream_t present_stream() const { return (user_stream || frames_in_flight == 1) ? shade_stream() : s_present; }
   int n_slots() const { return user_stream ? 1 : frames_in_flight; }
   int tile_w() const { return tile_mode == 0 ? 64 : 32; }
   int tile_h() const { return tile_mode == 0 ? 64 : 32; }
@@ -281,6 +284,7 @@ FrameParams make_params(const bbr_context *c) {
 int drain(bbr_context *c) {
   HIP_TRY(c, hipStreamSynchronize(c->geom_stream()));
   if (c->shade_stream() != c->geom_stream()) HIP_TRY(c, hipStreamSynchronize(c->shade_stream()));
+  if (c->s_present) HIP_TRY(c, hipStreamSynchronize(c->s_present));
   for (FrameSlot &s : c->slots) s.in_flight = false;
   return BBR_OK;
 }
@@ -550,6 +554,8 @@ int queue_present(bbr_context *c, FrameSlot &s) {
   int rc_tables = ensure_srgb_tables(c);
   if (rc_tables) return rc_tables;
   const size_t n = (size_t)c->width * (c->world > 1 ? c->shard_rows() : c->height);
+  hipStream_t ps = c->present_stream();
+  if (ps != c->shade_stream()) HIP_TRY(c, hipStreamWaitEvent(ps, s.ev_shade_done, 0));  // behind the frame's k_shade
   hipEvent_t *pe = nullptr;
   if (c->timing) {
     if (c->present_ring.empty()) {
@@ -557,19 +563,19 @@ int queue_present(bbr_context *c, FrameSlot &s) {
       for (auto &e : c->present_ring) HIP_TRY(c, hipEventCreate(&e));
     }
     pe = &c->present_ring[2 * (c->present_launches % bbr_context::kRingCap)];
-    HIP_TRY(c, hipEventRecord(pe[0], c->shade_stream()));
+    HIP_TRY(c, hipEventRecord(pe[0], ps));
   }
   const size_t per_block = (size_t)kPresentThreads * kPresentPerThread;
   hipLaunchKernelGGL(k_present, dim3((unsigned)((n + per_block - 1) / per_block)), dim3(kPresentThreads), 0,
-                     c->shade_stream(), s.out_used, s.present.out, n, c->d_srgb_tables.ptr, s.present.enable,
+                     ps, s.out_used, s.present.out, n, c->d_srgb_tables.ptr, s.present.enable,
                      s.present.exposure, s.present.hdr16);
   HIP_TRY(c, hipGetLastError());
   if (pe) {
-    HIP_TRY(c, hipEventRecord(pe[1], c->shade_stream()));
+    HIP_TRY(c, hipEventRecord(pe[1], ps));
     ++c->present_launches;
   }
   // the slot is busy until the presented image exists
-  HIP_TRY(c, hipEventRecord(s.ev_shade_done, c->shade_stream()));
+  HIP_TRY(c, hipEventRecord(s.ev_shade_done, ps));
   return BBR_OK;
 }
 
@@ -866,6 +872,7 @@ int bbr_create(int32_t width, int32_t height, int32_t device, bbr_context **out_
     // (measured on C3/C5: swapping or equalising the two priorities changes the pipelined frame time by < 2 %)
     CREATE_TRY(hipStreamCreateWithPriority(&c->s_geom, hipStreamNonBlocking, prio_high));
     CREATE_TRY(hipStreamCreateWithPriority(&c->s_shade, hipStreamNonBlocking, prio_low));
+    CREATE_TRY(hipStreamCreateWithPriority(&c->s_present, hipStreamNonBlocking, prio_low));
   }
   // `default` material maps (resources/pbr/default/*.png are uniform images): 1x1 RGBA8 each
   static const uint8_t k_default[kMapCount][4] = {{255, 255, 255, 255}, {0, 0, 0, 255},       {0, 0, 0, 255},
@@ -922,6 +929,7 @@ int bbr_destroy(bbr_context *c) {
   c->d_srgb_tables.release();
   if (c->s_geom) (void)hipStreamDestroy(c->s_geom);
   if (c->s_shade) (void)hipStreamDestroy(c->s_shade);
+  if (c->s_present) (void)hipStreamDestroy(c->s_present);
   delete c;
   return BBR_OK;
 }
