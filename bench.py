@@ -119,6 +119,9 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="exercise the all-gather path with WORLD_SIZE = 1")
     ap.add_argument("--render-pass", default="forward", choices=["forward", "deferred"],
                     help="forward_brdf.* (the path BASELINE measures) or the reference's deferred path, gbuffer.* + brdf.*")
+    ap.add_argument("--present-fused", action="store_true",
+                    help="with --present: the kernels write presented RGBA8 pixels themselves (option present_fused), no fp32 "
+                         "frame and no separate presentation pass")
     ap.add_argument("--verify", action="store_true",
                     help="after the timed region, compare the last gathered frame with the same frame rendered unpartitioned "
                          "on this rank's GPU (bit for bit)")
@@ -168,6 +171,10 @@ def main():
         r.set_option("tile_mode", args.tile_mode)
     r.set_option("frames_in_flight", args.frames_in_flight)
     r.set_option("render_pass", 1 if args.render_pass == "deferred" else 0)
+    if args.present_fused:
+        if not args.present:
+            raise SystemExit("--present-fused needs --present")
+        r.set_option("present_fused", 1)
     material = r.upload_material(maps)
     scene, cam, settings = S.config_scene(r, cfg, ball)
 
@@ -287,7 +294,7 @@ def main():
                     # shaded pixel from the committed counters (2*fma + mul + add wave-instructions x 64 lanes / N_shaded)
                     "limiter": "vector ALU issue (see DESIGN.md, k_shade)"}
 
-    if roofline is not None and not dist_path:
+    if roofline is not None and not dist_path and not args.present_fused:
         # Outside the timed region: the same kernels with one frame in flight, i.e. without the other frame's
         # geometry/raster sharing the CUs -- what each kernel costs by itself (the timed region above overlaps them).
         r.set_option("frames_in_flight", 1)
@@ -371,7 +378,7 @@ def main():
             raise SystemExit(f"GPU shaded {n_shaded_total} pixels, oracle {cpu['n_shaded']}: parity broken")
         # the frame the bench has been rendering, against the frame the oracle just rendered (forward pass only: the
         # CPU baseline is the forward oracle)
-        if args.render_pass == "forward" and not dist_path:
+        if args.render_pass == "forward" and not dist_path and not args.present_fused:
             gpu_frame = r.read_framebuffer()
             tol = 1e-4 * np.maximum(1.0, np.abs(oracle_frame))
             d = np.abs(gpu_frame - oracle_frame)
@@ -393,7 +400,8 @@ def main():
                        "partition": "single GPU" if world == 1 else f"interleaved {args.band_rows or r.tile_height()}-row bands, "
                                     f"{world} ranks, ncclAllGather + un-interleave",
                        "tile": f"{stats['tile_w']}x{stats['tile_h']}",
-                       "output": "RGBA32F frame + presented RGBA8" if args.present else "RGBA32F frame",
+                       "output": ("presented RGBA8 (fused)" if args.present_fused else "RGBA32F frame + presented RGBA8")
+                                 if args.present else "RGBA32F frame",
                        "render_pass": args.render_pass},
             "roofline": roofline, "cpu_baseline": cpu,
         }

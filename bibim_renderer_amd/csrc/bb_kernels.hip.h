@@ -80,6 +80,60 @@ BB_DEV float bb_half_round(float x) {
   return (float)(_Float16)x;
 }
 
+BB_DEV float bb_exp(float x) {
+  if (!(x >= -104.0f)) return x < -104.0f ? 0.0f : x;
+  if (x > 88.7228317f) return __uint_as_float(0x7F800000u);
+  const float n = __builtin_rintf(x * 1.44269502f);
+  float r = fmaf(n, -0.693145752f, x);
+  r = fmaf(n, -1.42860677e-06f, r);
+  float p = 1.98412701e-04f;
+  p = fmaf(p, r, 1.38888892e-03f);
+  p = fmaf(p, r, 8.33333377e-03f);
+  p = fmaf(p, r, 4.16666679e-02f);
+  p = fmaf(p, r, 1.66666672e-01f);
+  p = fmaf(p, r, 0.5f);
+  p = fmaf(p, r, 1.0f);
+  p = fmaf(p, r, 1.0f);
+  const int ni = (int)n, h = ni / 2;
+  const float s1 = __uint_as_float((uint32_t)(h + 127) << 23), s2 = __uint_as_float((uint32_t)(ni - h + 127) << 23);
+  return (p * s1) * s2;
+}
+
+// sRGB byte = number of thresholds t_k <= c (NaN -> 0).  Instead of a binary search (eight dependent LDS probes)
+// the byte is read from a table keyed by the top 16 bits of the float: 256 cells per octave over the 13 octaves
+// [2^-13, 1) that contain all thresholds.  A cell is narrower than the closest pair of thresholds (0.39 % against
+// >= 0.88 %; checked when the table is built), so it holds the count at its lower edge and at most one more
+// threshold, which one compare settles: two LDS reads, same bytes as the search for every float.
+constexpr uint32_t kSrgbLutFirstExp = 114u;             // 2^-13
+constexpr uint32_t kSrgbLutCells = 13u * 256u;          // biased exponents 114..126
+struct SrgbTables {                                      // device copy built by the host
+  float thr[256];                                        // t_1..t_255, then +inf
+  uint8_t lut[kSrgbLutCells];                            // thresholds <= lower edge of the cell
+};
+
+BB_DEV uint32_t srgb8(float c, const SrgbTables &t) {
+  const uint32_t u = __float_as_uint(c);
+  if ((int32_t)u < (int32_t)(kSrgbLutFirstExp << 23)) return 0u;  // below 2^-13, zero, negative, negative NaN
+  if (u >= (127u << 23)) return u <= 0x7F800000u ? 255u : 0u;     // >= 1 (and +inf) -> 255, NaN -> 0
+  const uint32_t k = t.lut[(u >> 15) - (kSrgbLutFirstExp << 8)];
+  return k + (t.thr[k] <= c ? 1u : 0u);
+}
+
+// One presented pixel (hdr_tone_mapping.frag:9-18 + the sRGB UNORM8 attachment write): binary16 HDR value, tone map,
+// sRGB byte per channel, alpha 255.  Shared by k_present and the fused output of k_shade / k_raster.
+BB_DEV uint32_t present_pixel(float r, float g, float b, const SrgbTables &t, int enable, float exposure, int hdr16) {
+  float v[3] = {r, g, b};
+  uint32_t px = 0xFF000000u;  // outColor.a = 1.0
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float x = v[k];
+    if (hdr16) x = bb_half_round(x);
+    if (enable) x = 1.0f - bb_exp(-x * exposure);
+    px |= srgb8(x, t) << (8 * k);
+  }
+  return px;
+}
+
 BB_DEV f3 normalize3(f3 a) { return scale3(a, bb_rsqrt(dot3(a, a))); }
 BB_DEV float max0(float a) { return a > 0.0f ? a : 0.0f; }
 
@@ -707,6 +761,8 @@ struct ShadeParams {
   float view_pos[3];
   int32_t enable_normal_map;
   int32_t num_lights;
+  int32_t tone_enable;  // fused presentation only (option "present_fused"): FrameUniformBlock.EnableToneMapping / Exposure
+  float exposure;
 };
 
 // pixel index inside the tile, 8x8-blocked so that 64 consecutive indices form one 8x8 pixel block
@@ -1000,7 +1056,8 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
     const uint32_t *__restrict__ bins, const BroadTri *__restrict__ broad_list,
     unsigned long long *__restrict__ frags, uint32_t *__restrict__ frag_count, float4 *__restrict__ out,
     uint32_t *__restrict__ vis_prim, float *__restrict__ vis_depth, const uint32_t *__restrict__ tile_order,
-    const float4 *__restrict__ background, float *__restrict__ depth_io, uint32_t *__restrict__ host_flags) {
+    const float4 *__restrict__ background, float *__restrict__ depth_io, uint32_t *__restrict__ host_flags,
+    uint32_t *__restrict__ out8) {
   constexpr int TILE_PIXELS = TILE_W * TILE_H;
   __shared__ unsigned long long keys[TILE_PIXELS];
   __shared__ StagedTri st;
@@ -1209,7 +1266,9 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
     } else if (in_frame && !OVERLAY) {
       size_t o = (size_t)(out_y0 + y) * (size_t)fp.width + (size_t)gx;
       // forward: the clear colour (src/main.cpp:84); deferred: brdf.frag on the cleared G-buffer texel (k_deferred_background)
-      out[o] = background ? background[0] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      // fused presentation: the same colours as presented pixels (the clear colour presents as (0, 0, 0, 255))
+      if (out8) out8[o] = background ? __float_as_uint(background[1].x) : 0xFF000000u;
+      else out[o] = background ? background[0] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     }
     if (vis_prim && in_frame) {
       size_t o = (size_t)gy * (size_t)fp.width + (size_t)gx;
@@ -1296,9 +1355,14 @@ BB_DEV float4 light_surface(const ShadeParams &sp, const Light *__restrict__ lig
 // Deferred path: brdf.frag runs on every pixel of its full-screen triangle (src/main.cpp:101-104), also where the
 // G-buffer still holds its clear value 0; that colour is the same for all such pixels (it depends on the lights and
 // the camera only -- and is not always 0: a light at the world origin makes it NaN), so it is evaluated once.
-__global__ void k_deferred_background(ShadeParams sp, const Light *__restrict__ lights, float4 *__restrict__ out) {
-  if (threadIdx.x == 0 && blockIdx.x == 0)
-    out[0] = light_surface(sp, lights, mk3(0.f, 0.f, 0.f), mk3(0.f, 0.f, 0.f), mk3(0.f, 0.f, 0.f), 0.f, 0.f, 0.f);
+__global__ void k_deferred_background(ShadeParams sp, const Light *__restrict__ lights, float4 *__restrict__ out,
+                                      const SrgbTables *__restrict__ tables) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const float4 c = light_surface(sp, lights, mk3(0.f, 0.f, 0.f), mk3(0.f, 0.f, 0.f), mk3(0.f, 0.f, 0.f), 0.f, 0.f, 0.f);
+    out[0] = c;
+    // out[1].x: the same colour as a presented pixel (fused presentation)
+    if (tables) out[1] = make_float4(__uint_as_float(present_pixel(c.x, c.y, c.z, *tables, sp.tone_enable, sp.exposure, 1)), 0.f, 0.f, 0.f);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1315,12 +1379,15 @@ __global__ void k_deferred_background(ShadeParams sp, const Light *__restrict__ 
 #endif
 constexpr int kShadeThreads = BB_SHADE_THREADS;
 
-template <int TILE_W, int TILE_H, bool DEFERRED>
+// PRESENT = true (option "present_fused"): the colour goes through present_pixel and is stored as RGBA8 -- the tone-map
+// subpass fused into the producing kernel: 4 bytes written per pixel instead of 16, and no k_present pass (16 B read +
+// 4 B written per pixel) afterwards.
+template <int TILE_W, int TILE_H, bool DEFERRED, bool PRESENT = false>
 __global__ __launch_bounds__(kShadeThreads) void k_shade(
     FrameParams fp, ShadeParams sp, const Light *__restrict__ lights, const ShadeRec *__restrict__ recs,
     const ClipSlot *__restrict__ clip_arena, const unsigned long long *__restrict__ frags,
     const uint32_t *__restrict__ frag_count, const MaterialDesc *__restrict__ materials, float4 *__restrict__ out,
-    uint2 *__restrict__ gbuffer) {
+    uint2 *__restrict__ gbuffer, const SrgbTables *__restrict__ tables, uint32_t *__restrict__ out8) {
   constexpr int TILE_PIXELS = TILE_W * TILE_H;
   constexpr int CHUNKS = TILE_PIXELS / kShadeThreads;
   const int tx = blockIdx.x / CHUNKS, chunk = blockIdx.x - tx * CHUNKS;
@@ -1340,7 +1407,7 @@ __global__ __launch_bounds__(kShadeThreads) void k_shade(
   const int gx = tx * TILE_W + x, gy = ty * TILE_H + y;
   const size_t o = (size_t)(out_tile_row * TILE_H + y) * (size_t)fp.width + (size_t)gx;
   if (fp.ablate & 2u) {
-    if (valid) out[o] = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (valid && !PRESENT) out[o] = make_float4(1.f, 1.f, 1.f, 1.f);
     return;
   }
 
@@ -1479,7 +1546,8 @@ __global__ __launch_bounds__(kShadeThreads) void k_shade(
     } else {
       color = light_surface(sp, lights, mk3(a[2], a[3], a[4]), normal, albedo, metallic, roughness, ao);
     }
-    out[o] = color;
+    if (PRESENT) out8[o] = present_pixel(color.x, color.y, color.z, *tables, sp.tone_enable, sp.exposure, 1);
+    else out[o] = color;
   }
 }
 
@@ -1517,25 +1585,6 @@ __global__ void k_unpack_gathered(const float4 *__restrict__ gathered, float4 *_
 // Same fixed sequences as the CPU oracle (binary16 rounding, exp, threshold table): byte-exact.
 // ------------------------------------------------------------------------------------------------
 
-BB_DEV float bb_exp(float x) {
-  if (!(x >= -104.0f)) return x < -104.0f ? 0.0f : x;
-  if (x > 88.7228317f) return __uint_as_float(0x7F800000u);
-  const float n = __builtin_rintf(x * 1.44269502f);
-  float r = fmaf(n, -0.693145752f, x);
-  r = fmaf(n, -1.42860677e-06f, r);
-  float p = 1.98412701e-04f;
-  p = fmaf(p, r, 1.38888892e-03f);
-  p = fmaf(p, r, 8.33333377e-03f);
-  p = fmaf(p, r, 4.16666679e-02f);
-  p = fmaf(p, r, 1.66666672e-01f);
-  p = fmaf(p, r, 0.5f);
-  p = fmaf(p, r, 1.0f);
-  p = fmaf(p, r, 1.0f);
-  const int ni = (int)n, h = ni / 2;
-  const float s1 = __uint_as_float((uint32_t)(h + 127) << 23), s2 = __uint_as_float((uint32_t)(ni - h + 127) << 23);
-  return (p * s1) * s2;
-}
-
 // hdr_tone_mapping.frag:9-18 on the fp32 frame, in place
 __global__ void k_tone_map(float4 *__restrict__ frame, size_t n, int enable, float exposure) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1548,26 +1597,6 @@ __global__ void k_tone_map(float4 *__restrict__ frame, size_t n, int enable, flo
   }
   c.w = 1.0f;
   frame[i] = c;
-}
-
-// sRGB byte = number of thresholds t_k <= c (NaN -> 0).  Instead of a binary search (eight dependent LDS probes)
-// the byte is read from a table keyed by the top 16 bits of the float: 256 cells per octave over the 13 octaves
-// [2^-13, 1) that contain all thresholds.  A cell is narrower than the closest pair of thresholds (0.39 % against
-// >= 0.88 %; checked when the table is built), so it holds the count at its lower edge and at most one more
-// threshold, which one compare settles: two LDS reads, same bytes as the search for every float.
-constexpr uint32_t kSrgbLutFirstExp = 114u;             // 2^-13
-constexpr uint32_t kSrgbLutCells = 13u * 256u;          // biased exponents 114..126
-struct SrgbTables {                                      // device copy built by the host
-  float thr[256];                                        // t_1..t_255, then +inf
-  uint8_t lut[kSrgbLutCells];                            // thresholds <= lower edge of the cell
-};
-
-BB_DEV uint32_t srgb8(float c, const SrgbTables &t) {
-  const uint32_t u = __float_as_uint(c);
-  if ((int32_t)u < (int32_t)(kSrgbLutFirstExp << 23)) return 0u;  // below 2^-13, zero, negative, negative NaN
-  if (u >= (127u << 23)) return u <= 0x7F800000u ? 255u : 0u;     // >= 1 (and +inf) -> 255, NaN -> 0
-  const uint32_t k = t.lut[(u >> 15) - (kSrgbLutFirstExp << 8)];
-  return k + (t.thr[k] <= c ? 1u : 0u);
 }
 
 // 16 B read + 4 B written per pixel: 20 algorithmic bytes, HBM-bound by construction.  A workgroup loads the 4.3 KB
@@ -1590,15 +1619,7 @@ __global__ __launch_bounds__(kPresentThreads) void k_present(const float4 *__res
     const size_t i = base + (size_t)j * kPresentThreads;
     if (i >= n) break;
     const float4 c = frame[i];
-    float v[3] = {c.x, c.y, c.z};
-    uint32_t px = 0xFF000000u;  // outColor.a = 1.0
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      float x = v[k];
-      if (hdr16) x = bb_half_round(x);
-      if (enable) x = 1.0f - bb_exp(-x * exposure);
-      px |= srgb8(x, t) << (8 * k);
-    }
+    const uint32_t px = present_pixel(c.x, c.y, c.z, t, enable, exposure, hdr16);
     out_rgba8[i] = px;
   }
 }

@@ -109,12 +109,14 @@ struct FrameSlot {
   DeviceBuffer<float4> d_background;  // deferred path: colour of the pixels no geometry covers
   DeviceBuffer<float> d_depth;        // option "overlays": the frame's resolved depth, for bbr_draw_overlays
   bool has_depth = false;
+  bool fused = false;                 // rendered with option "present_fused": d_present holds the frame, d_frame nothing
   FrameUniformBlock frame_u = {};     // the uniforms the frame in this slot was rendered with (overlays need them)
   ViewUniformBlock view_u = {};
   DeviceBuffer<uint32_t> d_present;  // RGBA8 presented image of this slot's frame (bbr_present)
   struct {
     bool active = false;  // bbr_present was queued for the frame in this slot (re-queued if the frame is replayed)
     uint32_t *out = nullptr;
+    void *copy_to = nullptr;  // fused presentation: the caller's buffer the image was copied to
     int32_t enable = 0, hdr16 = 1;
     float exposure = 1.f;
   } present;
@@ -198,6 +200,7 @@ struct bbr_context {
   // k_shade and the extra kernel plus the co-scheduled heavy tiles cost throughput (C3 184 -> 190 us, C5 +2 %):
   // off by default, option "tile_order".
   bool tile_order = false;
+  bool present_fused = false;  // option "present_fused": frames are written as presented RGBA8, no fp32 frame
   bool overlays = false;  // option "overlays": frames keep their depth so that bbr_draw_overlays can test against it
   Mesh marker_mesh, gizmo_mesh;  // generateUVSphereMesh(0.1, 16, 16) and the caller's gizmo, both as Vertex meshes
   FrameSlot ov;           // buffers of the overlay pass (its own little frame)
@@ -289,6 +292,8 @@ int drain(bbr_context *c) {
   return BBR_OK;
 }
 
+int ensure_srgb_tables(bbr_context *c);
+
 int ensure_slot_buffers(bbr_context *c, FrameSlot &s) {
   size_t tiles = (size_t)c->tiles_x() * c->tiles_y();
   size_t out_rows = (size_t)std::max(c->height, c->shard_rows());
@@ -311,8 +316,13 @@ int ensure_slot_buffers(bbr_context *c, FrameSlot &s) {
   HIP_TRY(c, s.d_frag_count.ensure(tiles, true));
 #endif
   HIP_TRY(c, s.d_tile_order.ensure(tiles * kOrderBuckets));
-  if (c->deferred) HIP_TRY(c, s.d_background.ensure(1));
+  if (c->deferred) HIP_TRY(c, s.d_background.ensure(2));
   if (c->overlays && &s != &c->ov) HIP_TRY(c, s.d_depth.ensure((size_t)c->width * c->height));
+  if (c->present_fused && &s != &c->ov) {
+    HIP_TRY(c, s.d_present.ensure((size_t)c->width * out_rows));
+    int rc_t = ensure_srgb_tables(c);
+    if (rc_t) return rc_t;
+  }
   if (c->dump_gbuffer) HIP_TRY(c, c->d_gbuffer.ensure((size_t)c->width * c->height * 4, true));
   if (!c->ext_out) HIP_TRY(c, s.d_frame.ensure(out_rows * c->width));
   if (c->dump_vis) {
@@ -359,7 +369,11 @@ void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const Fra
   if (prev && prev->in_flight && prev->out_used == out && ss != sg) (void)hipStreamWaitEvent(sg, prev->ev_shade_done, 0);
   // a rank without bands (more ranks than bands) still launches one row: its blocks fall off tiles_y and exit
   int grid_y = std::max(1, c->world > 1 ? c->local_bands() * fp.band_tiles : fp.tiles_y);
-  if (fp.deferred) hipLaunchKernelGGL(k_deferred_background, dim3(1), dim3(64), 0, sg, sp, d_lights, s.d_background.ptr);
+  // option "present_fused": k_raster / k_shade write presented pixels into the slot's RGBA8 image
+  uint32_t *out8 = c->present_fused ? s.d_present.ptr : nullptr;
+  const SrgbTables *tables = c->present_fused ? c->d_srgb_tables.ptr : nullptr;
+  if (fp.deferred)
+    hipLaunchKernelGGL(k_deferred_background, dim3(1), dim3(64), 0, sg, sp, d_lights, s.d_background.ptr, tables);
   const bool ordered = c->tile_order && c->n_prims;
   if (ordered)
     hipLaunchKernelGGL(k_tile_order, dim3((fp.tiles_x * grid_y + kOrderThreads - 1) / kOrderThreads), dim3(kOrderThreads),
@@ -369,7 +383,7 @@ void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const Fra
                      s.d_frag_count.ptr, out, c->dump_vis ? c->d_vis_prim.ptr : nullptr,
                      c->dump_vis ? c->d_vis_depth.ptr : nullptr, ordered ? s.d_tile_order.ptr : nullptr,
                      fp.deferred ? s.d_background.ptr : nullptr, (c->overlays && c->world == 1) ? s.d_depth.ptr : nullptr,
-                     s.h_flags);
+                     s.h_flags, out8);
   s.has_depth = c->overlays && c->world == 1;
   if (ev && c->timing == 1) (void)hipEventRecord(ev[2], sg);
   if (ss != sg) {
@@ -383,14 +397,19 @@ void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const Fra
   // (k_shade 102 -> 169 us), interleaved 2-row bands still leave a 3:2 imbalance (132 us); the L2-miss traffic they
   // save (FETCH_SIZE -20 %) does not matter to kernels that are issue- and latency-bound, not L2-bandwidth-bound.
   constexpr int kChunks = TW * TH / kShadeThreads;
-  if (fp.deferred)
-    hipLaunchKernelGGL((k_shade<TW, TH, true>), dim3(fp.tiles_x * kChunks, grid_y), dim3(kShadeThreads), 0, ss, fp, sp, d_lights,
-                       s.d_attrs.ptr, s.d_clip.ptr, s.d_frags.ptr, s.d_frag_count.ptr, c->d_materials.ptr, out,
-                       c->dump_gbuffer ? c->d_gbuffer.ptr : nullptr);
-  else
-    hipLaunchKernelGGL((k_shade<TW, TH, false>), dim3(fp.tiles_x * kChunks, grid_y), dim3(kShadeThreads), 0, ss, fp, sp, d_lights,
-                       s.d_attrs.ptr, s.d_clip.ptr, s.d_frags.ptr, s.d_frag_count.ptr, c->d_materials.ptr, out,
-                       (uint2 *)nullptr);
+  uint2 *gbuf = (fp.deferred && c->dump_gbuffer) ? c->d_gbuffer.ptr : nullptr;
+  auto shade = [&](auto deferred, auto present) {
+    hipLaunchKernelGGL((k_shade<TW, TH, decltype(deferred)::value, decltype(present)::value>), dim3(fp.tiles_x * kChunks, grid_y),
+                       dim3(kShadeThreads), 0, ss, fp, sp, d_lights, s.d_attrs.ptr, s.d_clip.ptr, s.d_frags.ptr,
+                       s.d_frag_count.ptr, c->d_materials.ptr, out, gbuf, tables, out8);
+  };
+  if (fp.deferred) {
+    if (out8) shade(std::true_type{}, std::true_type{});
+    else shade(std::true_type{}, std::false_type{});
+  } else {
+    if (out8) shade(std::false_type{}, std::true_type{});
+    else shade(std::false_type{}, std::false_type{});
+  }
   (void)hipEventRecord(s.ev_shade_done, ss);
   if (ev) {
     (void)hipEventRecord(ev[4], ss);
@@ -497,6 +516,8 @@ int submit_frame_into(bbr_context *c, int slot_index) {
   ShadeParams sp;
   std::memcpy(sp.view_pos, c->view_u.view_pos, sizeof sp.view_pos);
   sp.enable_normal_map = c->view_u.enable_normal_map;
+  sp.tone_enable = c->frame_u.enable_tone_mapping;
+  sp.exposure = c->frame_u.exposure;
   sp.num_lights = std::min(std::max(c->frame_u.num_lights, 0), kMaxNumLights);
   float4 *out = c->ext_out ? reinterpret_cast<float4 *>(c->ext_out) : s.d_frame.ptr;
   const FrameSlot *prev = (c->last_slot >= 0 && c->last_slot != slot_index) ? &c->slots[c->last_slot] : nullptr;
@@ -505,7 +526,13 @@ int submit_frame_into(bbr_context *c, int slot_index) {
   else launch_frame<32, 32>(c, s, prev, fp, pv, view, sp, d_lights, d_draws, c->n_live_draws, out);
   HIP_TRY(c, hipGetLastError());
   s.in_flight = true;
-  s.present.active = false;
+  s.fused = c->present_fused;
+  s.present.active = c->present_fused;  // fused presentation: the frame IS the presented image
+  s.present.out = c->present_fused ? s.d_present.ptr : nullptr;
+  s.present.enable = c->frame_u.enable_tone_mapping;
+  s.present.exposure = c->frame_u.exposure;
+  s.present.hdr16 = 1;
+  s.present.copy_to = nullptr;
   s.frame_u = c->frame_u;
   s.view_u = c->view_u;
   s.tone_enable = c->frame_u.enable_tone_mapping;
@@ -602,10 +629,16 @@ int sync_and_fix(bbr_context *c, Counters *out_counters) {
     const auto present = s.present;
     rc = submit_frame_into(c, c->last_slot);
     if (rc) return rc;
-    if (present.active) {  // the presented image was made from the overflowed frame: make it again
+    if (present.active && !s.fused) {  // the presented image was made from the overflowed frame: make it again
       s.present = present;
       rc = queue_present(c, s);
       if (rc) return rc;
+    } else if (s.fused && present.copy_to) {  // fused: the re-rendered frame is the image; redo the caller's copy
+      const size_t n = (size_t)c->width * (c->world > 1 ? c->shard_rows() : c->height);
+      s.present.copy_to = present.copy_to;
+      HIP_TRY(c, hipStreamWaitEvent(c->present_stream(), s.ev_shade_done, 0));
+      HIP_TRY(c, hipMemcpyAsync(present.copy_to, s.d_present.ptr, n * 4, hipMemcpyDeviceToDevice, c->present_stream()));
+      HIP_TRY(c, hipEventRecord(s.ev_shade_done, c->present_stream()));
     }
   }
   return fail(c, BBR_ERR_CAPACITY, "bin capacity still exceeded after 8 growth steps");
@@ -806,7 +839,7 @@ extern "C" int bbr_draw_overlays(bbr_context *c, int32_t gizmo_extent) {
       hipLaunchKernelGGL((k_raster<TW, TH, true>), dim3(fp.tiles_x, fp.tiles_y), dim3(kTileThreads), 0, st, fp, s.d_tris.ptr,
                          s.d_clip.ptr, ctr, s.d_tile_count.ptr, s.d_bins.ptr, s.d_broad.ptr, s.d_frags.ptr, s.d_frag_count.ptr,
                          (float4 *)nullptr, (uint32_t *)nullptr, (float *)nullptr, (const uint32_t *)nullptr,
-                         (const float4 *)nullptr, fs.d_depth.ptr, (uint32_t *)nullptr);
+                         (const float4 *)nullptr, fs.d_depth.ptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
       constexpr int kChunks = TW * TH / kShadeThreads;
       hipLaunchKernelGGL((k_shade_overlay<TW, TH>), dim3(fp.tiles_x * kChunks, fp.tiles_y), dim3(kShadeThreads), 0, st, fp,
                          s.d_attrs.ptr, s.d_clip.ptr, s.d_frags.ptr, s.d_frag_count.ptr, c->d_srgb_tables.ptr, fs.present.out);
@@ -1146,6 +1179,8 @@ int bbr_read_framebuffer(bbr_context *c, float *host) {
   if (!host) return fail(c, BBR_ERR_INVALID_ARGUMENT, "read_framebuffer: NULL");
   if (c->world > 1) return fail(c, BBR_ERR_INVALID_ARGUMENT, "read_framebuffer on a partitioned context: use bbr_read_shard");
   if (!c->have_frame) return fail(c, BBR_ERR_NOT_IN_FRAME, "read_framebuffer: nothing rendered");
+  if (c->last_slot >= 0 && c->slots[c->last_slot].fused)
+    return fail(c, BBR_ERR_INVALID_ARGUMENT, "read_framebuffer: the frame was rendered with option present_fused (no fp32 frame); use bbr_read_presented");
   int rc = sync_and_fix(c, nullptr);
   if (rc) return rc;
   HIP_TRY(c, hipMemcpy(host, last_output(c), (size_t)c->width * c->height * 16, hipMemcpyDeviceToHost));
@@ -1156,6 +1191,8 @@ int bbr_read_shard(bbr_context *c, float *host) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
   if (!host) return fail(c, BBR_ERR_INVALID_ARGUMENT, "read_shard: NULL");
   if (!c->have_frame) return fail(c, BBR_ERR_NOT_IN_FRAME, "read_shard: nothing rendered");
+  if (c->last_slot >= 0 && c->slots[c->last_slot].fused)
+    return fail(c, BBR_ERR_INVALID_ARGUMENT, "read_shard: the frame was rendered with option present_fused (no fp32 frame); use bbr_read_presented");
   int rc = sync_and_fix(c, nullptr);
   if (rc) return rc;
   HIP_TRY(c, hipMemcpy(host, last_output(c), (size_t)c->width * c->shard_rows() * 16, hipMemcpyDeviceToHost));
@@ -1430,6 +1467,8 @@ int bbr_set_option(bbr_context *c, const char *name, int64_t value) {
     for (FrameSlot &s : c->slots) s.d_bins.release();
   } else if (n == "ablate") {
     c->ablate = (uint32_t)value;
+  } else if (n == "present_fused") {
+    c->present_fused = value != 0;
   } else if (n == "overlays") {
     c->overlays = value != 0;
   } else if (n == "tile_order") {
@@ -1467,6 +1506,17 @@ int bbr_present(bbr_context *c, void *rgba8_device, int32_t hdr16) {
   if (!c->have_frame || c->last_slot < 0) return fail(c, BBR_ERR_NOT_IN_FRAME, "present: nothing rendered");
   FrameSlot &s = c->slots[c->last_slot];
   const size_t n = (size_t)c->width * (c->world > 1 ? c->shard_rows() : c->height);
+  if (c->present_fused && s.present.active && s.present.out == s.d_present.ptr) {
+    // the frame was rendered as presented pixels already (binary16 stage included); a caller buffer gets a copy
+    if (!hdr16) return fail(c, BBR_ERR_INVALID_ARGUMENT, "present: option present_fused always applies the binary16 stage");
+    s.present.copy_to = rgba8_device;
+    if (rgba8_device) {
+      HIP_TRY(c, hipStreamWaitEvent(c->present_stream(), s.ev_shade_done, 0));
+      HIP_TRY(c, hipMemcpyAsync(rgba8_device, s.d_present.ptr, n * 4, hipMemcpyDeviceToDevice, c->present_stream()));
+      HIP_TRY(c, hipEventRecord(s.ev_shade_done, c->present_stream()));
+    }
+    return BBR_OK;
+  }
   if (!rgba8_device) HIP_TRY(c, s.d_present.ensure(n));
   s.present.active = true;
   s.present.out = rgba8_device ? (uint32_t *)rgba8_device : s.d_present.ptr;
@@ -1544,6 +1594,7 @@ int bbr_selftest_rcp(bbr_context *c, uint32_t lo_bits, uint32_t hi_bits, uint64_
 int bbr_tone_map(bbr_context *c, int32_t enable, float exposure) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
   if (!c->have_frame || c->last_slot < 0) return fail(c, BBR_ERR_NOT_IN_FRAME, "tone_map: nothing rendered");
+  if (c->slots[c->last_slot].fused) return fail(c, BBR_ERR_INVALID_ARGUMENT, "tone_map: no fp32 frame with option present_fused");
   float4 *frame = c->slots[c->last_slot].out_used;
   size_t n = (size_t)c->width * (c->world > 1 ? c->shard_rows() : c->height);
   // same stream as the frame's shade kernel: ordered after it

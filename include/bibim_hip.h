@@ -164,6 +164,9 @@ int bbr_timing_summary(bbr_context *ctx, uint32_t *out_frames, float *out_avg_fr
  *   "bin_cap" n              initial references per (tile, raster class); grows by itself on overflow
  *   "broad_threshold" n      triangles touching more than n x n tiles go to the every-tile list
  *   "render_pass" 0|1        0: forward path (default, the path BASELINE measures), 1: deferred path
+ *   "present_fused" 0|1      frames are produced as presented RGBA8 pixels directly (binary16 stage, tone map and sRGB
+ *                            encode fused into the raster / shade kernels): no fp32 frame, no k_present pass; bbr_present
+ *                            then only marks (or copies to a caller buffer), bbr_read_framebuffer / bbr_read_shard fail
  *   "overlays" 0|1           keep every frame's resolved depth for bbr_draw_overlays (default 0)
  *   "tile_order" 0|1         launch the heaviest raster tiles first (shorter single frame, lower pipelined
  *                            throughput; default 0)

@@ -494,3 +494,70 @@ def test_api_lifecycle_user_stream_frees_and_timing(maps64):
     ref2, _, _, _ = bbo.render(sc2)
     assert np.array_equal(r2.read_framebuffer().view(np.uint32), ref2.view(np.uint32))
     r2.close()
+
+
+@pytest.mark.parametrize("deferred", [0, 1])
+@pytest.mark.parametrize("enable,exposure", [(0, 1.0), (1, 1.6)])
+def test_fused_presentation_writes_the_same_bytes(maps64, deferred, enable, exposure):
+    """option present_fused: the raster / shade kernels produce the presented RGBA8 image themselves (no fp32 frame, no
+    k_present): byte-identical to rendering + bbr_present, i.e. to the oracle's bbo_present of the oracle's frame"""
+    import torch
+    sc = scenes.shaderball_scene(configs.C3.scaled(640, 360, 64), bbo.MaterialData(maps64))
+    sc.frame["enable_tone_mapping"], sc.frame["exposure"] = enable, exposure
+    ref = bbo.render_deferred(sc)[0] if deferred else bbo.render(sc)[0]
+    want = bbo.present(ref, enable, exposure)
+    r = Renderer(sc.width, sc.height)
+    r.set_option("render_pass", deferred)
+    r.set_option("present_fused", 1)
+    r.set_option("bin_cap", 16)                          # the first frame overflows and is re-rendered on the read
+    out = torch.zeros((sc.height, sc.width, 4), dtype=torch.uint8, device="cuda")
+    h = r.render_scene(sc)
+    r.present(out.data_ptr())                            # fused: a copy of the image into the caller's buffer
+    got = r.read_presented()
+    assert np.array_equal(got, want)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), want)
+    with pytest.raises(BibimError):
+        r.read_framebuffer()                             # there is no fp32 frame in this mode
+    r.set_option("present_fused", 0)                     # and back: the fp32 frame returns
+    r.render_scene(sc, h)
+    assert np.array_equal(r.read_framebuffer().view(np.uint32), ref.view(np.uint32))
+    r.close()
+
+
+def test_fused_presentation_special_values_partition_and_overlays(maps64):
+    from bibim_renderer_amd import partition as P
+    tri = scenes.triangle_scene(96, 96)                  # default material: NaN where N.H = 1
+    ref, _, _, _ = bbo.render(tri)
+    r = Renderer(96, 96)
+    r.set_option("present_fused", 1)
+    r.render_scene(tri)
+    assert np.array_equal(r.read_presented(), bbo.present(ref, 0, 1.0))
+    r.close()
+    cfg = configs.C3.scaled(512, 300, 64)
+    sc = scenes.shaderball_scene(cfg, bbo.MaterialData(maps64))
+    sc.frame["enable_tone_mapping"], sc.frame["exposure"] = 1, 1.2
+    ref, _, depth, _ = bbo.render(sc)
+    want = bbo.present(ref, 1, 1.2)
+    shards = []
+    for rank in range(3):
+        r = Renderer(cfg.width, cfg.height)
+        r.set_option("present_fused", 1)
+        r.set_partition(rank, 3, 32)
+        r.render_scene(sc)
+        shards.append(r.read_presented())
+        r.close()
+    assert np.array_equal(P.unpack_gathered(np.stack(shards), cfg.height, 32), want)
+    g = np.load(os.path.join(GOLDEN, "gizmo.npz"))
+    gv = np.zeros(len(g["vertices"]), bbo.GIZMO_VERTEX_DTYPE)
+    gv["pos"], gv["color"], gv["normal"] = g["vertices"][:, 0:3], g["vertices"][:, 3:6], g["vertices"][:, 6:9]
+    over, _ = bbo.overlay(sc.frame, sc.view, depth, want, gv, g["indices"], 100)
+    r = Renderer(cfg.width, cfg.height)
+    r.set_option("present_fused", 1)
+    r.set_option("overlays", 1)
+    r.upload_gizmo(g["vertices"], g["indices"])
+    r.render_scene(sc)
+    r.present()
+    r.draw_overlays(100)
+    assert np.array_equal(r.read_presented(), over)
+    r.close()
