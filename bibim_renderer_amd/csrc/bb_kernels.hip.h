@@ -47,7 +47,7 @@ BB_DEV float bb_rsqrt(float x) {
 #ifdef BB_EXPERIMENT_HW_TRANS
   return __builtin_amdgcn_rsqf(x);
 #endif
-  if (!(x >= 1.17549435e-38f && x <= 3.40282347e+38f)) return 1.0f / sqrtf(x);
+  if (!__builtin_amdgcn_classf(x, 0x100)) return 1.0f / sqrtf(x);  // anything but a positive normal number (one v_cmp_class)
   float y = __uint_as_float(0x5F375A86u - (__float_as_uint(x) >> 1));
   const float h = 0.5f * x;
   y = y * fmaf(-(h * y), y, 1.5f);
@@ -64,9 +64,10 @@ BB_DEV float bb_rcp(float x) {
 #ifdef BB_EXPERIMENT_HW_TRANS
   return __builtin_amdgcn_rcpf(x);
 #endif
-  const float ax = fabsf(x);
-  if (!(ax >= 1.17549435e-38f && ax <= 8.5e37f)) return 1.0f / x;
-  float y = __builtin_amdgcn_rcpf(x);
+  const float y = __builtin_amdgcn_rcpf(x);
+  // a seed that is not a normal number (x zero, denormal, huge, infinite or NaN): the IEEE division.  One v_cmp_class
+  // on the seed replaces two range compares on x.
+  if (!__builtin_amdgcn_classf(y, 0x108)) return 1.0f / x;
   return fmaf(y, fmaf(-x, y, 1.0f), y);
 }
 // nearest binary16 value (ties to even), as binary32: v_cvt_f16_f32 / v_cvt_f32_f16 do exactly this on gfx950
