@@ -47,7 +47,9 @@ BB_DEV float bb_rsqrt(float x) {
 #ifdef BB_EXPERIMENT_HW_TRANS
   return __builtin_amdgcn_rsqf(x);
 #endif
+#ifndef BB_EXPERIMENT_NO_GUARD
   if (!__builtin_amdgcn_classf(x, 0x100)) return 1.0f / sqrtf(x);  // anything but a positive normal number (one v_cmp_class)
+#endif
   float y = __uint_as_float(0x5F375A86u - (__float_as_uint(x) >> 1));
   const float h = 0.5f * x;
   y = y * fmaf(-(h * y), y, 1.5f);
@@ -67,7 +69,19 @@ BB_DEV float bb_rcp(float x) {
   const float y = __builtin_amdgcn_rcpf(x);
   // a seed that is not a normal number (x zero, denormal, huge, infinite or NaN): the IEEE division.  One v_cmp_class
   // on the seed replaces two range compares on x.
+#ifndef BB_EXPERIMENT_NO_GUARD
   if (!__builtin_amdgcn_classf(y, 0x108)) return 1.0f / x;
+#endif
+  return fmaf(y, fmaf(-x, y, 1.0f), y);
+}
+// bb_rcp for a call site that can PROVE its argument is a normal number with a normal reciprocal (the guard and its
+// branch are a twentieth of k_shade's instruction stream).  Each use states its proof; k_selftest_rcp checks the
+// whole range [2^-100, 2^100] against the IEEE division.
+BB_DEV float bb_rcp_normal(float x) {
+#ifdef BB_EXPERIMENT_HW_TRANS
+  return __builtin_amdgcn_rcpf(x);
+#endif
+  const float y = __builtin_amdgcn_rcpf(x);
   return fmaf(y, fmaf(-x, y, 1.0f), y);
 }
 // nearest binary16 value (ties to even), as binary32: v_cvt_f16_f32 / v_cvt_f32_f16 do exactly this on gfx950
@@ -136,7 +150,10 @@ BB_DEV uint32_t present_pixel(float r, float g, float b, const SrgbTables &t, in
 }
 
 BB_DEV f3 normalize3(f3 a) { return scale3(a, bb_rsqrt(dot3(a, a))); }
-BB_DEV float max0(float a) { return a > 0.0f ? a : 0.0f; }
+// max(a, 0) with the oracle's `a > 0 ? a : 0` semantics: NaN -> +0, -0 -> +0.  v_max_f32 does exactly that (IEEE
+// maxNum with -0 < +0; k_selftest_rcp checks every bit pattern), and costs one instruction where the compiler, which
+// may not assume the -0 case, emits a compare and a select.
+BB_DEV float max0(float a) { return __builtin_fmaxf(a, 0.0f); }
 
 BB_DEV f4 mat4_mul(const Mat4 &m, f4 v) {
   f4 r;
@@ -746,9 +763,12 @@ BB_DEV float distribution_ggx(float NdotH_raw, float roughness) {
   return a2 * bb_rcp(denom);
 }
 
+// roughness comes out of filter_channel (a bilinear blend of bytes / 255, possibly rounded to binary16): it is in
+// [0, 1], so k = (r + 1)^2 / 8 is in [0.125, 0.5]; NdotX = max0(dot of two vectors that are unit length, zero or NaN) is
+// in [0, 1 + 2^-20] (max0 removes the NaN).  Hence denom is in [0.125, 1.01]: a normal number, no guard needed.
 BB_DEV float geometry_schlick_ggx(float NdotX, float k) {
   float denom = fmaf(NdotX, 1.0f - k, k);
-  return NdotX * bb_rcp(denom);
+  return NdotX * bb_rcp_normal(denom);
 }
 
 BB_DEV float mixf(float a, float b, float t) { return fmaf(b, t, a * (1.0f - t)); }
@@ -1337,8 +1357,8 @@ BB_DEV float4 light_surface(const ShadeParams &sp, const Light *__restrict__ lig
     f3 radiance = mk3((att * light.color[0]) * light.intensity, (att * light.color[1]) * light.intensity,
                       (att * light.color[2]) * light.intensity);
     float sden = (4.0f * NdotV) * NdotL;
-    if (!(sden > 0.001f)) sden = 0.001f;
-    float rden = bb_rcp(sden);
+    sden = __builtin_fmaxf(sden, 0.001f);  // NaN -> 0.001, as `!(sden > 0.001) ? 0.001 : sden`
+    float rden = bb_rcp_normal(sden);      // in [0.001, 4.01] by the line above
     f3 spec = mk3(((D * F.x) * G) * rden, ((D * F.y) * G) * rden, ((D * F.z) * G) * rden);
     f3 kD = mk3((1.0f - F.x) * om, (1.0f - F.y) * om, (1.0f - F.z) * om);
     Lo.x = fmaf(fmaf(kD.x * albedo.x, kInvPi, spec.x) * radiance.x, NdotL, Lo.x);
@@ -1556,7 +1576,8 @@ __global__ __launch_bounds__(kShadeThreads) void k_shade(
 // small utility kernels
 // ------------------------------------------------------------------------------------------------
 
-// bb_rcp against the IEEE division for every float with bit pattern in [lo, hi): number of differing results
+// bb_rcp / bb_rcp_normal against the IEEE division and max0 against its select form, for every float with bit pattern
+// in [lo, hi) and its negation: number of differing results
 __global__ void k_selftest_rcp(unsigned long long *__restrict__ mismatches, uint32_t lo, uint32_t hi) {
   const uint32_t stride = gridDim.x * blockDim.x;
   unsigned long long bad = 0;
@@ -1564,6 +1585,14 @@ __global__ void k_selftest_rcp(unsigned long long *__restrict__ mismatches, uint
     const float x = __uint_as_float((uint32_t)u);
     const float a = bb_rcp(x), b = 1.0f / x, c = bb_rcp(-x);
     bad += (__float_as_uint(a) != __float_as_uint(b) && !(a != a && b != b)) || (__float_as_uint(c) != (__float_as_uint(b) ^ 0x80000000u) && !(c != c && b != b));
+    // the unguarded variant on its documented domain [2^-100, 2^100]
+    if (u >= 0x0D800000u && u <= 0x71800000u) bad += __float_as_uint(bb_rcp_normal(x)) != __float_as_uint(b);
+    // max0 == (a > 0 ? a : 0), both signs, every pattern (NaN -> +0, -0 -> +0)
+    const float nx = -x;
+    bad += __float_as_uint(max0(x)) != __float_as_uint(x > 0.0f ? x : 0.0f);
+    bad += __float_as_uint(max0(nx)) != __float_as_uint(nx > 0.0f ? nx : 0.0f);
+    bad += __float_as_uint(__builtin_fmaxf(x, 0.001f)) != __float_as_uint(!(x > 0.001f) ? 0.001f : x);
+    bad += __float_as_uint(__builtin_fmaxf(nx, 0.001f)) != __float_as_uint(!(nx > 0.001f) ? 0.001f : nx);
   }
   if (bad) atomicAdd(mismatches, bad);
 }
