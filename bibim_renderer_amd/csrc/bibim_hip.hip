@@ -1270,6 +1270,43 @@ int bbr_set_partition(bbr_context *c, int32_t rank, int32_t world, int32_t band_
   return BBR_OK;
 }
 
+// onWindowResize (src/main.cpp:1042-1061): wait for the device, drop everything whose size follows the swap-chain
+// extent, keep meshes, materials and options.  Buffers come back lazily with the next frame.
+int bbr_resize(bbr_context *c, int32_t width, int32_t height) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  if (width <= 0 || height <= 0 || width > 32768 || height > 32768)
+    return fail(c, BBR_ERR_INVALID_ARGUMENT, "resize: width/height out of range");
+  if (c->in_frame) return fail(c, BBR_ERR_INVALID_ARGUMENT, "resize: between begin_frame and end_frame");
+  int rc = drain(c);
+  if (rc) return rc;
+  if (width == c->width && height == c->height) return BBR_OK;
+  c->width = width;
+  c->height = height;
+  auto drop = [](FrameSlot &s) {
+    s.release_tile_buffers();
+    s.d_frame.release(); s.d_present.release(); s.d_depth.release();
+    s.has_depth = false;
+    s.fused = false;
+    s.present.active = false;
+    s.present.out = nullptr;
+    s.present.copy_to = nullptr;
+    s.out_used = nullptr;
+    s.in_flight = false;
+    if (s.h_flags) s.h_flags[0] = s.h_flags[1] = 0u;
+  };
+  for (FrameSlot &s : c->slots) drop(s);
+  drop(c->ov);
+  c->d_vis_prim.release();
+  c->d_vis_depth.release();
+  c->d_gbuffer.release();
+  c->have_frame = false;
+  c->last_slot = -1;
+  // a caller-owned output buffer was sized for the old extent: the caller sets it again (bbr_set_output_device_ptr)
+  c->ext_out = nullptr;
+  c->ext_out_bytes = 0;
+  return BBR_OK;
+}
+
 int bbr_shard_rows(const bbr_context *c, int32_t *out_rows) {
   if (!c || !out_rows) return BBR_ERR_INVALID_ARGUMENT;
   *out_rows = c->shard_rows();

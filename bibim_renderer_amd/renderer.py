@@ -38,6 +38,11 @@ class Renderer:
             self._L.bbr_destroy(self._ctx)
             self._ctx = C.c_void_p()
 
+    def resize(self, width, height):
+        """onWindowResize: new extent, same meshes / materials / options."""
+        self._check(self._L.bbr_resize(self._ctx, width, height))
+        self.width, self.height = int(width), int(height)
+
     def __del__(self):
         try:
             self.close()

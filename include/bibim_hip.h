@@ -82,6 +82,12 @@ typedef struct bbr_stats {
 /* ---- lifetime ---- */
 int bbr_create(int32_t width, int32_t height, int32_t device, bbr_context **out_ctx);
 int bbr_destroy(bbr_context *ctx);
+/* onWindowResize (src/main.cpp:1042-1061: vkDeviceWaitIdle, cleanupReloadableResources, initReloadableResources): waits
+ * for the frames in flight, drops every buffer whose size follows the extent and continues with the new one.  Meshes,
+ * materials, options, the partition and the grown capacities stay.  There is no current frame afterwards (read-backs
+ * fail with BBR_ERR_NOT_IN_FRAME until one is rendered) and a caller-owned output buffer has to be set again.
+ * Not allowed between bbr_begin_frame and bbr_end_frame. */
+int bbr_resize(bbr_context *ctx, int32_t width, int32_t height);
 const char *bbr_last_error(const bbr_context *ctx); /* ctx may be NULL: last creation error */
 int bbr_device_count(void);
 

@@ -561,3 +561,46 @@ def test_fused_presentation_special_values_partition_and_overlays(maps64):
     r.draw_overlays(100)
     assert np.array_equal(r.read_presented(), over)
     r.close()
+
+
+def test_resize_keeps_resources_and_renders_the_new_extent_exactly(maps64):
+    """onWindowResize (src/main.cpp:1042-1061): same context, meshes and materials; bigger, smaller, off the tile grid,
+    with three frames in flight, presentation and the deferred pass switched on along the way"""
+    mat = bbo.MaterialData(maps64)
+    r = Renderer(320, 180)
+    r.set_option("frames_in_flight", 3)
+    handles, deferred, keep = None, 0, []
+    for (w, h, cfg, extra) in [(320, 180, configs.C3, {}), (701, 397, configs.C3, {}), (96, 50, configs.C2, {}),
+                               (640, 360, configs.C5, {"render_pass": 1}), (320, 180, configs.C3, {"render_pass": 0})]:
+        if (w, h) != (r.width, r.height):
+            r.resize(w, h)
+            with pytest.raises(BibimError) as e:
+                r.read_framebuffer()                     # nothing rendered at the new extent yet
+            assert e.value.code == -6
+        for k, v in extra.items():
+            r.set_option(k, v)
+        deferred = extra.get("render_pass", deferred)
+        sc = scenes.shaderball_scene(cfg.scaled(w, h, 64), mat)
+        keep.append(sc)                                  # (handles are keyed by object identity)
+        for _ in range(4):                               # every slot gets its buffers back
+            handles = r.render_scene(sc, handles)
+        img = r.read_framebuffer()
+        prim, depth = r.read_visibility()
+        if deferred == 1:
+            ref, _, rprim, rdepth, _ = bbo.render_deferred(sc, want_gbuffer=False)
+        else:
+            ref, rprim, rdepth, _ = bbo.render(sc)
+        assert img.shape == (h, w, 4)
+        assert np.array_equal(prim, rprim) and np.array_equal(depth.view(np.uint32), rdepth.view(np.uint32))
+        assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+        r.present()
+        assert np.array_equal(r.read_presented(), bbo.present(ref, int(sc.frame["enable_tone_mapping"]), float(sc.frame["exposure"])))
+    assert len(handles["mat"]) == 1 and len(handles["mesh"]) == 1 + len(keep)   # the ball and the maps went up once
+    r.begin_frame()
+    with pytest.raises(BibimError):
+        r.resize(64, 64)                                 # not inside a frame
+    r.end_frame()
+    with pytest.raises(BibimError):
+        r.resize(0, 64)
+    r.resize(320, 180)                                   # same extent: a no-op apart from the wait
+    r.close()
