@@ -120,7 +120,7 @@ struct FrameSlot {
     int32_t enable = 0, hdr16 = 1;
     float exposure = 1.f;
   } present;
-  hipEvent_t ev_raster_done = nullptr, ev_shade_done = nullptr;
+  hipEvent_t ev_geom_done = nullptr, ev_raster_done = nullptr, ev_shade_done = nullptr;
   bool in_flight = false;
   int32_t tone_enable = 0;  // FrameUniformBlock.EnableToneMapping / Exposure of the frame in this slot
   float tone_exposure = 1.f;
@@ -157,7 +157,7 @@ bool is_live(const bbr_context *c) {
 struct bbr_context {
   int device = 0;
   int32_t width = 0, height = 0;
-  hipStream_t s_geom = nullptr, s_shade = nullptr, s_present = nullptr;  // context-owned streams
+  hipStream_t s_geom = nullptr, s_raster = nullptr, s_shade = nullptr, s_present = nullptr;  // context-owned streams
   hipStream_t user_stream = nullptr;                 // bbr_set_stream: everything on the caller's stream, 1 frame in flight
   std::string last_error;
 
@@ -219,6 +219,30 @@ struct bbr_context {
   int retries = 0;
 
   hipStream_t geom_stream() const { return user_stream ? user_stream : s_geom; }
+  // k_raster on a stream of its own: geometry of frame N+1 (other slot, other counter block) need not wait for the
+  // raster of frame N.  At 1080p that chain -- not the GPU -- set the frame rate (C2: 72 -> 41 us per frame)
+  int raster_stream_mode = -1;  // option "raster_stream": 0 shares the geometry stream, 1 own stream, -1 measure and pick
+  bool raster_own = false;      // the stream choice of the frame being submitted
+  // Automatic choice: both arrangements render the same bits, which one is faster depends on whether the
+  // geometry -> raster chain or the shading sets the frame rate (C2 1080p: own stream 67 -> 47 us per frame; C3 4K:
+  // own stream 3 % slower).  So the first frames of a workload are timed: after kTuneWarm frames (clocks, caches),
+  // kTuneRounds x (shared, own) spans of kTuneSpan frames, each after kTuneSkip frames for the switch to settle -- two
+  // events per span on the shade stream, polled without blocking.  Alternating the spans cancels what a single A/B
+  // pair does not: the first span of a fresh context runs on a GPU that is still ramping up.  Until the answer is
+  // in, and whenever it is a tie, k_raster stays on the geometry stream.
+  static constexpr int kTuneWarm = 32, kTuneSkip = 8, kTuneSpan = 24, kTuneRounds = 2, kTuneSpans = 2 * kTuneRounds;
+  struct {
+    int phase = 0;   // 0 not started, 1 .. kTuneSpans timing (odd: shared stream, even: own), then waiting, then decided
+    int count = 0;   // frames submitted in the current phase
+    bool own = false;
+    hipEvent_t ev[2 * kTuneSpans] = {};  // begin / end of each span
+    uint32_t key_prims = 0;
+    int32_t key_lights = -1;
+    bool key_deferred = false;
+    float ms_shared = 0.f, ms_own = 0.f;
+  } tune;
+  static constexpr int kTuneWaiting = kTuneSpans + 1, kTuneDecided = kTuneSpans + 2;
+  hipStream_t raster_stream() const { return user_stream ? user_stream : ((frames_in_flight > 1 && raster_own) ? s_raster : s_geom); }
   hipStream_t shade_stream() const { return user_stream ? user_stream : (frames_in_flight > 1 ? s_shade : s_geom); }
   // k_present is bandwidth-bound, k_shade issue-bound: on its own stream the presentation of frame N overlaps the
   // shading of frame N+1 instead of delaying it
@@ -287,6 +311,7 @@ FrameParams make_params(const bbr_context *c) {
 int drain(bbr_context *c) {
   HIP_TRY(c, hipStreamSynchronize(c->geom_stream()));
   if (c->shade_stream() != c->geom_stream()) HIP_TRY(c, hipStreamSynchronize(c->shade_stream()));
+  if (c->s_raster) HIP_TRY(c, hipStreamSynchronize(c->s_raster));
   if (c->s_present) HIP_TRY(c, hipStreamSynchronize(c->s_present));
   for (FrameSlot &s : c->slots) s.in_flight = false;
   return BBR_OK;
@@ -333,6 +358,7 @@ int ensure_slot_buffers(bbr_context *c, FrameSlot &s) {
     HIP_TRY(c, hipHostMalloc((void **)&s.h_flags, 2 * sizeof(uint32_t), hipHostMallocDefault));
     s.h_flags[0] = s.h_flags[1] = 0u;
   }
+  if (!s.ev_geom_done) HIP_TRY(c, hipEventCreateWithFlags(&s.ev_geom_done, hipEventDisableTiming));
   if (!s.ev_raster_done) HIP_TRY(c, hipEventCreateWithFlags(&s.ev_raster_done, hipEventDisableTiming));
   if (!s.ev_shade_done) HIP_TRY(c, hipEventCreateWithFlags(&s.ev_shade_done, hipEventDisableTiming));
   return BBR_OK;
@@ -354,7 +380,7 @@ int upload_material_table(bbr_context *c) {
 template <int TW, int TH>
 void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const FrameParams &fp, const Mat4 &pv,
                   const Mat4 &view, const ShadeParams &sp, const Light *d_lights, const DrawDesc *d_draws, uint32_t n_draws, float4 *out) {
-  hipStream_t sg = c->geom_stream(), ss = c->shade_stream();
+  hipStream_t sg = c->geom_stream(), sr = c->raster_stream(), ss = c->shade_stream();
   Counters *ctr = c->d_counters.ptr + s.ctr_index, *ctr_next = c->d_counters.ptr + (s.ctr_index + 1) % bbr_context::kCounterBlocks;
   hipEvent_t *ev = c->timing ? &c->ring[bbr_context::kRingEvents * (c->ring_frames % bbr_context::kRingCap)] : nullptr;
   if (c->n_prims)
@@ -364,30 +390,34 @@ void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const Fra
   else
     (void)hipMemsetAsync(ctr_next, 0, sizeof(Counters), sg);
   if (ev && c->timing == 1) (void)hipEventRecord(ev[1], sg);
+  if (sr != sg) {
+    (void)hipEventRecord(s.ev_geom_done, sg);
+    (void)hipStreamWaitEvent(sr, s.ev_geom_done, 0);
+  }
   // k_raster writes the background pixels of `out`: if the frame still shading on the other stream writes the
   // same buffer (single external output), raster has to wait for it; geometry above still overlapped
-  if (prev && prev->in_flight && prev->out_used == out && ss != sg) (void)hipStreamWaitEvent(sg, prev->ev_shade_done, 0);
+  if (prev && prev->in_flight && prev->out_used == out && ss != sr) (void)hipStreamWaitEvent(sr, prev->ev_shade_done, 0);
   // a rank without bands (more ranks than bands) still launches one row: its blocks fall off tiles_y and exit
   int grid_y = std::max(1, c->world > 1 ? c->local_bands() * fp.band_tiles : fp.tiles_y);
   // option "present_fused": k_raster / k_shade write presented pixels into the slot's RGBA8 image
   uint32_t *out8 = c->present_fused ? s.d_present.ptr : nullptr;
   const SrgbTables *tables = c->present_fused ? c->d_srgb_tables.ptr : nullptr;
   if (fp.deferred)
-    hipLaunchKernelGGL(k_deferred_background, dim3(1), dim3(64), 0, sg, sp, d_lights, s.d_background.ptr, tables);
+    hipLaunchKernelGGL(k_deferred_background, dim3(1), dim3(64), 0, sr, sp, d_lights, s.d_background.ptr, tables);
   const bool ordered = c->tile_order && c->n_prims;
   if (ordered)
     hipLaunchKernelGGL(k_tile_order, dim3((fp.tiles_x * grid_y + kOrderThreads - 1) / kOrderThreads), dim3(kOrderThreads),
-                       0, sg, fp, s.d_tile_count.ptr, ctr, s.d_tile_order.ptr, fp.tiles_x, grid_y);
-  hipLaunchKernelGGL((k_raster<TW, TH>), dim3(fp.tiles_x, grid_y), dim3(kTileThreads), 0, sg, fp, s.d_tris.ptr,
+                       0, sr, fp, s.d_tile_count.ptr, ctr, s.d_tile_order.ptr, fp.tiles_x, grid_y);
+  hipLaunchKernelGGL((k_raster<TW, TH>), dim3(fp.tiles_x, grid_y), dim3(kTileThreads), 0, sr, fp, s.d_tris.ptr,
                      s.d_clip.ptr, ctr, s.d_tile_count.ptr, s.d_bins.ptr, s.d_broad.ptr, s.d_frags.ptr,
                      s.d_frag_count.ptr, out, c->dump_vis ? c->d_vis_prim.ptr : nullptr,
                      c->dump_vis ? c->d_vis_depth.ptr : nullptr, ordered ? s.d_tile_order.ptr : nullptr,
                      fp.deferred ? s.d_background.ptr : nullptr, (c->overlays && c->world == 1) ? s.d_depth.ptr : nullptr,
                      s.h_flags, out8);
   s.has_depth = c->overlays && c->world == 1;
-  if (ev && c->timing == 1) (void)hipEventRecord(ev[2], sg);
-  if (ss != sg) {
-    (void)hipEventRecord(s.ev_raster_done, sg);
+  if (ev && c->timing == 1) (void)hipEventRecord(ev[2], sr);
+  if (ss != sr) {
+    (void)hipEventRecord(s.ev_raster_done, sr);
     (void)hipStreamWaitEvent(ss, s.ev_raster_done, 0);
   }
   // one workgroup per (tile, 256-fragment chunk); empty ones exit after one load
@@ -419,6 +449,9 @@ void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const Fra
 
 // A capacity overflowed (bit0 bins, bit1 every-tile list, bit2 clip arena): grow it.  Everything must have left the GPU.
 int apply_growth(bbr_context *c, uint32_t overflow, uint32_t bin_need) {
+  if (getenv("BBR_DEBUG"))
+    fprintf(stderr, "[bbr] capacity growth: overflow bits %u, bin_need %u (bin_cap %u, broad_cap %u, clip_cap %u), frame %llu\n", overflow,
+            bin_need, c->bin_cap, c->broad_cap, c->clip_cap, (unsigned long long)c->frame_counter);
   if (overflow & 1u) {
     // bin_need is exact for the frame that overflowed; round up with headroom so small scene changes do not re-trigger
     uint32_t need = std::max(bin_need + bin_need / 4u, c->bin_cap * 2u);
@@ -522,9 +555,56 @@ int submit_frame_into(bbr_context *c, int slot_index) {
   float4 *out = c->ext_out ? reinterpret_cast<float4 *>(c->ext_out) : s.d_frame.ptr;
   const FrameSlot *prev = (c->last_slot >= 0 && c->last_slot != slot_index) ? &c->slots[c->last_slot] : nullptr;
 
+  int tune_mark = -1;  // which of tune.ev to record behind this frame's k_shade
+  if (c->raster_stream_mode >= 0 || c->n_slots() < 2) {
+    c->raster_own = c->raster_stream_mode == 1;
+  } else {
+    auto &t = c->tune;
+    const bool same_workload = t.key_lights == sp.num_lights && t.key_deferred == c->deferred &&
+                               c->n_prims <= t.key_prims + t.key_prims / 4 && c->n_prims + c->n_prims / 4 >= t.key_prims;
+    if (t.phase == 0 || !same_workload) {
+      t.phase = 1;
+      t.count = 0;
+      t.key_prims = c->n_prims;
+      t.key_lights = sp.num_lights;
+      t.key_deferred = c->deferred;
+      for (hipEvent_t &e : t.ev)
+        if (!e) HIP_TRY(c, hipEventCreate(&e));
+    }
+    if (t.phase >= 1 && t.phase <= bbr_context::kTuneSpans) {
+      c->raster_own = (t.phase & 1) == 0;
+      const int skip = bbr_context::kTuneSkip + (t.phase == 1 ? bbr_context::kTuneWarm : 0);
+      if (t.count == skip) tune_mark = (t.phase - 1) * 2;
+      if (t.count == skip + bbr_context::kTuneSpan) tune_mark = (t.phase - 1) * 2 + 1;
+    } else if (t.phase == bbr_context::kTuneWaiting) {
+      c->raster_own = false;
+      if (hipEventQuery(t.ev[2 * bbr_context::kTuneSpans - 1]) == hipSuccess) {
+        t.ms_shared = t.ms_own = 0.f;
+        for (int k = 0; k < bbr_context::kTuneSpans; ++k) {
+          float ms = 0.f;
+          (void)hipEventElapsedTime(&ms, t.ev[2 * k], t.ev[2 * k + 1]);
+          (k & 1 ? t.ms_own : t.ms_shared) += ms;
+        }
+        t.own = t.ms_own > 0.f && t.ms_own < 0.98f * t.ms_shared;
+        t.phase = bbr_context::kTuneDecided;
+        if (getenv("BBR_DEBUG"))
+          fprintf(stderr, "[bbr] raster stream: %d frames shared %.3f ms, own %.3f ms -> %s\n",
+                  bbr_context::kTuneSpan * bbr_context::kTuneRounds, t.ms_shared, t.ms_own, t.own ? "own" : "shared");
+      }
+    }
+    if (t.phase == bbr_context::kTuneDecided) c->raster_own = t.own;
+  }
   if (c->tile_mode == 0) launch_frame<64, 64>(c, s, prev, fp, pv, view, sp, d_lights, d_draws, c->n_live_draws, out);
   else launch_frame<32, 32>(c, s, prev, fp, pv, view, sp, d_lights, d_draws, c->n_live_draws, out);
   HIP_TRY(c, hipGetLastError());
+  if (c->raster_stream_mode < 0 && c->n_slots() >= 2 && c->tune.phase >= 1 && c->tune.phase <= bbr_context::kTuneSpans) {
+    auto &t = c->tune;
+    if (tune_mark >= 0) HIP_TRY(c, hipEventRecord(t.ev[tune_mark], c->shade_stream()));
+    if (t.count++ == bbr_context::kTuneSkip + bbr_context::kTuneSpan + (t.phase == 1 ? bbr_context::kTuneWarm : 0)) {
+      ++t.phase;
+      t.count = 0;
+    }
+  }
   s.in_flight = true;
   s.fused = c->present_fused;
   s.present.active = c->present_fused;  // fused presentation: the frame IS the presented image
@@ -904,6 +984,8 @@ int bbr_create(int32_t width, int32_t height, int32_t device, bbr_context **out_
     CREATE_TRY(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
     // (measured on C3/C5: swapping or equalising the two priorities changes the pipelined frame time by < 2 %)
     CREATE_TRY(hipStreamCreateWithPriority(&c->s_geom, hipStreamNonBlocking, prio_high));
+    // (created here, next to s_geom: a stream made later, once the others are busy, was measured to serialise with them)
+    CREATE_TRY(hipStreamCreateWithPriority(&c->s_raster, hipStreamNonBlocking, prio_high));
     CREATE_TRY(hipStreamCreateWithPriority(&c->s_shade, hipStreamNonBlocking, prio_low));
     CREATE_TRY(hipStreamCreateWithPriority(&c->s_present, hipStreamNonBlocking, prio_low));
   }
@@ -945,6 +1027,7 @@ int bbr_destroy(bbr_context *c) {
   c->d_vis_depth.release();
   for (FrameSlot &s : c->slots) {
     s.release_all();
+    if (s.ev_geom_done) (void)hipEventDestroy(s.ev_geom_done);
     if (s.ev_raster_done) (void)hipEventDestroy(s.ev_raster_done);
     if (s.ev_shade_done) (void)hipEventDestroy(s.ev_shade_done);
   }
@@ -953,6 +1036,7 @@ int bbr_destroy(bbr_context *c) {
     if (m->d_indices) (void)hipFree(m->d_indices);
   }
   c->ov.release_all();
+  if (c->ov.ev_geom_done) (void)hipEventDestroy(c->ov.ev_geom_done);
   if (c->ov.ev_raster_done) (void)hipEventDestroy(c->ov.ev_raster_done);
   if (c->ov.ev_shade_done) (void)hipEventDestroy(c->ov.ev_shade_done);
   for (auto &e : c->ring)
@@ -961,6 +1045,9 @@ int bbr_destroy(bbr_context *c) {
     if (e) (void)hipEventDestroy(e);
   c->d_srgb_tables.release();
   if (c->s_geom) (void)hipStreamDestroy(c->s_geom);
+  if (c->s_raster) (void)hipStreamDestroy(c->s_raster);
+  for (hipEvent_t e : c->tune.ev)
+    if (e) (void)hipEventDestroy(e);
   if (c->s_shade) (void)hipStreamDestroy(c->s_shade);
   if (c->s_present) (void)hipStreamDestroy(c->s_present);
   delete c;
@@ -1260,6 +1347,7 @@ int bbr_set_partition(bbr_context *c, int32_t rank, int32_t world, int32_t band_
   c->rank = rank;
   c->world = world;
   c->band_rows = band_rows;
+  c->tune.phase = 0;
   if (c->ext_out) {
     uint64_t need = (uint64_t)c->width * (world > 1 ? c->shard_rows() : c->height) * 16;
     if (c->ext_out_bytes < need) {
@@ -1301,9 +1389,20 @@ int bbr_resize(bbr_context *c, int32_t width, int32_t height) {
   c->d_gbuffer.release();
   c->have_frame = false;
   c->last_slot = -1;
+  c->tune.phase = 0;
   // a caller-owned output buffer was sized for the old extent: the caller sets it again (bbr_set_output_device_ptr)
   c->ext_out = nullptr;
   c->ext_out_bytes = 0;
+  return BBR_OK;
+}
+
+int bbr_raster_stream_state(const bbr_context *c, int32_t *out_own, int32_t *out_decided, float *out_ms_shared, float *out_ms_own) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  const bool fixed = c->raster_stream_mode >= 0 || c->n_slots() < 2;
+  if (out_own) *out_own = fixed ? (c->raster_stream_mode == 1 && c->n_slots() >= 2) : (c->tune.phase == bbr_context::kTuneDecided && c->tune.own);
+  if (out_decided) *out_decided = fixed || c->tune.phase == bbr_context::kTuneDecided;
+  if (out_ms_shared) *out_ms_shared = fixed ? 0.f : c->tune.ms_shared;
+  if (out_ms_own) *out_ms_own = fixed ? 0.f : c->tune.ms_own;
   return BBR_OK;
 }
 
@@ -1491,11 +1590,13 @@ int bbr_set_option(bbr_context *c, const char *name, int64_t value) {
     if (value < 1 || value > bbr_context::kMaxSlots) return fail(c, BBR_ERR_INVALID_ARGUMENT, "frames_in_flight: 1, 2 or 3");
     c->frames_in_flight = (int)value;
     c->frame_counter = 0;
+    c->tune.phase = 0;
   } else if (n == "tile_mode") {
     if (value != 0 && value != 1) return fail(c, BBR_ERR_INVALID_ARGUMENT, "tile_mode: 0 (64x64) or 1 (32x32)");
     if (c->world > 1 && c->band_rows % (value == 0 ? 64 : 32))
       return fail(c, BBR_ERR_INVALID_ARGUMENT, "tile_mode: band_rows not a multiple of the new tile height");
     c->tile_mode = (int)value;
+    c->tune.phase = 0;
     // bins and fragment lists are laid out per tile: drop them so that ensure() re-zeroes the counters
     for (FrameSlot &s : c->slots) s.release_tile_buffers();
   } else if (n == "bin_cap") {
@@ -1510,6 +1611,10 @@ int bbr_set_option(bbr_context *c, const char *name, int64_t value) {
     c->overlays = value != 0;
   } else if (n == "tile_order") {
     c->tile_order = value != 0;
+  } else if (n == "raster_stream") {
+    if (value < -1 || value > 1) return fail(c, BBR_ERR_INVALID_ARGUMENT, "raster_stream: -1 (automatic), 0 or 1");
+    c->raster_stream_mode = (int)value;
+    c->tune.phase = 0;
   } else if (n == "broad_threshold") {
     if (value < 1) return fail(c, BBR_ERR_INVALID_ARGUMENT, "broad_threshold must be >= 1");
     c->broad_threshold = (uint32_t)value;

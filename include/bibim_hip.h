@@ -165,7 +165,7 @@ int bbr_timing_summary(bbr_context *ctx, uint32_t *out_frames, float *out_avg_fr
 /* Options (all but "render_pass" drain the context first):
  *   "timing" 0|1|2           1: five HIP events per frame (frame start, geometry, raster, shade start, shade done);
  *                            2: only the two around k_shade (frame/geometry/raster averages read 0); restarts the ring
- *   "frames_in_flight" 1|2   default 2
+ *   "frames_in_flight" 1|2|3 default 2
  *   "tile_mode" 0|1          0: 64x64 tiles, 1: 32x32 tiles (default)
  *   "bin_cap" n              initial references per (tile, raster class); grows by itself on overflow
  *   "broad_threshold" n      triangles touching more than n x n tiles go to the every-tile list
@@ -176,8 +176,16 @@ int bbr_timing_summary(bbr_context *ctx, uint32_t *out_frames, float *out_avg_fr
  *   "overlays" 0|1           keep every frame's resolved depth for bbr_draw_overlays (default 0)
  *   "tile_order" 0|1         launch the heaviest raster tiles first (shorter single frame, lower pipelined
  *                            throughput; default 0)
+ *   "raster_stream" -1|0|1   k_raster on the geometry stream (0) or on a stream of its own (1), so that the geometry of
+ *                            frame N+1 overlaps the raster of frame N.  Same pixels either way; which is faster depends
+ *                            on the workload (1080p, one ShaderBall: own stream 67 -> 47 us per frame; 4K, sixteen:
+ *                            3 % slower).  -1 (default): the context times both, alternating, over the first 170 frames of a workload
+ *                            (no blocking, shared stream meanwhile) and keeps the faster; bbr_raster_stream_state reports
  *   "ablate" bits            diagnostics only: skip parts of the pipeline (see bb_kernels.hip.h) */
 int bbr_set_option(bbr_context *ctx, const char *name, int64_t value);
+/* What option "raster_stream" resolved to: *out_decided = 0 while the automatic choice is still being measured. */
+int bbr_raster_stream_state(const bbr_context *ctx, int32_t *out_own, int32_t *out_decided, float *out_ms_shared,
+                            float *out_ms_own);
 /* Self-test of the arithmetic contract on this device: the shader's reciprocal (v_rcp_f32 + one Newton step) against
  * the IEEE division for +x and -x of every float with bit pattern in [lo_bits, hi_bits); 0 mismatches expected.
  * The whole positive range 0 .. 0x7FFFFFFF takes about half a second. */

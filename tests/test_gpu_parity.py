@@ -604,3 +604,35 @@ def test_resize_keeps_resources_and_renders_the_new_extent_exactly(maps64):
         r.resize(0, 64)
     r.resize(320, 180)                                   # same extent: a no-op apart from the wait
     r.close()
+
+
+@pytest.mark.parametrize("mode", [0, 1, -1])
+def test_raster_stream_arrangements_render_the_same_frames(maps64, mode):
+    """option "raster_stream": k_raster on the geometry stream, on its own stream, or switched back and forth while the
+    context times the two (the automatic setting) -- the frames are the oracle's, bit for bit, throughout"""
+    sc = scenes.shaderball_scene(configs.C3.scaled(640, 360, 64), bbo.MaterialData(maps64))
+    ref, _, _, _ = bbo.render(sc)
+    r = Renderer(sc.width, sc.height)
+    r.set_option("frames_in_flight", 3)
+    r.set_option("raster_stream", mode)
+    h = None
+    for i in range(200):
+        h = r.render_scene(sc, h)
+        if i % 23 == 0 or i == 199:      # the read-back drains the pipeline: the switches happen at different depths
+            assert np.array_equal(r.read_framebuffer().view(np.uint32), ref.view(np.uint32)), f"frame {i}"
+    own, decided, ms_shared, ms_own = r.raster_stream_state()
+    if mode >= 0:
+        assert decided and own == (mode == 1) and ms_own == 0
+    else:
+        for _ in range(4):
+            h = r.render_scene(sc, h)
+        own, decided, ms_shared, ms_own = r.raster_stream_state()
+        assert decided and ms_shared > 0 and ms_own > 0
+        sc2 = scenes.shaderball_scene(configs.C2.scaled(640, 360, 64), sc.draws[0].material)   # another workload: timed afresh
+        r.render_scene(sc2, h)
+        assert not r.raster_stream_state()[1]
+        ref2, _, _, _ = bbo.render(sc2)
+        assert np.array_equal(r.read_framebuffer().view(np.uint32), ref2.view(np.uint32))
+    with pytest.raises(BibimError):
+        r.set_option("raster_stream", 2)
+    r.close()
