@@ -116,8 +116,8 @@ def main():
     ap.add_argument("--no-timing-events", action="store_true")
     ap.add_argument("--frames-in-flight", type=int, default=3, choices=[1, 2, 3],
                     help="frames queued on the GPU at once (the reference keeps 2; 3 keeps the host off the critical path: +2 %%)")
-    ap.add_argument("--raster-stream", default="auto", choices=["auto", "shared", "own"],
-                    help="option raster_stream of the library: k_raster on the geometry stream, on its own, or timed and chosen")
+    ap.add_argument("--stream-layout", type=int, default=-1, choices=[-1, 0, 1, 2],
+                    help="option stream_layout of the library (include/bibim_hip.h); -1: timed at start-up and chosen")
     ap.add_argument("--force-dist", action="store_true", help="exercise the all-gather path with WORLD_SIZE = 1")
     ap.add_argument("--render-pass", default="forward", choices=["forward", "deferred"],
                     help="forward_brdf.* (the path BASELINE measures) or the reference's deferred path, gbuffer.* + brdf.*")
@@ -172,7 +172,7 @@ def main():
     if args.tile_mode is not None:
         r.set_option("tile_mode", args.tile_mode)
     r.set_option("frames_in_flight", args.frames_in_flight)
-    r.set_option("raster_stream", {"auto": -1, "shared": 0, "own": 1}[args.raster_stream])
+    r.set_option("stream_layout", args.stream_layout)
     r.set_option("render_pass", 1 if args.render_pass == "deferred" else 0)
     if args.present_fused:
         if not args.present:
@@ -249,16 +249,16 @@ def main():
     import gc
     gc.collect()
     gc.disable()
-    # The context then times its two stream arrangements over the first frames of a workload (option "raster_stream",
+    # The context then times its three stream layouts over the first frames of a workload (option "stream_layout",
     # include/bibim_hip.h) and keeps the faster: let it finish before the warm-up, like the capacity sizing above.
     # (a fixed number of frames: with N > 1 every rank must issue the same collectives)
-    for _ in range(176):
+    for _ in range(240):
         step()
     fence()
     for _ in range(2):   # the answer is picked up by the next submission once the events are complete
         step()
     fence()
-    rs_own, rs_decided, rs_ms_shared, rs_ms_own = r.raster_stream_state()
+    layout, layout_decided, layout_ms = r.stream_layout_state()
     for _ in range(args.warmup):
         step()
     use_events = not args.no_timing_events
@@ -423,9 +423,7 @@ def main():
                        "output": ("presented RGBA8 (fused)" if args.present_fused else "RGBA32F frame + presented RGBA8")
                                  if args.present else "RGBA32F frame",
                        "render_pass": args.render_pass,
-                       "raster_stream": ("own" if rs_own else "shared with geometry") + (
-                           f" (timed at start-up: {rs_ms_shared:.3f} ms shared vs {rs_ms_own:.3f} ms own for 48 frames)"
-                           if rs_ms_own > 0 else "")},
+                       "stream_layout": layout, "stream_layout_timed_ms_per_48_frames": [round(x, 3) for x in layout_ms]},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         if verified is not None:

@@ -42,7 +42,7 @@ SIGNATURES = {
     "bbr_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(_P)]),
     "bbr_destroy": (C.c_int, [_P]),
     "bbr_resize": (C.c_int, [_P, C.c_int32, C.c_int32]),
-    "bbr_raster_stream_state": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "bbr_stream_layout_state": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
     "bbr_last_error": (C.c_char_p, [_P]),
     "bbr_device_count": (C.c_int, []),
     "bbr_upload_mesh": (C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint32, C.POINTER(C.c_int32)]),

@@ -125,6 +125,7 @@ struct FrameSlot {
   int32_t tone_enable = 0;  // FrameUniformBlock.EnableToneMapping / Exposure of the frame in this slot
   float tone_exposure = 1.f;
   float4 *out_used = nullptr;  // where the frame in this slot wrote its pixels
+  hipStream_t stream_used = nullptr;  // the stream its k_shade ran on
   uint32_t n_prims = 0;
 
   void release_tile_buffers() {
@@ -221,28 +222,40 @@ struct bbr_context {
   hipStream_t geom_stream() const { return user_stream ? user_stream : s_geom; }
   // k_raster on a stream of its own: geometry of frame N+1 (other slot, other counter block) need not wait for the
   // raster of frame N.  At 1080p that chain -- not the GPU -- set the frame rate (C2: 72 -> 41 us per frame)
-  int raster_stream_mode = -1;  // option "raster_stream": 0 shares the geometry stream, 1 own stream, -1 measure and pick
-  bool raster_own = false;      // the stream choice of the frame being submitted
-  // Automatic choice: both arrangements render the same bits, which one is faster depends on whether the
-  // geometry -> raster chain or the shading sets the frame rate (C2 1080p: own stream 67 -> 47 us per frame; C3 4K:
-  // own stream 3 % slower).  So the first frames of a workload are timed: after kTuneWarm frames (clocks, caches),
-  // kTuneRounds x (shared, own) spans of kTuneSpan frames, each after kTuneSkip frames for the switch to settle -- two
-  // events per span on the shade stream, polled without blocking.  Alternating the spans cancels what a single A/B
-  // pair does not: the first span of a fresh context runs on a GPU that is still ramping up.  Until the answer is
-  // in, and whenever it is a tie, k_raster stays on the geometry stream.
-  static constexpr int kTuneWarm = 32, kTuneSkip = 8, kTuneSpan = 24, kTuneRounds = 2, kTuneSpans = 2 * kTuneRounds;
+  // Stream layout of the frames in flight (option "stream_layout").  All three render the same bits:
+  //   0  geometry + raster on s_geom, shade on s_shade, present on s_present          (stage streams)
+  //   1  as 0, but k_raster on s_raster: geometry of frame N+1 need not wait for the raster of frame N
+  //   2  geometry on s_geom; raster + shade + present of a frame on the stream of its slot (s_raster / s_shade /
+  //      s_present double as the three slot streams: a process that owns more than a handful of HIP streams gets
+  //      slower as a whole -- with seven streams every layout lost 60 %)
+  // Which one is fastest depends on whether the geometry -> raster chain, the kernels' tails or the vector ALUs set
+  // the frame rate (1080p, one ShaderBall: 67 / 47 / 39 us per frame; 4K, sixteen: 157 / 162 / 159 us).  The automatic
+  // setting therefore times them on the first frames of a workload: after kTuneWarm frames (clocks, caches),
+  // kTuneRounds rounds of one span per layout, kTuneSpan frames each after kTuneSkip frames for the switch to settle;
+  // two events per span on the frame's shade stream, polled without blocking.  Alternating the spans cancels what a
+  // single pass does not (the first span of a fresh context runs on a GPU that is still ramping up).  Until the answer
+  // is in, and unless another layout wins by 2 %, layout 0 is used.
+  static constexpr int kLayouts = 3;
+  int layout_mode = -1;  // the option: -1 automatic
+  int layout = 0;        // layout of the frame being submitted
+  static constexpr int kTuneWarm = 32, kTuneSkip = 8, kTuneSpan = 24, kTuneRounds = 2, kTuneSpans = kLayouts * kTuneRounds;
   struct {
-    int phase = 0;   // 0 not started, 1 .. kTuneSpans timing (odd: shared stream, even: own), then waiting, then decided
+    int phase = 0;   // 0 not started, 1 .. kTuneSpans timing layout (phase - 1) % kLayouts, then waiting, then decided
     int count = 0;   // frames submitted in the current phase
-    bool own = false;
+    int best = 0;
     hipEvent_t ev[2 * kTuneSpans] = {};  // begin / end of each span
     uint32_t key_prims = 0;
     int32_t key_lights = -1;
     bool key_deferred = false;
-    float ms_shared = 0.f, ms_own = 0.f;
+    float ms[kLayouts] = {0.f, 0.f, 0.f};
   } tune;
   static constexpr int kTuneWaiting = kTuneSpans + 1, kTuneDecided = kTuneSpans + 2;
-  hipStream_t raster_stream() const { return user_stream ? user_stream : ((frames_in_flight > 1 && raster_own) ? s_raster : s_geom); }
+  bool pipelined() const { return !user_stream && frames_in_flight > 1; }
+  hipStream_t slot_stream(int i) const { return i == 0 ? s_raster : (i == 1 ? s_shade : s_present); }
+  hipStream_t raster_stream(int slot) const {
+    return !pipelined() ? geom_stream() : (layout == 2 ? slot_stream(slot) : (layout == 1 ? s_raster : s_geom));
+  }
+  hipStream_t frame_shade_stream(int slot) const { return (pipelined() && layout == 2) ? slot_stream(slot) : shade_stream(); }
   hipStream_t shade_stream() const { return user_stream ? user_stream : (frames_in_flight > 1 ? s_shade : s_geom); }
   // k_present is bandwidth-bound, k_shade issue-bound: on its own stream the presentation of frame N overlaps the
   // shading of frame N+1 instead of delaying it
@@ -312,6 +325,7 @@ int drain(bbr_context *c) {
   HIP_TRY(c, hipStreamSynchronize(c->geom_stream()));
   if (c->shade_stream() != c->geom_stream()) HIP_TRY(c, hipStreamSynchronize(c->shade_stream()));
   if (c->s_raster) HIP_TRY(c, hipStreamSynchronize(c->s_raster));
+
   if (c->s_present) HIP_TRY(c, hipStreamSynchronize(c->s_present));
   for (FrameSlot &s : c->slots) s.in_flight = false;
   return BBR_OK;
@@ -380,7 +394,8 @@ int upload_material_table(bbr_context *c) {
 template <int TW, int TH>
 void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const FrameParams &fp, const Mat4 &pv,
                   const Mat4 &view, const ShadeParams &sp, const Light *d_lights, const DrawDesc *d_draws, uint32_t n_draws, float4 *out) {
-  hipStream_t sg = c->geom_stream(), sr = c->raster_stream(), ss = c->shade_stream();
+  const int slot_index = (int)(&s - c->slots);
+  hipStream_t sg = c->geom_stream(), sr = c->raster_stream(slot_index), ss = c->frame_shade_stream(slot_index);
   Counters *ctr = c->d_counters.ptr + s.ctr_index, *ctr_next = c->d_counters.ptr + (s.ctr_index + 1) % bbr_context::kCounterBlocks;
   hipEvent_t *ev = c->timing ? &c->ring[bbr_context::kRingEvents * (c->ring_frames % bbr_context::kRingCap)] : nullptr;
   if (c->n_prims)
@@ -396,7 +411,11 @@ void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const Fra
   }
   // k_raster writes the background pixels of `out`: if the frame still shading on the other stream writes the
   // same buffer (single external output), raster has to wait for it; geometry above still overlapped
-  if (prev && prev->in_flight && prev->out_used == out && ss != sr) (void)hipStreamWaitEvent(sr, prev->ev_shade_done, 0);
+  // (every frame still in flight, not just the previous one: with one stream per slot, or while the layout is being
+  //  switched, "after the previous frame" no longer implies "after the one before")
+  (void)prev;
+  for (const FrameSlot &o : c->slots)
+    if (&o != &s && o.in_flight && o.out_used == out && o.stream_used != sr) (void)hipStreamWaitEvent(sr, o.ev_shade_done, 0);
   // a rank without bands (more ranks than bands) still launches one row: its blocks fall off tiles_y and exit
   int grid_y = std::max(1, c->world > 1 ? c->local_bands() * fp.band_tiles : fp.tiles_y);
   // option "present_fused": k_raster / k_shade write presented pixels into the slot's RGBA8 image
@@ -441,6 +460,7 @@ void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const Fra
     else shade(std::false_type{}, std::false_type{});
   }
   (void)hipEventRecord(s.ev_shade_done, ss);
+  s.stream_used = ss;
   if (ev) {
     (void)hipEventRecord(ev[4], ss);
     ++c->ring_frames;
@@ -556,8 +576,8 @@ int submit_frame_into(bbr_context *c, int slot_index) {
   const FrameSlot *prev = (c->last_slot >= 0 && c->last_slot != slot_index) ? &c->slots[c->last_slot] : nullptr;
 
   int tune_mark = -1;  // which of tune.ev to record behind this frame's k_shade
-  if (c->raster_stream_mode >= 0 || c->n_slots() < 2) {
-    c->raster_own = c->raster_stream_mode == 1;
+  if (c->layout_mode >= 0 || !c->pipelined()) {
+    c->layout = std::max(c->layout_mode, 0);
   } else {
     auto &t = c->tune;
     const bool same_workload = t.key_lights == sp.num_lights && t.key_deferred == c->deferred &&
@@ -572,34 +592,36 @@ int submit_frame_into(bbr_context *c, int slot_index) {
         if (!e) HIP_TRY(c, hipEventCreate(&e));
     }
     if (t.phase >= 1 && t.phase <= bbr_context::kTuneSpans) {
-      c->raster_own = (t.phase & 1) == 0;
+      c->layout = (t.phase - 1) % bbr_context::kLayouts;
       const int skip = bbr_context::kTuneSkip + (t.phase == 1 ? bbr_context::kTuneWarm : 0);
       if (t.count == skip) tune_mark = (t.phase - 1) * 2;
       if (t.count == skip + bbr_context::kTuneSpan) tune_mark = (t.phase - 1) * 2 + 1;
     } else if (t.phase == bbr_context::kTuneWaiting) {
-      c->raster_own = false;
+      c->layout = 0;
       if (hipEventQuery(t.ev[2 * bbr_context::kTuneSpans - 1]) == hipSuccess) {
-        t.ms_shared = t.ms_own = 0.f;
+        for (float &m : t.ms) m = 0.f;
         for (int k = 0; k < bbr_context::kTuneSpans; ++k) {
           float ms = 0.f;
           (void)hipEventElapsedTime(&ms, t.ev[2 * k], t.ev[2 * k + 1]);
-          (k & 1 ? t.ms_own : t.ms_shared) += ms;
+          t.ms[k % bbr_context::kLayouts] += ms;
         }
-        t.own = t.ms_own > 0.f && t.ms_own < 0.98f * t.ms_shared;
+        t.best = 0;
+        for (int l = 1; l < bbr_context::kLayouts; ++l)
+          if (t.ms[l] > 0.f && t.ms[l] < 0.98f * t.ms[0] && (t.best == 0 || t.ms[l] < t.ms[t.best])) t.best = l;
         t.phase = bbr_context::kTuneDecided;
         if (getenv("BBR_DEBUG"))
-          fprintf(stderr, "[bbr] raster stream: %d frames shared %.3f ms, own %.3f ms -> %s\n",
-                  bbr_context::kTuneSpan * bbr_context::kTuneRounds, t.ms_shared, t.ms_own, t.own ? "own" : "shared");
+          fprintf(stderr, "[bbr] stream layout: %d frames take %.3f / %.3f / %.3f ms -> layout %d\n",
+                  bbr_context::kTuneSpan * bbr_context::kTuneRounds, t.ms[0], t.ms[1], t.ms[2], t.best);
       }
     }
-    if (t.phase == bbr_context::kTuneDecided) c->raster_own = t.own;
+    if (t.phase == bbr_context::kTuneDecided) c->layout = t.best;
   }
   if (c->tile_mode == 0) launch_frame<64, 64>(c, s, prev, fp, pv, view, sp, d_lights, d_draws, c->n_live_draws, out);
   else launch_frame<32, 32>(c, s, prev, fp, pv, view, sp, d_lights, d_draws, c->n_live_draws, out);
   HIP_TRY(c, hipGetLastError());
-  if (c->raster_stream_mode < 0 && c->n_slots() >= 2 && c->tune.phase >= 1 && c->tune.phase <= bbr_context::kTuneSpans) {
+  if (c->layout_mode < 0 && c->pipelined() && c->tune.phase >= 1 && c->tune.phase <= bbr_context::kTuneSpans) {
     auto &t = c->tune;
-    if (tune_mark >= 0) HIP_TRY(c, hipEventRecord(t.ev[tune_mark], c->shade_stream()));
+    if (tune_mark >= 0) HIP_TRY(c, hipEventRecord(t.ev[tune_mark], s.stream_used));
     if (t.count++ == bbr_context::kTuneSkip + bbr_context::kTuneSpan + (t.phase == 1 ? bbr_context::kTuneWarm : 0)) {
       ++t.phase;
       t.count = 0;
@@ -661,8 +683,9 @@ int queue_present(bbr_context *c, FrameSlot &s) {
   int rc_tables = ensure_srgb_tables(c);
   if (rc_tables) return rc_tables;
   const size_t n = (size_t)c->width * (c->world > 1 ? c->shard_rows() : c->height);
-  hipStream_t ps = c->present_stream();
-  if (ps != c->shade_stream()) HIP_TRY(c, hipStreamWaitEvent(ps, s.ev_shade_done, 0));  // behind the frame's k_shade
+  // layout 2: on the slot's own stream, behind its k_shade (the other slots' streams keep the GPU busy meanwhile)
+  hipStream_t ps = (c->pipelined() && s.stream_used && s.stream_used != c->shade_stream()) ? s.stream_used : c->present_stream();
+  if (ps != s.stream_used) HIP_TRY(c, hipStreamWaitEvent(ps, s.ev_shade_done, 0));  // behind the frame's k_shade
   hipEvent_t *pe = nullptr;
   if (c->timing) {
     if (c->present_ring.empty()) {
@@ -1396,13 +1419,14 @@ int bbr_resize(bbr_context *c, int32_t width, int32_t height) {
   return BBR_OK;
 }
 
-int bbr_raster_stream_state(const bbr_context *c, int32_t *out_own, int32_t *out_decided, float *out_ms_shared, float *out_ms_own) {
+int bbr_stream_layout_state(const bbr_context *c, int32_t *out_layout, int32_t *out_decided, float *out_ms) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
-  const bool fixed = c->raster_stream_mode >= 0 || c->n_slots() < 2;
-  if (out_own) *out_own = fixed ? (c->raster_stream_mode == 1 && c->n_slots() >= 2) : (c->tune.phase == bbr_context::kTuneDecided && c->tune.own);
-  if (out_decided) *out_decided = fixed || c->tune.phase == bbr_context::kTuneDecided;
-  if (out_ms_shared) *out_ms_shared = fixed ? 0.f : c->tune.ms_shared;
-  if (out_ms_own) *out_ms_own = fixed ? 0.f : c->tune.ms_own;
+  const bool fixed = c->layout_mode >= 0 || !c->pipelined();
+  const bool decided = fixed || c->tune.phase == bbr_context::kTuneDecided;
+  if (out_layout) *out_layout = fixed ? (c->pipelined() ? c->layout_mode : 0) : (decided ? c->tune.best : 0);
+  if (out_decided) *out_decided = decided;
+  if (out_ms)
+    for (int l = 0; l < bbr_context::kLayouts; ++l) out_ms[l] = (fixed || !decided) ? 0.f : c->tune.ms[l];
   return BBR_OK;
 }
 
@@ -1611,9 +1635,9 @@ int bbr_set_option(bbr_context *c, const char *name, int64_t value) {
     c->overlays = value != 0;
   } else if (n == "tile_order") {
     c->tile_order = value != 0;
-  } else if (n == "raster_stream") {
-    if (value < -1 || value > 1) return fail(c, BBR_ERR_INVALID_ARGUMENT, "raster_stream: -1 (automatic), 0 or 1");
-    c->raster_stream_mode = (int)value;
+  } else if (n == "stream_layout") {
+    if (value < -1 || value >= bbr_context::kLayouts) return fail(c, BBR_ERR_INVALID_ARGUMENT, "stream_layout: -1 (automatic), 0, 1 or 2");
+    c->layout_mode = (int)value;
     c->tune.phase = 0;
   } else if (n == "broad_threshold") {
     if (value < 1) return fail(c, BBR_ERR_INVALID_ARGUMENT, "broad_threshold must be >= 1");
@@ -1740,7 +1764,7 @@ int bbr_tone_map(bbr_context *c, int32_t enable, float exposure) {
   float4 *frame = c->slots[c->last_slot].out_used;
   size_t n = (size_t)c->width * (c->world > 1 ? c->shard_rows() : c->height);
   // same stream as the frame's shade kernel: ordered after it
-  hipLaunchKernelGGL(k_tone_map, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->shade_stream(), frame, n, enable, exposure);
+  hipLaunchKernelGGL(k_tone_map, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->slots[c->last_slot].stream_used, frame, n, enable, exposure);
   HIP_TRY(c, hipGetLastError());
   return BBR_OK;
 }

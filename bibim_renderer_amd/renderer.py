@@ -199,11 +199,11 @@ class Renderer:
         self._check(self._L.bbr_unpack_gathered_rgba8(self._ctx, C.c_void_p(gathered_ptr), C.c_void_p(frame_ptr),
                                                       C.c_void_p(stream) if stream else None))
 
-    def raster_stream_state(self):
-        """(own stream?, decided?, ms of the timed span on the shared stream, on the own stream)"""
-        own, dec, a, b = C.c_int32(), C.c_int32(), C.c_float(), C.c_float()
-        self._check(self._L.bbr_raster_stream_state(self._ctx, C.byref(own), C.byref(dec), C.byref(a), C.byref(b)))
-        return bool(own.value), bool(dec.value), a.value, b.value
+    def stream_layout_state(self):
+        """(layout in use, decided?, [ms of the timed spans per layout])"""
+        lay, dec, ms = C.c_int32(), C.c_int32(), (C.c_float * 3)()
+        self._check(self._L.bbr_stream_layout_state(self._ctx, C.byref(lay), C.byref(dec), ms))
+        return lay.value, bool(dec.value), [float(x) for x in ms]
 
     # -- multi-GPU partition --
     def set_partition(self, rank, world, band_rows=0):

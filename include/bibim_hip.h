@@ -176,16 +176,20 @@ int bbr_timing_summary(bbr_context *ctx, uint32_t *out_frames, float *out_avg_fr
  *   "overlays" 0|1           keep every frame's resolved depth for bbr_draw_overlays (default 0)
  *   "tile_order" 0|1         launch the heaviest raster tiles first (shorter single frame, lower pipelined
  *                            throughput; default 0)
- *   "raster_stream" -1|0|1   k_raster on the geometry stream (0) or on a stream of its own (1), so that the geometry of
- *                            frame N+1 overlaps the raster of frame N.  Same pixels either way; which is faster depends
- *                            on the workload (1080p, one ShaderBall: own stream 67 -> 47 us per frame; 4K, sixteen:
- *                            3 % slower).  -1 (default): the context times both, alternating, over the first 170 frames of a workload
- *                            (no blocking, shared stream meanwhile) and keeps the faster; bbr_raster_stream_state reports
+ *   "stream_layout" -1|0|1|2 how the kernels of the frames in flight are spread over HIP streams.  Same pixels in every
+ *                            layout; which is fastest depends on the workload.  0: geometry + raster on one stream,
+ *                            shade on a second, present on a third.  1: as 0 with k_raster on a stream of its own (the
+ *                            geometry of frame N+1 overlaps the raster of frame N).  2: geometry on one stream, raster +
+ *                            shade + present of a frame on the stream of its frame slot (whole frames overlap).
+ *                            1080p, one ShaderBall: 67 / 47 / 39 us per frame; 4K, sixteen: 157 / 162 / 159 us.
+ *                            -1 (default): the context times the three, alternating, over the first 230 frames of a
+ *                            workload (nothing blocks; layout 0 meanwhile) and keeps the fastest;
+ *                            bbr_stream_layout_state reports
  *   "ablate" bits            diagnostics only: skip parts of the pipeline (see bb_kernels.hip.h) */
 int bbr_set_option(bbr_context *ctx, const char *name, int64_t value);
-/* What option "raster_stream" resolved to: *out_decided = 0 while the automatic choice is still being measured. */
-int bbr_raster_stream_state(const bbr_context *ctx, int32_t *out_own, int32_t *out_decided, float *out_ms_shared,
-                            float *out_ms_own);
+/* What option "stream_layout" resolved to: *out_decided = 0 while the automatic choice is still being measured;
+ * out_ms[3] = the time the measured spans took per layout (0 when the layout was set by hand). */
+int bbr_stream_layout_state(const bbr_context *ctx, int32_t *out_layout, int32_t *out_decided, float *out_ms);
 /* Self-test of the arithmetic contract on this device: the shader's reciprocal (v_rcp_f32 + one Newton step) against
  * the IEEE division for +x and -x of every float with bit pattern in [lo_bits, hi_bits); 0 mismatches expected.
  * The whole positive range 0 .. 0x7FFFFFFF takes about half a second. */

@@ -606,33 +606,75 @@ def test_resize_keeps_resources_and_renders_the_new_extent_exactly(maps64):
     r.close()
 
 
-@pytest.mark.parametrize("mode", [0, 1, -1])
-def test_raster_stream_arrangements_render_the_same_frames(maps64, mode):
-    """option "raster_stream": k_raster on the geometry stream, on its own stream, or switched back and forth while the
-    context times the two (the automatic setting) -- the frames are the oracle's, bit for bit, throughout"""
+@pytest.mark.parametrize("mode", [0, 1, 2, -1])
+def test_stream_layouts_render_the_same_frames(maps64, mode):
+    """option "stream_layout": stage streams, k_raster on its own stream, one stream per frame slot, or switched back and
+    forth while the context times the three (the automatic setting) -- the frames, their presented images and tone-mapped
+    copies are the oracle's, bit for bit, throughout"""
     sc = scenes.shaderball_scene(configs.C3.scaled(640, 360, 64), bbo.MaterialData(maps64))
+    sc.frame["enable_tone_mapping"], sc.frame["exposure"] = 1, 1.3
     ref, _, _, _ = bbo.render(sc)
+    want8 = bbo.present(ref, 1, 1.3)
     r = Renderer(sc.width, sc.height)
     r.set_option("frames_in_flight", 3)
-    r.set_option("raster_stream", mode)
+    r.set_option("stream_layout", mode)
     h = None
-    for i in range(200):
+    for i in range(260):
         h = r.render_scene(sc, h)
-        if i % 23 == 0 or i == 199:      # the read-back drains the pipeline: the switches happen at different depths
+        if i % 5 == 0:
+            r.present()                  # queued behind the frame's k_shade, whichever stream that ran on
+        if i % 23 == 0 or i == 259:      # the read-back drains the pipeline: the switches happen at different depths
             assert np.array_equal(r.read_framebuffer().view(np.uint32), ref.view(np.uint32)), f"frame {i}"
-    own, decided, ms_shared, ms_own = r.raster_stream_state()
+            if i % 5 == 0:
+                assert np.array_equal(r.read_presented(), want8), f"presented frame {i}"
+    layout, decided, ms = r.stream_layout_state()
     if mode >= 0:
-        assert decided and own == (mode == 1) and ms_own == 0
+        assert decided and layout == mode and ms == [0, 0, 0]
     else:
         for _ in range(4):
             h = r.render_scene(sc, h)
-        own, decided, ms_shared, ms_own = r.raster_stream_state()
-        assert decided and ms_shared > 0 and ms_own > 0
+        layout, decided, ms = r.stream_layout_state()
+        assert decided and layout in (0, 1, 2) and min(ms) > 0
         sc2 = scenes.shaderball_scene(configs.C2.scaled(640, 360, 64), sc.draws[0].material)   # another workload: timed afresh
         r.render_scene(sc2, h)
-        assert not r.raster_stream_state()[1]
+        assert not r.stream_layout_state()[1]
         ref2, _, _, _ = bbo.render(sc2)
         assert np.array_equal(r.read_framebuffer().view(np.uint32), ref2.view(np.uint32))
+    r.tone_map(1, 1.3)                   # in place, on the stream the frame's k_shade ran on
     with pytest.raises(BibimError):
-        r.set_option("raster_stream", 2)
+        r.set_option("stream_layout", 3)
+    r.close()
+
+
+@pytest.mark.parametrize("layout", [0, 1, 2])
+def test_caller_buffers_shared_by_frames_in_flight(maps64, layout):
+    """three frames in flight into two caller-owned buffers, no synchronisation in between: a slow frame into A, an empty
+    one into B, an empty one into A.  The last frame's clear must land after the slow frame's shading although the frame
+    right before it wrote elsewhere: "behind the previous frame" is not enough"""
+    import torch
+    from dataclasses import replace
+    cfg = replace(configs.C5.scaled(1920, 1080, 64), lights=(configs.C5.lights * 4)[:32])     # slow to shade
+    heavy = scenes.shaderball_scene(cfg, bbo.MaterialData(maps64))
+    r = Renderer(cfg.width, cfg.height)
+    r.set_option("frames_in_flight", 3)
+    r.set_option("stream_layout", layout)
+    h = r.render_scene(heavy)
+    r.synchronize()                                   # capacities sized
+    out_a = torch.full((cfg.height, cfg.width, 4), 7.0, dtype=torch.float32, device="cuda")
+    out_b = torch.full((cfg.height, cfg.width, 4), 7.0, dtype=torch.float32, device="cuda")
+    empty_f, empty_v = scenes.frame_uniforms([]), heavy.view
+    def target(t):
+        r.set_output_device_ptr(t.data_ptr(), t.numel() * 4)
+    def empty_frame():
+        r.set_frame_uniforms(empty_f); r.set_view_uniforms(empty_v)
+        r.begin_frame(); r.end_frame()
+    for rep in range(6):                              # four frames a round: the slow one visits every slot (and priority)
+        target(out_b); empty_frame()
+        target(out_a); h = r.render_scene(heavy, h)
+        target(out_b); empty_frame()                  # the frame before the last one writes elsewhere ...
+        target(out_a); empty_frame()                  # ... and the last one must still wait for the slow one
+        r.synchronize()
+        torch.cuda.synchronize()
+        assert int((out_a != 0).sum().item()) == 0, f"round {rep}: pixels of an earlier frame survived the last frame's clear"
+        assert int((out_b != 0).sum().item()) == 0
     r.close()

@@ -1,4 +1,4 @@
-"""Experiment (GPU box): frame rate with k_raster on the geometry stream (0) or on its own (1), over resolutions and
+"""Experiment (GPU box): frame rate with the three stream layouts of option stream_layout, over resolutions and
 light counts -- where does the geometry -> raster chain, rather than the GPU, set the rate?
    python tools/_gpu_raster_stream.py"""
 import gc, os, sys, time
@@ -20,10 +20,10 @@ if os.environ.get("QUICK"):
     cases = [c for c in cases if c.name in os.environ["QUICK"].split(",")]
 for cfg in cases:
     res = []
-    for mode in (0, 1):
+    for mode in (0, 1, 2):
         r = Renderer(cfg.width, cfg.height)
         r.set_option("frames_in_flight", 3)
-        r.set_option("raster_stream", mode)
+        r.set_option("stream_layout", mode)
         mat = r.upload_material(maps)
         scene, cam, settings = S.config_scene(r, cfg, ball)
         S.draw_frame(r, scene, cam, settings, mat); r.synchronize()
@@ -47,4 +47,4 @@ for cfg in cases:
             print(f"   mode {mode}: slowest submit {worst * 1e3:.2f} ms at frame {worst_i}, capacity retries {r.stats()['bin_overflow']}", flush=True)
         scene.close(); r.close()
     load = cfg.width * cfg.height * max(len(cfg.lights), 1) / 1e6
-    print(f"{cfg.name:28s} load {load:7.1f}M  shared {res[0]:8.1f} us  own {res[1]:8.1f} us  own/shared {res[1] / res[0]:.3f}", flush=True)
+    print(f"{cfg.name:28s} load {load:7.1f}M  shared {res[0]:8.1f} us  own {res[1]:8.1f} us ({res[1] / res[0]:.3f})  per-slot {res[2]:8.1f} us ({res[2] / res[0]:.3f})", flush=True)
