@@ -234,7 +234,7 @@ struct bbr_context {
   // kTuneRounds rounds of one span per layout, kTuneSpan frames each after kTuneSkip frames for the switch to settle;
   // two events per span on the frame's shade stream, polled without blocking.  Alternating the spans cancels what a
   // single pass does not (the first span of a fresh context runs on a GPU that is still ramping up).  Until the answer
-  // is in, and unless another layout wins by 2 %, layout 0 is used.
+  // is in, and unless another layout wins by 7 %, layout 0 is used.
   static constexpr int kLayouts = 3;
   int layout_mode = -1;  // the option: -1 automatic
   int layout = 0;        // layout of the frame being submitted
@@ -607,7 +607,7 @@ int submit_frame_into(bbr_context *c, int slot_index) {
         }
         t.best = 0;
         for (int l = 1; l < bbr_context::kLayouts; ++l)
-          if (t.ms[l] > 0.f && t.ms[l] < 0.98f * t.ms[0] && (t.best == 0 || t.ms[l] < t.ms[t.best])) t.best = l;
+          if (t.ms[l] > 0.f && t.ms[l] < 0.93f * t.ms[0] && (t.best == 0 || t.ms[l] < t.ms[t.best])) t.best = l;
         t.phase = bbr_context::kTuneDecided;
         if (getenv("BBR_DEBUG"))
           fprintf(stderr, "[bbr] stream layout: %d frames take %.3f / %.3f / %.3f ms -> layout %d\n",
@@ -621,7 +621,12 @@ int submit_frame_into(bbr_context *c, int slot_index) {
   HIP_TRY(c, hipGetLastError());
   if (c->layout_mode < 0 && c->pipelined() && c->tune.phase >= 1 && c->tune.phase <= bbr_context::kTuneSpans) {
     auto &t = c->tune;
-    if (tune_mark >= 0) HIP_TRY(c, hipEventRecord(t.ev[tune_mark], s.stream_used));
+    if (tune_mark >= 0) {
+      // "every frame up to this one is done": with one stream per slot frames may finish out of order
+      for (const FrameSlot &o : c->slots)
+        if (&o != &s && o.in_flight && o.stream_used != s.stream_used) HIP_TRY(c, hipStreamWaitEvent(s.stream_used, o.ev_shade_done, 0));
+      HIP_TRY(c, hipEventRecord(t.ev[tune_mark], s.stream_used));
+    }
     if (t.count++ == bbr_context::kTuneSkip + bbr_context::kTuneSpan + (t.phase == 1 ? bbr_context::kTuneWarm : 0)) {
       ++t.phase;
       t.count = 0;
