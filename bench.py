@@ -300,7 +300,8 @@ def main():
         shade_bytes = stats["n_shaded"] * (16 + 4 * m) + 6432 + 144
         achieved = shade_bytes / (avg_shade_ms * 1e-3) / 1e9 if avg_shade_ms > 0 else 0.0
         balg = algorithmic_bytes(cfg, n_shaded_total, ball.shape[0])
-        traffic, traffic_src = profiled_traffic(args.workload)
+        # (the committed PMC passes are of the unpartitioned launch: no figure for a rank's share of the frame)
+        traffic, traffic_src = profiled_traffic(args.workload) if world == 1 and not args.force_dist else (None, None)
         roofline = {"bound": "hbm", "kernel": "k_shade", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "traffic_source": traffic_src,
