@@ -118,6 +118,9 @@ def main():
                     help="frames queued on the GPU at once (the reference keeps 2; 3 keeps the host off the critical path: +2 %%)")
     ap.add_argument("--stream-layout", type=int, default=-1, choices=[-1, 0, 1, 2],
                     help="option stream_layout of the library (include/bibim_hip.h); -1: timed at start-up and chosen")
+    ap.add_argument("--gather", default="packed", choices=["packed", "rgba32f"],
+                    help="N > 1: what the all-gather moves -- the shard as rgb + one alpha bit per pixel (lossless, 12.1 B per "
+                         "pixel; default) or as plain RGBA32F (16 B); the reassembled frame is the same, bit for bit")
     ap.add_argument("--force-dist", action="store_true", help="exercise the all-gather path with WORLD_SIZE = 1")
     ap.add_argument("--render-pass", default="forward", choices=["forward", "deferred"],
                     help="forward_brdf.* (the path BASELINE measures) or the reference's deferred path, gbuffer.* + brdf.*")
@@ -193,6 +196,11 @@ def main():
         shard_t = [torch.empty((shard_rows, W, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
         gathered_t = [torch.empty((world * shard_rows, W, 4), dtype=torch.float32, device="cuda") for _ in range(2)]  # [rank][shard row]
         frame_t = [torch.empty((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
+        packed = args.gather == "packed" and not args.present
+        if packed:
+            pb = r.packed_shard_bytes()
+            packed_t = [torch.empty((pb,), dtype=torch.uint8, device="cuda") for _ in range(2)]
+            gathered_packed_t = [torch.empty((world * pb,), dtype=torch.uint8, device="cuda") for _ in range(2)]
         if args.present:
             shard8_t = [torch.empty((shard_rows, W, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
             gathered8_t = [torch.empty((world * shard_rows, W, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
@@ -218,7 +226,10 @@ def main():
             r.present(shard8_t[b].data_ptr())
         r.stream_wait_frame(ag_stream.cuda_stream)
         with torch.cuda.stream(ag_stream):
-            src, dst = (shard8_t[b], gathered8_t[b]) if args.present else (shard_t[b], gathered_t[b])
+            if packed:
+                r.pack_shard(packed_t[b].data_ptr(), ag_stream.cuda_stream)
+            src, dst = (shard8_t[b], gathered8_t[b]) if args.present else (
+                (packed_t[b], gathered_packed_t[b]) if packed else (shard_t[b], gathered_t[b]))
             if backend == "nccl":
                 dist.all_gather_into_tensor(dst, src)
             else:  # rehearsal: through host memory
@@ -228,6 +239,8 @@ def main():
                 dst.copy_(h_dst)
             if args.present:
                 r.unpack_gathered_rgba8(gathered8_t[b].data_ptr(), frame8_t[b].data_ptr(), ag_stream.cuda_stream)
+            elif packed:
+                r.unpack_gathered_packed(gathered_packed_t[b].data_ptr(), frame_t[b].data_ptr(), ag_stream.cuda_stream)
             else:
                 r.unpack_gathered(gathered_t[b].data_ptr(), frame_t[b].data_ptr(), ag_stream.cuda_stream)
             consumed[b].record(ag_stream)
@@ -419,7 +432,10 @@ def main():
                        "instances": cfg.n_instances, "lights": len(cfg.lights), "triangles": int(stats["n_prims"]),
                        "textures": f"{cfg.texture_size}x{cfg.texture_size} RGBA8 x5 (seed 0x5EED)",
                        "partition": "single GPU" if world == 1 else f"interleaved {args.band_rows or r.tile_height()}-row bands, "
-                                    f"{world} ranks, ncclAllGather + un-interleave",
+                                    f"{world} ranks, ncclAllGather of " + (
+                                        "RGBA8 shards" if args.present else
+                                        "shards packed as rgb + alpha bit (lossless, 12.1 B/pixel)" if args.gather == "packed"
+                                        else "RGBA32F shards") + " + un-interleave",
                        "tile": f"{stats['tile_w']}x{stats['tile_h']}",
                        "output": ("presented RGBA8 (fused)" if args.present_fused else "RGBA32F frame + presented RGBA8")
                                  if args.present else "RGBA32F frame",

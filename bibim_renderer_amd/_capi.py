@@ -64,6 +64,9 @@ SIGNATURES = {
     "bbr_shard_rows": (C.c_int, [_P, C.POINTER(C.c_int32)]),
     "bbr_read_shard": (C.c_int, [_P, _P]),
     "bbr_unpack_gathered": (C.c_int, [_P, _P, _P, _P]),
+    "bbr_packed_shard_bytes": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    "bbr_pack_shard": (C.c_int, [_P, _P, _P]),
+    "bbr_unpack_gathered_packed": (C.c_int, [_P, _P, _P, _P]),
     "bbr_wait_event": (C.c_int, [_P, _P]),
     "bbr_stream_wait_frame": (C.c_int, [_P, _P]),
     "bbr_tile_height": (C.c_int, [_P, C.POINTER(C.c_int32)]),

@@ -1654,6 +1654,41 @@ __global__ __launch_bounds__(kPresentThreads) void k_present(const float4 *__res
   }
 }
 
+// Lossless 12.1-byte form of a shard for the all-gather (a quarter less than RGBA32F over links that are the bottleneck
+// at N > 1): alpha is 1.0 where geometry was shaded and 0.0 on cleared pixels (forward_brdf.frag:75 writes 1, the clear
+// colour is 0, src/main.cpp:84; the deferred path writes 1 everywhere), so it travels as one bit.
+//   packed block of a rank = rgb[n][3] float, then (8-byte aligned) one 64-bit mask per 64 pixels, n = shard_rows * width
+__global__ void k_pack_shard(const float4 *__restrict__ shard, float *__restrict__ rgb, unsigned long long *__restrict__ mask,
+                             size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = i < n;
+  float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (live) {
+    p = shard[i];
+    rgb[3 * i + 0] = p.x;
+    rgb[3 * i + 1] = p.y;
+    rgb[3 * i + 2] = p.z;
+  }
+  const unsigned long long m = __ballot(live && __float_as_uint(p.w) == 0x3F800000u);
+  if ((threadIdx.x & 63) == 0 && live) mask[i >> 6] = m;
+}
+
+// [world] packed blocks -> row-major RGBA32F frame (the un-interleave of k_unpack_gathered on the packed form)
+__global__ void k_unpack_gathered_packed(const uint8_t *__restrict__ gathered, float4 *__restrict__ frame, int width, int height,
+                                         int world, int band_rows, int shard_rows, size_t block_bytes, size_t mask_offset) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t n = (size_t)width * (size_t)height;
+  if (i >= n) return;
+  int y = (int)(i / (size_t)width), x = (int)(i - (size_t)y * width);
+  int band = y / band_rows, r = y - band * band_rows;
+  int rank = band % world, lb = band / world;
+  const size_t j = ((size_t)lb * band_rows + r) * (size_t)width + x;
+  const uint8_t *block = gathered + (size_t)rank * block_bytes;
+  const float *rgb = reinterpret_cast<const float *>(block) + 3 * j;
+  const unsigned long long m = reinterpret_cast<const unsigned long long *>(block + mask_offset)[j >> 6];
+  frame[i] = make_float4(rgb[0], rgb[1], rgb[2], ((m >> (j & 63)) & 1ull) ? 1.0f : 0.0f);
+}
+
 // [world][shard_rows][width] RGBA8 -> row-major presented frame (same un-interleave as k_unpack_gathered)
 __global__ void k_unpack_gathered_rgba8(const uint32_t *__restrict__ gathered, uint32_t *__restrict__ frame, int width,
                                         int height, int world, int band_rows, int shard_rows) {

@@ -1746,6 +1746,47 @@ int bbr_unpack_gathered_rgba8(bbr_context *c, const void *gathered, void *frame,
   return BBR_OK;
 }
 
+namespace {
+// packed shard: rgb[n][3] float, padding to 8 bytes, one 64-bit alpha mask per 64 pixels, padding to 16 bytes
+size_t packed_mask_offset(const bbr_context *c) { return (((size_t)c->width * c->shard_rows() * 12) + 7) & ~(size_t)7; }
+size_t packed_block_bytes(const bbr_context *c) {
+  const size_t n = (size_t)c->width * c->shard_rows();
+  return (packed_mask_offset(c) + ((n + 63) / 64) * 8 + 15) & ~(size_t)15;
+}
+}  // namespace
+
+int bbr_packed_shard_bytes(const bbr_context *c, uint64_t *out_bytes) {
+  if (!c || !out_bytes) return BBR_ERR_INVALID_ARGUMENT;
+  *out_bytes = packed_block_bytes(c);
+  return BBR_OK;
+}
+
+int bbr_pack_shard(bbr_context *c, void *packed, void *stream) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  if (!packed) return fail(c, BBR_ERR_INVALID_ARGUMENT, "pack_shard: NULL");
+  if (!c->have_frame || c->last_slot < 0) return fail(c, BBR_ERR_NOT_IN_FRAME, "pack_shard: nothing rendered");
+  const FrameSlot &s = c->slots[c->last_slot];
+  if (s.fused) return fail(c, BBR_ERR_INVALID_ARGUMENT, "pack_shard: no fp32 frame with option present_fused");
+  const size_t n = (size_t)c->width * c->shard_rows();
+  hipStream_t st = stream ? (hipStream_t)stream : s.stream_used;  // a caller's stream must already wait for the frame
+  hipLaunchKernelGGL(k_pack_shard, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float4 *)s.out_used,
+                     (float *)packed, (unsigned long long *)((uint8_t *)packed + packed_mask_offset(c)), n);
+  HIP_TRY(c, hipGetLastError());
+  return BBR_OK;
+}
+
+int bbr_unpack_gathered_packed(bbr_context *c, const void *gathered, void *frame, void *stream) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  if (!gathered || !frame) return fail(c, BBR_ERR_INVALID_ARGUMENT, "unpack_gathered_packed: NULL");
+  size_t n = (size_t)c->width * c->height;
+  hipStream_t st = stream ? (hipStream_t)stream : c->shade_stream();
+  hipLaunchKernelGGL(k_unpack_gathered_packed, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint8_t *)gathered,
+                     (float4 *)frame, c->width, c->height, c->world, c->eff_band_rows(), c->shard_rows(),
+                     packed_block_bytes(c), packed_mask_offset(c));
+  HIP_TRY(c, hipGetLastError());
+  return BBR_OK;
+}
+
 int bbr_selftest_rcp(bbr_context *c, uint32_t lo_bits, uint32_t hi_bits, uint64_t *out_mismatches) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
   if (!out_mismatches || hi_bits < lo_bits) return fail(c, BBR_ERR_INVALID_ARGUMENT, "selftest_rcp: bad arguments");

@@ -239,6 +239,19 @@ class Renderer:
         self._check(self._L.bbr_unpack_gathered(self._ctx, C.c_void_p(gathered_ptr), C.c_void_p(frame_ptr),
                                                 C.c_void_p(stream_handle) if stream_handle else None))
 
+    def packed_shard_bytes(self):
+        n = C.c_uint64()
+        self._check(self._L.bbr_packed_shard_bytes(self._ctx, C.byref(n)))
+        return n.value
+
+    def pack_shard(self, packed_ptr, stream_handle=None):
+        """the last frame's shard as rgb[n][3] float + one alpha bit per pixel (lossless, 12.1 B per pixel)"""
+        self._check(self._L.bbr_pack_shard(self._ctx, C.c_void_p(packed_ptr), C.c_void_p(stream_handle) if stream_handle else None))
+
+    def unpack_gathered_packed(self, gathered_ptr, frame_ptr, stream_handle=None):
+        self._check(self._L.bbr_unpack_gathered_packed(self._ctx, C.c_void_p(gathered_ptr), C.c_void_p(frame_ptr),
+                                                       C.c_void_p(stream_handle) if stream_handle else None))
+
     def wait_event(self, event_handle):
         self._check(self._L.bbr_wait_event(self._ctx, C.c_void_p(event_handle)))
 

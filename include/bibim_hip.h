@@ -147,6 +147,16 @@ int bbr_read_shard(bbr_context *ctx, float *rgba32f_host); /* shard_rows*width*4
 /* Device-side un-interleave of an all-gathered buffer [world][shard_rows][width][4] into a row-major frame, queued on
  * `hip_stream` (NULL = the context's shading stream). */
 int bbr_unpack_gathered(bbr_context *ctx, const void *gathered_device, void *frame_device, void *hip_stream);
+/* The same exchange with a quarter less payload, lossless: alpha is 1.0 on shaded pixels and 0.0 on cleared ones
+ * (forward_brdf.frag:75, clear colour src/main.cpp:84; the deferred path writes 1 everywhere), so a shard travels as
+ * rgb[n][3] float + one bit per pixel, n = shard_rows * width: bbr_packed_shard_bytes() bytes per rank.
+ *   bbr_pack_shard              the last frame's shard -> `packed_device`, queued on `hip_stream` (NULL = the stream the
+ *                               frame was shaded on; a caller's stream must already wait for the frame, bbr_stream_wait_frame)
+ *   bbr_unpack_gathered_packed  [world] packed blocks -> the row-major RGBA32F frame, bit for bit what bbr_unpack_gathered
+ *                               makes of the RGBA32F shards */
+int bbr_packed_shard_bytes(const bbr_context *ctx, uint64_t *out_bytes);
+int bbr_pack_shard(bbr_context *ctx, void *packed_device, void *hip_stream);
+int bbr_unpack_gathered_packed(bbr_context *ctx, const void *gathered_device, void *frame_device, void *hip_stream);
 int bbr_tile_height(const bbr_context *ctx, int32_t *out_tile_h);
 
 /* ---- diagnostics ---- */

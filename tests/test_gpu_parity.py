@@ -263,6 +263,7 @@ def test_frames_in_flight_streams_of_different_frames(maps64, frames_in_flight):
     # single external output buffer shared by consecutive frames: raster of N+1 must wait for shade of N
     import torch
     out = torch.zeros((sa.height, sa.width, 4), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()   # torch fills on its own stream; the library does not wait for that one
     r.set_output_device_ptr(out.data_ptr(), out.numel() * 4)
     for i in range(6):
         h = r.render_scene(sb if i % 2 == 0 else sa, h)
@@ -405,6 +406,7 @@ def test_present_buffer_on_every_rounding_boundary():
     src = bits.view(np.float32).reshape(-1, 4).copy()
     d_src = torch.from_numpy(src).cuda()
     d_out = torch.zeros(src.shape, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()   # torch fills on its own stream; the library does not wait for that one
     r = Renderer(64, 64)
     for enable, exposure, hdr16 in ((0, 1.0, 0), (0, 1.0, 1), (1, 0.9, 1), (1, 2.5, 0)):
         r.present_buffer(d_src.data_ptr(), d_out.data_ptr(), src.shape[0], enable, exposure, hdr16)
@@ -426,6 +428,7 @@ def test_present_after_an_overflow_replay_and_into_a_caller_buffer(maps64):
     r = Renderer(sc.width, sc.height)
     r.set_option("bin_cap", 8)                      # the frame overflows its bins and is rendered again on sync
     out = torch.zeros((sc.height, sc.width, 4), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()   # torch fills on its own stream; the library does not wait for that one
     r.render_scene(sc)
     r.present(out.data_ptr())
     got = r.read_presented()                        # synchronises, replays, presents again
@@ -445,6 +448,7 @@ def test_api_lifecycle_user_stream_frees_and_timing(maps64):
     # (1) everything on a caller-owned stream, ordered with the caller's own work on it
     stream = torch.cuda.Stream()
     out = torch.full((sc.height, sc.width, 4), 7.0, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()   # torch fills on its own stream; the library does not wait for that one
     stream.wait_stream(torch.cuda.current_stream())   # the fill above ran on torch's current stream
     r.set_stream(stream.cuda_stream)
     r.set_output_device_ptr(out.data_ptr(), out.numel() * 4)
@@ -511,6 +515,7 @@ def test_fused_presentation_writes_the_same_bytes(maps64, deferred, enable, expo
     r.set_option("present_fused", 1)
     r.set_option("bin_cap", 16)                          # the first frame overflows and is re-rendered on the read
     out = torch.zeros((sc.height, sc.width, 4), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()   # torch fills on its own stream; the library does not wait for that one
     h = r.render_scene(sc)
     r.present(out.data_ptr())                            # fused: a copy of the image into the caller's buffer
     got = r.read_presented()
@@ -662,6 +667,7 @@ def test_caller_buffers_shared_by_frames_in_flight(maps64, layout):
     r.synchronize()                                   # capacities sized
     out_a = torch.full((cfg.height, cfg.width, 4), 7.0, dtype=torch.float32, device="cuda")
     out_b = torch.full((cfg.height, cfg.width, 4), 7.0, dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()   # torch fills on its own stream; the library does not wait for that one
     empty_f, empty_v = scenes.frame_uniforms([]), heavy.view
     def target(t):
         r.set_output_device_ptr(t.data_ptr(), t.numel() * 4)

@@ -116,6 +116,7 @@ def test_presented_shards_reassemble(maps64):
         if rank == world - 1:
             gathered = torch.from_numpy(np.stack(shards)).cuda()
             frame = torch.zeros((cfg.height, cfg.width, 4), dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()   # torch fills on its own stream; the library does not wait for that one
             r.unpack_gathered_rgba8(gathered.data_ptr(), frame.data_ptr())
             r.synchronize()
             torch.cuda.synchronize()
@@ -133,6 +134,7 @@ def test_device_side_unpack_matches_host_unpack(maps64):
     rs = [Renderer(cfg.width, cfg.height) for _ in range(world)]
     shard_rows = P.shard_rows(cfg.height, world, band)
     gathered = torch.zeros((world, shard_rows, cfg.width, 4), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()   # torch fills on its own stream; the library does not wait for that one
     for rank, r in enumerate(rs):
         r.set_partition(rank, world, band)
         r.set_output_device_ptr(gathered[rank].data_ptr(), gathered[rank].numel() * 4)  # render straight into the gather slot
@@ -277,6 +279,7 @@ def test_frames_stay_identical_while_other_processes_share_the_gpu(maps64):
             # zeros: the rows of a band that hang over the bottom of the frame are padding nobody writes
             shard = [torch.zeros((rows, W, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
             keep = torch.empty((steps, rows, W, 4), dtype=torch.float32, device="cuda")
+            torch.cuda.synchronize()   # torch fills on its own stream; the library does not wait for that one
             side = torch.cuda.Stream()
             consumed = [torch.cuda.Event(), torch.cuda.Event()]
             for n in range(steps):
@@ -314,6 +317,7 @@ def test_a_host_that_never_synchronises_still_outgrows_an_overflow(maps64):
         steps = 16
         out = torch.zeros((cfg.height, cfg.width, 4), dtype=torch.float32, device="cuda")
         keep = torch.empty((steps,) + tuple(out.shape), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()   # torch fills on its own stream; the library does not wait for that one
         side = torch.cuda.Stream()
         r.set_output_device_ptr(out.data_ptr(), out.numel() * 4)
         h = None
@@ -359,3 +363,47 @@ def test_two_and_a_half_million_triangles_at_4k(maps256):
         wrong = [y0 for y0, ok in ex.map(band, range(0, cfg.height, 24)) if not ok]
     assert not wrong, wrong[:8]
     r.close()
+
+
+@pytest.mark.parametrize("width,height,world,band,deferred", [(384, 200, 4, 64, 0), (390, 203, 3, 32, 0), (384, 200, 2, 32, 1),
+                                                              (1000, 70, 8, 32, 0)])
+def test_packed_shards_reassemble_the_same_frame(maps64, width, height, world, band, deferred):
+    """the all-gather payload as rgb + one alpha bit per pixel (bbr_pack_shard / bbr_unpack_gathered_packed): the frame
+    every rank ends up with is the unpartitioned frame, bit for bit -- forward (alpha 0 on cleared pixels, 1 on shaded
+    ones) and deferred (1 everywhere), widths off the 64-pixel mask grid, more ranks than bands"""
+    import torch
+    cfg = configs.C3.scaled(width, height, 64)
+    sc = scenes.shaderball_scene(cfg, bbo.MaterialData(maps64))
+    whole = Renderer(cfg.width, cfg.height)
+    whole.set_option("render_pass", deferred)
+    whole.render_scene(sc)
+    want = whole.read_framebuffer()
+    whole.close()
+    assert set(np.unique(want[..., 3]).tolist()) <= {0.0, 1.0}
+    rs = [Renderer(cfg.width, cfg.height) for _ in range(world)]
+    pb = None
+    for rank, r in enumerate(rs):
+        r.set_option("render_pass", deferred)
+        r.set_partition(rank, world, band)
+        assert pb in (None, r.packed_shard_bytes())
+        pb = r.packed_shard_bytes()
+    shard_rows = rs[0].shard_rows()
+    assert pb % 16 == 0 and pb >= shard_rows * cfg.width * 12 + (shard_rows * cfg.width + 7) // 8
+    gathered = torch.full((world * pb,), 0xAB, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()                                # torch's fill runs on torch's stream, the library on its own
+    for rank, r in enumerate(rs):
+        r.render_scene(sc)
+        r.synchronize()                                     # (a first frame may be re-rendered with larger capacities)
+        r.render_scene(sc)
+        r.pack_shard(gathered[rank * pb:].data_ptr())       # on the frame's own stream: straight into the gather slot
+        r.synchronize()
+    torch.cuda.synchronize()
+    for r in (rs[0], rs[-1]):
+        frame = torch.full((cfg.height, cfg.width, 4), 3.0, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        r.unpack_gathered_packed(gathered.data_ptr(), frame.data_ptr())
+        r.synchronize()
+        torch.cuda.synchronize()
+        assert np.array_equal(frame.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    for r in rs:
+        r.close()
