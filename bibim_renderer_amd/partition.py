@@ -48,3 +48,42 @@ def unpack_gathered(gathered, height, band_rows):
     world = gathered.shape[0]
     rk, sr = shard_row_of(height, world, band_rows)
     return gathered[rk, sr]
+
+
+# ---- the packed form of a shard (bbr_pack_shard / bbr_unpack_gathered_packed): rgb + one alpha bit per pixel ----
+
+def packed_layout(shard_rows_, width):
+    """(block bytes, byte offset of the alpha masks) of one rank's packed block: rgb[n][3] float32, padding to 8 bytes,
+    one little-endian 64-bit mask per 64 pixels (bit k of word w = pixel 64 w + k), padding to 16 bytes."""
+    n = shard_rows_ * width
+    mask_offset = (n * 12 + 7) & ~7
+    return (mask_offset + ((n + 63) // 64) * 8 + 15) & ~15, mask_offset
+
+
+def pack_shard_bits(shard):
+    """shard [rows, W, 4] float32 with alpha in {0, 1} -> packed block (uint8).  Lossless for what the path produces:
+    alpha is 1.0 on shaded pixels and 0.0 on cleared ones."""
+    rows, width = shard.shape[:2]
+    n = rows * width
+    block, mask_offset = packed_layout(rows, width)
+    out = np.zeros(block, np.uint8)
+    flat = np.ascontiguousarray(shard, np.float32).reshape(n, 4)
+    out[:n * 12] = np.ascontiguousarray(flat[:, :3]).view(np.uint8).reshape(-1)
+    bits = np.zeros(((n + 63) // 64) * 64, np.uint8)
+    bits[:n] = flat[:, 3].view(np.uint32) == 0x3F800000
+    out[mask_offset:mask_offset + bits.size // 8] = np.packbits(bits, bitorder="little")
+    return out
+
+
+def unpack_gathered_packed(gathered, height, width, world, band_rows):
+    """gathered: world packed blocks back to back (uint8) -> row-major frame [H, W, 4] float32."""
+    rows = shard_rows(height, world, band_rows)
+    n = rows * width
+    block, mask_offset = packed_layout(rows, width)
+    g = np.ascontiguousarray(gathered, np.uint8).reshape(world, block)
+    shards = np.zeros((world, rows, width, 4), np.float32)
+    for r in range(world):
+        shards[r, ..., :3] = g[r, :n * 12].view(np.float32).reshape(rows, width, 3)
+        bits = np.unpackbits(g[r, mask_offset:mask_offset + ((n + 63) // 64) * 8], bitorder="little")[:n]
+        shards[r, ..., 3] = bits.reshape(rows, width).astype(np.float32)
+    return unpack_gathered(shards, height, band_rows)

@@ -398,6 +398,17 @@ def test_packed_shards_reassemble_the_same_frame(maps64, width, height, world, b
         r.pack_shard(gathered[rank * pb:].data_ptr())       # on the frame's own stream: straight into the gather slot
         r.synchronize()
     torch.cuda.synchronize()
+    # the device's bytes are the host model's (bibim_renderer_amd/partition.py), padding aside
+    g = gathered.cpu().numpy().reshape(world, pb)
+    block, mask_offset = P.packed_layout(shard_rows, cfg.width)
+    assert block == pb
+    n = shard_rows * cfg.width
+    for rank, r in enumerate(rs):
+        model = P.pack_shard_bits(r.read_shard())
+        assert np.array_equal(g[rank, :n * 12], model[:n * 12])
+        assert np.array_equal(g[rank, mask_offset:mask_offset + (n + 63) // 64 * 8], model[mask_offset:mask_offset + (n + 63) // 64 * 8])
+    assert np.array_equal(P.unpack_gathered_packed(gathered.cpu().numpy(), cfg.height, cfg.width, world, band).view(np.uint32),
+                          want.view(np.uint32))
     for r in (rs[0], rs[-1]):
         frame = torch.full((cfg.height, cfg.width, 4), 3.0, dtype=torch.float32, device="cuda")
         torch.cuda.synchronize()

@@ -34,6 +34,24 @@ def test_pack_unpack_round_trip():
         assert np.array_equal(P.unpack_gathered(gathered, H, band), frame)
 
 
+def test_packed_form_round_trip_and_layout():
+    """rgb + one alpha bit per pixel: lossless for alpha in {0, 1} (what the path produces), NaN / inf colours included;
+    block sizes: 12 bytes per pixel, masks 8-byte aligned, blocks 16-byte aligned"""
+    rng = np.random.Generator(np.random.PCG64(5))
+    for H, W, world, band in ((270, 17, 4, 32), (130, 390, 3, 64), (64, 64, 2, 32), (70, 1000, 8, 32)):
+        frame = rng.standard_normal((H, W, 4)).astype(np.float32)
+        frame[..., 3] = rng.integers(0, 2, (H, W)).astype(np.float32)
+        frame[0, 0, :3] = (np.nan, np.inf, -0.0)
+        rows = P.shard_rows(H, world, band)
+        block, mask_offset = P.packed_layout(rows, W)
+        assert block % 16 == 0 and mask_offset % 8 == 0 and mask_offset >= rows * W * 12
+        assert block - mask_offset >= (rows * W + 7) // 8 and block < rows * W * 12.2 + 64
+        gathered = np.concatenate([P.pack_shard_bits(P.pack_shard(frame, r, world, band)) for r in range(world)])
+        assert gathered.size == world * block
+        back = P.unpack_gathered_packed(gathered, H, W, world, band)
+        assert np.array_equal(back.view(np.uint32), frame.view(np.uint32))
+
+
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
@@ -58,6 +76,12 @@ def _rank_main(rank, world, port, band_rows, q):
     gathered = torch.empty((world * shard.shape[0],) + tuple(shard.shape[1:]), dtype=torch.float32)
     dist.all_gather_into_tensor(gathered, shard)  # concatenation along dim 0 == [rank][shard row]
     frame = P.unpack_gathered(gathered.view((world,) + tuple(shard.shape)).numpy(), H, band_rows)
+    # the same exchange in the packed form bench.py gathers by default (rgb + one alpha bit per pixel)
+    packed = torch.from_numpy(P.pack_shard_bits(shard.numpy()))
+    gathered_packed = torch.empty((world * packed.numel(),), dtype=torch.uint8)
+    dist.all_gather_into_tensor(gathered_packed, packed)
+    frame_packed = P.unpack_gathered_packed(gathered_packed.numpy(), H, W, world, band_rows)
+    assert np.array_equal(frame_packed.view(np.uint32), frame.view(np.uint32))
     total = torch.tensor([n]); dist.all_reduce(total)
     if rank == 0:
         full, _, _, st = bbo.render(sc, want_prim=False, want_depth=False)
