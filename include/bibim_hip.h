@@ -175,6 +175,8 @@ int bbr_timing_summary(bbr_context *ctx, uint32_t *out_frames, float *out_avg_fr
 /* Options (all but "render_pass" drain the context first):
  *   "timing" 0|1|2           1: five HIP events per frame (frame start, geometry, raster, shade start, shade done);
  *                            2: only the two around k_shade (frame/geometry/raster averages read 0); restarts the ring
+ *   "timing_stride" n        with "timing" on, only every n-th frame carries events (default 1): the events themselves
+ *                            perturb a pipelined frame stream (two per frame: ~4 % of the C3 frame rate)
  *   "frames_in_flight" 1|2|3 default 2
  *   "tile_mode" 0|1          0: 64x64 tiles, 1: 32x32 tiles (default)
  *   "bin_cap" n              initial references per (tile, raster class); grows by itself on overflow
