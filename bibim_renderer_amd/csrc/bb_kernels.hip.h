@@ -962,17 +962,21 @@ BB_DEV void raster_triangle_group16(const RasterTri &t, uint32_t ref, int px0, i
     sy[i] = e.dx[i] * 256;
   }
   const int lx = gl & 3, ly = gl >> 2;
-  for (int by = 0; by < h; by += 4) {
-    for (int bx = 0; bx < w; bx += 4) {
-      int x = bx + lx, y = by + ly;
-      if (x < w && y < h) {
-        int e0 = __mul24(x, sx[0]) + __mul24(y, sy[0]) + o[0];
-        int e1 = __mul24(x, sx[1]) + __mul24(y, sy[1]) + o[1];
-        int e2 = __mul24(x, sx[2]) + __mul24(y, sy[2]) + o[2];
-        if ((e0 | e1 | e2) >= 0)
-          depth_max(t, px0 + x, py0 + y, ref, keys, tile_index<TILE_W>(px0 + x - tile_x0, py0 + y - tile_y0), zbias);
-      }
+  // this lane's pixel of the first block; stepping a block to the right / down is an add (exact: same values as the
+  // multiply-add form, all terms < 2^30)
+  int r0 = __mul24(lx, sx[0]) + __mul24(ly, sy[0]) + o[0];
+  int r1 = __mul24(lx, sx[1]) + __mul24(ly, sy[1]) + o[1];
+  int r2 = __mul24(lx, sx[2]) + __mul24(ly, sy[2]) + o[2];
+  const int bx0 = 4 * sx[0], bx1 = 4 * sx[1], bx2 = 4 * sx[2];
+  const int by0 = 4 * sy[0], by1 = 4 * sy[1], by2 = 4 * sy[2];
+  for (int y = ly; y < h; y += 4) {
+    int e0 = r0, e1 = r1, e2 = r2;
+    for (int x = lx; x < w; x += 4) {
+      if ((e0 | e1 | e2) >= 0)
+        depth_max(t, px0 + x, py0 + y, ref, keys, tile_index<TILE_W>(px0 + x - tile_x0, py0 + y - tile_y0), zbias);
+      e0 += bx0; e1 += bx1; e2 += bx2;
     }
+    r0 += by0; r1 += by1; r2 += by2;
   }
 }
 
