@@ -139,6 +139,12 @@ def main():
                          "for N > 1 the RGBA8 shards are gathered instead of the fp32 ones (a quarter of the payload)")
     args = ap.parse_args()
 
+    # The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints a version banner when its
+    # communicator comes up): from here on file descriptor 1 is stderr, and the JSON line goes to the real stdout.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -454,7 +460,8 @@ def main():
             out["verified_against_unpartitioned_render"] = verified
         if parity is not None:
             out["parity_vs_oracle"] = parity
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
     scene.close()
     r.close()
