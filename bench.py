@@ -258,7 +258,7 @@ def main():
     def fence():
         r.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if dist is not None:   # (--force-dist runs the same collectives with one rank)
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -300,7 +300,7 @@ def main():
     elapsed = time.perf_counter() - t0
     gc.enable()
 
-    if world > 1:
+    if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
