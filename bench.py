@@ -198,8 +198,9 @@ def main():
     dist_path = world > 1 or args.force_dist
     if dist_path:
         # Each rank renders its interleaved screen bands into a compact shard; RCCL all-gathers the shards over xGMI
-        # and a copy kernel un-interleaves them into the row-major frame.  Two shard / gather buffers alternate so that
-        # the gather of frame N (on its own stream) overlaps the rendering of frame N+1.
+        # and a copy kernel un-interleaves them into the row-major frame.  Every buffer exists twice, so that the exchange
+        # of frame N (pack, all-gather, un-interleave, on a stream of their own) overlaps the rendering of frame N+1; the
+        # shard is handed back to the renderer as soon as the pack kernel (or the gather) has read it.
         band_rows = args.band_rows or r.tile_height()
         r.set_partition(rank, world, band_rows)
         shard_rows = r.shard_rows()
@@ -215,8 +216,14 @@ def main():
             shard8_t = [torch.empty((shard_rows, W, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
             gathered8_t = [torch.empty((world * shard_rows, W, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
             frame8_t = [torch.empty((H, W, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
+        # (one stream for pack + gather + un-interleave: with the un-interleave on a stream of its own the link would
+        #  never wait for it, but on one GPU the extra stream cost 40 % of the frame rate -- see DESIGN.md on stream
+        #  counts -- and what it does to eight ranks could not be measured here)
         ag_stream = torch.cuda.Stream()
-        consumed = [torch.cuda.Event(), torch.cuda.Event()]
+        up_stream = ag_stream
+        consumed = [torch.cuda.Event(), torch.cuda.Event()]    # the shard has been read (by the pack kernel / the gather)
+        gathered_ev = [torch.cuda.Event(), torch.cuda.Event()]  # the gathered buffer is complete
+        unpacked = [torch.cuda.Event(), torch.cuda.Event()]     # ... and has been un-interleaved: free for gather n+2
     step_no = [0]
 
     def step():
@@ -238,8 +245,11 @@ def main():
         with torch.cuda.stream(ag_stream):
             if packed:
                 r.pack_shard(packed_t[b].data_ptr(), ag_stream.cuda_stream)
+                consumed[b].record(ag_stream)
             src, dst = (shard8_t[b], gathered8_t[b]) if args.present else (
                 (packed_t[b], gathered_packed_t[b]) if packed else (shard_t[b], gathered_t[b]))
+            if n >= 2:
+                ag_stream.wait_event(unpacked[b])                # un-interleave n-2 has finished reading dst
             if backend == "nccl":
                 dist.all_gather_into_tensor(dst, src)
             else:  # rehearsal: through host memory
@@ -247,13 +257,18 @@ def main():
                 h_dst = torch.empty(dst.shape, dtype=dst.dtype)
                 dist.all_gather_into_tensor(h_dst, h_src)
                 dst.copy_(h_dst)
+            if not packed:
+                consumed[b].record(ag_stream)
+            gathered_ev[b].record(ag_stream)
+        with torch.cuda.stream(up_stream):
+            up_stream.wait_event(gathered_ev[b])
             if args.present:
-                r.unpack_gathered_rgba8(gathered8_t[b].data_ptr(), frame8_t[b].data_ptr(), ag_stream.cuda_stream)
+                r.unpack_gathered_rgba8(gathered8_t[b].data_ptr(), frame8_t[b].data_ptr(), up_stream.cuda_stream)
             elif packed:
-                r.unpack_gathered_packed(gathered_packed_t[b].data_ptr(), frame_t[b].data_ptr(), ag_stream.cuda_stream)
+                r.unpack_gathered_packed(gathered_packed_t[b].data_ptr(), frame_t[b].data_ptr(), up_stream.cuda_stream)
             else:
-                r.unpack_gathered(gathered_t[b].data_ptr(), frame_t[b].data_ptr(), ag_stream.cuda_stream)
-            consumed[b].record(ag_stream)
+                r.unpack_gathered(gathered_t[b].data_ptr(), frame_t[b].data_ptr(), up_stream.cuda_stream)
+            unpacked[b].record(up_stream)
 
     def fence():
         r.synchronize()
