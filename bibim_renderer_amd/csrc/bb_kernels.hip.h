@@ -1381,9 +1381,11 @@ BB_DEV float4 light_surface(const ShadeParams &sp, const Light *__restrict__ lig
 // G-buffer still holds its clear value 0; that colour is the same for all such pixels (it depends on the lights and
 // the camera only -- and is not always 0: a light at the world origin makes it NaN), so it is evaluated once.
 __global__ void k_deferred_background(ShadeParams sp, const Light *__restrict__ lights, float4 *__restrict__ out,
-                                      const SrgbTables *__restrict__ tables) {
+                                      const SrgbTables *__restrict__ tables, int gbuffer_view) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
-    const float4 c = light_surface(sp, lights, mk3(0.f, 0.f, 0.f), mk3(0.f, 0.f, 0.f), mk3(0.f, 0.f, 0.f), 0.f, 0.f, 0.f);
+    // (buffer_visualize.frag on a cleared texel: rgb 0, alpha 1)
+    const float4 c = gbuffer_view >= 0 ? make_float4(0.f, 0.f, 0.f, 1.f)
+                                       : light_surface(sp, lights, mk3(0.f, 0.f, 0.f), mk3(0.f, 0.f, 0.f), mk3(0.f, 0.f, 0.f), 0.f, 0.f, 0.f);
     out[0] = c;
     // out[1].x: the same colour as a presented pixel (fused presentation)
     if (tables) out[1] = make_float4(__uint_as_float(present_pixel(c.x, c.y, c.z, *tables, sp.tone_enable, sp.exposure, 1)), 0.f, 0.f, 0.f);
@@ -1567,7 +1569,13 @@ __global__ __launch_bounds__(kShadeThreads) void k_shade(
         dst[0] = lo;
         dst[1] = hi;
       }
-      color = light_surface(sp, lights, P, normal, albedo, metallic, roughness, ao);
+      if (fp.gbuffer_view >= 0) {
+        // buffer_visualize.frag:8-12 instead of brdf.frag (recordCommand, src/main.cpp:96-121): the rgb of one attachment
+        const f3 shown = fp.gbuffer_view == 0 ? P : (fp.gbuffer_view == 1 ? normal : (fp.gbuffer_view == 2 ? albedo : mk3(metallic, roughness, ao)));
+        color = make_float4(shown.x, shown.y, shown.z, 1.0f);
+      } else {
+        color = light_surface(sp, lights, P, normal, albedo, metallic, roughness, ao);
+      }
     } else {
       color = light_surface(sp, lights, mk3(a[2], a[3], a[4]), normal, albedo, metallic, roughness, ao);
     }

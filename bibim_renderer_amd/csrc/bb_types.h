@@ -187,6 +187,7 @@ struct FrameParams {
   int32_t shard_rows;                // rows of the compact output when world > 1
   uint32_t ablate;                   // diagnostics only: bit0 skip raster, bit1 skip shading, bit2 skip broad list
   int32_t deferred;                  // 1: the reference's deferred path (gbuffer.vert/.frag + brdf.frag), 0: forward
+  int32_t gbuffer_view;              // deferred only: -1 the lit scene, 0..3 buffer_visualize.frag on that G-buffer attachment
   // overlay pass only (k_*<..., OVERLAY>): primitives >= ov_first_gizmo_prim are the gizmo -- own viewport (centre
   // ov_cx/ov_cy, half extent ov_half), scissor rectangle [ov_x0, ov_x1) x [ov_y0, ov_y1), and a depth bias that lets
   // them win over everything drawn before (the reference clears the rectangle's depth first, src/main.cpp:150-160)

@@ -205,6 +205,7 @@ struct bbr_context {
   bool overlays = false;  // option "overlays": frames keep their depth so that bbr_draw_overlays can test against it
   Mesh marker_mesh, gizmo_mesh;  // generateUVSphereMesh(0.1, 16, 16) and the caller's gizmo, both as Vertex meshes
   FrameSlot ov;           // buffers of the overlay pass (its own little frame)
+  int gbuffer_view = -1;  // option "gbuffer_view": GBufferVisualizingOption (src/scene.h:27-35) while the deferred path runs
   bool deferred = false;  // option "render_pass": the reference's deferred path (its default) instead of the forward one
   bool dump_gbuffer = false;
   DeviceBuffer<uint2> d_gbuffer;  // width*height*4 (four RGBA16F texels per pixel), only while bbr_read_gbuffer runs
@@ -320,6 +321,7 @@ FrameParams make_params(const bbr_context *c) {
   fp.shard_rows = c->shard_rows();
   fp.ablate = c->ablate;
   fp.deferred = c->deferred ? 1 : 0;
+  fp.gbuffer_view = c->deferred ? c->gbuffer_view : -1;
   return fp;
 }
 
@@ -425,7 +427,7 @@ void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const Fra
   uint32_t *out8 = c->present_fused ? s.d_present.ptr : nullptr;
   const SrgbTables *tables = c->present_fused ? c->d_srgb_tables.ptr : nullptr;
   if (fp.deferred)
-    hipLaunchKernelGGL(k_deferred_background, dim3(1), dim3(64), 0, sr, sp, d_lights, s.d_background.ptr, tables);
+    hipLaunchKernelGGL(k_deferred_background, dim3(1), dim3(64), 0, sr, sp, d_lights, s.d_background.ptr, tables, fp.gbuffer_view);
   const bool ordered = c->tile_order && c->n_prims;
   if (ordered)
     hipLaunchKernelGGL(k_tile_order, dim3((fp.tiles_x * grid_y + kOrderThreads - 1) / kOrderThreads), dim3(kOrderThreads),
@@ -933,6 +935,7 @@ extern "C" int bbr_draw_overlays(bbr_context *c, int32_t gizmo_extent) {
     HIP_TRY(c, s.d_frag_count.ensure(tiles, true));
     FrameParams fp = make_params(c);
     fp.deferred = 0;
+    fp.gbuffer_view = -1;
     fp.ov_first_gizmo_prim = gizmo ? marker_tris * (uint32_t)n_lights : 0xFFFFFFFFu;
     const int x0 = c->width - gizmo_extent;
     fp.ov_half = 0.5f * (float)gizmo_extent;
@@ -1606,6 +1609,11 @@ int bbr_set_option(bbr_context *c, const char *name, int64_t value) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
   if (!name) return fail(c, BBR_ERR_INVALID_ARGUMENT, "set_option: NULL name");
   std::string n(name);
+  if (n == "gbuffer_view") {  // like render_pass: takes effect with the next submitted frame
+    if (value < -1 || value > 3) return fail(c, BBR_ERR_INVALID_ARGUMENT, "gbuffer_view: -1 (the lit scene) or 0..3 (position, normal, albedo, MRAH)");
+    c->gbuffer_view = (int)value;
+    return BBR_OK;
+  }
   if (n == "render_pass") {  // takes effect with the next submitted frame; no need to wait for the ones in flight
     if (value != 0 && value != 1) return fail(c, BBR_ERR_INVALID_ARGUMENT, "render_pass: 0 (forward) or 1 (deferred)");
     c->deferred = value == 1;
