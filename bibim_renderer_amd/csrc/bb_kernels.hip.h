@@ -497,7 +497,7 @@ __global__ __launch_bounds__(256) void k_geometry(const DrawDesc *__restrict__ d
   __shared__ BlockStats bs;
   // the NEXT frame's counter block is cleared here (frames in flight + 1 blocks rotate; the one cleared now is idle: its previous
   // frame left the GPU before this one was submitted) -- saves a memset node per frame
-  if (blockIdx.x == 0 && threadIdx.x < sizeof(Counters) / 4) reinterpret_cast<uint32_t *>(ctr_next)[threadIdx.x] = 0u;
+  if (ctr_next && blockIdx.x == 0 && threadIdx.x < sizeof(Counters) / 4) reinterpret_cast<uint32_t *>(ctr_next)[threadIdx.x] = 0u;
   __shared__ ClipWork s_clip[4];  // one per wave
   if (threadIdx.x == 0) bs = BlockStats{0u, 0u, 0u};
   __syncthreads();
@@ -1414,9 +1414,17 @@ __global__ __launch_bounds__(kShadeThreads) void k_shade(
     FrameParams fp, ShadeParams sp, const Light *__restrict__ lights, const ShadeRec *__restrict__ recs,
     const ClipSlot *__restrict__ clip_arena, const unsigned long long *__restrict__ frags,
     const uint32_t *__restrict__ frag_count, const MaterialDesc *__restrict__ materials, float4 *__restrict__ out,
-    uint2 *__restrict__ gbuffer, const SrgbTables *__restrict__ tables, uint32_t *__restrict__ out8) {
+    uint2 *__restrict__ gbuffer, const SrgbTables *__restrict__ tables, uint32_t *__restrict__ out8,
+    Counters *__restrict__ ctr, Counters *__restrict__ ctr_done) {
   constexpr int TILE_PIXELS = TILE_W * TILE_H;
   constexpr int CHUNKS = TILE_PIXELS / kShadeThreads;
+  // The frame's counter block has done its job (k_geometry filled it, k_raster read it): keep a copy for the host's
+  // statistics / overflow check and clear the block for the next frame of this slot.  Frames of different slots
+  // share nothing, so their kernels may overlap freely.
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < sizeof(Counters) / 4) {
+    reinterpret_cast<uint32_t *>(ctr_done)[threadIdx.x] = reinterpret_cast<uint32_t *>(ctr)[threadIdx.x];
+    reinterpret_cast<uint32_t *>(ctr)[threadIdx.x] = 0u;
+  }
   const int tx = blockIdx.x / CHUNKS, chunk = blockIdx.x - tx * CHUNKS;
   int ty, out_tile_row;
   if (!tile_row(fp, blockIdx.y, ty, out_tile_row)) return;

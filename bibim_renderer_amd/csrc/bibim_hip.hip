@@ -97,7 +97,7 @@ struct FrameSlot {
   DeviceBuffer<RasterTri> d_tris;
   DeviceBuffer<ShadeRec> d_attrs;
   DeviceBuffer<ClipSlot> d_clip;
-  int ctr_index = 0;                        // which of the context's counter blocks this slot's frame used
+  int ctr_index = 0;                        // the slot's counter block (slot index; the overlay slot has the last one)
   DeviceBuffer<BlockStats> d_block_stats;  // one record per k_geometry workgroup
   DeviceBuffer<uint32_t> d_tile_count;
   DeviceBuffer<uint32_t> d_bins;
@@ -178,10 +178,10 @@ struct bbr_context {
   uint32_t n_live_draws = 0;
 
   static constexpr int kMaxSlots = 3;
-  static constexpr int kCounterBlocks = kMaxSlots + 1;  // (the overlay pass runs on a drained context: any block is idle)
+  static constexpr int kCounterBlocks = kMaxSlots + 1;  // one per frame slot + one for the overlay pass
   FrameSlot slots[kMaxSlots];
-  DeviceBuffer<Counters> d_counters;  // kMaxSlots + 1 blocks in rotation: each k_geometry clears the next frame's block
-  uint64_t submit_epoch = 0;
+  DeviceBuffer<Counters> d_counters;       // zero between frames: a frame's k_shade clears its slot's block ...
+  DeviceBuffer<Counters> d_counters_done;  // ... after copying it here (statistics, overflow check)
   int frames_in_flight = 2;
   uint64_t frame_counter = 0;
   int last_slot = -1;
@@ -349,6 +349,7 @@ int ensure_slot_buffers(bbr_context *c, FrameSlot &s) {
   HIP_TRY(c, s.d_clip.ensure(c->clip_cap));
 #endif
   HIP_TRY(c, c->d_counters.ensure(bbr_context::kCounterBlocks, true));
+  HIP_TRY(c, c->d_counters_done.ensure(bbr_context::kCounterBlocks, true));
   HIP_TRY(c, s.d_block_stats.ensure(std::max<size_t>((c->n_prims + 255) / 256, 1), true));
   HIP_TRY(c, s.d_tile_count.ensure(tiles * kBinClasses, true));
   HIP_TRY(c, s.d_bins.ensure(tiles * kBinClasses * c->bin_cap));
@@ -401,14 +402,12 @@ void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const Fra
                   const Mat4 &view, const ShadeParams &sp, const Light *d_lights, const DrawDesc *d_draws, uint32_t n_draws, float4 *out) {
   const int slot_index = (int)(&s - c->slots);
   hipStream_t sg = c->geom_stream(), sr = c->raster_stream(slot_index), ss = c->frame_shade_stream(slot_index);
-  Counters *ctr = c->d_counters.ptr + s.ctr_index, *ctr_next = c->d_counters.ptr + (s.ctr_index + 1) % bbr_context::kCounterBlocks;
+  Counters *ctr = c->d_counters.ptr + s.ctr_index, *ctr_done = c->d_counters_done.ptr + s.ctr_index;
   hipEvent_t *ev = c->timing_this ? &c->ring[bbr_context::kRingEvents * (c->ring_frames % bbr_context::kRingCap)] : nullptr;
   if (c->n_prims)
     hipLaunchKernelGGL((k_geometry<TW, TH>), dim3((c->n_prims + 255) / 256), dim3(256), 0, sg, d_draws, n_draws,
                        c->n_prims, pv, view, fp, s.d_tris.ptr, s.d_attrs.ptr, s.d_clip.ptr, ctr, s.d_tile_count.ptr,
-                       s.d_bins.ptr, s.d_broad.ptr, c->d_materials.ptr, s.d_block_stats.ptr, ctr_next);
-  else
-    (void)hipMemsetAsync(ctr_next, 0, sizeof(Counters), sg);
+                       s.d_bins.ptr, s.d_broad.ptr, c->d_materials.ptr, s.d_block_stats.ptr, (Counters *)nullptr);
   if (ev && c->timing == 1) (void)hipEventRecord(ev[1], sg);
   if (sr != sg) {
     (void)hipEventRecord(s.ev_geom_done, sg);
@@ -455,7 +454,7 @@ void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const Fra
   auto shade = [&](auto deferred, auto present) {
     hipLaunchKernelGGL((k_shade<TW, TH, decltype(deferred)::value, decltype(present)::value>), dim3(fp.tiles_x * kChunks, grid_y),
                        dim3(kShadeThreads), 0, ss, fp, sp, d_lights, s.d_attrs.ptr, s.d_clip.ptr, s.d_frags.ptr,
-                       s.d_frag_count.ptr, c->d_materials.ptr, out, gbuf, tables, out8);
+                       s.d_frag_count.ptr, c->d_materials.ptr, out, gbuf, tables, out8, ctr, ctr_done);
   };
   if (fp.deferred) {
     if (out8) shade(std::true_type{}, std::true_type{});
@@ -563,7 +562,7 @@ int submit_frame_into(bbr_context *c, int slot_index) {
     }
     if (c->timing == 1) HIP_TRY(c, hipEventRecord(c->ring[bbr_context::kRingEvents * (c->ring_frames % bbr_context::kRingCap)], sg));
   }
-  s.ctr_index = (int)(c->submit_epoch++ % bbr_context::kCounterBlocks);
+  s.ctr_index = slot_index;
   HIP_TRY(c, hipMemcpyAsync(s.d_staging.ptr, s.h_staging, total, hipMemcpyHostToDevice, sg));
 
   const Light *d_lights = reinterpret_cast<const Light *>(s.d_staging.ptr);
@@ -734,7 +733,7 @@ int sync_and_fix(bbr_context *c, Counters *out_counters) {
     if (rc) return rc;
     Counters h = {};
     if (c->have_frame && c->last_slot >= 0 && c->d_counters.ptr)
-      HIP_TRY(c, hipMemcpy(&h, c->d_counters.ptr + c->slots[c->last_slot].ctr_index, sizeof h, hipMemcpyDeviceToHost));
+      HIP_TRY(c, hipMemcpy(&h, c->d_counters_done.ptr + c->slots[c->last_slot].ctr_index, sizeof h, hipMemcpyDeviceToHost));
     if (out_counters) *out_counters = h;
     if (!h.overflow) return BBR_OK;
     rc = apply_growth(c, h.overflow, h.bin_need);
@@ -942,15 +941,15 @@ extern "C" int bbr_draw_overlays(bbr_context *c, int32_t gizmo_extent) {
     fp.ov_cx = (float)x0 + fp.ov_half;
     fp.ov_cy = fp.ov_half;
     fp.ov_x0 = std::max(x0, 0); fp.ov_y0 = 0; fp.ov_x1 = c->width; fp.ov_y1 = std::min(gizmo_extent, c->height);
-    s.ctr_index = (int)(c->submit_epoch++ % bbr_context::kCounterBlocks);
-    Counters *ctr = c->d_counters.ptr + s.ctr_index, *ctr_next = c->d_counters.ptr + (s.ctr_index + 1) % bbr_context::kCounterBlocks;
+    s.ctr_index = bbr_context::kMaxSlots;
+    Counters *ctr = c->d_counters.ptr + s.ctr_index;
     hipStream_t st = c->shade_stream();
     const Mat4 ident = {};
     auto launch = [&](auto tw, auto th) {
       constexpr int TW = decltype(tw)::value, TH = decltype(th)::value;
       hipLaunchKernelGGL((k_geometry<TW, TH, true>), dim3((n_prims + 255) / 256), dim3(256), 0, st, d_draws, (uint32_t)draws.size(),
                          n_prims, ident, ident, fp, s.d_tris.ptr, s.d_attrs.ptr, s.d_clip.ptr, ctr, s.d_tile_count.ptr,
-                         s.d_bins.ptr, s.d_broad.ptr, c->d_materials.ptr, s.d_block_stats.ptr, ctr_next);
+                         s.d_bins.ptr, s.d_broad.ptr, c->d_materials.ptr, s.d_block_stats.ptr, (Counters *)nullptr);
       hipLaunchKernelGGL((k_raster<TW, TH, true>), dim3(fp.tiles_x, fp.tiles_y), dim3(kTileThreads), 0, st, fp, s.d_tris.ptr,
                          s.d_clip.ptr, ctr, s.d_tile_count.ptr, s.d_bins.ptr, s.d_broad.ptr, s.d_frags.ptr, s.d_frag_count.ptr,
                          (float4 *)nullptr, (uint32_t *)nullptr, (float *)nullptr, (const uint32_t *)nullptr,
@@ -965,6 +964,7 @@ extern "C" int bbr_draw_overlays(bbr_context *c, int32_t gizmo_extent) {
     HIP_TRY(c, hipStreamSynchronize(st));
     Counters h = {};
     HIP_TRY(c, hipMemcpy(&h, ctr, sizeof h, hipMemcpyDeviceToHost));
+    HIP_TRY(c, zero_fill_sync(ctr, sizeof(Counters)));  // (the pass is synchronous: cleared here, not by a kernel)
     if (!h.overflow) return BBR_OK;
     // an overlay triangle did not fit: the presented pixels it already wrote are a subset of the right ones (same
     // colours), so growing and drawing again on top is correct
@@ -1058,6 +1058,7 @@ int bbr_destroy(bbr_context *c) {
   if (c->d_default_texels) (void)hipFree(c->d_default_texels);
   c->d_materials.release();
   c->d_counters.release();
+  c->d_counters_done.release();
   c->d_vis_prim.release();
   c->d_vis_depth.release();
   for (FrameSlot &s : c->slots) {
