@@ -118,7 +118,7 @@ def main():
                     help="HIP events around k_shade on every n-th step of the timed region (events on every step cost "
                          "about 6 %% of the frame rate they are there to describe: each pair keeps consecutive k_shade launches "
                          "from overlapping head to tail)")
-    ap.add_argument("--frames-in-flight", type=int, default=3, choices=[1, 2, 3],
+    ap.add_argument("--frames-in-flight", type=int, default=3, choices=[1, 2, 3, 4],
                     help="frames queued on the GPU at once (the reference keeps 2; 3 keeps the host off the critical path: +2 %%)")
     ap.add_argument("--stream-layout", type=int, default=-1, choices=[-1, 0, 1, 2],
                     help="option stream_layout of the library (include/bibim_hip.h); -1: timed at start-up and chosen")

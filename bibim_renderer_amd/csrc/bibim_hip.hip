@@ -177,7 +177,7 @@ struct bbr_context {
   uint32_t n_prims = 0;
   uint32_t n_live_draws = 0;
 
-  static constexpr int kMaxSlots = 3;
+  static constexpr int kMaxSlots = 4;
   static constexpr int kCounterBlocks = kMaxSlots + 1;  // one per frame slot + one for the overlay pass
   FrameSlot slots[kMaxSlots];
   DeviceBuffer<Counters> d_counters;       // zero between frames: a frame's k_shade clears its slot's block ...
@@ -229,11 +229,12 @@ struct bbr_context {
   // Stream layout of the frames in flight (option "stream_layout").  All three render the same bits:
   //   0  geometry + raster on s_geom, shade on s_shade, present on s_present          (stage streams)
   //   1  as 0, but k_raster on s_raster: geometry of frame N+1 need not wait for the raster of frame N
-  //   2  geometry on s_geom; raster + shade + present of a frame on the stream of its slot (s_raster / s_shade /
-  //      s_present double as the three slot streams: a process that owns more than a handful of HIP streams gets
-  //      slower as a whole -- with seven streams every layout lost 60 %)
+  //   2  every kernel of a frame (copy, geometry, raster, shade, present) on the stream of its slot: frames share
+  //      nothing (each slot has its own buffers and counter block), so whole frames overlap and no event is needed
+  //      inside a frame.  The four context streams double as the slot streams: a process that owns more than a
+  //      handful of HIP streams gets slower as a whole -- with seven streams every layout lost 60 %
   // Which one is fastest depends on whether the geometry -> raster chain, the kernels' tails or the vector ALUs set
-  // the frame rate (1080p, one ShaderBall: 67 / 47 / 39 us per frame; 4K, sixteen: 157 / 162 / 159 us).  The automatic
+  // the frame rate (1080p, one ShaderBall: 65 / 44 / 34 us per frame; 4K, sixteen: 156 / 160 / 152 us).  The automatic
   // setting therefore times them on the first frames of a workload: after kTuneWarm frames (clocks, caches),
   // kTuneRounds rounds of one span per layout, kTuneSpan frames each after kTuneSkip frames for the switch to settle;
   // two events per span on the frame's shade stream, polled without blocking.  Alternating the spans cancels what a
@@ -255,7 +256,9 @@ struct bbr_context {
   } tune;
   static constexpr int kTuneWaiting = kTuneSpans + 1, kTuneDecided = kTuneSpans + 2;
   bool pipelined() const { return !user_stream && frames_in_flight > 1; }
-  hipStream_t slot_stream(int i) const { return i == 0 ? s_raster : (i == 1 ? s_shade : s_present); }
+  hipStream_t slot_stream(int i) const { return i == 0 ? s_raster : (i == 1 ? s_shade : (i == 2 ? s_present : s_geom)); }
+  hipStream_t frame_geom_stream(int slot) const { return (pipelined() && layout == 2) ? slot_stream(slot) : geom_stream(); }
+  std::vector<hipEvent_t> pending_waits;  // bbr_wait_event: applied to the first stream of the next frame
   hipStream_t raster_stream(int slot) const {
     return !pipelined() ? geom_stream() : (layout == 2 ? slot_stream(slot) : (layout == 1 ? s_raster : s_geom));
   }
@@ -401,7 +404,7 @@ template <int TW, int TH>
 void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const FrameParams &fp, const Mat4 &pv,
                   const Mat4 &view, const ShadeParams &sp, const Light *d_lights, const DrawDesc *d_draws, uint32_t n_draws, float4 *out) {
   const int slot_index = (int)(&s - c->slots);
-  hipStream_t sg = c->geom_stream(), sr = c->raster_stream(slot_index), ss = c->frame_shade_stream(slot_index);
+  hipStream_t sg = c->frame_geom_stream(slot_index), sr = c->raster_stream(slot_index), ss = c->frame_shade_stream(slot_index);
   Counters *ctr = c->d_counters.ptr + s.ctr_index, *ctr_done = c->d_counters_done.ptr + s.ctr_index;
   hipEvent_t *ev = c->timing_this ? &c->ring[bbr_context::kRingEvents * (c->ring_frames % bbr_context::kRingCap)] : nullptr;
   if (c->n_prims)
@@ -553,45 +556,19 @@ int submit_frame_into(bbr_context *c, int slot_index) {
   }
   if (inst_bytes) std::memcpy((uint8_t *)s.h_staging + lights_bytes + draws_bytes, c->host_instances.data(), inst_bytes);
 
-  hipStream_t sg = c->geom_stream();
-  c->timing_this = c->timing && (c->timing_tick++ % (uint64_t)c->timing_stride) == 0;
-  if (c->timing_this) {
-    if (c->ring.empty()) {
-      c->ring.resize(bbr_context::kRingEvents * bbr_context::kRingCap);
-      for (auto &e : c->ring) HIP_TRY(c, hipEventCreate(&e));
-    }
-    if (c->timing == 1) HIP_TRY(c, hipEventRecord(c->ring[bbr_context::kRingEvents * (c->ring_frames % bbr_context::kRingCap)], sg));
-  }
-  s.ctr_index = slot_index;
-  HIP_TRY(c, hipMemcpyAsync(s.d_staging.ptr, s.h_staging, total, hipMemcpyHostToDevice, sg));
-
-  const Light *d_lights = reinterpret_cast<const Light *>(s.d_staging.ptr);
-  const DrawDesc *d_draws = reinterpret_cast<const DrawDesc *>(s.d_staging.ptr + lights_bytes);
-  FrameParams fp = make_params(c);
-  // forward: gl_Position = (P*V) * posWorld; deferred: P * (V * posWorld) -- the kernel gets P and V separately
-  Mat4 pv = c->deferred ? c->view_u.proj : proj_view(c->view_u);
-  const Mat4 view = c->view_u.view;
-  ShadeParams sp;
-  std::memcpy(sp.view_pos, c->view_u.view_pos, sizeof sp.view_pos);
-  sp.enable_normal_map = c->view_u.enable_normal_map;
-  sp.tone_enable = c->frame_u.enable_tone_mapping;
-  sp.exposure = c->frame_u.exposure;
-  sp.num_lights = std::min(std::max(c->frame_u.num_lights, 0), kMaxNumLights);
-  float4 *out = c->ext_out ? reinterpret_cast<float4 *>(c->ext_out) : s.d_frame.ptr;
-  const FrameSlot *prev = (c->last_slot >= 0 && c->last_slot != slot_index) ? &c->slots[c->last_slot] : nullptr;
-
+  const int n_lights = std::min(std::max(c->frame_u.num_lights, 0), kMaxNumLights);
   int tune_mark = -1;  // which of tune.ev to record behind this frame's k_shade
   if (c->layout_mode >= 0 || !c->pipelined()) {
     c->layout = std::max(c->layout_mode, 0);
   } else {
     auto &t = c->tune;
-    const bool same_workload = t.key_lights == sp.num_lights && t.key_deferred == c->deferred &&
+    const bool same_workload = t.key_lights == n_lights && t.key_deferred == c->deferred &&
                                c->n_prims <= t.key_prims + t.key_prims / 4 && c->n_prims + c->n_prims / 4 >= t.key_prims;
     if (t.phase == 0 || !same_workload) {
       t.phase = 1;
       t.count = 0;
       t.key_prims = c->n_prims;
-      t.key_lights = sp.num_lights;
+      t.key_lights = n_lights;
       t.key_deferred = c->deferred;
       for (hipEvent_t &e : t.ev)
         if (!e) HIP_TRY(c, hipEventCreate(&e));
@@ -621,6 +598,35 @@ int submit_frame_into(bbr_context *c, int slot_index) {
     }
     if (t.phase == bbr_context::kTuneDecided) c->layout = t.best;
   }
+  hipStream_t sg = c->frame_geom_stream(slot_index);
+  for (hipEvent_t e : c->pending_waits) HIP_TRY(c, hipStreamWaitEvent(sg, e, 0));  // bbr_wait_event
+  c->pending_waits.clear();
+  c->timing_this = c->timing && (c->timing_tick++ % (uint64_t)c->timing_stride) == 0;
+  if (c->timing_this) {
+    if (c->ring.empty()) {
+      c->ring.resize(bbr_context::kRingEvents * bbr_context::kRingCap);
+      for (auto &e : c->ring) HIP_TRY(c, hipEventCreate(&e));
+    }
+    if (c->timing == 1) HIP_TRY(c, hipEventRecord(c->ring[bbr_context::kRingEvents * (c->ring_frames % bbr_context::kRingCap)], sg));
+  }
+  s.ctr_index = slot_index;
+  HIP_TRY(c, hipMemcpyAsync(s.d_staging.ptr, s.h_staging, total, hipMemcpyHostToDevice, sg));
+
+  const Light *d_lights = reinterpret_cast<const Light *>(s.d_staging.ptr);
+  const DrawDesc *d_draws = reinterpret_cast<const DrawDesc *>(s.d_staging.ptr + lights_bytes);
+  FrameParams fp = make_params(c);
+  // forward: gl_Position = (P*V) * posWorld; deferred: P * (V * posWorld) -- the kernel gets P and V separately
+  Mat4 pv = c->deferred ? c->view_u.proj : proj_view(c->view_u);
+  const Mat4 view = c->view_u.view;
+  ShadeParams sp;
+  std::memcpy(sp.view_pos, c->view_u.view_pos, sizeof sp.view_pos);
+  sp.enable_normal_map = c->view_u.enable_normal_map;
+  sp.tone_enable = c->frame_u.enable_tone_mapping;
+  sp.exposure = c->frame_u.exposure;
+  sp.num_lights = n_lights;
+  float4 *out = c->ext_out ? reinterpret_cast<float4 *>(c->ext_out) : s.d_frame.ptr;
+  const FrameSlot *prev = (c->last_slot >= 0 && c->last_slot != slot_index) ? &c->slots[c->last_slot] : nullptr;
+
   if (c->tile_mode == 0) launch_frame<64, 64>(c, s, prev, fp, pv, view, sp, d_lights, d_draws, c->n_live_draws, out);
   else launch_frame<32, 32>(c, s, prev, fp, pv, view, sp, d_lights, d_draws, c->n_live_draws, out);
   HIP_TRY(c, hipGetLastError());
@@ -1356,7 +1362,8 @@ int bbr_set_stream(bbr_context *c, void *stream) {
 int bbr_wait_event(bbr_context *c, void *hip_event) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
   if (!hip_event) return fail(c, BBR_ERR_INVALID_ARGUMENT, "wait_event: NULL");
-  HIP_TRY(c, hipStreamWaitEvent(c->geom_stream(), (hipEvent_t)hip_event, 0));
+  c->pending_waits.push_back((hipEvent_t)hip_event);  // the next frame's first stream waits for it (which stream that is
+                                                      // depends on the stream layout)
   return BBR_OK;
 }
 
@@ -1634,7 +1641,7 @@ int bbr_set_option(bbr_context *c, const char *name, int64_t value) {
     c->timing_tick = 0;
   }
   else if (n == "frames_in_flight") {
-    if (value < 1 || value > bbr_context::kMaxSlots) return fail(c, BBR_ERR_INVALID_ARGUMENT, "frames_in_flight: 1, 2 or 3");
+    if (value < 1 || value > bbr_context::kMaxSlots) return fail(c, BBR_ERR_INVALID_ARGUMENT, "frames_in_flight: 1 .. 4");
     c->frames_in_flight = (int)value;
     c->frame_counter = 0;
     c->tune.phase = 0;

@@ -177,7 +177,7 @@ int bbr_timing_summary(bbr_context *ctx, uint32_t *out_frames, float *out_avg_fr
  *                            2: only the two around k_shade (frame/geometry/raster averages read 0); restarts the ring
  *   "timing_stride" n        with "timing" on, only every n-th frame carries events (default 1): the events themselves
  *                            perturb a pipelined frame stream (two per frame: ~4 % of the C3 frame rate)
- *   "frames_in_flight" 1|2|3 default 2
+ *   "frames_in_flight" 1..4  default 2
  *   "tile_mode" 0|1          0: 64x64 tiles, 1: 32x32 tiles (default)
  *   "bin_cap" n              initial references per (tile, raster class); grows by itself on overflow
  *   "broad_threshold" n      triangles touching more than n x n tiles go to the every-tile list
@@ -195,9 +195,9 @@ int bbr_timing_summary(bbr_context *ctx, uint32_t *out_frames, float *out_avg_fr
  *   "stream_layout" -1|0|1|2 how the kernels of the frames in flight are spread over HIP streams.  Same pixels in every
  *                            layout; which is fastest depends on the workload.  0: geometry + raster on one stream,
  *                            shade on a second, present on a third.  1: as 0 with k_raster on a stream of its own (the
- *                            geometry of frame N+1 overlaps the raster of frame N).  2: geometry on one stream, raster +
- *                            shade + present of a frame on the stream of its frame slot (whole frames overlap).
- *                            1080p, one ShaderBall: 67 / 47 / 39 us per frame; 4K, sixteen: 157 / 162 / 159 us.
+ *                            geometry of frame N+1 overlaps the raster of frame N).  2: every kernel of a frame on the
+ *                            stream of its frame slot (frames share nothing, whole frames overlap).
+ *                            1080p, one ShaderBall: 65 / 44 / 34 us per frame; 4K, sixteen: 156 / 160 / 152 us.
  *                            -1 (default): the context times the three, alternating, over the first 230 frames of a
  *                            workload (nothing blocks; layout 0 meanwhile) and keeps the fastest;
  *                            bbr_stream_layout_state reports

@@ -59,7 +59,7 @@ while time.time() < t_end:
     elif op == "layout":
         r.set_option("stream_layout", rng.choice([-1, 0, 1, 2]))
     elif op == "fif":
-        r.set_option("frames_in_flight", rng.choice([1, 2, 3]))
+        r.set_option("frames_in_flight", rng.choice([1, 2, 3, 4]))
     elif op == "resize":
         ext = rng.choice(extents)
         r.resize(*ext)

@@ -22,7 +22,7 @@ for cfg in cases:
     res = []
     for mode in (0, 1, 2):
         r = Renderer(cfg.width, cfg.height)
-        r.set_option("frames_in_flight", 3)
+        r.set_option("frames_in_flight", int(os.environ.get("FIF", "3")))
         r.set_option("stream_layout", mode)
         mat = r.upload_material(maps)
         scene, cam, settings = S.config_scene(r, cfg, ball)
