@@ -239,7 +239,7 @@ struct bbr_context {
   // kTuneRounds rounds of one span per layout, kTuneSpan frames each after kTuneSkip frames for the switch to settle;
   // two events per span on the frame's shade stream, polled without blocking.  Alternating the spans cancels what a
   // single pass does not (the first span of a fresh context runs on a GPU that is still ramping up).  Until the answer
-  // is in, and unless another layout wins by 10 %, layout 0 is used.
+  // is in, and unless another layout wins by 15 %, layout 0 is used.
   static constexpr int kLayouts = 3;
   int layout_mode = -1;  // the option: -1 automatic
   int layout = 0;        // layout of the frame being submitted
@@ -589,7 +589,7 @@ int submit_frame_into(bbr_context *c, int slot_index) {
         }
         t.best = 0;
         for (int l = 1; l < bbr_context::kLayouts; ++l)
-          if (t.ms[l] > 0.f && t.ms[l] < 0.90f * t.ms[0] && (t.best == 0 || t.ms[l] < t.ms[t.best])) t.best = l;
+          if (t.ms[l] > 0.f && t.ms[l] < 0.85f * t.ms[0] && (t.best == 0 || t.ms[l] < t.ms[t.best])) t.best = l;
         t.phase = bbr_context::kTuneDecided;
         if (getenv("BBR_DEBUG"))
           fprintf(stderr, "[bbr] stream layout: %d frames take %.3f / %.3f / %.3f ms -> layout %d\n",
