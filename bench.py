@@ -290,7 +290,7 @@ def main():
     # The context then times its three stream layouts over the first frames of a workload (option "stream_layout",
     # include/bibim_hip.h) and keeps the faster: let it finish before the warm-up, like the capacity sizing above.
     # (a fixed number of frames: with N > 1 every rank must issue the same collectives)
-    for _ in range(240):
+    for _ in range(520):
         step()
     fence()
     for _ in range(2):   # the answer is picked up by the next submission once the events are complete
@@ -468,7 +468,7 @@ def main():
                        "output": ("presented RGBA8 (fused)" if args.present_fused else "RGBA32F frame + presented RGBA8")
                                  if args.present else "RGBA32F frame",
                        "render_pass": args.render_pass,
-                       "stream_layout": layout, "stream_layout_timed_ms_per_48_frames": [round(x, 3) for x in layout_ms]},
+                       "stream_layout": layout, "stream_layout_timed_ms_per_128_frames": [round(x, 3) for x in layout_ms]},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         if verified is not None:

@@ -198,8 +198,8 @@ int bbr_timing_summary(bbr_context *ctx, uint32_t *out_frames, float *out_avg_fr
  *                            geometry of frame N+1 overlaps the raster of frame N).  2: every kernel of a frame on the
  *                            stream of its frame slot (frames share nothing, whole frames overlap).
  *                            1080p, one ShaderBall: 65 / 44 / 34 us per frame; 4K, sixteen: 156 / 160 / 152 us.
- *                            -1 (default): the context times the three, alternating, over the first 230 frames of a
- *                            workload (nothing blocks; layout 0 meanwhile, and kept unless another wins by 15 %);
+ *                            -1 (default): the context times the three, alternating, over the first 500 frames of a
+ *                            workload (nothing blocks; layout 0 meanwhile, and kept unless another wins by 5 %);
  *                            bbr_stream_layout_state reports
  *   "ablate" bits            diagnostics only: skip parts of the pipeline (see bb_kernels.hip.h) */
 int bbr_set_option(bbr_context *ctx, const char *name, int64_t value);

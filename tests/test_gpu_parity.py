@@ -624,11 +624,11 @@ def test_stream_layouts_render_the_same_frames(maps64, mode):
     r.set_option("frames_in_flight", 3)
     r.set_option("stream_layout", mode)
     h = None
-    for i in range(260):
+    for i in range(520):
         h = r.render_scene(sc, h)
         if i % 5 == 0:
             r.present()                  # queued behind the frame's k_shade, whichever stream that ran on
-        if i % 23 == 0 or i == 259:      # the read-back drains the pipeline: the switches happen at different depths
+        if i % 23 == 0 or i == 519:      # the read-back drains the pipeline: the switches happen at different depths
             assert np.array_equal(r.read_framebuffer().view(np.uint32), ref.view(np.uint32)), f"frame {i}"
             if i % 5 == 0:
                 assert np.array_equal(r.read_presented(), want8), f"presented frame {i}"
