@@ -20,7 +20,7 @@ cd $R
 for wl in c2 c5; do
   steps=200; [ $wl = c5 ] && steps=60
   python3 tools/profile_summary.py stats $O/${tag}_${wl}_stats $O/${tag}_${wl}_bench_kernel_stats.csv
-  python3 tools/profile_summary.py phases $O/${tag}_${wl}_stats 253 $steps $O/${tag}_${wl}_bench_kernel_phases.txt
+  python3 tools/profile_summary.py phases $O/${tag}_${wl}_stats 533 $steps $O/${tag}_${wl}_bench_kernel_phases.txt
   python3 tools/profile_summary.py hbm $wl $O/${tag}_${wl}_pmc_fetch $O/${tag}_${wl}_pmc_write $O/${tag}_${wl}_pmc_hbm.json
   cat $O/${tag}_${wl}_bench_kernel_phases.txt $O/${tag}_${wl}_bench_under_rocprof.json
 done

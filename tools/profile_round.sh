@@ -18,7 +18,7 @@ rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_THREAD_CYCLES_VALU -d $O/${tag}_pmc_sq3 --output-format csv -- $B > /dev/null 2>&1
 cd $R
 python3 tools/profile_summary.py stats $O/${tag}_stats $O/${tag}_bench_kernel_stats.csv
-python3 tools/profile_summary.py phases $O/${tag}_stats 263 200 $O/${tag}_bench_kernel_phases.txt
+python3 tools/profile_summary.py phases $O/${tag}_stats 543 200 $O/${tag}_bench_kernel_phases.txt
 python3 tools/profile_summary.py hbm c3 $O/${tag}_pmc_fetch $O/${tag}_pmc_write $O/${tag}_pmc_hbm.json
 python3 tools/profile_summary.py counters $O/${tag}_pmc_sq.txt $O/${tag}_pmc_sq1 $O/${tag}_pmc_sq2 $O/${tag}_pmc_sq3
 cat $O/${tag}_bench_kernel_stats.csv; cat $O/${tag}_bench_kernel_phases.txt; cat $O/${tag}_pmc_hbm.json; cat $O/${tag}_bench_under_rocprof.json
