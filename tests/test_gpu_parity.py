@@ -684,3 +684,32 @@ def test_caller_buffers_shared_by_frames_in_flight(maps64, layout):
         assert int((out_a != 0).sum().item()) == 0, f"round {rep}: pixels of an earlier frame survived the last frame's clear"
         assert int((out_b != 0).sum().item()) == 0
     r.close()
+
+
+def test_ninety_nine_lights_of_every_type_and_many_draws(maps64):
+    """the most the reference allows (NumLights < 100, src/main.cpp:1289) with point, spot and directional lights mixed
+    (and a few of an unknown type, which the shader skips), and the scene split into many small draws"""
+    rng = np.random.Generator(np.random.PCG64(99))
+    base = scenes.shaderball_scene(configs.C3.scaled(320, 180, 64), bbo.MaterialData(maps64))
+    lights = []
+    for i in range(99):
+        kind = (0, 1, 2, 0, 1, 2, 0, 7)[i % 8]
+        lights.append(scenes.light(type=kind, pos=tuple(rng.uniform(-4, 4, 3) + (0, 3, 3)), dir=tuple(rng.uniform(-1, 1, 3)),
+                                   color=tuple(rng.uniform(0.2, 1.0, 3)), intensity=float(rng.uniform(0.5, 6.0)),
+                                   inner=float(rng.uniform(0.7, 0.95)), outer=float(rng.uniform(0.3, 0.7))))
+    frame = scenes.frame_uniforms(lights)
+    draws = []
+    ball = base.draws[0]
+    for k in range(len(ball.instances)):          # one draw per ShaderBall instance instead of one instanced draw
+        draws.append(bbo.DrawData(ball.vertices, ball.indices, ball.instances[k:k + 1].copy(), ball.material))
+    draws += base.draws[1:]
+    sc = bbo.Scene(frame, base.view, draws, base.width, base.height)
+    img, ref, st = check(sc)
+    assert st["n_shaded"] > 10000 and np.isfinite(ref[..., :3]).all()
+    # the same frame through the deferred path
+    dref, _, dprim, ddepth, _ = bbo.render_deferred(sc, want_gbuffer=False)
+    r = Renderer(sc.width, sc.height)
+    r.set_option("render_pass", 1)
+    r.render_scene(sc)
+    assert np.array_equal(r.read_framebuffer().view(np.uint32), dref.view(np.uint32))
+    r.close()
