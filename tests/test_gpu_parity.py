@@ -136,7 +136,8 @@ def test_two_materials_and_extra_indexed_draw(maps64):
 
 
 def test_framebuffer_sizes_not_multiple_of_tile(maps64):
-    for w, h in ((1, 1), (7, 3), (65, 64), (64, 65), (130, 33), (333, 211)):
+    # ... and very wide / very tall ones (aspect ratios of 500:1 either way, 16384 pixels on a side)
+    for w, h in ((1, 1), (7, 3), (65, 64), (64, 65), (130, 33), (333, 211), (16384, 33), (31, 16384)):
         check(scenes.shaderball_scene(configs.C2.scaled(w, h, 64), bbo.MaterialData(maps64)))
 
 
