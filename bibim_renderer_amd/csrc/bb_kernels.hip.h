@@ -486,8 +486,7 @@ __global__ __launch_bounds__(256) void k_geometry(const DrawDesc *__restrict__ d
                                                   Counters *__restrict__ ctr, uint32_t *__restrict__ tile_count,
                                                   uint32_t *__restrict__ bins, BroadTri *__restrict__ broad_list,
                                                   const MaterialDesc *__restrict__ materials,
-                                                  BlockStats *__restrict__ block_stats,
-                                                  Counters *__restrict__ ctr_next) {
+                                                  BlockStats *__restrict__ block_stats) {
 #ifdef BB_STAMPS
 #define BB_STAMP(i) do { if (threadIdx.x == 0) reinterpret_cast<unsigned long long *>(clip_arena + fp.clip_cap)[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
 #else
@@ -495,9 +494,6 @@ __global__ __launch_bounds__(256) void k_geometry(const DrawDesc *__restrict__ d
 #endif
   BB_STAMP(0);
   __shared__ BlockStats bs;
-  // the NEXT frame's counter block is cleared here (frames in flight + 1 blocks rotate; the one cleared now is idle: its previous
-  // frame left the GPU before this one was submitted) -- saves a memset node per frame
-  if (ctr_next && blockIdx.x == 0 && threadIdx.x < sizeof(Counters) / 4) reinterpret_cast<uint32_t *>(ctr_next)[threadIdx.x] = 0u;
   __shared__ ClipWork s_clip[4];  // one per wave
   if (threadIdx.x == 0) bs = BlockStats{0u, 0u, 0u};
   __syncthreads();

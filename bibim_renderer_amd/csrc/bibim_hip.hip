@@ -411,7 +411,7 @@ void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const Fra
   if (c->n_prims)
     hipLaunchKernelGGL((k_geometry<TW, TH>), dim3((c->n_prims + 255) / 256), dim3(256), 0, sg, d_draws, n_draws,
                        c->n_prims, pv, view, fp, s.d_tris.ptr, s.d_attrs.ptr, s.d_clip.ptr, ctr, s.d_tile_count.ptr,
-                       s.d_bins.ptr, s.d_broad.ptr, c->d_materials.ptr, s.d_block_stats.ptr, (Counters *)nullptr);
+                       s.d_bins.ptr, s.d_broad.ptr, c->d_materials.ptr, s.d_block_stats.ptr);
   if (ev && c->timing == 1) (void)hipEventRecord(ev[1], sg);
   if (sr != sg) {
     (void)hipEventRecord(s.ev_geom_done, sg);
@@ -956,7 +956,7 @@ extern "C" int bbr_draw_overlays(bbr_context *c, int32_t gizmo_extent) {
       constexpr int TW = decltype(tw)::value, TH = decltype(th)::value;
       hipLaunchKernelGGL((k_geometry<TW, TH, true>), dim3((n_prims + 255) / 256), dim3(256), 0, st, d_draws, (uint32_t)draws.size(),
                          n_prims, ident, ident, fp, s.d_tris.ptr, s.d_attrs.ptr, s.d_clip.ptr, ctr, s.d_tile_count.ptr,
-                         s.d_bins.ptr, s.d_broad.ptr, c->d_materials.ptr, s.d_block_stats.ptr, (Counters *)nullptr);
+                         s.d_bins.ptr, s.d_broad.ptr, c->d_materials.ptr, s.d_block_stats.ptr);
       hipLaunchKernelGGL((k_raster<TW, TH, true>), dim3(fp.tiles_x, fp.tiles_y), dim3(kTileThreads), 0, st, fp, s.d_tris.ptr,
                          s.d_clip.ptr, ctr, s.d_tile_count.ptr, s.d_bins.ptr, s.d_broad.ptr, s.d_frags.ptr, s.d_frag_count.ptr,
                          (float4 *)nullptr, (uint32_t *)nullptr, (float *)nullptr, (const uint32_t *)nullptr,
