@@ -98,6 +98,7 @@ struct FbxReader {
   const uint8_t *buf;
   size_t size;
   std::string err;
+  bool wide = false;  // FBX >= 7500: EndOffset / NumProperties / PropertyListLen are 64-bit, the NULL record has 25 bytes
 
   bool need(size_t pos, size_t n) {
     if (pos > size || n > size - pos) {
@@ -172,16 +173,27 @@ struct FbxReader {
       err = "FBX nesting too deep";
       return false;
     }
-    if (!need(pos, 13)) return false;
-    uint32_t end = rd<uint32_t>(buf + pos), nprops = rd<uint32_t>(buf + pos + 4), plen = rd<uint32_t>(buf + pos + 8);
-    uint8_t nlen = buf[pos + 12];
+    const size_t hdr = wide ? 25 : 13;
+    if (!need(pos, hdr)) return false;
+    uint64_t end, nprops64, plen;
+    if (wide) {
+      end = rd<uint64_t>(buf + pos); nprops64 = rd<uint64_t>(buf + pos + 8); plen = rd<uint64_t>(buf + pos + 16);
+    } else {
+      end = rd<uint32_t>(buf + pos); nprops64 = rd<uint32_t>(buf + pos + 4); plen = rd<uint32_t>(buf + pos + 8);
+    }
+    uint8_t nlen = buf[pos + hdr - 1];
     if (end == 0) {
       is_null = true;
-      pos += 13;
+      pos += hdr;
       return true;
     }
     is_null = false;
-    pos += 13;
+    pos += hdr;
+    if (nprops64 > size) {  // every property takes at least one byte
+      err = "bad FBX record (property count)";
+      return false;
+    }
+    const uint32_t nprops = (uint32_t)nprops64;
     if (!need(pos, nlen) || end > size || end < pos) {
       err = "bad FBX record offsets";
       return false;
@@ -463,8 +475,8 @@ int bba_load_fbx_vertices(const char *path, void **out_vertices, uint32_t *out_n
     if (!read_file(path, file)) return fail(BBA_ERR_IO, std::string("cannot read ") + path);
     if (file.size() < 27 || std::memcmp(file.data(), "Kaydara FBX Binary  ", 20) != 0) return fail(BBA_ERR_FORMAT, "not a binary FBX file");
     const uint32_t version = rd<uint32_t>(file.data() + 23);
-    if (version >= 7500) return fail(BBA_ERR_UNSUPPORTED, "FBX >= 7500 (64-bit records) not supported");
     FbxReader r{file.data(), file.size(), {}};
+    r.wide = version >= 7500;
     FbxNode root;
     size_t pos = 27;
     while (pos < file.size()) {
