@@ -1,6 +1,6 @@
 """Experiment (GPU box): frame rate with the three stream layouts of option stream_layout, over resolutions and
 light counts -- where does the geometry -> raster chain, rather than the GPU, set the rate?
-   python tools/_gpu_raster_stream.py"""
+   python tools/_gpu_stream_layout.py"""
 import gc, os, sys, time
 from dataclasses import replace
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
