@@ -4,7 +4,7 @@
 //
 //   g++ -std=c++17 -O2 -Iinclude examples/shaderball_demo.cpp -Lbibim_renderer_amd -lbibim_hip -Wl,-rpath,$PWD/bibim_renderer_amd -o demo
 //   ./demo --fbx resources/ShaderBall.fbx            (or --vertices-bin file: raw bb::Vertex records)
-//          [--size 1920 1080] [--grid 4] [--frames 100] [--deferred] [--tone-map 1.0] [--pbr-dir resources/pbr/bark1]
+//          [--size 1920 1080] [--grid 4] [--frames 100] [--frames-in-flight 2] [--deferred] [--tone-map 1.0] [--pbr-dir resources/pbr/bark1]
 //          [--gizmo resources/gizmo.obj] [--out frame.ppm]        (--gizmo also turns the light markers on)
 #include <chrono>
 #include <cstdio>
@@ -22,7 +22,7 @@ static int die(const char *what, bbr_context *ctx = nullptr) {
 }
 
 int main(int argc, char **argv) {
-  int width = 1920, height = 1080, grid = 1, frames = 100;
+  int width = 1920, height = 1080, grid = 1, frames = 100, in_flight = 2;  // the reference keeps 2 (src/main.cpp:38)
   bool deferred = false, tone = false;
   float exposure = 1.f;
   std::string fbx, vbin, out = "frame.ppm", pbr, gizmo;
@@ -33,6 +33,7 @@ int main(int argc, char **argv) {
     else if (a == "--size" && i + 2 < argc) { width = std::atoi(argv[++i]); height = std::atoi(argv[++i]); }
     else if (a == "--grid" && i + 1 < argc) grid = std::atoi(argv[++i]);
     else if (a == "--frames" && i + 1 < argc) frames = std::atoi(argv[++i]);
+    else if (a == "--frames-in-flight" && i + 1 < argc) in_flight = std::atoi(argv[++i]);
     else if (a == "--deferred") deferred = true;
     else if (a == "--tone-map" && i + 1 < argc) { tone = true; exposure = (float)std::atof(argv[++i]); }
     else if (a == "--pbr-dir" && i + 1 < argc) pbr = argv[++i];
@@ -65,6 +66,7 @@ int main(int argc, char **argv) {
 
   bbr_context *ctx = nullptr;
   if (bbr_create(width, height, 0, &ctx) != BBR_OK) return die("bbr_create", nullptr), 1;
+  if (bbr_set_option(ctx, "frames_in_flight", in_flight) != BBR_OK) return die("frames_in_flight", ctx), 1;
   int rc = 0;
   {
     // --- material: a pbr/<name>/ directory of the reference, or the built-in default maps
@@ -105,9 +107,12 @@ int main(int argc, char **argv) {
     double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     bbr_stats st;
     bbr_get_stats(ctx, &st);
-    std::printf("%dx%d, %u triangles, %llu shaded pixels, %s pass: %.1f us/frame = %.0f Mpixels/s\n", width, height,
-                (unsigned)st.n_prims, (unsigned long long)st.n_shaded, deferred ? "deferred" : "forward",
-                frames ? dt / frames * 1e6 : 0.0, frames ? (double)width * height * frames / dt / 1e6 : 0.0);
+    int32_t layout = 0, decided = 0;
+    bbr_stream_layout_state(ctx, &layout, &decided, nullptr);
+    std::printf("%dx%d, %u triangles, %llu shaded pixels, %s pass, %d frames in flight, stream layout %d%s: %.1f us/frame = %.0f Mpixels/s\n",
+                width, height, (unsigned)st.n_prims, (unsigned long long)st.n_shaded, deferred ? "deferred" : "forward", in_flight,
+                layout, decided ? "" : " (still being timed)", frames ? dt / frames * 1e6 : 0.0,
+                frames ? (double)width * height * frames / dt / 1e6 : 0.0);
 
     // --- present (tone map + sRGB + RGBA8) and write it out
     std::vector<uint8_t> rgba((size_t)width * height * 4);

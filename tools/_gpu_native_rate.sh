@@ -10,5 +10,5 @@ z = np.load("tests/golden/shaderball_vertices.npz")
 z[z.files[0]].tofile("/tmp/ball.bin")
 PY
 for args in "--size 1920 1080 --grid 1" "--size 3840 2160 --grid 4"; do
-  /tmp/shaderball_demo --vertices-bin /tmp/ball.bin $args --frames 4000 --out /tmp/o.ppm | head -1
+  /tmp/shaderball_demo --vertices-bin /tmp/ball.bin $args --frames 4000 --frames-in-flight 3 --out /tmp/o.ppm | head -1
 done
