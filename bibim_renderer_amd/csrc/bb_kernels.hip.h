@@ -43,12 +43,17 @@ BB_DEV f3 cross3(f3 a, f3 b) {
 }
 // GLSL inversesqrt as a fixed sequence (integer seed + three Newton steps, max error 1.1 ulp): the same bits as the
 // oracle's bb_rsqrt, at a third of the instruction count of IEEE sqrt + divide.
+// The IEEE paths behind the guards are real function calls: taken for zero, denormal, infinite and NaN arguments only,
+// they would otherwise be expanded inline (a 12-instruction division, a 25-instruction square root) at each of the
+// shader's 25 call sites -- a tenth of k_shade's code and the source of most of its register copies (k_shade alone -2 %).
+__attribute__((noinline)) __device__ float bb_rsqrt_slow(float x) { return 1.0f / sqrtf(x); }
+__attribute__((noinline)) __device__ float bb_rcp_slow(float x) { return 1.0f / x; }
 BB_DEV float bb_rsqrt(float x) {
 #ifdef BB_EXPERIMENT_HW_TRANS
   return __builtin_amdgcn_rsqf(x);
 #endif
 #ifndef BB_EXPERIMENT_NO_GUARD
-  if (!__builtin_amdgcn_classf(x, 0x100)) return 1.0f / sqrtf(x);  // anything but a positive normal number (one v_cmp_class)
+  if (__builtin_expect(!__builtin_amdgcn_classf(x, 0x100), 0)) return bb_rsqrt_slow(x);  // anything but a positive normal number (one v_cmp_class)
 #endif
   float y = __uint_as_float(0x5F375A86u - (__float_as_uint(x) >> 1));
   const float h = 0.5f * x;
@@ -70,7 +75,7 @@ BB_DEV float bb_rcp(float x) {
   // a seed that is not a normal number (x zero, denormal, huge, infinite or NaN): the IEEE division.  One v_cmp_class
   // on the seed replaces two range compares on x.
 #ifndef BB_EXPERIMENT_NO_GUARD
-  if (!__builtin_amdgcn_classf(y, 0x108)) return 1.0f / x;
+  if (__builtin_expect(!__builtin_amdgcn_classf(y, 0x108), 0)) return bb_rcp_slow(x);
 #endif
   return fmaf(y, fmaf(-x, y, 1.0f), y);
 }

@@ -240,7 +240,7 @@ struct bbr_context {
   // (24-frame spans flattered layout 2 by 5 % at 4K; 64-frame spans agree with steady-state runs to 1 %);
   // two events per span on the frame's shade stream, polled without blocking.  Alternating the spans cancels what a
   // single pass does not (the first span of a fresh context runs on a GPU that is still ramping up).  Until the answer
-  // is in, and unless another layout wins by 5 %, layout 0 is used.
+  // is in, and unless another layout wins by 7 %, layout 0 is used.
   static constexpr int kLayouts = 3;
   int layout_mode = -1;  // the option: -1 automatic
   int layout = 0;        // layout of the frame being submitted
@@ -590,7 +590,7 @@ int submit_frame_into(bbr_context *c, int slot_index) {
         }
         t.best = 0;
         for (int l = 1; l < bbr_context::kLayouts; ++l)
-          if (t.ms[l] > 0.f && t.ms[l] < 0.95f * t.ms[0] && (t.best == 0 || t.ms[l] < t.ms[t.best])) t.best = l;
+          if (t.ms[l] > 0.f && t.ms[l] < 0.93f * t.ms[0] && (t.best == 0 || t.ms[l] < t.ms[t.best])) t.best = l;
         t.phase = bbr_context::kTuneDecided;
         if (getenv("BBR_DEBUG"))
           fprintf(stderr, "[bbr] stream layout: %d frames take %.3f / %.3f / %.3f ms -> layout %d\n",

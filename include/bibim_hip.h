@@ -199,7 +199,7 @@ int bbr_timing_summary(bbr_context *ctx, uint32_t *out_frames, float *out_avg_fr
  *                            stream of its frame slot (frames share nothing, whole frames overlap).
  *                            1080p, one ShaderBall: 65 / 44 / 34 us per frame; 4K, sixteen: 156 / 160 / 152 us.
  *                            -1 (default): the context times the three, alternating, over the first 500 frames of a
- *                            workload (nothing blocks; layout 0 meanwhile, and kept unless another wins by 5 %);
+ *                            workload (nothing blocks; layout 0 meanwhile, and kept unless another wins by 7 %);
  *                            bbr_stream_layout_state reports
  *   "ablate" bits            diagnostics only: skip parts of the pipeline (see bb_kernels.hip.h) */
 int bbr_set_option(bbr_context *ctx, const char *name, int64_t value);
