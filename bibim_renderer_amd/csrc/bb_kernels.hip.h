@@ -45,7 +45,7 @@ BB_DEV f3 cross3(f3 a, f3 b) {
 // oracle's bb_rsqrt, at a third of the instruction count of IEEE sqrt + divide.
 // The IEEE paths behind the guards are real function calls: taken for zero, denormal, infinite and NaN arguments only,
 // they would otherwise be expanded inline (a 12-instruction division, a 25-instruction square root) at each of the
-// shader's 25 call sites -- a tenth of k_shade's code and the source of most of its register copies (k_shade alone -2 %).
+// shader's 25 call sites -- a tenth of k_shade's code.
 __attribute__((noinline)) __device__ float bb_rsqrt_slow(float x) { return 1.0f / sqrtf(x); }
 __attribute__((noinline)) __device__ float bb_rcp_slow(float x) { return 1.0f / x; }
 BB_DEV float bb_rsqrt(float x) {
