@@ -493,10 +493,26 @@ int bba_load_fbx_vertices(const char *path, void **out_vertices, uint32_t *out_n
     if (!vn || !pn || vn->props.empty() || pn->props.empty()) return fail(BBA_ERR_FORMAT, "FBX geometry without Vertices / PolygonVertexIndex");
     const std::vector<double> &ctrl = vn->props[0].f64;
     const std::vector<int64_t> &pvi = pn->props[0].i64;
-    const size_t n = pvi.size(), n_ctrl = ctrl.size() / 3;
-    if (n == 0 || n % 3) return fail(BBA_ERR_UNSUPPORTED, "FBX: polygon-vertex count is not a multiple of three");
-    for (size_t k = 0; k < n; ++k)
-      if ((pvi[k] < 0) != (k % 3 == 2)) return fail(BBA_ERR_UNSUPPORTED, "FBX: non-triangle polygons (triangulation not implemented)");
+    const size_t n_pv = pvi.size(), n_ctrl = ctrl.size() / 3;
+    if (n_pv == 0) return fail(BBA_ERR_FORMAT, "FBX: empty PolygonVertexIndex");
+    // Polygon-vertex k of every emitted triangle corner.  A polygon ends at the negative (bit-inverted) index; triangles
+    // pass through, larger polygons are fanned from their first corner -- (0, i, i+1) -- which is what assimp's
+    // aiProcess_Triangulate (src/scene.cpp:61) does for convex quads; ShaderBall.fbx has triangles only.
+    std::vector<uint32_t> corner;
+    corner.reserve(n_pv);
+    for (size_t first = 0, k = 0; k < n_pv; ++k) {
+      if (pvi[k] >= 0) continue;
+      const size_t count = k - first + 1;
+      if (count < 3) return fail(BBA_ERR_FORMAT, "FBX: polygon with fewer than three vertices");
+      for (size_t i = 1; i + 1 < count; ++i) {
+        corner.push_back((uint32_t)first);
+        corner.push_back((uint32_t)(first + i));
+        corner.push_back((uint32_t)(first + i + 1));
+      }
+      first = k + 1;
+    }
+    if (pvi[n_pv - 1] >= 0) return fail(BBA_ERR_FORMAT, "FBX: last polygon is not closed");
+    const size_t n = corner.size();
     std::string err;
     Layer ln, lt, lu;
     if (!get_layer(*geom, "LayerElementNormal", "Normals", "NormalsIndex", ln, err) ||
@@ -515,10 +531,11 @@ int bba_load_fbx_vertices(const char *path, void **out_vertices, uint32_t *out_n
     };
     float *v = (float *)std::malloc(n * 11 * sizeof(float));
     if (!v) return fail(BBA_ERR_IO, "out of memory");
-    for (size_t k = 0; k < n; ++k) {
+    for (size_t t = 0; t < n; ++t) {
+      const size_t k = corner[t];
       const int64_t raw = pvi[k];
       const size_t ci = (size_t)(raw < 0 ? ~raw : raw);
-      float *o = v + 11 * k;
+      float *o = v + 11 * t;
       if (ci >= n_ctrl || !fetch(lu, k, 2, o + 3) || !fetch(ln, k, 3, o + 5) || !fetch(lt, k, 3, o + 8)) {
         std::free(v);
         return fail(BBA_ERR_FORMAT, "FBX: index out of range");

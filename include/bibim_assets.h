@@ -30,7 +30,7 @@ typedef enum bba_status {
   BBA_OK = 0,
   BBA_ERR_IO = -1,          /* cannot open / read */
   BBA_ERR_FORMAT = -2,      /* not the expected file format, or corrupt */
-  BBA_ERR_UNSUPPORTED = -3, /* valid file using a feature outside the path's needs (non-triangle polygons, ...) */
+  BBA_ERR_UNSUPPORTED = -3, /* valid file using a feature outside the path's needs (layer mappings other than ByPolygonVertex, ...) */
   BBA_ERR_ARGUMENT = -4
 } bba_status;
 
@@ -39,7 +39,8 @@ void bba_free(void *p);
 
 /* Binary FBX 7.x (32-bit records, or the 64-bit records of 7500 and later): the first Geometry object expanded to the non-indexed triangle list
  * ShaderBallScene builds -- vertex k = (Vertices[PolygonVertexIndex[k] (decoded)], UV0[UVIndex0[k]], Normals[k],
- * Tangents[k]), doubles cast to float, file tangents kept, no UV flip, no unit scaling.  out_vertices: 44-byte
+ * Tangents[k]), doubles cast to float, file tangents kept, no UV flip, no unit scaling.  Polygons with more than three
+ * corners are fanned from their first corner (aiProcess_Triangulate on convex polygons).  out_vertices: 44-byte
  * bb::Vertex records. */
 int bba_load_fbx_vertices(const char *path, void **out_vertices, uint32_t *out_n_vertices);
 

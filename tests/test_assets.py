@@ -273,6 +273,29 @@ def test_fbx_reader_on_a_written_file(tmp_path, compress, uv_indexed, version):
         assert np.array_equal(py.view(np.uint32), got.view(np.uint32))
 
 
+def test_fbx_polygons_are_fanned_from_their_first_corner(tmp_path):
+    """aiProcess_Triangulate (src/scene.cpp:61) on quads and larger convex polygons: triangles (0, i, i+1); per-corner
+    layers (ByPolygonVertex) follow the corners"""
+    rng = np.random.default_rng(5)
+    ctrl = rng.standard_normal((9, 3))
+    polys = [[0, 1, 2], [2, 3, 4, 5], [5, 6, 7, 8, 0], [1, 3, 5]]
+    pvi = np.concatenate([np.array(q[:-1] + [~q[-1]]) for q in polys])
+    n_pv = len(pvi)
+    normals, tangents = rng.standard_normal((n_pv, 3)), rng.standard_normal((n_pv, 3))
+    uv_table, uv_index = rng.random((6, 2)), rng.integers(0, 6, n_pv)
+    path = str(tmp_path / "poly.fbx")
+    write_fbx(path, ctrl, pvi, normals, tangents, uv_table, uv_index)
+    got = assets.load_fbx_vertices(path)
+    corners, first = [], 0
+    for q in polys:
+        for i in range(1, len(q) - 1):
+            corners += [first, first + i, first + i + 1]
+        first += len(q)
+    flat = np.concatenate([np.array(q) for q in polys])
+    want = np.concatenate([ctrl[flat[corners]], uv_table[uv_index[corners]], normals[corners], tangents[corners]], axis=1).astype(np.float32)
+    assert got.shape == (3 * (1 + 2 + 3 + 1), 11) and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
 def test_fbx_reader_errors(tmp_path):
     p = tmp_path / "x.fbx"
     p.write_bytes(b"Kaydara FBX Binary  \x00\x1a\x00" + struct.pack("<I", 7500) + b"\x00" * 64)
@@ -282,9 +305,13 @@ def test_fbx_reader_errors(tmp_path):
     with pytest.raises(assets.AssetError):
         assets.load_fbx_vertices(str(p))
     rng = np.random.default_rng(1)
-    quad = np.array([0, 1, 2, ~3])                           # a quad: triangulation is not implemented
-    write_fbx(str(p), rng.random((4, 3)), quad, rng.random((4, 3)), rng.random((4, 3)), rng.random((4, 2)), np.arange(4))
-    with pytest.raises(assets.AssetError, match="triang|multiple of three"):
+    open_poly = np.array([0, 1, 2, 3])                       # the last polygon never ends
+    write_fbx(str(p), rng.random((4, 3)), open_poly, rng.random((4, 3)), rng.random((4, 3)), rng.random((4, 2)), np.arange(4))
+    with pytest.raises(assets.AssetError, match="closed"):
+        assets.load_fbx_vertices(str(p))
+    two = np.array([0, ~1, 2, 3, ~0])                        # a two-vertex "polygon"
+    write_fbx(str(p), rng.random((4, 3)), two, rng.random((5, 3)), rng.random((5, 3)), rng.random((5, 2)), np.arange(5))
+    with pytest.raises(assets.AssetError, match="fewer than three"):
         assets.load_fbx_vertices(str(p))
     good = tmp_path / "g.fbx"
     write_fbx(str(good), rng.random((3, 3)), np.array([0, 1, ~2]), rng.random((3, 3)), rng.random((3, 3)), rng.random((3, 2)), np.arange(3))
