@@ -2,9 +2,10 @@
 //
 //   k_geometry   forward_brdf.vert + clip/cull/viewport/snap + triangle setup + tile binning
 //                (reference: src/shaders/forward_brdf.vert:24-37; state src/render.cpp:1069-1125)
-//   k_tile       per screen tile: LDS-resident 64-bit visibility keys (depth | primitive) filled with
-//                ds_max_u64, ballot/popcount compaction of covered pixels, then forward_brdf.frag +
-//                brdf.glsl once per visible pixel (src/shaders/forward_brdf.frag:15-76, brdf.glsl:2-36)
+//   k_raster     per screen tile: LDS-resident 64-bit visibility keys (depth | primitive) filled with
+//                ds_max_u64, ballot/popcount compaction of the covered pixels into the tile's fragment list
+//   k_shade      forward_brdf.frag + brdf.glsl once per visible pixel (src/shaders/forward_brdf.frag:15-76,
+//                brdf.glsl:2-36)
 //
 // Arithmetic contract: every floating-point expression below has the same operand order and the same
 // explicit fmaf() placement as the CPU oracle; the file is compiled with -ffp-contract=off, IEEE
@@ -19,6 +20,14 @@
 namespace bbr {
 
 #define BB_DEV __device__ __forceinline__
+
+// Diagnostic ablations (skip parts of the pipeline to see what they cost) exist only in -DBB_ABLATE builds; in the
+// shipped library the tests fold to constants.
+#ifdef BB_ABLATE
+#define BB_ABLATE(bits) ((fp.ablate & (bits)) != 0u)
+#else
+#define BB_ABLATE(bits) false
+#endif
 
 constexpr float kGuardBand = 32.0f;
 constexpr float kPi = 3.14159265358979323846f;
@@ -616,7 +625,7 @@ __global__ __launch_bounds__(256) void k_geometry(const DrawDesc *__restrict__ d
 #ifdef BB_STAMPS
           BB_STAMP(7);
 #endif
-          if (!(fp.ablate & 64u)) {
+          if (!BB_ABLATE(64u)) {
             tris[prim] = t;
             pa.X0 = t.X0; pa.Y0 = t.Y0;
             pa.l1dx = t.l1dx; pa.l1dy = t.l1dy; pa.l2dx = t.l2dx; pa.l2dy = t.l2dy;
@@ -629,7 +638,7 @@ __global__ __launch_bounds__(256) void k_geometry(const DrawDesc *__restrict__ d
           else binned = true;
           cls = raster_class(t, fp);
         }
-      } else if (!(fp.ablate & 128u)) {
+      } else if (!BB_ABLATE(128u)) {
         needs_clip = true;
       }
     }
@@ -640,7 +649,7 @@ __global__ __launch_bounds__(256) void k_geometry(const DrawDesc *__restrict__ d
   uint32_t refs = 0;
   {
     const int tw = binned ? tr.tx1 - tr.tx0 + 1 : 0;
-    const int nt = (binned && !(fp.ablate & 32u)) ? tw * (tr.ty1 - tr.ty0 + 1) : 0;
+    const int nt = (binned && !BB_ABLATE(32u)) ? tw * (tr.ty1 - tr.ty0 + 1) : 0;
     for (int k0 = 0; __ballot(k0 < nt) != 0ull; k0 += 4) {
       bool has[4];
       uint32_t seg[4];
@@ -1131,8 +1140,8 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
   __shared__ uint32_t s_n_cls[kBinClasses];
   __shared__ uint32_t s_n_valid, s_full_ref;  // staged entries that touch the tile; (reference + 1) of one that covers all of it
   if (tid < (int)kBinClasses)
-    s_n_cls[tid] = (fp.ablate & (1u | (256u << tid))) ? 0u : min(tile_count[tile * kBinClasses + tid], fp.bin_cap);
-  const uint32_t n_broad = (fp.ablate & 5u) ? 0u : min(ctr->n_broad, fp.broad_cap);
+    s_n_cls[tid] = BB_ABLATE(1u | (256u << tid)) ? 0u : min(tile_count[tile * kBinClasses + tid], fp.bin_cap);
+  const uint32_t n_broad = BB_ABLATE(5u) ? 0u : min(ctr->n_broad, fp.broad_cap);
   for (int p = tid; p < TILE_PIXELS; p += kTileThreads) {
     unsigned long long k0 = 0ull;
     if (OVERLAY) {  // depth test against what the scene left behind; low word 0 = "no overlay primitive here"
@@ -1318,57 +1327,123 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
 
 // The light loop and the ambient term: forward_brdf.frag:27-75 == brdf.frag:26-72 (same statements), on a surface
 // point given by position, (unnormalised) normal, albedo, metallic, roughness, ao.
-BB_DEV float4 light_surface(const ShadeParams &sp, const Light *__restrict__ lights, f3 P, f3 normal, f3 albedo, float metallic,
+//
+// Evaluation order = the CPU checker's "contract" form of the light loop, bit for bit.  Everything that feeds the
+// one ill-conditioned quantity of the shader, the GGX denominator q = NdotH^2 (a^2 - 1) + 1, follows the GLSL statement
+// by statement (V, N, L, att, H, NdotH); the well-conditioned products behind it are re-associated:
+//   D G / max(4 NdotV NdotL, .001) = (a2 NdotV NdotL) / ((q q) (PI dV dL) sden)   one reciprocal instead of four
+//   kD albedo / PI                 = (1 - F) ((1 - metallic) albedo / PI)         hoisted out of the loop
+//   radiance NdotL                 = (color intensity) (att NdotL)                color * intensity once per light
+// Why the shape matters on gfx950 (tools/microbench/issue_rate.hip, profiles/r02_issue_rate.txt): v_fma/mul/add_f32 on
+// VGPR operands issue every 2 cycles per SIMD, but ANY scalar-register operand, v_max, v_cmp, every conversion and
+// v_pk_* cost 4, v_rcp 8.  Light data therefore reaches the loop through LDS (ds_read broadcasts cost no vector-ALU
+// cycle) instead of scalar loads, per-light constants are cooked once per workgroup, and the loop body is 216 issue
+// cycles per light against 286 for the statement-by-statement form.
+// ------------------------------------------------------------------------------------------------
+
+// One light as the loop consumes it: 48 bytes in LDS, written once per workgroup by cook_light.
+struct CookedLight {
+  float px, py, pz;
+  int32_t type;
+  float cr, cg, cb;  // color * intensity
+  float outer;
+  float dx, dy, dz;  // type 1: normalize(-dir); type 2: -normalize(dir)
+  float inv_eps;     // type 1: 1 / (inner - outer)
+};
+struct ShadeShared {
+  CookedLight lights[kMaxNumLights];
+  float view_pos[4];
+};
+
+BB_DEV CookedLight cook_light(const Light &l) {
+  CookedLight c;
+  c.px = l.pos[0]; c.py = l.pos[1]; c.pz = l.pos[2];
+  c.type = l.type;
+  c.cr = l.color[0] * l.intensity; c.cg = l.color[1] * l.intensity; c.cb = l.color[2] * l.intensity;
+  c.outer = l.outer_cutoff;
+  c.dx = c.dy = c.dz = 0.0f;
+  c.inv_eps = 0.0f;
+  if (l.type == 1) {
+    const f3 d = normalize3(neg3(ld3(l.dir)));
+    c.dx = d.x; c.dy = d.y; c.dz = d.z;
+    c.inv_eps = bb_rcp(l.inner_cutoff - l.outer_cutoff);
+  } else if (l.type == 2) {
+    const f3 d = neg3(normalize3(ld3(l.dir)));
+    c.dx = d.x; c.dy = d.y; c.dz = d.z;
+  }
+  return c;
+}
+
+// every thread of the workgroup; the caller synchronises
+template <int THREADS>
+BB_DEV void stage_lights(const ShadeParams &sp, const Light *__restrict__ lights, ShadeShared &sh) {
+  for (int li = (int)threadIdx.x; li < sp.num_lights; li += THREADS) sh.lights[li] = cook_light(lights[li]);
+  if (threadIdx.x < 3) sh.view_pos[threadIdx.x] = sp.view_pos[threadIdx.x];
+}
+
+BB_DEV float4 light_surface(const ShadeParams &sp, const ShadeShared &sh, f3 P, f3 normal, f3 albedo, float metallic,
                             float roughness, float ao) {
-  // loop invariants of forward_brdf.frag:51-52 hoisted (bit-identical: same inputs, same operations)
-  const f3 V = normalize3(sub3(ld3(sp.view_pos), P));
+  // per-pixel invariants
+  const f3 V = normalize3(sub3(mk3(sh.view_pos[0], sh.view_pos[1], sh.view_pos[2]), P));
   const f3 N = normalize3(normal);
   const float NdotV = max0(dot3(V, N));
   const float rr = roughness + 1.0f;
-  const float kk = (rr * rr) * 0.125f;
-  const float G_V = geometry_schlick_ggx(NdotV, kk);
+  const float kk = (rr * rr) * 0.125f, omk = 1.0f - kk;
+  const float pidV = kPi * fmaf(NdotV, omk, kk);
+  const float a = roughness * roughness, a2 = a * a, a2m1 = a2 - 1.0f;
+  const float a2nv = a2 * NdotV, c4 = 4.0f * NdotV;
   const f3 F0 = mk3(mixf(0.04f, albedo.x, metallic), mixf(0.04f, albedo.y, metallic), mixf(0.04f, albedo.z, metallic));
+  const f3 omF0 = mk3(1.0f - F0.x, 1.0f - F0.y, 1.0f - F0.z);
   const float om = 1.0f - metallic;
+  const f3 kda = mk3((om * albedo.x) * kInvPi, (om * albedo.y) * kInvPi, (om * albedo.z) * kInvPi);
 
   f3 Lo = mk3(0.0f, 0.0f, 0.0f);
+  // The light's position, type and colour are fetched one iteration ahead (LDS broadcasts into registers), so the
+  // loop never waits for them.
+  float n_px = 0.f, n_py = 0.f, n_pz = 0.f, n_cr = 0.f, n_cg = 0.f, n_cb = 0.f;
+  int n_type = 0;
+  if (sp.num_lights > 0) {
+    const CookedLight &c0 = sh.lights[0];
+    n_px = c0.px; n_py = c0.py; n_pz = c0.pz; n_type = c0.type; n_cr = c0.cr; n_cg = c0.cg; n_cb = c0.cb;
+  }
   for (int li = 0; li < sp.num_lights; ++li) {
-    const Light &light = lights[li];
+    const CookedLight &cl = sh.lights[li];
+    const float px = n_px, py = n_py, pz = n_pz, cr = n_cr, cg = n_cg, cb = n_cb;
+    const int type = __builtin_amdgcn_readfirstlane(n_type);
+    {
+      const CookedLight &cn = sh.lights[li + 1 < sp.num_lights ? li + 1 : li];
+      n_px = cn.px; n_py = cn.py; n_pz = cn.pz; n_type = cn.type; n_cr = cn.cr; n_cg = cn.cg; n_cb = cn.cb;
+    }
     f3 L;
     float att;
-    if (light.type == 0 || light.type == 1) {
-      f3 Lv = sub3(ld3(light.pos), P);
-      float inv_d = bb_rsqrt(dot3(Lv, Lv));
+    if (type == 0 || type == 1) {
+      const f3 Lv = sub3(mk3(px, py, pz), P);
+      const float inv_d = bb_rsqrt(dot3(Lv, Lv));
       att = inv_d * inv_d;
       L = scale3(Lv, inv_d);
-      if (light.type == 1) {
-        float theta = dot3(L, normalize3(neg3(ld3(light.dir))));
-        float epsilon = light.inner_cutoff - light.outer_cutoff;
-        att *= clamp01((theta - light.outer_cutoff) * bb_rcp(epsilon));
-      }
-    } else if (light.type == 2) {
-      L = neg3(normalize3(ld3(light.dir)));
+      if (type == 1) att *= clamp01((dot3(L, mk3(cl.dx, cl.dy, cl.dz)) - cl.outer) * cl.inv_eps);
+    } else if (type == 2) {
+      L = mk3(cl.dx, cl.dy, cl.dz);
       att = 1.0f;
     } else {
-      continue;
+      continue;  // upstream leaves L / att uninitialised; the contract contributes nothing
     }
-    f3 H = normalize3(add3(L, V));
-    float D = distribution_ggx(dot3(N, H), roughness);
-    float x = 1.0f - max0(dot3(H, V));
-    float x2 = x * x;
-    float p5 = (x2 * x2) * x;
-    f3 F = mk3(fmaf(1.0f - F0.x, p5, F0.x), fmaf(1.0f - F0.y, p5, F0.y), fmaf(1.0f - F0.z, p5, F0.z));
-    float NdotL = max0(dot3(N, L));
-    float G = G_V * geometry_schlick_ggx(NdotL, kk);
-    f3 radiance = mk3((att * light.color[0]) * light.intensity, (att * light.color[1]) * light.intensity,
-                      (att * light.color[2]) * light.intensity);
-    float sden = (4.0f * NdotV) * NdotL;
-    sden = __builtin_fmaxf(sden, 0.001f);  // NaN -> 0.001, as `!(sden > 0.001) ? 0.001 : sden`
-    float rden = bb_rcp_normal(sden);      // in [0.001, 4.01] by the line above
-    f3 spec = mk3(((D * F.x) * G) * rden, ((D * F.y) * G) * rden, ((D * F.z) * G) * rden);
-    f3 kD = mk3((1.0f - F.x) * om, (1.0f - F.y) * om, (1.0f - F.z) * om);
-    Lo.x = fmaf(fmaf(kD.x * albedo.x, kInvPi, spec.x) * radiance.x, NdotL, Lo.x);
-    Lo.y = fmaf(fmaf(kD.y * albedo.y, kInvPi, spec.y) * radiance.y, NdotL, Lo.y);
-    Lo.z = fmaf(fmaf(kD.z * albedo.z, kInvPi, spec.z) * radiance.z, NdotL, Lo.z);
+    const f3 H = normalize3(add3(L, V));
+    const float NdotH = max0(dot3(N, H));
+    const float q = fmaf(NdotH * NdotH, a2m1, 1.0f);
+    const float x = 1.0f - max0(dot3(H, V));
+    const float x2 = x * x;
+    const float p5 = (x2 * x2) * x;
+    const float NdotL = max0(dot3(N, L));
+    const float dL = fmaf(NdotL, omk, kk);
+    const float sden = __builtin_fmaxf(c4 * NdotL, 0.001f);  // NaN -> 0.001
+    const float den = ((q * q) * (pidV * dL)) * sden;
+    const float S = (a2nv * NdotL) * bb_rcp(den);
+    const f3 F = mk3(fmaf(omF0.x, p5, F0.x), fmaf(omF0.y, p5, F0.y), fmaf(omF0.z, p5, F0.z));
+    const float rl = att * NdotL;
+    Lo.x = fmaf(fmaf(1.0f - F.x, kda.x, F.x * S), cr * rl, Lo.x);
+    Lo.y = fmaf(fmaf(1.0f - F.y, kda.y, F.y * S), cg * rl, Lo.y);
+    Lo.z = fmaf(fmaf(1.0f - F.z, kda.z, F.z * S), cb * rl, Lo.z);
   }
   float4 color;
   color.x = fmaf(0.03f * albedo.x, ao, Lo.x);
@@ -1381,12 +1456,17 @@ BB_DEV float4 light_surface(const ShadeParams &sp, const Light *__restrict__ lig
 // Deferred path: brdf.frag runs on every pixel of its full-screen triangle (src/main.cpp:101-104), also where the
 // G-buffer still holds its clear value 0; that colour is the same for all such pixels (it depends on the lights and
 // the camera only -- and is not always 0: a light at the world origin makes it NaN), so it is evaluated once.
-__global__ void k_deferred_background(ShadeParams sp, const Light *__restrict__ lights, float4 *__restrict__ out,
-                                      const SrgbTables *__restrict__ tables, int gbuffer_view) {
+constexpr int kBackgroundThreads = 64;
+__global__ __launch_bounds__(kBackgroundThreads) void k_deferred_background(ShadeParams sp, const Light *__restrict__ lights,
+                                                                            float4 *__restrict__ out,
+                                                                            const SrgbTables *__restrict__ tables, int gbuffer_view) {
+  __shared__ ShadeShared sh;
+  stage_lights<kBackgroundThreads>(sp, lights, sh);
+  __syncthreads();
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     // (buffer_visualize.frag on a cleared texel: rgb 0, alpha 1)
     const float4 c = gbuffer_view >= 0 ? make_float4(0.f, 0.f, 0.f, 1.f)
-                                       : light_surface(sp, lights, mk3(0.f, 0.f, 0.f), mk3(0.f, 0.f, 0.f), mk3(0.f, 0.f, 0.f), 0.f, 0.f, 0.f);
+                                       : light_surface(sp, sh, mk3(0.f, 0.f, 0.f), mk3(0.f, 0.f, 0.f), mk3(0.f, 0.f, 0.f), 0.f, 0.f, 0.f);
     out[0] = c;
     // out[1].x: the same colour as a presented pixel (fused presentation)
     if (tables) out[1] = make_float4(__uint_as_float(present_pixel(c.x, c.y, c.z, *tables, sp.tone_enable, sp.exposure, 1)), 0.f, 0.f, 0.f);
@@ -1395,17 +1475,19 @@ __global__ void k_deferred_background(ShadeParams sp, const Light *__restrict__ 
 
 // ------------------------------------------------------------------------------------------------
 // k_shade: forward_brdf.frag + brdf.glsl once per visible pixel.  One lane per fragment of the compacted lists,
-// 256 consecutive fragments of one tile per workgroup: no LDS, no barriers, every wave does the same amount of
-// work, so the hardware dispatcher balances the frame by itself.
-//
-// Measured dead ends (kept out of the code, recorded in DESIGN.md): shading two fragments per lane with packed
-// FP32 (v_pk_fma_f32 issues at ~10 cycles per wave instruction on gfx950 against ~2.4 for v_fma_f32: tools/
-// microbench/pk_rate.hip), and a persistent grid walking the work items (+15 % from its batch barriers).
+// 256 consecutive fragments of one tile per workgroup; the only LDS is the cooked light table (one barrier at the
+// start), every wave does the same amount of work, so the hardware dispatcher balances the frame by itself.
 // ------------------------------------------------------------------------------------------------
 #ifndef BB_SHADE_THREADS
 #define BB_SHADE_THREADS 256
 #endif
 constexpr int kShadeThreads = BB_SHADE_THREADS;
+
+// One texel of a packed material: 9 bytes, unaligned (albedo.rgb metallic | normal.xyz roughness | ao), fetched as one
+// global_load_dwordx3 (the three bytes behind the record are the next texel's; the allocation is padded).
+struct PackedTaps {
+  uint32_t x[4], y[4], z[4];  // per tap: dword 0, dword 1, dword 2 of the record
+};
 
 // PRESENT = true (option "present_fused"): the colour goes through present_pixel and is stored as RGBA8 -- the tone-map
 // subpass fused into the producing kernel: 4 bytes written per pixel instead of 16, and no k_present pass (16 B read +
@@ -1419,6 +1501,11 @@ __global__ __launch_bounds__(kShadeThreads) void k_shade(
     Counters *__restrict__ ctr, Counters *__restrict__ ctr_done) {
   constexpr int TILE_PIXELS = TILE_W * TILE_H;
   constexpr int CHUNKS = TILE_PIXELS / kShadeThreads;
+  __shared__ ShadeShared sh;
+#ifdef BB_EXP_LDS_PAD
+  __shared__ char exp_pad[BB_EXP_LDS_PAD];  // experiment: fewer workgroups per CU
+  if (fp.width < 0) exp_pad[threadIdx.x] = 1;
+#endif
   // The frame's counter block has done its job (k_geometry filled it, k_raster read it): keep a copy for the host's
   // statistics / overflow check and clear the block for the next frame of this slot.  Frames of different slots
   // share nothing, so their kernels may overlap freely.
@@ -1430,167 +1517,190 @@ __global__ __launch_bounds__(kShadeThreads) void k_shade(
   int ty, out_tile_row;
   if (!tile_row(fp, blockIdx.y, ty, out_tile_row)) return;
   const uint32_t tile = (uint32_t)ty * (uint32_t)fp.tiles_x + (uint32_t)tx;
-  const uint32_t i = (uint32_t)chunk * kShadeThreads + threadIdx.x;
-  // the fragment is fetched together with the count (entries past the count are stale but mapped memory)
-  const unsigned long long frag = frags[(size_t)tile * TILE_PIXELS + i];
   const uint32_t n_frag = frag_count[tile];
-  if ((uint32_t)chunk * kShadeThreads + (threadIdx.x & ~63u) >= n_frag) return;  // whole wave past the end
-  const bool valid = i < n_frag;
+  if ((uint32_t)chunk * kShadeThreads >= n_frag) return;  // the whole workgroup (uniform): nothing of this chunk is covered
+  // Lanes past the end of the list shade the list's last fragment again and do not store; waves entirely past the end
+  // only wait at the barrier below (their workgroup still needs them there).
+  const uint32_t i_raw = (uint32_t)chunk * kShadeThreads + threadIdx.x;
+  const bool valid = i_raw < n_frag;
+  const bool wave_live = (uint32_t)chunk * kShadeThreads + (threadIdx.x & ~63u) < n_frag;
+  const uint32_t i = valid ? i_raw : n_frag - 1u;
+  const unsigned long long frag = frags[(size_t)tile * TILE_PIXELS + i];
+  // The cooked light table is written now and only needed by the light loop: the barrier sits right in front of the
+  // loop, so the light fetch overlaps the fragment's own memory round trips (fragment -> primitive record -> texels).
+  stage_lights<kShadeThreads>(sp, lights, sh);
+  if (!wave_live) {
+    __syncthreads();
+    return;
+  }
   const uint32_t ref = (uint32_t)frag;
-  const uint32_t prim = (fp.ablate & 16u) ? 0u : (ref >> 3);
+  uint32_t prim = BB_ABLATE(16u) ? 0u : (ref >> 3);
+  if (BB_ABLATE(1024u)) prim = (uint32_t)__builtin_amdgcn_readfirstlane((int)prim);  // the record through the scalar cache
+  if (BB_ABLATE(2048u)) sp.num_lights = 0;
   int x, y;
   tile_pixel<TILE_W>((int)(frag >> 32) & (TILE_PIXELS - 1), x, y);
   const int gx = tx * TILE_W + x, gy = ty * TILE_H + y;
   const size_t o = (size_t)(out_tile_row * TILE_H + y) * (size_t)fp.width + (size_t)gx;
-  if (fp.ablate & 2u) {
-    if (valid && !PRESENT) out[o] = make_float4(1.f, 1.f, 1.f, 1.f);
+  if (BB_ABLATE(2u)) {
+    if (!PRESENT && valid) out[o] = make_float4(1.f, 1.f, 1.f, 1.f);
+    __syncthreads();
     return;
   }
 
-  if (!valid) return;
   // One 224-byte record per fragment, gathered directly (neighbouring pixels share primitives, so most of these
-  // loads hit the same L1 lines).  Staging each distinct record of the wave through LDS first was measured
-  // SLOWER (112 vs 100 us): the ballot loop and the extra LDS round trip cost more than the L1 gather.
-  const ShadeRec pa = recs[prim];
-  {
-    // perspective-correct barycentrics
-    const bool clipped = pa.clip_base != kNotClipped;
-    const ClipSlot *cs = clipped ? &clip_arena[pa.clip_base + (ref & 7u)] : nullptr;
-    int X0 = pa.X0, Y0 = pa.Y0;
-    float l1dx = pa.l1dx, l1dy = pa.l1dy, l2dx = pa.l2dx, l2dy = pa.l2dy, rw0 = pa.rw0, rw1 = pa.rw1, rw2 = pa.rw2;
-    if (clipped) {  // the sub-triangle's own planes
-      X0 = cs->tri.X0; Y0 = cs->tri.Y0;
-      l1dx = cs->tri.l1dx; l1dy = cs->tri.l1dy; l2dx = cs->tri.l2dx; l2dy = cs->tri.l2dy;
-      rw0 = cs->tri.rw0; rw1 = cs->tri.rw1; rw2 = cs->tri.rw2;
-    }
-    int Xc = gx * 256 + 128, Yc = gy * 256 + 128;
-    float dxp = (float)(Xc - X0), dyp = (float)(Yc - Y0);
-    float l1 = fmaf(l1dx, dxp, l1dy * dyp);
-    float l2 = fmaf(l2dx, dxp, l2dy * dyp);
-    float l0 = (1.0f - l1) - l2;
-    float u0 = l0 * rw0, u1 = l1 * rw1, u2 = l2 * rw2;
-    float r = bb_rcp((u0 + u1) + u2);
-    float b0 = u0 * r, b1 = u1 * r, b2 = u2 * r;
-    if (clipped) {
-      float c0 = fmaf(b2, cs->bary[2][0], fmaf(b1, cs->bary[1][0], b0 * cs->bary[0][0]));
-      float c1 = fmaf(b2, cs->bary[2][1], fmaf(b1, cs->bary[1][1], b0 * cs->bary[0][1]));
-      float c2 = fmaf(b2, cs->bary[2][2], fmaf(b1, cs->bary[1][2], b0 * cs->bary[0][2]));
-      b0 = c0; b1 = c1; b2 = c2;
-    }
-
-    float a[kNumVary];
+  // loads hit the same L1 lines).
+  const ShadeRec &pa = recs[prim];
+  // perspective-correct barycentrics from the screen-space planes of the (sub-)triangle
+  int X0 = pa.X0, Y0 = pa.Y0;
+  float l1dx = pa.l1dx, l1dy = pa.l1dy, l2dx = pa.l2dx, l2dy = pa.l2dy, rw0 = pa.rw0, rw1 = pa.rw1, rw2 = pa.rw2;
+  const uint32_t clip_base = pa.clip_base;
+  const bool clipped = clip_base != kNotClipped;
+  float cb[3][3];
+  if (clipped) {  // a sub-triangle of a clipped primitive (the ground plane, mostly): its own planes
+    const ClipSlot &cs = clip_arena[clip_base + (ref & 7u)];
+    X0 = cs.tri.X0; Y0 = cs.tri.Y0;
+    l1dx = cs.tri.l1dx; l1dy = cs.tri.l1dy; l2dx = cs.tri.l2dx; l2dy = cs.tri.l2dy;
+    rw0 = cs.tri.rw0; rw1 = cs.tri.rw1; rw2 = cs.tri.rw2;
 #pragma unroll
-    for (int k = 0; k < kNumVary; ++k) a[k] = fmaf(b2, pa.vary[2][k], fmaf(b1, pa.vary[1][k], b0 * pa.vary[0][k]));
-    // texture fetches, forward_brdf.frag:16-22
-    const float u = (fp.ablate & 8u) ? 0.5f : a[0], v = (fp.ablate & 8u) ? 0.5f : a[1];
-    f3 albedo, normal;
-    float metallic, roughness, ao;
-    if (pa.packed_dims != 0u) {
-      // packed material: one set of taps, four 16-byte loads
-      const BilinearTaps tp = bilinear_taps(u, v, (int)(pa.packed_dims & 0xFFFFu), (int)(pa.packed_dims >> 16));
-      const uint4 *tx = reinterpret_cast<const uint4 *>(pa.packed);
-      const uint4 t00 = tx[tp.o00], t10 = tx[tp.o10], t01 = tx[tp.o01], t11 = tx[tp.o11];
-      albedo.x = filter_channel(t00.x, t10.x, t01.x, t11.x, 0, tp.fx, tp.fy);
-      albedo.y = filter_channel(t00.x, t10.x, t01.x, t11.x, 8, tp.fx, tp.fy);
-      albedo.z = filter_channel(t00.x, t10.x, t01.x, t11.x, 16, tp.fx, tp.fy);
-      metallic = filter_channel(t00.x, t10.x, t01.x, t11.x, 24, tp.fx, tp.fy);
-      roughness = filter_channel(t00.y, t10.y, t01.y, t11.y, 24, tp.fx, tp.fy);
-      ao = filter_channel(t00.z, t10.z, t01.z, t11.z, 0, tp.fx, tp.fy);
-      if (sp.enable_normal_map != 0) {
-        f3 nt = mk3(fmaf(filter_channel(t00.y, t10.y, t01.y, t11.y, 0, tp.fx, tp.fy), 2.0f, -1.0f),
-                    fmaf(filter_channel(t00.y, t10.y, t01.y, t11.y, 8, tp.fx, tp.fy), 2.0f, -1.0f),
-                    fmaf(filter_channel(t00.y, t10.y, t01.y, t11.y, 16, tp.fx, tp.fy), 2.0f, -1.0f));
-        // vTBN * nt, vTBN = mat3(T, B, N)
-        normal.x = fmaf(a[5], nt.z, fmaf(a[11], nt.y, a[8] * nt.x));
-        normal.y = fmaf(a[6], nt.z, fmaf(a[12], nt.y, a[9] * nt.x));
-        normal.z = fmaf(a[7], nt.z, fmaf(a[13], nt.y, a[10] * nt.x));
-      } else {
-        normal = DEFERRED ? mk3(a[5], a[6], a[7]) : normalize3(mk3(a[5], a[6], a[7]));  // gbuffer.frag:29 / forward :24
-      }
-    } else {
-      // maps of different sizes: one set of taps per map
-      const MaterialDesc &md = materials[pa.material];
-      {
-        const TexDesc &td = md.maps[kMapAlbedo];
-        BilinearTaps tp = bilinear_taps(u, v, td.w, td.h);
-        const uint32_t *tx32 = reinterpret_cast<const uint32_t *>(td.texels);
-        uint32_t t00 = tx32[tp.o00], t10 = tx32[tp.o10], t01 = tx32[tp.o01], t11 = tx32[tp.o11];
-        albedo.x = filter_channel(t00, t10, t01, t11, 0, tp.fx, tp.fy);
-        albedo.y = filter_channel(t00, t10, t01, t11, 8, tp.fx, tp.fy);
-        albedo.z = filter_channel(t00, t10, t01, t11, 16, tp.fx, tp.fy);
-      }
-      {
-        const TexDesc &td = md.maps[kMapMetallic];
-        BilinearTaps tp = bilinear_taps(u, v, td.w, td.h);
-        const uint32_t *tx32 = reinterpret_cast<const uint32_t *>(td.texels);
-        metallic = filter_channel(tx32[tp.o00], tx32[tp.o10], tx32[tp.o01], tx32[tp.o11], 0, tp.fx, tp.fy);
-      }
-      {
-        const TexDesc &td = md.maps[kMapRoughness];
-        BilinearTaps tp = bilinear_taps(u, v, td.w, td.h);
-        const uint32_t *tx32 = reinterpret_cast<const uint32_t *>(td.texels);
-        roughness = filter_channel(tx32[tp.o00], tx32[tp.o10], tx32[tp.o01], tx32[tp.o11], 0, tp.fx, tp.fy);
-      }
-      {
-        const TexDesc &td = md.maps[kMapAO];
-        BilinearTaps tp = bilinear_taps(u, v, td.w, td.h);
-        const uint32_t *tx32 = reinterpret_cast<const uint32_t *>(td.texels);
-        ao = filter_channel(tx32[tp.o00], tx32[tp.o10], tx32[tp.o01], tx32[tp.o11], 0, tp.fx, tp.fy);
-      }
-      if (sp.enable_normal_map != 0) {
-        const TexDesc &td = md.maps[kMapNormal];
-        BilinearTaps tp = bilinear_taps(u, v, td.w, td.h);
-        const uint32_t *tx32 = reinterpret_cast<const uint32_t *>(td.texels);
-        uint32_t t00 = tx32[tp.o00], t10 = tx32[tp.o10], t01 = tx32[tp.o01], t11 = tx32[tp.o11];
-        f3 nt = mk3(fmaf(filter_channel(t00, t10, t01, t11, 0, tp.fx, tp.fy), 2.0f, -1.0f),
-                    fmaf(filter_channel(t00, t10, t01, t11, 8, tp.fx, tp.fy), 2.0f, -1.0f),
-                    fmaf(filter_channel(t00, t10, t01, t11, 16, tp.fx, tp.fy), 2.0f, -1.0f));
-        normal.x = fmaf(a[5], nt.z, fmaf(a[11], nt.y, a[8] * nt.x));
-        normal.y = fmaf(a[6], nt.z, fmaf(a[12], nt.y, a[9] * nt.x));
-        normal.z = fmaf(a[7], nt.z, fmaf(a[13], nt.y, a[10] * nt.x));
-      } else {
-        normal = DEFERRED ? mk3(a[5], a[6], a[7]) : normalize3(mk3(a[5], a[6], a[7]));
-      }
-    }
-
-    float4 color;
-    if (DEFERRED) {
-      // gbuffer.frag:24-32 into four RGBA16F attachments (binary16, round to nearest even), then brdf.frag:12-73 on
-      // the pixel's own texel: fused, the texel only goes to memory when somebody asked to see it
-      f3 P = mk3(bb_half_round(a[2]), bb_half_round(a[3]), bb_half_round(a[4]));
-      normal = mk3(bb_half_round(normal.x), bb_half_round(normal.y), bb_half_round(normal.z));
-      albedo = mk3(bb_half_round(albedo.x), bb_half_round(albedo.y), bb_half_round(albedo.z));
-      metallic = bb_half_round(metallic); roughness = bb_half_round(roughness); ao = bb_half_round(ao);
-      if (gbuffer) {
-        const MaterialDesc &md = materials[pa.material];
-        const TexDesc &td = md.maps[kMapHeight];
-        BilinearTaps tp = bilinear_taps(u, v, td.w, td.h);
-        const uint32_t *tx32 = reinterpret_cast<const uint32_t *>(td.texels);
-        const float height = bb_half_round(filter_channel(tx32[tp.o00], tx32[tp.o10], tx32[tp.o01], tx32[tp.o11], 0, tp.fx, tp.fy));
-        _Float16 g[16] = {(_Float16)P.x, (_Float16)P.y, (_Float16)P.z, (_Float16)1.0f,
-                          (_Float16)normal.x, (_Float16)normal.y, (_Float16)normal.z, (_Float16)0.0f,
-                          (_Float16)albedo.x, (_Float16)albedo.y, (_Float16)albedo.z, (_Float16)0.0f,
-                          (_Float16)metallic, (_Float16)roughness, (_Float16)ao, (_Float16)height};
-        uint4 *dst = reinterpret_cast<uint4 *>(gbuffer) + 2 * ((size_t)gy * (size_t)fp.width + (size_t)gx);
-        uint4 lo, hi;
-        __builtin_memcpy(&lo, g, 16);
-        __builtin_memcpy(&hi, g + 8, 16);
-        dst[0] = lo;
-        dst[1] = hi;
-      }
-      if (fp.gbuffer_view >= 0) {
-        // buffer_visualize.frag:8-12 instead of brdf.frag (recordCommand, src/main.cpp:96-121): the rgb of one attachment
-        const f3 shown = fp.gbuffer_view == 0 ? P : (fp.gbuffer_view == 1 ? normal : (fp.gbuffer_view == 2 ? albedo : mk3(metallic, roughness, ao)));
-        color = make_float4(shown.x, shown.y, shown.z, 1.0f);
-      } else {
-        color = light_surface(sp, lights, P, normal, albedo, metallic, roughness, ao);
-      }
-    } else {
-      color = light_surface(sp, lights, mk3(a[2], a[3], a[4]), normal, albedo, metallic, roughness, ao);
-    }
-    if (PRESENT) out8[o] = present_pixel(color.x, color.y, color.z, *tables, sp.tone_enable, sp.exposure, 1);
-    else out[o] = color;
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) cb[j][k] = cs.bary[j][k];
   }
+  const int Xc = gx * 256 + 128, Yc = gy * 256 + 128;
+  const float dxp = (float)(Xc - X0), dyp = (float)(Yc - Y0);
+  const float l1 = fmaf(l1dx, dxp, l1dy * dyp);
+  const float l2 = fmaf(l2dx, dxp, l2dy * dyp);
+  const float l0 = (1.0f - l1) - l2;
+  const float u0 = l0 * rw0, u1 = l1 * rw1, u2 = l2 * rw2;
+  const float r = bb_rcp((u0 + u1) + u2);
+  float b0 = u0 * r, b1 = u1 * r, b2 = u2 * r;
+  if (clipped) {  // barycentrics with respect to the unclipped primitive
+    const float c0 = fmaf(b2, cb[2][0], fmaf(b1, cb[1][0], b0 * cb[0][0]));
+    const float c1 = fmaf(b2, cb[2][1], fmaf(b1, cb[1][1], b0 * cb[0][1]));
+    const float c2 = fmaf(b2, cb[2][2], fmaf(b1, cb[1][2], b0 * cb[0][2]));
+    b0 = c0; b1 = c1; b2 = c2;
+  }
+
+  float a[kNumVary];
+#pragma unroll
+  for (int k = 0; k < kNumVary; ++k) a[k] = fmaf(b2, pa.vary[2][k], fmaf(b1, pa.vary[1][k], b0 * pa.vary[0][k]));
+  // texture fetches, forward_brdf.frag:16-22
+  const float u = BB_ABLATE(8u) ? 0.5f : a[0], v = BB_ABLATE(8u) ? 0.5f : a[1];
+  f3 albedo, normal;
+  float metallic, roughness, ao;
+  const uint32_t packed_dims = pa.packed_dims;
+  if (packed_dims != 0u) {
+    // packed material: one set of taps, four 12-byte loads of 9-byte records
+    const BilinearTaps tp = bilinear_taps(u, v, (int)(packed_dims & 0xFFFFu), (int)(packed_dims >> 16));
+    const uint8_t *tb = pa.packed;
+    uint32_t t00[3], t10[3], t01[3], t11[3];
+    __builtin_memcpy(t00, tb + kPackedTexelBytes * tp.o00, 12);
+    __builtin_memcpy(t10, tb + kPackedTexelBytes * tp.o10, 12);
+    __builtin_memcpy(t01, tb + kPackedTexelBytes * tp.o01, 12);
+    __builtin_memcpy(t11, tb + kPackedTexelBytes * tp.o11, 12);
+    albedo.x = filter_channel(t00[0], t10[0], t01[0], t11[0], 0, tp.fx, tp.fy);
+    albedo.y = filter_channel(t00[0], t10[0], t01[0], t11[0], 8, tp.fx, tp.fy);
+    albedo.z = filter_channel(t00[0], t10[0], t01[0], t11[0], 16, tp.fx, tp.fy);
+    metallic = filter_channel(t00[0], t10[0], t01[0], t11[0], 24, tp.fx, tp.fy);
+    roughness = filter_channel(t00[1], t10[1], t01[1], t11[1], 24, tp.fx, tp.fy);
+    ao = filter_channel(t00[2], t10[2], t01[2], t11[2], 0, tp.fx, tp.fy);
+    if (sp.enable_normal_map != 0) {
+      const f3 nt = mk3(fmaf(filter_channel(t00[1], t10[1], t01[1], t11[1], 0, tp.fx, tp.fy), 2.0f, -1.0f),
+                        fmaf(filter_channel(t00[1], t10[1], t01[1], t11[1], 8, tp.fx, tp.fy), 2.0f, -1.0f),
+                        fmaf(filter_channel(t00[1], t10[1], t01[1], t11[1], 16, tp.fx, tp.fy), 2.0f, -1.0f));
+      // vTBN * nt, vTBN = mat3(T, B, N)
+      normal.x = fmaf(a[5], nt.z, fmaf(a[11], nt.y, a[8] * nt.x));
+      normal.y = fmaf(a[6], nt.z, fmaf(a[12], nt.y, a[9] * nt.x));
+      normal.z = fmaf(a[7], nt.z, fmaf(a[13], nt.y, a[10] * nt.x));
+    } else {
+      normal = DEFERRED ? mk3(a[5], a[6], a[7]) : normalize3(mk3(a[5], a[6], a[7]));  // gbuffer.frag:29 / forward :24
+    }
+  } else {
+    // maps of different sizes: one set of taps per map
+    const MaterialDesc &md = materials[pa.material];
+    {
+      const TexDesc &td = md.maps[kMapAlbedo];
+      BilinearTaps tp = bilinear_taps(u, v, td.w, td.h);
+      const uint32_t *tx32 = reinterpret_cast<const uint32_t *>(td.texels);
+      uint32_t t00 = tx32[tp.o00], t10 = tx32[tp.o10], t01 = tx32[tp.o01], t11 = tx32[tp.o11];
+      albedo.x = filter_channel(t00, t10, t01, t11, 0, tp.fx, tp.fy);
+      albedo.y = filter_channel(t00, t10, t01, t11, 8, tp.fx, tp.fy);
+      albedo.z = filter_channel(t00, t10, t01, t11, 16, tp.fx, tp.fy);
+    }
+    {
+      const TexDesc &td = md.maps[kMapMetallic];
+      BilinearTaps tp = bilinear_taps(u, v, td.w, td.h);
+      const uint32_t *tx32 = reinterpret_cast<const uint32_t *>(td.texels);
+      metallic = filter_channel(tx32[tp.o00], tx32[tp.o10], tx32[tp.o01], tx32[tp.o11], 0, tp.fx, tp.fy);
+    }
+    {
+      const TexDesc &td = md.maps[kMapRoughness];
+      BilinearTaps tp = bilinear_taps(u, v, td.w, td.h);
+      const uint32_t *tx32 = reinterpret_cast<const uint32_t *>(td.texels);
+      roughness = filter_channel(tx32[tp.o00], tx32[tp.o10], tx32[tp.o01], tx32[tp.o11], 0, tp.fx, tp.fy);
+    }
+    {
+      const TexDesc &td = md.maps[kMapAO];
+      BilinearTaps tp = bilinear_taps(u, v, td.w, td.h);
+      const uint32_t *tx32 = reinterpret_cast<const uint32_t *>(td.texels);
+      ao = filter_channel(tx32[tp.o00], tx32[tp.o10], tx32[tp.o01], tx32[tp.o11], 0, tp.fx, tp.fy);
+    }
+    if (sp.enable_normal_map != 0) {
+      const TexDesc &td = md.maps[kMapNormal];
+      BilinearTaps tp = bilinear_taps(u, v, td.w, td.h);
+      const uint32_t *tx32 = reinterpret_cast<const uint32_t *>(td.texels);
+      uint32_t t00 = tx32[tp.o00], t10 = tx32[tp.o10], t01 = tx32[tp.o01], t11 = tx32[tp.o11];
+      f3 nt = mk3(fmaf(filter_channel(t00, t10, t01, t11, 0, tp.fx, tp.fy), 2.0f, -1.0f),
+                  fmaf(filter_channel(t00, t10, t01, t11, 8, tp.fx, tp.fy), 2.0f, -1.0f),
+                  fmaf(filter_channel(t00, t10, t01, t11, 16, tp.fx, tp.fy), 2.0f, -1.0f));
+      normal.x = fmaf(a[5], nt.z, fmaf(a[11], nt.y, a[8] * nt.x));
+      normal.y = fmaf(a[6], nt.z, fmaf(a[12], nt.y, a[9] * nt.x));
+      normal.z = fmaf(a[7], nt.z, fmaf(a[13], nt.y, a[10] * nt.x));
+    } else {
+      normal = DEFERRED ? mk3(a[5], a[6], a[7]) : normalize3(mk3(a[5], a[6], a[7]));
+    }
+  }
+
+  float4 color;
+  if (DEFERRED) {
+    // gbuffer.frag:24-32 into four RGBA16F attachments (binary16, round to nearest even), then brdf.frag:12-73 on
+    // the pixel's own texel: fused, the texel only goes to memory when somebody asked to see it
+    f3 P = mk3(bb_half_round(a[2]), bb_half_round(a[3]), bb_half_round(a[4]));
+    normal = mk3(bb_half_round(normal.x), bb_half_round(normal.y), bb_half_round(normal.z));
+    albedo = mk3(bb_half_round(albedo.x), bb_half_round(albedo.y), bb_half_round(albedo.z));
+    metallic = bb_half_round(metallic); roughness = bb_half_round(roughness); ao = bb_half_round(ao);
+    if (gbuffer && valid) {
+      const MaterialDesc &md = materials[pa.material];
+      const TexDesc &td = md.maps[kMapHeight];
+      BilinearTaps tp = bilinear_taps(u, v, td.w, td.h);
+      const uint32_t *tx32 = reinterpret_cast<const uint32_t *>(td.texels);
+      const float height = bb_half_round(filter_channel(tx32[tp.o00], tx32[tp.o10], tx32[tp.o01], tx32[tp.o11], 0, tp.fx, tp.fy));
+      _Float16 g[16] = {(_Float16)P.x, (_Float16)P.y, (_Float16)P.z, (_Float16)1.0f,
+                        (_Float16)normal.x, (_Float16)normal.y, (_Float16)normal.z, (_Float16)0.0f,
+                        (_Float16)albedo.x, (_Float16)albedo.y, (_Float16)albedo.z, (_Float16)0.0f,
+                        (_Float16)metallic, (_Float16)roughness, (_Float16)ao, (_Float16)height};
+      uint4 *dst = reinterpret_cast<uint4 *>(gbuffer) + 2 * ((size_t)gy * (size_t)fp.width + (size_t)gx);
+      uint4 lo, hi;
+      __builtin_memcpy(&lo, g, 16);
+      __builtin_memcpy(&hi, g + 8, 16);
+      dst[0] = lo;
+      dst[1] = hi;
+    }
+    __syncthreads();  // cooked lights visible (the only barrier of the kernel; every wave of the workgroup reaches one)
+    if (fp.gbuffer_view >= 0) {
+      // buffer_visualize.frag:8-12 instead of brdf.frag (recordCommand, src/main.cpp:96-121): the rgb of one attachment
+      const f3 shown = fp.gbuffer_view == 0 ? P : (fp.gbuffer_view == 1 ? normal : (fp.gbuffer_view == 2 ? albedo : mk3(metallic, roughness, ao)));
+      color = make_float4(shown.x, shown.y, shown.z, 1.0f);
+    } else {
+      color = light_surface(sp, sh, P, normal, albedo, metallic, roughness, ao);
+    }
+  } else {
+    __syncthreads();  // cooked lights visible (the only barrier of the kernel; every wave of the workgroup reaches one)
+    color = light_surface(sp, sh, mk3(a[2], a[3], a[4]), normal, albedo, metallic, roughness, ao);
+  }
+  if (!valid) return;
+  if (PRESENT) out8[o] = present_pixel(color.x, color.y, color.z, *tables, sp.tone_enable, sp.exposure, 1);
+  else out[o] = color;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -111,26 +111,28 @@ struct BroadTri {
 };
 static_assert(sizeof(BroadTri) == 80, "BroadTri");
 
-// One texel of a packed material: the five maps the forward shader reads, interleaved so that a bilinear tap is
-// ONE 16-byte load instead of five 4-byte loads from five arrays.
-//   x = albedo.r | albedo.g << 8 | albedo.b << 16 | metallic.r << 24
-//   y = normal.x | normal.y << 8 | normal.z << 16 | roughness.r << 24
-//   z = ao.r,  w = 0
-struct PackedTexel {
-  uint32_t x, y, z, w;
-};
+// One texel of a packed material: the five maps the forward shader reads, interleaved into a 9-byte record so that a
+// bilinear tap is ONE 12-byte load (global_load_dwordx3 at an unaligned address; the last three bytes belong to the
+// next record and are ignored) instead of five 4-byte loads from five arrays -- and so that a bilinear footprint costs
+// 36 bytes of HBM traffic, not 64 (16-byte texels) or 80 (five RGBA8 maps):
+//   byte 0..2 albedo.rgb, 3 metallic.r, 4..6 normal.xyz, 7 roughness.r, 8 ao.r
+#ifndef BB_PACKED_STRIDE
+#define BB_PACKED_STRIDE 9  // (12 and 16 were measured too: DESIGN.md)
+#endif
+constexpr uint32_t kPackedTexelBytes = BB_PACKED_STRIDE;
+constexpr uint32_t kPackedTexelPad = 16;  // bytes allocated behind the last record (the 12-byte load of the last texel)
 
 // Everything k_shade needs about one primitive, in ONE 224-byte record (56 dwords): the post-vertex-stage varyings
 // of its three vertices, the screen-space barycentric planes and 1/w of the (unclipped) triangle, and its material
-// binding.  A wave fetches the record of each DISTINCT primitive among its 64 fragments once, fully coalesced, into
-// LDS (neighbouring pixels share primitives), instead of 64 lanes gathering 16 x 16 B each through the L1.
+// binding.  Every lane gathers the record of its own fragment's primitive (neighbouring pixels share primitives, so
+// the loads of a wave hit few L1 lines).
 struct ShadeRec {
   float vary[3][kNumVary];
   int32_t X0, Y0;                // vertex 0 of the triangle, 24.8 (planes are relative to it)
   float l1dx, l1dy, l2dx, l2dy;  // screen-space barycentric planes
   float rw0, rw1, rw2;           // 1/w at the vertices
   uint32_t material;
-  const PackedTexel *packed;     // packed material texels (nullptr: use the material table)
+  const uint8_t *packed;         // packed material texels, 9-byte records (nullptr: use the material table)
   uint32_t packed_dims;          // width | height << 16, 0 = not packed
   uint32_t clip_base;            // first clip-arena slot of a clipped primitive, kNotClipped otherwise
 };
@@ -155,7 +157,7 @@ struct TexDesc {
 
 struct MaterialDesc {
   TexDesc maps[kMapCount];
-  const PackedTexel *packed;  // non-null when the five shaded maps share one size (or are defaults)
+  const uint8_t *packed;  // 9-byte records; non-null when the five shaded maps share one size (or are defaults)
   int32_t pw, ph;
 };
 

@@ -35,7 +35,7 @@ struct Mesh {
 
 struct Material {
   uint8_t *d_texels[kMapCount] = {};
-  PackedTexel *d_packed = nullptr;
+  uint8_t *d_packed = nullptr;
   MaterialDesc desc = {};
   bool alive = false;
 };
@@ -430,7 +430,7 @@ void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const Fra
   uint32_t *out8 = c->present_fused ? s.d_present.ptr : nullptr;
   const SrgbTables *tables = c->present_fused ? c->d_srgb_tables.ptr : nullptr;
   if (fp.deferred)
-    hipLaunchKernelGGL(k_deferred_background, dim3(1), dim3(64), 0, sr, sp, d_lights, s.d_background.ptr, tables, fp.gbuffer_view);
+    hipLaunchKernelGGL(k_deferred_background, dim3(1), dim3(kBackgroundThreads), 0, sr, sp, d_lights, s.d_background.ptr, tables, fp.gbuffer_view);
   const bool ordered = c->tile_order && c->n_prims;
   if (ordered)
     hipLaunchKernelGGL(k_tile_order, dim3((fp.tiles_x * grid_y + kOrderThreads - 1) / kOrderThreads), dim3(kOrderThreads),
@@ -1166,7 +1166,7 @@ int bbr_upload_material(bbr_context *c, const bbr_image maps[BBR_MAP_COUNT], int
     }
   }
   // Interleave the five shaded maps when they agree on one size (missing maps are uniform, so they broadcast):
-  // a bilinear tap then costs one 16-byte load instead of five 4-byte loads from five arrays.
+  // a bilinear tap then costs one 12-byte load of a 9-byte record instead of five 4-byte loads from five arrays.
   {
     static const uint8_t k_default[kMapCount][4] = {{255, 255, 255, 255}, {0, 0, 0, 255},       {0, 0, 0, 255},
                                                     {255, 255, 255, 255}, {127, 127, 255, 255}, {0, 0, 0, 255}};
@@ -1184,23 +1184,22 @@ int bbr_upload_material(bbr_context *c, const bbr_image maps[BBR_MAP_COUNT], int
       }
     }
     if (ok) {
-      std::vector<PackedTexel> host((size_t)pw * ph);
+      const size_t n_texels = (size_t)pw * ph;
+      std::vector<uint8_t> host(n_texels * kPackedTexelBytes + kPackedTexelPad, 0);
       auto texel = [&](int k, size_t i) -> const uint8_t * {
         const bbr_image &im = maps[k];
         return (im.rgba && im.width > 0 && im.height > 0) ? im.rgba + 4 * i : k_default[k];
       };
-      for (size_t i = 0; i < host.size(); ++i) {
+      for (size_t i = 0; i < n_texels; ++i) {
         const uint8_t *al = texel(kMapAlbedo, i), *me = texel(kMapMetallic, i), *ro = texel(kMapRoughness, i);
         const uint8_t *ao = texel(kMapAO, i), *no = texel(kMapNormal, i);
-        PackedTexel t;
-        t.x = (uint32_t)al[0] | ((uint32_t)al[1] << 8) | ((uint32_t)al[2] << 16) | ((uint32_t)me[0] << 24);
-        t.y = (uint32_t)no[0] | ((uint32_t)no[1] << 8) | ((uint32_t)no[2] << 16) | ((uint32_t)ro[0] << 24);
-        t.z = (uint32_t)ao[0];
-        t.w = 0;
-        host[i] = t;
+        uint8_t *t = host.data() + i * kPackedTexelBytes;
+        t[0] = al[0]; t[1] = al[1]; t[2] = al[2]; t[3] = me[0];
+        t[4] = no[0]; t[5] = no[1]; t[6] = no[2]; t[7] = ro[0];
+        t[8] = ao[0];
       }
-      HIP_TRY(c, hipMalloc(&m.d_packed, host.size() * sizeof(PackedTexel)));
-      HIP_TRY(c, upload_sync(m.d_packed, host.data(), host.size() * sizeof(PackedTexel)));
+      HIP_TRY(c, hipMalloc(&m.d_packed, host.size()));
+      HIP_TRY(c, upload_sync(m.d_packed, host.data(), host.size()));
       m.desc.packed = m.d_packed;
       m.desc.pw = pw;
       m.desc.ph = ph;
@@ -1659,7 +1658,11 @@ int bbr_set_option(bbr_context *c, const char *name, int64_t value) {
     c->bin_cap = (uint32_t)value;
     for (FrameSlot &s : c->slots) s.d_bins.release();
   } else if (n == "ablate") {
+#ifdef BB_ABLATE
     c->ablate = (uint32_t)value;
+#else
+    if (value != 0) return fail(c, BBR_ERR_INVALID_ARGUMENT, "ablate: diagnostic builds only (make EXTRA=-DBB_ABLATE)");
+#endif
   } else if (n == "present_fused") {
     c->present_fused = value != 0;
   } else if (n == "overlays") {

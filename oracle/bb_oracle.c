@@ -24,12 +24,10 @@
  *                    unlike a hardware v_rsq_f32 or a correctly rounded 1/sqrt -- it is the same bits on CPU and
  *                    GPU at a third of the GPU instruction cost of IEEE sqrt + divide.  Arguments outside the
  *                    normal positive range fall back to 1.0f / sqrtf(x) (zero -> inf, negative -> NaN).
- *   rcp(x)         = reciprocal as a FIXED sequence: seed 0x7EF311C7 - bits(|x|), three Newton steps
- *                    r = fma(r, fma(-|x|, r, 1), r), sign restored.  Max error 0.5004 ulp (i.e. the correctly
- *                    rounded result except for rare last-bit ties); |x| outside [FLT_MIN, 8.5e37] falls back to
- *                    1.0f / x (zero -> inf, inf -> 0, NaN -> NaN).  GLSL divisions a / b of the fragment stage are
- *                    evaluated as a * rcp(b) (GLSL allows 2.5 ulp), which is what shader compilers emit; unlike the
- *                    IEEE divide sequence it consists of fma only, so the GPU can run it packed two pixels at a time.
+ *   rcp(x)         = the correctly rounded 1/x (an IEEE division here).  The GPU reaches the same bits with
+ *                    v_rcp_f32 plus ONE Newton step for every normal input with a normal reciprocal (checked
+ *                    exhaustively by bbr_selftest_rcp) and takes the IEEE division outside that range.  GLSL
+ *                    divisions a / b of the fragment stage are evaluated as a * rcp(b) (GLSL allows 2.5 ulp).
  *   normalize(v)   = v * rsqrt(dot3(v,v));  length-based attenuation 1/(d*d) = rsqrt(d2)^2
  *   mat*vec        = fmaf(c3,w, fmaf(c2,z, fmaf(c1,y, c0*x)))   per row
  *   mix(a,b,t)     = fmaf(b,t, a*(1-t));  pow(x,5) = ((x*x)*(x*x))*x;  x/PI = x*(float)(1/pi)
@@ -333,11 +331,120 @@ static void light_surface(const bbo_frame_uniforms *fu, const bbo_view_uniforms 
   out[3] = 1.0f;
 }
 
-static void shade_fragment(const bbo_frame_uniforms *fu, const bbo_view_uniforms *vu, const bbo_material *mat,
+/* ------------------------------------------------------------------------------------------ */
+/* The SHIPPED evaluation order of the same light loop ("contract" mode; the default of bbo_render /
+ * bbo_render_deferred).  light_surface() above follows the GLSL statement by statement; this one is what
+ * k_shade executes, bit for bit.  It differs from the literal form only DOWNSTREAM of the one
+ * ill-conditioned quantity of the shader -- the GGX denominator q = NdotH^2 (a^2 - 1) + 1, which cancels to
+ * ~a^2 at a highlight's peak and amplifies a 1-ulp change of N, V, L or H about 2000-fold.  Everything that
+ * feeds q (V, N, L, att, H, NdotH) is computed exactly as in light_surface().  Behind q the products are
+ * re-associated the way a shader compiler does for a non-`precise` GLSL expression:
+ *   D G / max(4 NdotV NdotL, .001)  =  (a2 NdotV NdotL) / ((q q) (PI dV dL) sden)     one reciprocal instead of four
+ *       with dX = NdotX (1 - k) + k (geometrySchlickGGX's denominator), sden = max(4 NdotV NdotL, .001)
+ *   kD albedo / PI                  =  (1 - F) ((1 - metallic) albedo (1/PI))         hoisted out of the loop
+ *   radiance NdotL                  =  (color intensity) (att NdotL)                  color*intensity once per light
+ * The per-light constants (color*intensity, the normalised spot / directional direction, 1/epsilon) are
+ * evaluated once per light and frame ("cooked" lights) -- the same operations as the literal form, hoisted.
+ * The two forms agree to a few ulp of the result (tests/test_oracle_contract.py checks <= 1e-5 relative on
+ * random inputs and <= 1e-4 max(1,|ref|) on whole frames); the GPU is compared bit for bit with THIS form
+ * and within BASELINE's tolerance with the literal one.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  v3 pos;
+  int32_t type;
+  v3 ci;      /* color * intensity */
+  v3 dirn;    /* type 1: normalize(-dir); type 2: -normalize(dir) */
+  float outer, inv_eps;
+} cooked_light;
+
+static void cook_light(const bbo_light *l, cooked_light *c) {
+  c->pos = v3_ld(l->pos);
+  c->type = l->type;
+  c->ci = v3_make(l->color[0] * l->intensity, l->color[1] * l->intensity, l->color[2] * l->intensity);
+  c->dirn = v3_make(0.0f, 0.0f, 0.0f);
+  c->outer = l->outer_cutoff;
+  c->inv_eps = 0.0f;
+  if (l->type == 1) {
+    c->dirn = normalize3(neg3(v3_ld(l->dir)));
+    c->inv_eps = bb_rcp(l->inner_cutoff - l->outer_cutoff);
+  } else if (l->type == 2) {
+    c->dirn = neg3(normalize3(v3_ld(l->dir)));
+  }
+}
+
+static inline float fmax_nan_lo(float a, float lo) { return a > lo ? a : lo; } /* max(a, lo), NaN -> lo */
+
+static void light_surface_contract(const bbo_frame_uniforms *fu, const bbo_view_uniforms *vu, const surface *s, float *out) {
+  const v3 P = s->P, albedo = s->albedo;
+  const float metallic = s->metallic, roughness = s->roughness, ao = s->ao;
+  int n_lights = fu->num_lights;
+  if (n_lights > BBO_MAX_LIGHTS) n_lights = BBO_MAX_LIGHTS;
+  /* per-pixel invariants */
+  const v3 V = normalize3(sub3(v3_ld(vu->view_pos), P));
+  const v3 N = normalize3(s->normal);
+  const float NdotV = max0(dot3(V, N));
+  const float rr = roughness + 1.0f;
+  const float kk = (rr * rr) * 0.125f, omk = 1.0f - kk;
+  const float pidV = BB_PI * fmaf(NdotV, omk, kk);
+  const float a = roughness * roughness, a2 = a * a, a2m1 = a2 - 1.0f;
+  const float a2nv = a2 * NdotV, c4 = 4.0f * NdotV;
+  const v3 F0 = v3_make(mixf(0.04f, albedo.x, metallic), mixf(0.04f, albedo.y, metallic), mixf(0.04f, albedo.z, metallic));
+  const v3 omF0 = v3_make(1.0f - F0.x, 1.0f - F0.y, 1.0f - F0.z);
+  const float om = 1.0f - metallic;
+  const v3 kda = v3_make((om * albedo.x) * BB_INV_PI, (om * albedo.y) * BB_INV_PI, (om * albedo.z) * BB_INV_PI);
+
+  v3 Lo = v3_make(0.0f, 0.0f, 0.0f);
+  for (int i = 0; i < n_lights; ++i) {
+    cooked_light cl;
+    cook_light(&fu->lights[i], &cl);
+    v3 L;
+    float att;
+    if (cl.type == 0 || cl.type == 1) {
+      v3 Lv = sub3(cl.pos, P);
+      float inv_d = bb_rsqrt(dot3(Lv, Lv));
+      att = inv_d * inv_d;
+      L = scale3(Lv, inv_d);
+      if (cl.type == 1) att *= clamp01((dot3(L, cl.dirn) - cl.outer) * cl.inv_eps);
+    } else if (cl.type == 2) {
+      L = cl.dirn;
+      att = 1.0f;
+    } else {
+      continue;
+    }
+    const v3 H = normalize3(add3(L, V));
+    const float NdotH = max0(dot3(N, H));
+    const float q = fmaf(NdotH * NdotH, a2m1, 1.0f);
+    const float x = 1.0f - max0(dot3(H, V));
+    const float x2 = x * x;
+    const float p5 = (x2 * x2) * x;
+    const float NdotL = max0(dot3(N, L));
+    const float dL = fmaf(NdotL, omk, kk);
+    const float sden = fmax_nan_lo(c4 * NdotL, 0.001f);
+    const float den = ((q * q) * (pidV * dL)) * sden;
+    const float S = (a2nv * NdotL) * bb_rcp(den);
+    const v3 F = v3_make(fmaf(omF0.x, p5, F0.x), fmaf(omF0.y, p5, F0.y), fmaf(omF0.z, p5, F0.z));
+    const float rl = att * NdotL;
+    Lo.x = fmaf(fmaf(1.0f - F.x, kda.x, F.x * S), cl.ci.x * rl, Lo.x);
+    Lo.y = fmaf(fmaf(1.0f - F.y, kda.y, F.y * S), cl.ci.y * rl, Lo.y);
+    Lo.z = fmaf(fmaf(1.0f - F.z, kda.z, F.z * S), cl.ci.z * rl, Lo.z);
+  }
+  out[0] = fmaf(0.03f * albedo.x, ao, Lo.x);
+  out[1] = fmaf(0.03f * albedo.y, ao, Lo.y);
+  out[2] = fmaf(0.03f * albedo.z, ao, Lo.z);
+  out[3] = 1.0f;
+}
+
+/* literal != 0: the statement-by-statement form (BBO_FLAG_LITERAL); 0: the shipped evaluation order */
+static void light_surface_mode(int literal, const bbo_frame_uniforms *fu, const bbo_view_uniforms *vu, const surface *s, float *out) {
+  if (literal) light_surface(fu, vu, s, out);
+  else light_surface_contract(fu, vu, s, out);
+}
+
+static void shade_fragment(int literal, const bbo_frame_uniforms *fu, const bbo_view_uniforms *vu, const bbo_material *mat,
                            const float *vary, float *out) {
   surface s;
   surface_inputs(vu, mat, vary, 0, &s);
-  light_surface(fu, vu, &s, out);
+  light_surface_mode(literal, fu, vu, &s, out);
 }
 
 /* One G-buffer texel: four R16G16B16A16_SFLOAT attachments (src/main.cpp:443, 453-459) as 16 binary32 values that
@@ -355,16 +462,27 @@ static void gbuffer_fragment(const bbo_view_uniforms *vu, const bbo_material *ma
 }
 
 /* brdf.frag:12-73 on one G-buffer texel (nearest fetch of the pixel's own texel) */
-static void brdf_pixel(const bbo_frame_uniforms *fu, const bbo_view_uniforms *vu, const float *g, float *out) {
+static void brdf_pixel(int literal, const bbo_frame_uniforms *fu, const bbo_view_uniforms *vu, const float *g, float *out) {
   surface s;
   s.P = v3_ld(g); s.normal = v3_ld(g + 4); s.albedo = v3_ld(g + 8);
   s.metallic = g[12]; s.roughness = g[13]; s.ao = g[14]; s.height = g[15];
-  light_surface(fu, vu, &s, out);
+  light_surface_mode(literal, fu, vu, &s, out);
 }
 
 void bbo_shade_fragment(const bbo_frame_uniforms *frame, const bbo_view_uniforms *view, const bbo_material *mat,
                         const float *vary, float *out_rgba) {
-  shade_fragment(frame, view, mat, vary, out_rgba);
+  shade_fragment(1, frame, view, mat, vary, out_rgba);
+}
+void bbo_shade_fragment_contract(const bbo_frame_uniforms *frame, const bbo_view_uniforms *view, const bbo_material *mat,
+                                 const float *vary, float *out_rgba) {
+  shade_fragment(0, frame, view, mat, vary, out_rgba);
+}
+/* both forms of the light loop on an explicit surface point: surface[12] = P(3) normal(3) albedo(3) metallic roughness ao */
+void bbo_light_surface(int literal, const bbo_frame_uniforms *frame, const bbo_view_uniforms *view, const float *surf, float *out_rgba) {
+  surface s;
+  s.P = v3_ld(surf); s.normal = v3_ld(surf + 3); s.albedo = v3_ld(surf + 6);
+  s.metallic = surf[9]; s.roughness = surf[10]; s.ao = surf[11]; s.height = 0.0f;
+  light_surface_mode(literal, frame, view, &s, out_rgba);
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -746,6 +864,7 @@ typedef struct {
   const bbo_view_uniforms *vu;
   float *gbuffer; /* program 2, optional: width*height*16 floats */
   int32_t width;
+  int literal;    /* BBO_FLAG_LITERAL: statement-by-statement light loop instead of the shipped evaluation order */
 } pipeline;
 
 static void shade_pixel(const pipeline *pl, const raster_tri *t, const float vary[3][NVARY], const void *mat,
@@ -754,13 +873,13 @@ static void shade_pixel(const pipeline *pl, const raster_tri *t, const float var
   tri_bary(t, px * SUBPIXEL_ONE + SUBPIXEL_ONE / 2, py * SUBPIXEL_ONE + SUBPIXEL_ONE / 2, beta);
   if (pl->program == 0) {
     interpolate(beta, vary, NVARY, attr);
-    shade_fragment(pl->fu, pl->vu, (const bbo_material *)mat, attr, out);
+    shade_fragment(pl->literal, pl->fu, pl->vu, (const bbo_material *)mat, attr, out);
   } else if (pl->program == 2) {
     float g[16];
     interpolate(beta, vary, NVARY, attr);
     gbuffer_fragment(pl->vu, (const bbo_material *)mat, attr, g);
     if (pl->gbuffer) memcpy(pl->gbuffer + 16 * ((size_t)py * (size_t)pl->width + (size_t)px), g, sizeof g);
-    brdf_pixel(pl->fu, pl->vu, g, out);
+    brdf_pixel(pl->literal, pl->fu, pl->vu, g, out);
   } else {
     interpolate(beta, vary, 6, attr);
     gizmo_shade(attr, out);
@@ -852,7 +971,7 @@ static int render_core(const pipeline *pl, uint32_t n_prims, int32_t width, int3
       if (!k && pl->program == 2) {
         /* brdf.frag runs on every pixel of its full-screen triangle (src/main.cpp:101-104): the cleared texel too */
         static const float cleared[16] = {0};
-        brdf_pixel(pl->fu, pl->vu, cleared, out_rgba + 4 * o);
+        brdf_pixel(pl->literal, pl->fu, pl->vu, cleared, out_rgba + 4 * o);
       }
       if (!k) continue;
       ++st.n_shaded;
@@ -900,7 +1019,8 @@ static int render_pbr(const bbo_frame_uniforms *frame, const bbo_view_uniforms *
   ctx.fu = frame; ctx.vu = view; ctx.draws = di; ctx.n_draws = m;
   ctx.deferred = (flags & BBO_FLAG_DEFERRED) != 0;
   bbo_proj_view(view, &ctx.pv);
-  pipeline pl = {ctx.deferred ? 2 : 0, &ctx, pbr_fetch, frame, view, ctx.deferred ? out_gbuffer : NULL, width};
+  pipeline pl = {ctx.deferred ? 2 : 0, &ctx, pbr_fetch, frame, view, ctx.deferred ? out_gbuffer : NULL, width,
+                 (flags & BBO_FLAG_LITERAL) != 0};
   int rc = render_core(&pl, (uint32_t)total, width, height, y0, y1, flags, out_rgba, out_prim, out_depth, stats);
   free(di);
   return rc;
@@ -917,6 +1037,13 @@ int bbo_render_deferred(const bbo_frame_uniforms *frame, const bbo_view_uniforms
                         float *out_gbuffer, uint32_t *out_prim, float *out_depth, bbo_stats *stats) {
   return render_pbr(frame, view, draws, n_draws, width, height, y0, y1, BBO_FLAG_DEFERRED, out_rgba, out_gbuffer, out_prim,
                     out_depth, stats);
+}
+
+int bbo_render_deferred_flags(const bbo_frame_uniforms *frame, const bbo_view_uniforms *view, const bbo_draw *draws,
+                              uint32_t n_draws, int32_t width, int32_t height, int32_t y0, int32_t y1, uint32_t flags,
+                              float *out_rgba, float *out_gbuffer, uint32_t *out_prim, float *out_depth, bbo_stats *stats) {
+  return render_pbr(frame, view, draws, n_draws, width, height, y0, y1, (flags & BBO_FLAG_LITERAL) | BBO_FLAG_DEFERRED, out_rgba,
+                    out_gbuffer, out_prim, out_depth, stats);
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -1141,7 +1268,7 @@ int bbo_render_gizmo(const bbo_view_uniforms *view, const bbo_gizmo_vertex *vert
   gv.proj.M[0][0] = d;
   gv.proj.M[1][1] = -d;
   bbo_proj_view(&gv, &ctx.pv);
-  pipeline pl = {1, &ctx, gizmo_fetch, NULL, view, NULL, width};
+  pipeline pl = {1, &ctx, gizmo_fetch, NULL, view, NULL, width, 0};
   return render_core(&pl, n / 3, width, height, 0, height, 0, out_rgba, out_prim, out_depth, stats);
 }
 

@@ -106,6 +106,12 @@ typedef struct {
 #define BBO_FLAG_DEFERRED 2      /* the reference's deferred path (its default, src/scene.h:77): gbuffer.vert/.frag into
                                     four RGBA16F attachments, then brdf.frag on every pixel */
 
+#define BBO_FLAG_LITERAL 4       /* evaluate the light loop statement by statement as the GLSL is written
+                                    (forward_brdf.frag:29-70) instead of in the shipped evaluation order, which
+                                    re-associates the well-conditioned products behind the GGX denominator (see
+                                    light_surface_contract in bb_oracle.c).  The GPU is bit-identical to the
+                                    default and within BASELINE's 1e-4 of the literal form. */
+
 typedef struct {
   uint64_t n_prims;         /* triangles submitted */
   uint64_t n_raster_tris;   /* sub-triangles that survived clip + cull */
@@ -132,6 +138,11 @@ int bbo_render(const bbo_frame_uniforms *frame, const bbo_view_uniforms *view, c
 int bbo_render_deferred(const bbo_frame_uniforms *frame, const bbo_view_uniforms *view, const bbo_draw *draws,
                         uint32_t n_draws, int32_t width, int32_t height, int32_t y0, int32_t y1, float *out_rgba,
                         float *out_gbuffer, uint32_t *out_prim, float *out_depth, bbo_stats *stats);
+
+/* as bbo_render_deferred, with flags (BBO_FLAG_LITERAL) */
+int bbo_render_deferred_flags(const bbo_frame_uniforms *frame, const bbo_view_uniforms *view, const bbo_draw *draws,
+                              uint32_t n_draws, int32_t width, int32_t height, int32_t y0, int32_t y1, uint32_t flags,
+                              float *out_rgba, float *out_gbuffer, uint32_t *out_prim, float *out_depth, bbo_stats *stats);
 
 /* BASELINE config #1: gizmo.vert/.frag (src/shaders/gizmo.vert:12-28, gizmo.frag:10-17) rasterised
  * with the same fixed-function rules into a width x height target (viewport = whole target). */
@@ -164,6 +175,13 @@ void bbo_sample(const bbo_image *img, int map_type, float u, float v, float *out
 /* forward_brdf.frag on explicit varyings */
 void bbo_shade_fragment(const bbo_frame_uniforms *frame, const bbo_view_uniforms *view,
                         const bbo_material *mat, const float *vary, float *out_rgba);
+/* the same in the shipped evaluation order (what k_shade computes, bit for bit) */
+void bbo_shade_fragment_contract(const bbo_frame_uniforms *frame, const bbo_view_uniforms *view,
+                                 const bbo_material *mat, const float *vary, float *out_rgba);
+/* the light loop + ambient term on an explicit surface point, surf[12] = P(3) normal(3) albedo(3) metallic roughness
+ * ao; literal != 0: statement by statement, 0: shipped evaluation order */
+void bbo_light_surface(int literal, const bbo_frame_uniforms *frame, const bbo_view_uniforms *view, const float *surf,
+                       float *out_rgba);
 /* brdf.glsl scalar pieces */
 float bbo_distribution_ggx(const float *N, const float *H, float roughness);
 float bbo_geometry_smith(const float *N, const float *V, const float *L, float roughness);

@@ -84,6 +84,7 @@ class Stats(C.Structure):
 
 NO_PRIM = 0xFFFFFFFF
 FLAG_FORWARD_SHADE = 1
+FLAG_LITERAL = 4  # light loop statement by statement as the GLSL is written, instead of the shipped evaluation order
 
 _lib = None
 
@@ -103,6 +104,9 @@ def lib():
         L.bbo_proj_view.argtypes = [C.c_void_p] * 2
         L.bbo_sample.argtypes = [C.POINTER(Image), C.c_int, C.c_float, C.c_float, C.c_void_p]
         L.bbo_shade_fragment.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Material), C.c_void_p, C.c_void_p]
+        L.bbo_shade_fragment_contract.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Material), C.c_void_p, C.c_void_p]
+        L.bbo_light_surface.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.bbo_light_surface.restype = None
         L.bbo_distribution_ggx.restype = C.c_float
         L.bbo_distribution_ggx.argtypes = [C.c_void_p, C.c_void_p, C.c_float]
         L.bbo_geometry_smith.restype = C.c_float
@@ -273,7 +277,7 @@ def render(scene: Scene, y0=0, y1=None, flags=0, want_prim=True, want_depth=True
     return rgba, prim, depth, st.as_dict()
 
 
-def render_deferred(scene: Scene, y0=0, y1=None, want_gbuffer=True):
+def render_deferred(scene: Scene, y0=0, y1=None, want_gbuffer=True, flags=0):
     """The reference's deferred path (gbuffer.vert/.frag + brdf.frag).  Returns (rgba[h,w,4], gbuffer[h,w,4,4]|None,
     prim, depth, stats); gbuffer[..., a, :] = attachment a (position, normal, albedo, MRAH), binary16-representable."""
     W, H = scene.width, scene.height
@@ -286,10 +290,10 @@ def render_deferred(scene: Scene, y0=0, y1=None, want_gbuffer=True):
     arr = (Draw * max(1, len(scene.draws)))(*[d.c_struct() for d in scene.draws])
     st = Stats()
     L = lib()
-    L.bbo_render_deferred.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, C.c_int32, C.c_int32,
-                                      C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-    rc = L.bbo_render_deferred(_p(scene.frame), _p(scene.view), arr, len(scene.draws), W, H, y0, y1, _p(rgba), _p(gbuf),
-                               _p(prim), _p(depth), C.byref(st))
+    L.bbo_render_deferred_flags.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, C.c_int32, C.c_int32,
+                                            C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    rc = L.bbo_render_deferred_flags(_p(scene.frame), _p(scene.view), arr, len(scene.draws), W, H, y0, y1, flags, _p(rgba),
+                                     _p(gbuf), _p(prim), _p(depth), C.byref(st))
     if rc != 0:
         raise RuntimeError(f"bbo_render_deferred failed: {rc}")
     return rgba, gbuf, prim, depth, st.as_dict()
@@ -361,10 +365,23 @@ def sample(img, map_type, u, v):
     return out
 
 
-def shade_fragment(frame, view, material: MaterialData, vary):
+def shade_fragment(frame, view, material: MaterialData, vary, literal=True):
+    """forward_brdf.frag on explicit varyings: statement by statement (literal) or in the shipped evaluation order"""
     out = np.zeros(4, np.float32)
     vary = np.ascontiguousarray(vary, np.float32)
-    lib().bbo_shade_fragment(_p(frame), _p(view), C.byref(material._c), _p(vary), _p(out))
+    fn = lib().bbo_shade_fragment if literal else lib().bbo_shade_fragment_contract
+    fn(_p(frame), _p(view), C.byref(material._c), _p(vary), _p(out))
+    return out
+
+
+def light_surface(frame, view, surf, literal=True):
+    """The light loop + ambient term on surface points surf[n, 12] = P(3) normal(3) albedo(3) metallic roughness ao."""
+    surf = np.ascontiguousarray(surf, np.float32).reshape(-1, 12)
+    out = np.zeros((len(surf), 4), np.float32)
+    fn = lib().bbo_light_surface
+    fp, vp = _p(frame), _p(view)
+    for i in range(len(surf)):
+        fn(int(bool(literal)), fp, vp, surf[i].ctypes.data, out[i].ctypes.data)
     return out
 
 

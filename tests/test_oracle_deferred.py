@@ -19,7 +19,7 @@ def _scene(cfg=configs.C2, size=(160, 90), **kw):
 def test_frozen_fixture():
     z = np.load(os.path.join(GOLDEN, "deferred.npz"))
     info = json.load(open(os.path.join(GOLDEN, "deferred.json")))
-    rgba, gbuf, prim, depth, st = bbo.render_deferred(_scene())
+    rgba, gbuf, prim, depth, st = bbo.render_deferred(_scene(), flags=bbo.FLAG_LITERAL)   # frozen: the literal light loop
     assert st == info["c2_160x90"]
     assert np.array_equal(rgba.view(np.uint32), z["c2_160x90_rgba_bits"])
     assert np.array_equal(gbuf, z["c2_160x90_gbuffer_f16"].astype(np.float32))

@@ -29,7 +29,8 @@ def test_triangle_scene_golden():
 
 def test_c2_small_golden():
     mat = bbo.MaterialData(textures.make_material(64))
-    _check("c2_160x90", *bbo.render(scenes.shaderball_scene(configs.C2.scaled(160, 90, 64), mat)))
+    # the frozen frame is the LITERAL form of the light loop (statement by statement as the GLSL is written)
+    _check("c2_160x90", *bbo.render(scenes.shaderball_scene(configs.C2.scaled(160, 90, 64), mat), flags=bbo.FLAG_LITERAL))
 
 
 def gizmo_inputs():

@@ -1,0 +1,303 @@
+// Microbenchmark: issue cost of the vector opcodes k_shade / k_raster actually execute on gfx950, at 1, 2, 4 and 8
+// waves per SIMD.  The numbers decide what the issue floor of a kernel's instruction stream is (floor = sum over
+// opcodes of count x cycles) -- tools/shade_issue_floor.py combines this table with the opcode histogram of k_shade.
+//
+// Method: one workgroup of 256 x W threads per CU for W <= 4 (it takes all the LDS), two of 1024 threads for W = 8; a
+// workgroup's waves are dealt round-robin over the four SIMDs of its CU, so every SIMD holds W waves, all resident
+// together (checked: in-kernel cycles / wall time must come out as a plausible shader clock).  Each wave runs ITERS iterations of a block of 64 instructions of ONE opcode on 8 independent register
+// chains (an instruction depends on the one issued 8 earlier: 16+ cycles back, past the ALU latency), stamped with
+// s_memtime (= shader cycles) and s_memrealtime (100 MHz) before and after; the kernel is timed with HIP events.
+// cycles per wave instruction per SIMD = wall time x measured shader clock / (W x ITERS x 64).
+// "dep" rows use ONE chain (every instruction depends on the previous one): dependent-issue latency at W = 1.
+//
+// Build: hipcc -O3 --offload-arch=gfx950 issue_rate.hip -o issue_rate ; run: ./issue_rate > profiles/rNN_issue_rate.txt
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+#define R8(M) M("%0") M("%1") M("%2") M("%3") M("%4") M("%5") M("%6") M("%7")
+#define BLOCK64(M) R8(M) R8(M) R8(M) R8(M) R8(M) R8(M) R8(M) R8(M)
+#define D8(M) M("%0") M("%0") M("%0") M("%0") M("%0") M("%0") M("%0") M("%0")
+#define DEP64(M) D8(M) D8(M) D8(M) D8(M) D8(M) D8(M) D8(M) D8(M)
+
+constexpr int kIters = 2048;  // x 64 instructions = 131072 per wave
+
+// T: register type of a chain (float / uint32_t / v2f); PRE: asm run once before the block (sets vcc etc.)
+#define DEF_KERNEL(NAME, T, BODY, PRE)                                                                              \
+  __global__ __launch_bounds__(1024) void k_##NAME(unsigned long long *__restrict__ stamps, T a, T b, T *sink) {     \
+    extern __shared__ char lds[];                                                                                   \
+    T x0 = a, x1 = a, x2 = a, x3 = a, x4 = a, x5 = a, x6 = a, x7 = a;                                                \
+    if (threadIdx.x == 1023) lds[0] = 1;                                                                            \
+    asm volatile(PRE ::: "vcc", "s20", "s21", "scc", "v100");                                                                    \
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();                                                 \
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();                                                     \
+    for (int it = 0; it < kIters; ++it) {                                                                           \
+      asm volatile(BODY                                                                                             \
+                   : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7)                 \
+                   : "v"(a), "v"(b)                                                                                 \
+                   : "vcc", "s20", "s21", "scc", "v100");                                                                        \
+    }                                                                                                               \
+    asm volatile("s_nop 0" ::: "memory");                                                                           \
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();                                                     \
+    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();                                                 \
+    if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = ((r1 - r0) << 32) | (t1 - t0); \
+    if (t1 == 1) sink[0] = x0, sink[1] = x1, sink[2] = x2, sink[3] = x3, sink[4] = x4, sink[5] = x5, sink[6] = x6, sink[7] = x7; \
+  }
+
+#define DEF_OP(NAME, T, M, PRE) DEF_KERNEL(NAME, T, BLOCK64(M), PRE) DEF_KERNEL(NAME##_dep, T, DEP64(M), PRE)
+
+// ---- the opcodes (D = chain register, %8 = a, %9 = b) ----
+#define M_FMA(D) "v_fma_f32 " D ", " D ", %8, %9\n"
+#define M_FMAC(D) "v_fmac_f32 " D ", %8, %9\n"
+#define M_FMAAK(D) "v_fmaak_f32 " D ", " D ", %8, 0x3f8ccccd\n"
+#define M_MUL(D) "v_mul_f32 " D ", " D ", %8\n"
+#define M_MUL_LIT(D) "v_mul_f32 " D ", 0x3f8ccccd, " D "\n"
+#define M_MUL_SGPR(D) "v_mul_f32 " D ", s20, " D "\n"
+#define M_ADD(D) "v_add_f32 " D ", " D ", %8\n"
+#define M_SUB(D) "v_sub_f32 " D ", " D ", %8\n"
+#define M_MAX(D) "v_max_f32 " D ", " D ", %8\n"
+#define M_MAX3(D) "v_max3_f32 " D ", " D ", %8, %9\n"
+#define M_MED3(D) "v_med3_f32 " D ", " D ", %8, %9\n"
+#define M_PK_FMA(D) "v_pk_fma_f32 " D ", " D ", %8, %9\n"
+#define M_PK_MUL(D) "v_pk_mul_f32 " D ", " D ", %8\n"
+#define M_PK_ADD(D) "v_pk_add_f32 " D ", " D ", %8\n"
+#define M_CNDMASK(D) "v_cndmask_b32 " D ", " D ", %8, vcc\n"
+#define M_CVT_UB0(D) "v_cvt_f32_ubyte0 " D ", " D "\n"
+#define M_CVT_UB1(D) "v_cvt_f32_ubyte1 " D ", " D "\n"
+#define M_CVT_UB3(D) "v_cvt_f32_ubyte3 " D ", " D "\n"
+#define M_CVT_F32_I32(D) "v_cvt_f32_i32 " D ", " D "\n"
+#define M_CVT_F32_U32(D) "v_cvt_f32_u32 " D ", " D "\n"
+#define M_CVT_I32_F32(D) "v_cvt_i32_f32 " D ", " D "\n"
+#define M_CVT_F16_F32(D) "v_cvt_f16_f32 " D ", " D "\n"
+#define M_CVT_F32_F16(D) "v_cvt_f32_f16 " D ", " D "\n"
+#define M_FLOOR(D) "v_floor_f32 " D ", " D "\n"
+#define M_FRACT(D) "v_fract_f32 " D ", " D "\n"
+#define M_RNDNE(D) "v_rndne_f32 " D ", " D "\n"
+#define M_RCP(D) "v_rcp_f32 " D ", " D "\n"
+#define M_RSQ(D) "v_rsq_f32 " D ", " D "\n"
+#define M_SQRT(D) "v_sqrt_f32 " D ", " D "\n"
+#define M_EXP(D) "v_exp_f32 " D ", " D "\n"
+#define M_MOV(D) "v_mov_b32 " D ", %8\n"
+#define M_AND(D) "v_and_b32 " D ", " D ", %8\n"
+#define M_OR(D) "v_or_b32 " D ", " D ", %8\n"
+#define M_LSHR(D) "v_lshrrev_b32 " D ", 1, " D "\n"
+#define M_LSHL(D) "v_lshlrev_b32 " D ", 1, " D "\n"
+#define M_BFE(D) "v_bfe_u32 " D ", " D ", 8, 8\n"
+#define M_ADD_U32(D) "v_add_u32 " D ", " D ", %8\n"
+#define M_SUB_U32(D) "v_sub_u32 " D ", " D ", %8\n"
+#define M_ADD3_U32(D) "v_add3_u32 " D ", " D ", %8, %9\n"
+#define M_LSHL_ADD(D) "v_lshl_add_u32 " D ", " D ", 2, %8\n"
+#define M_AND_OR(D) "v_and_or_b32 " D ", " D ", %8, %9\n"
+#define M_PERM(D) "v_perm_b32 " D ", " D ", %8, %9\n"
+#define M_MUL_U24(D) "v_mul_u32_u24 " D ", " D ", %8\n"
+#define M_MAD_U24(D) "v_mad_u32_u24 " D ", " D ", %8, %9\n"
+#define M_MUL_LO(D) "v_mul_lo_u32 " D ", " D ", %8\n"
+#define M_CMP(D) "v_cmp_lt_f32 vcc, " D ", %8\n"
+#define M_CMP_SGPR(D) "v_cmp_lt_f32 s[20:21], " D ", %8\n"
+#define M_CMP_CLASS(D) "v_cmp_class_f32 vcc, " D ", %8\n"
+#define M_FMA_MIX(D) "v_fma_mix_f32 " D ", " D ", %8, %9 op_sel_hi:[0,1,1]\n"
+#define M_PK_ADD_F16(D) "v_pk_add_f16 " D ", " D ", %8\n"
+#define M_PK_FMA_F16(D) "v_pk_fma_f16 " D ", " D ", %8, %9\n"
+#define M_PK_SUB_I16(D) "v_pk_sub_i16 " D ", " D ", %8\n"
+#define M_MIN_I32(D) "v_min_i32 " D ", " D ", %8\n"
+#define M_READFIRST(D) "v_readfirstlane_b32 s20, " D "\n"
+#define M_MBCNT(D) "v_mbcnt_lo_u32_b32 " D ", %8, " D "\n"
+#define M_DPP(D) "v_mov_b32_dpp " D ", " D " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+#define M_FMA_NEG(D) "v_fma_f32 " D ", -" D ", %8, %9\n"
+#define M_FMA_SGPR(D) "v_fma_f32 " D ", " D ", s20, %9\n"
+// scalar and control instructions (the scalar unit is shared by the four SIMDs of a CU)
+#define M_S_ADD(D) "s_add_u32 s20, s20, 1\n"
+#define M_S_AND64(D) "s_and_b64 s[20:21], s[20:21], exec\n"
+#define M_S_SAVEEXEC(D) "s_and_saveexec_b64 s[20:21], vcc\ns_or_b64 exec, exec, s[20:21]\n"
+#define M_S_NOP(D) "s_nop 0\n"
+#define M_S_WAITCNT(D) "s_waitcnt vmcnt(0) lgkmcnt(0)\n"
+#define M_S_CBRANCH(D) "s_cbranch_execz 0\n"
+#define M_S_CMP_CBRANCH(D) "s_cmp_eq_u32 s20, 77\ns_cbranch_scc1 0\n"
+#define M_MIX_FMA_SADD(D) "v_fma_f32 " D ", " D ", %8, %9\ns_add_u32 s20, s20, 1\n"
+#define M_MIX_3FMA_SADD(D) "v_fma_f32 " D ", " D ", %8, %9\nv_fma_f32 " D ", " D ", %8, %9\nv_fma_f32 " D ", " D ", %8, %9\ns_add_u32 s20, s20, 1\n"
+#define M_MIX_GUARD(D) "v_mov_b32 v100, 0x3ff\nv_cmp_class_f32 vcc, " D ", v100\ns_and_saveexec_b64 s[20:21], vcc\nv_fma_f32 " D ", " D ", %8, %9\nv_fma_f32 " D ", " D ", %8, %9\ns_or_b64 exec, exec, s[20:21]\n"
+// two-opcode mixes: do the costs add?
+#define M_MIX_FMA_CND(D) "v_fma_f32 " D ", " D ", %8, %9\nv_cndmask_b32 " D ", " D ", %8, vcc\n"
+#define M_MIX_FMA_CVT(D) "v_fma_f32 " D ", " D ", %8, %9\nv_cvt_f32_ubyte1 " D ", " D "\n"
+#define M_MIX_FMA_RCP(D) "v_fma_f32 " D ", " D ", %8, %9\nv_fma_f32 " D ", " D ", %8, %9\nv_fma_f32 " D ", " D ", %8, %9\nv_rcp_f32 " D ", " D "\n"
+#define M_MIX_MUL_ADD(D) "v_mul_f32 " D ", " D ", %8\nv_add_f32 " D ", " D ", %9\n"
+
+#define PRE_NONE "s_mov_b32 s20, 0x3f800001\n"
+#define PRE_VCC_ALL "s_mov_b32 s20, 0x3f800001\ns_mov_b64 vcc, exec\n"
+#define PRE_VCC "s_mov_b32 s20, 0x3f800001\ns_mov_b32 vcc_lo, 0x55555555\ns_mov_b32 vcc_hi, 0x55555555\n"
+
+#define OPS(X)                          \
+  X(fma_f32, float, M_FMA, PRE_NONE, 1) \
+  X(fma_f32_neg_mod, float, M_FMA_NEG, PRE_NONE, 1) \
+  X(fma_f32_sgpr_operand, float, M_FMA_SGPR, PRE_NONE, 1) \
+  X(fmac_f32, float, M_FMAC, PRE_NONE, 1) \
+  X(fmaak_f32_literal, float, M_FMAAK, PRE_NONE, 1) \
+  X(mul_f32, float, M_MUL, PRE_NONE, 1) \
+  X(mul_f32_literal, float, M_MUL_LIT, PRE_NONE, 1) \
+  X(mul_f32_sgpr_operand, float, M_MUL_SGPR, PRE_NONE, 1) \
+  X(add_f32, float, M_ADD, PRE_NONE, 1) \
+  X(sub_f32, float, M_SUB, PRE_NONE, 1) \
+  X(max_f32, float, M_MAX, PRE_NONE, 1) \
+  X(max3_f32, float, M_MAX3, PRE_NONE, 1) \
+  X(med3_f32, float, M_MED3, PRE_NONE, 1) \
+  X(pk_fma_f32, v2f, M_PK_FMA, PRE_NONE, 1) \
+  X(pk_mul_f32, v2f, M_PK_MUL, PRE_NONE, 1) \
+  X(pk_add_f32, v2f, M_PK_ADD, PRE_NONE, 1) \
+  X(cndmask_b32, float, M_CNDMASK, PRE_VCC, 1) \
+  X(cvt_f32_ubyte0, float, M_CVT_UB0, PRE_NONE, 1) \
+  X(cvt_f32_ubyte1, float, M_CVT_UB1, PRE_NONE, 1) \
+  X(cvt_f32_ubyte3, float, M_CVT_UB3, PRE_NONE, 1) \
+  X(cvt_f32_i32, float, M_CVT_F32_I32, PRE_NONE, 1) \
+  X(cvt_f32_u32, float, M_CVT_F32_U32, PRE_NONE, 1) \
+  X(cvt_i32_f32, float, M_CVT_I32_F32, PRE_NONE, 1) \
+  X(cvt_f16_f32, float, M_CVT_F16_F32, PRE_NONE, 1) \
+  X(cvt_f32_f16, float, M_CVT_F32_F16, PRE_NONE, 1) \
+  X(floor_f32, float, M_FLOOR, PRE_NONE, 1) \
+  X(fract_f32, float, M_FRACT, PRE_NONE, 1) \
+  X(rndne_f32, float, M_RNDNE, PRE_NONE, 1) \
+  X(rcp_f32, float, M_RCP, PRE_NONE, 1) \
+  X(rsq_f32, float, M_RSQ, PRE_NONE, 1) \
+  X(sqrt_f32, float, M_SQRT, PRE_NONE, 1) \
+  X(exp_f32, float, M_EXP, PRE_NONE, 1) \
+  X(mov_b32, float, M_MOV, PRE_NONE, 1) \
+  X(and_b32, float, M_AND, PRE_NONE, 1) \
+  X(or_b32, float, M_OR, PRE_NONE, 1) \
+  X(lshrrev_b32, float, M_LSHR, PRE_NONE, 1) \
+  X(lshlrev_b32, float, M_LSHL, PRE_NONE, 1) \
+  X(bfe_u32, float, M_BFE, PRE_NONE, 1) \
+  X(add_u32, float, M_ADD_U32, PRE_NONE, 1) \
+  X(sub_u32, float, M_SUB_U32, PRE_NONE, 1) \
+  X(add3_u32, float, M_ADD3_U32, PRE_NONE, 1) \
+  X(lshl_add_u32, float, M_LSHL_ADD, PRE_NONE, 1) \
+  X(and_or_b32, float, M_AND_OR, PRE_NONE, 1) \
+  X(perm_b32, float, M_PERM, PRE_NONE, 1) \
+  X(mul_u32_u24, float, M_MUL_U24, PRE_NONE, 1) \
+  X(mad_u32_u24, float, M_MAD_U24, PRE_NONE, 1) \
+  X(mul_lo_u32, float, M_MUL_LO, PRE_NONE, 1) \
+  X(min_i32, float, M_MIN_I32, PRE_NONE, 1) \
+  X(cmp_lt_f32_vcc, float, M_CMP, PRE_NONE, 1) \
+  X(cmp_lt_f32_sgpr, float, M_CMP_SGPR, PRE_NONE, 1) \
+  X(cmp_class_f32, float, M_CMP_CLASS, PRE_NONE, 1) \
+  X(fma_mix_f32, float, M_FMA_MIX, PRE_NONE, 1) \
+  X(pk_add_f16, float, M_PK_ADD_F16, PRE_NONE, 1) \
+  X(pk_fma_f16, float, M_PK_FMA_F16, PRE_NONE, 1) \
+  X(pk_sub_i16, float, M_PK_SUB_I16, PRE_NONE, 1) \
+  X(readfirstlane, float, M_READFIRST, PRE_NONE, 1) \
+  X(mbcnt_lo, float, M_MBCNT, PRE_NONE, 1) \
+  X(mov_dpp_quad_perm, float, M_DPP, PRE_NONE, 1) \
+  X(s_add_u32, float, M_S_ADD, PRE_NONE, 1) \
+  X(s_and_b64, float, M_S_AND64, PRE_NONE, 1) \
+  X(s_saveexec_restore_pair, float, M_S_SAVEEXEC, PRE_VCC_ALL, 2) \
+  X(s_nop, float, M_S_NOP, PRE_NONE, 1) \
+  X(s_waitcnt_idle, float, M_S_WAITCNT, PRE_NONE, 1) \
+  X(s_cbranch_execz_nottaken, float, M_S_CBRANCH, PRE_NONE, 1) \
+  X(s_cmp_cbranch_nottaken, float, M_S_CMP_CBRANCH, PRE_NONE, 2) \
+  X(mix_fma_sadd, float, M_MIX_FMA_SADD, PRE_NONE, 2) \
+  X(mix_3fma_sadd, float, M_MIX_3FMA_SADD, PRE_NONE, 4) \
+  X(mix_guard_mov_cmp_saveexec_2fma, float, M_MIX_GUARD, PRE_NONE, 6) \
+  X(mix_fma_cndmask, float, M_MIX_FMA_CND, PRE_VCC, 2) \
+  X(mix_fma_cvt_ubyte, float, M_MIX_FMA_CVT, PRE_NONE, 2) \
+  X(mix_3fma_1rcp, float, M_MIX_FMA_RCP, PRE_NONE, 4) \
+  X(mix_mul_add, float, M_MIX_MUL_ADD, PRE_NONE, 2)
+
+#define X_DEF(NAME, T, M, PRE, N) DEF_OP(NAME, T, M, PRE)
+OPS(X_DEF)
+
+template <typename T>
+struct Init {
+  static T a() { return (T)1.0000001f; }
+  static T b() { return (T)0.25f; }
+};
+
+#define CHECK(x)                                                                 \
+  do {                                                                           \
+    hipError_t e_ = (x);                                                         \
+    if (e_ != hipSuccess) {                                                      \
+      fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_));                    \
+      return 1;                                                                  \
+    }                                                                            \
+  } while (0)
+
+struct Result {
+  double cyc;   // cycles per wave-instruction per SIMD from the in-kernel stamps
+  double ghz;   // s_memtime ticks per ns by the 100 MHz s_memrealtime: the shader clock during the run
+  double wall;  // the median wave's own duration / (W x instructions): what ONE wave saw (smaller than cyc when waves take turns)
+};
+
+template <typename T, typename K>
+static Result run(K kernel, int waves_per_simd, unsigned long long *d_stamps, void *d_sink, int per_block_instrs) {
+  // W <= 4: ONE workgroup of 256 x W threads per CU (all of the CU's LDS, so a second one cannot join it);
+  // W = 8: two workgroups of 1024 threads per CU (half the LDS each).  A workgroup's waves are dealt round-robin over
+  // the four SIMDs, so every SIMD holds exactly W waves and all waves of the grid are resident together.
+  const int W = waves_per_simd;
+  const int threads = 256 * std::min(W, 4), per_cu = W > 4 ? W / 4 : 1;
+  const int grid = 256 * per_cu;
+  const size_t lds = (size_t)(160 * 1024 / per_cu) - 64;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const size_t n_waves = (size_t)grid * threads / 64;
+  std::vector<unsigned long long> h(n_waves);
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  Result best{1e30, 0.0, 0.0};
+  for (int rep = 0; rep < 3; ++rep) {
+    (void)hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds, 0, d_stamps, Init<T>::a(), Init<T>::b(), (T *)d_sink);
+    (void)hipEventRecord(e1, 0);
+    if (hipDeviceSynchronize() != hipSuccess) return Result{-1.0, -1.0, -1.0};
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipMemcpy(h.data(), d_stamps, h.size() * 8, hipMemcpyDeviceToHost);
+    std::sort(h.begin(), h.end());
+    const double med = (double)(h[h.size() / 2] & 0xFFFFFFFFull);
+    const double real_us = (double)(h[h.size() / 2] >> 32) / 100.0;  // s_memrealtime ticks at 100 MHz
+    const double instrs = (double)W * kIters * 64.0 * per_block_instrs;
+    // The SIMD arbitrates by age: the oldest wave issues whenever it can and the younger ones share what is left, so waves
+    // of one launch finish at very different times and a single wave's own duration says little.  The rate is taken from
+    // the kernel's wall time (>= 0.3 ms here, launch overhead < 3 %) at the clock the stamps show.
+    const double ghz = med * 1e-3 / real_us;
+    const double cyc = (double)ms * 1e3 * ghz * 1e3 / instrs;
+    if (cyc < best.cyc) best = Result{cyc, ghz, med / instrs};
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return best;
+}
+
+static bool selected(const char *name, int argc, char **argv) {
+  if (argc < 2) return true;
+  for (int i = 1; i < argc; ++i)
+    if (strstr(name, argv[i]) == name) return true;  // prefix match
+  return false;
+}
+
+int main(int argc, char **argv) {
+  unsigned long long *d_stamps;
+  void *d_sink;
+  CHECK(hipMalloc(&d_stamps, 256 * 2 * 16 * 8));
+  CHECK(hipMalloc(&d_sink, 4096));
+  hipDeviceProp_t prop;
+  CHECK(hipGetDeviceProperties(&prop, 0));
+  printf("# issue_rate on %s (%d CUs), %d iterations x 64 instructions per wave\n", prop.gcnArchName, prop.multiProcessorCount, kIters);
+  printf("# cycles per wave-instruction per SIMD = kernel wall time x shader clock / (W x instructions per wave); independent chains;\n");
+  printf("# dep = one dependent chain, one wave per SIMD (dependent-issue latency)\n");
+  printf("# GHz: shader clock at W=8 (s_memtime ticks against the 100 MHz s_memrealtime);\n# wave8: the median wave's own duration / (8 x instructions) at W=8 -- below the W=8 column when waves take turns (age-ordered arbitration)\n");
+  printf("%-26s %7s %7s %7s %7s %7s   %5s %5s\n", "opcode", "W=1", "W=2", "W=4", "W=8", "dep", "GHz", "wave8");
+#define X_RUN(NAME, T, M, PRE, N)                                                                     \
+  if (selected(#NAME, argc, argv)) {                                                           \
+    Result c[4];                                                                                      \
+    int wi = 0;                                                                                       \
+    for (int W : {1, 2, 4, 8}) c[wi++] = run<T>(k_##NAME, W, d_stamps, d_sink, N);                     \
+    const Result dep = run<T>(k_##NAME##_dep, 1, d_stamps, d_sink, N);                                \
+    printf("%-26s %7.2f %7.2f %7.2f %7.2f %7.2f   %5.2f %5.2f\n", #NAME, c[0].cyc, c[1].cyc, c[2].cyc, c[3].cyc, dep.cyc, \
+           c[3].ghz, c[3].wall);                                                          \
+    fflush(stdout);                                                                                   \
+  }
+  OPS(X_RUN)
+  return 0;
+}
