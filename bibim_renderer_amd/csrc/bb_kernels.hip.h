@@ -55,20 +55,25 @@ BB_DEV f3 cross3(f3 a, f3 b) {
 // The IEEE paths behind the guards are real function calls: taken for zero, denormal, infinite and NaN arguments only,
 // they would otherwise be expanded inline (a 12-instruction division, a 25-instruction square root) at each of the
 // shader's 25 call sites -- a tenth of k_shade's code.
-__attribute__((noinline)) __device__ float bb_rsqrt_slow(float x) { return 1.0f / sqrtf(x); }
-__attribute__((noinline)) __device__ float bb_rcp_slow(float x) { return 1.0f / x; }
+BB_DEV float bb_rsqrt_slow(float x) { return 1.0f / sqrtf(x); }
+BB_DEV float bb_rcp_slow(float x) { return 1.0f / x; }
+// The guards are WAVE-level: the fast sequence runs unconditionally and a uniform, almost never taken branch repairs
+// the lanes whose argument was not a normal number.  (As a per-lane if/else the compiler wrapped every call site in an
+// exec-mask save / restore -- five scalar instructions and a branch around each of the shader's sixteen guards per
+// pixel, a tenth of a wave's issue slots.)
 BB_DEV float bb_rsqrt(float x) {
 #ifdef BB_EXPERIMENT_HW_TRANS
   return __builtin_amdgcn_rsqf(x);
-#endif
-#ifndef BB_EXPERIMENT_NO_GUARD
-  if (__builtin_expect(!__builtin_amdgcn_classf(x, 0x100), 0)) return bb_rsqrt_slow(x);  // anything but a positive normal number (one v_cmp_class)
 #endif
   float y = __uint_as_float(0x5F375A86u - (__float_as_uint(x) >> 1));
   const float h = 0.5f * x;
   y = y * fmaf(-(h * y), y, 1.5f);
   y = y * fmaf(-(h * y), y, 1.5f);
   y = y * fmaf(-(h * y), y, 1.5f);
+  const bool odd = !__builtin_amdgcn_classf(x, 0x100);  // anything but a positive normal number (one v_cmp_class)
+  if (__builtin_expect(__ballot(odd) != 0ull, 0)) {
+    if (odd) y = bb_rsqrt_slow(x);
+  }
   return y;
 }
 // Reciprocal: the correctly rounded 1/x, i.e. what the oracle computes with an IEEE division.  v_rcp_f32 (1 ulp) plus
@@ -80,13 +85,15 @@ BB_DEV float bb_rcp(float x) {
 #ifdef BB_EXPERIMENT_HW_TRANS
   return __builtin_amdgcn_rcpf(x);
 #endif
-  const float y = __builtin_amdgcn_rcpf(x);
+  const float y0 = __builtin_amdgcn_rcpf(x);
+  float y = fmaf(y0, fmaf(-x, y0, 1.0f), y0);
   // a seed that is not a normal number (x zero, denormal, huge, infinite or NaN): the IEEE division.  One v_cmp_class
   // on the seed replaces two range compares on x.
-#ifndef BB_EXPERIMENT_NO_GUARD
-  if (__builtin_expect(!__builtin_amdgcn_classf(y, 0x108), 0)) return bb_rcp_slow(x);
-#endif
-  return fmaf(y, fmaf(-x, y, 1.0f), y);
+  const bool odd = !__builtin_amdgcn_classf(y0, 0x108);
+  if (__builtin_expect(__ballot(odd) != 0ull, 0)) {
+    if (odd) y = bb_rcp_slow(x);
+  }
+  return y;
 }
 // bb_rcp for a call site that can PROVE its argument is a normal number with a normal reciprocal (the guard and its
 // branch are a twentieth of k_shade's instruction stream).  Each use states its proof; k_selftest_rcp checks the
@@ -481,7 +488,8 @@ BB_DEV void clip_primitive_wave(ClipWork &w, int owner, const float (*clip)[4], 
       BroadTri b;
       b.tri = s.tri;
       b.ref = (w.prim << 3) | (uint32_t)lane;  // the OWNER's primitive (prim is per lane)
-      b.pad[0] = b.pad[1] = b.pad[2] = 0;
+      b.pad[0] = base + (uint32_t)lane + 1u;     // its clip-arena slot + 1: travels into the fragment word (k_raster)
+      b.pad[1] = b.pad[2] = 0;
       broad_list[slot + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = b;
     }
     if (lane == owner) w.n_valid = n_valid;
@@ -920,6 +928,11 @@ BB_DEV void raster_triangle_wave(const RasterTri &t, uint32_t ref, int tile_x0, 
   }
 }
 
+constexpr int kItemsThreads = 256;  // launch slots per workgroup of k_shade_items
+constexpr int kItemGroupSlots = 32, kItemGroups = 2048;  // k_raster's chunk totals: one counter per 32 launch slots (fewer
+                                                          // addresses made the atomics cost k_raster 7 us at C3)
+constexpr int kItemChunkBits = 6, kItemTxBits = 13;  // item = grid row << 19 | tile column << 6 | chunk of 64 fragments
+constexpr int kFragPixBits = 12;  // pixel-in-tile field of a fragment's high word (tiles of up to 64x64); the clip slot + 1 sits above it
 constexpr int kTileThreads = 256;
 constexpr int kTileWaves = kTileThreads / 64;
 
@@ -1092,7 +1105,7 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
     unsigned long long *__restrict__ frags, uint32_t *__restrict__ frag_count, float4 *__restrict__ out,
     uint32_t *__restrict__ vis_prim, float *__restrict__ vis_depth, const uint32_t *__restrict__ tile_order,
     const float4 *__restrict__ background, float *__restrict__ depth_io, uint32_t *__restrict__ host_flags,
-    uint32_t *__restrict__ out8) {
+    uint32_t *__restrict__ out8, uint32_t *__restrict__ item_groups) {
   constexpr int TILE_PIXELS = TILE_W * TILE_H;
   __shared__ unsigned long long keys[TILE_PIXELS];
   __shared__ StagedTri st;
@@ -1139,6 +1152,12 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
   // ~100 wrong pixels in one tile of one frame in a few hundred, never on an otherwise idle GPU).
   __shared__ uint32_t s_n_cls[kBinClasses];
   __shared__ uint32_t s_n_valid, s_full_ref;  // staged entries that touch the tile; (reference + 1) of one that covers all of it
+  // Clipped sub-triangles that touch this tile: (reference, clip-arena slot + 1).  The slot goes into the fragment word,
+  // so that k_shade can fetch the sub-triangle's planes together with the primitive record instead of after it.
+  // More than kClipRefs of them: the field stays 0 and k_shade finds the slot through the record (one more round trip).
+  constexpr uint32_t kClipRefs = 32;
+  __shared__ uint32_t s_clip_ref[kClipRefs], s_clip_slot[kClipRefs], s_n_clip_refs, s_full_clip;
+  __shared__ unsigned long long s_pad_frag;
   if (tid < (int)kBinClasses)
     s_n_cls[tid] = BB_ABLATE(1u | (256u << tid)) ? 0u : min(tile_count[tile * kBinClasses + tid], fp.bin_cap);
   const uint32_t n_broad = BB_ABLATE(5u) ? 0u : min(ctr->n_broad, fp.broad_cap);
@@ -1157,6 +1176,8 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
     s_count = 0;
     s_n_valid = 0;
     s_full_ref = 0;
+    s_n_clip_refs = 0;
+    s_full_clip = 0;
   }
   __syncthreads();  // counts published, keys cleared
   uint32_t n_cls[kBinClasses];
@@ -1182,7 +1203,7 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
       uint32_t box = 0xFFFFFFFFu;
       if (e < e_end) {
         RasterTri t;
-        uint32_t ref;
+        uint32_t ref, clip_slot1 = 0u;
         if (e < e3) {
           const uint32_t c = e < e1 ? 0u : (e < e2 ? 1u : 2u);
           const uint32_t i = e - (c == 0u ? 0u : (c == 1u ? e1 : e2));
@@ -1192,6 +1213,7 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
           const BroadTri &b = broad_list[e - e3];
           t = b.tri;
           ref = b.ref;
+          clip_slot1 = b.pad[0];
         }
         int32_t minX = min(t.X0, min(t.X1, t.X2)), maxX = max(t.X0, max(t.X1, t.X2));
         int32_t minY = min(t.Y0, min(t.Y1, t.Y2)), maxY = max(t.Y0, max(t.Y1, t.Y2));
@@ -1209,7 +1231,17 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
         }
         if (ok) {
           atomicAdd(&s_n_valid, 1u);
-          if (cls_rect == 2 && px1 - px0 + 1 == TILE_W && py1 - py0 + 1 == TILE_H) s_full_ref = ref + 1u;  // covers every pixel of the tile
+          if (cls_rect == 2 && px1 - px0 + 1 == TILE_W && py1 - py0 + 1 == TILE_H) {  // covers every pixel of the tile
+            s_full_ref = ref + 1u;
+            s_full_clip = clip_slot1;
+          }
+          if (clip_slot1) {
+            const uint32_t k = atomicAdd(&s_n_clip_refs, 1u);
+            if (k < kClipRefs) {
+              s_clip_ref[k] = ref;
+              s_clip_slot[k] = clip_slot1;
+            }
+          }
           box = (uint32_t)(px0 - tile_x0) | ((uint32_t)(px1 - tile_x0) << 8) | ((uint32_t)(py0 - tile_y0) << 16) |
                 ((uint32_t)(py1 - tile_y0) << 24);
           st.X0[tid] = t.X0; st.Y0[tid] = t.Y0; st.X1[tid] = t.X1; st.Y1[tid] = t.Y1; st.X2[tid] = t.X2; st.Y2[tid] = t.Y2;
@@ -1275,13 +1307,19 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
   BB_RSTAMP(3);
 
   // ---- compaction: covered pixels -> fragment list (ballot + popcount prefix); background written here ----
+  // fragment = ((clip slot + 1) << kFragPixBits | pixel in tile) << 32 | reference
   unsigned long long *my_frags = frags + (size_t)tile * TILE_PIXELS;
   if (fast_full) {
     const unsigned long long ref = (unsigned long long)(s_full_ref - 1u);
-    for (int p = tid; p < TILE_PIXELS; p += kTileThreads) my_frags[p] = ((unsigned long long)(uint32_t)p << 32) | ref;
-    if (tid == 0) frag_count[tile] = (uint32_t)TILE_PIXELS;
+    const unsigned long long hi = (unsigned long long)s_full_clip << kFragPixBits;
+    for (int p = tid; p < TILE_PIXELS; p += kTileThreads) my_frags[p] = ((hi | (unsigned long long)(uint32_t)p) << 32) | ref;
+    if (tid == 0) {
+      frag_count[tile] = (uint32_t)TILE_PIXELS;
+      if (item_groups) atomicAdd(&item_groups[slot / kItemGroupSlots], (uint32_t)(TILE_PIXELS / 64));
+    }
     return;
   }
+  const uint32_t n_clip_refs = s_n_clip_refs <= kClipRefs ? s_n_clip_refs : 0u;  // too many: k_shade looks the slots up
   for (int base = 0; base < TILE_PIXELS; base += kTileThreads) {
     int p = base + tid;
     int x, y;
@@ -1297,7 +1335,14 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
     wave_base = (uint32_t)__shfl((int)wave_base, 0);
     if (covered) {
       uint32_t rank_in_wave = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-      my_frags[wave_base + rank_in_wave] = ((unsigned long long)(uint32_t)p << 32) | (unsigned long long)((uint32_t)key - 1u);
+      const uint32_t ref = (uint32_t)key - 1u;
+      uint32_t clip_slot1 = 0u;
+      for (uint32_t k = 0; k < n_clip_refs; ++k)  // (uniform trip count: a handful of clipped sub-triangles per tile at most)
+        if (s_clip_ref[k] == ref) clip_slot1 = s_clip_slot[k];
+      const unsigned long long fw =
+          ((((unsigned long long)clip_slot1 << kFragPixBits) | (unsigned long long)(uint32_t)p) << 32) | (unsigned long long)ref;
+      my_frags[wave_base + rank_in_wave] = fw;
+      if (wave_base + rank_in_wave == 0u) s_pad_frag = fw;  // the list's first fragment doubles as its padding (below)
     } else if (in_frame && !OVERLAY) {
       size_t o = (size_t)(out_y0 + y) * (size_t)fp.width + (size_t)gx;
       // forward: the clear colour (src/main.cpp:84); deferred: brdf.frag on the cleared G-buffer texel (k_deferred_background)
@@ -1314,7 +1359,17 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
     if (!OVERLAY && depth_io && in_frame) depth_io[(size_t)gy * (size_t)fp.width + (size_t)gx] = __uint_as_float((uint32_t)(key >> 32));
   }
   __syncthreads();
-  if (tid == 0) frag_count[tile] = s_count;  // (N_shaded = sum of these, taken on the host on demand)
+  // k_shade works in units of 64 fragments and loads them before it knows the count: the list is padded to a multiple of
+  // 64 with copies of its first fragment (the copies are shaded again and not stored).
+  {
+    const uint32_t n = s_count;
+    if (n != 0u && (n & 63u) != 0u && tid < (int)(64u - (n & 63u))) my_frags[n + (uint32_t)tid] = s_pad_frag;
+  }
+  if (tid == 0) {
+    frag_count[tile] = s_count;  // (N_shaded = sum of these, taken on the host on demand)
+    // 64-fragment chunks per group of 256 launch slots: what k_shade_items needs to place this group's items
+    if (item_groups && s_count) atomicAdd(&item_groups[slot / kItemGroupSlots], (s_count + 63u) >> 6);
+  }
   BB_RSTAMP(4);
   if (tid == 0) {
     BB_RSTAMP(5);
@@ -1474,33 +1529,129 @@ __global__ __launch_bounds__(kBackgroundThreads) void k_deferred_background(Shad
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_shade: forward_brdf.frag + brdf.glsl once per visible pixel.  One lane per fragment of the compacted lists,
-// 256 consecutive fragments of one tile per workgroup; the only LDS is the cooked light table (one barrier at the
-// start), every wave does the same amount of work, so the hardware dispatcher balances the frame by itself.
+// k_shade_items: the work list of k_shade.  One item = 64 consecutive fragments of one tile's list; the list of all
+// items of the frame lets a fixed number of resident waves walk the frame's fragments in a strided loop, prefetching
+// the next items' data while they shade the current one.  A single workgroup scans the per-tile fragment counts
+// (launch slots in k_raster's grid order): items[0] = number of items, items[1 + j] = slot << 4 | chunk64 ...
+// (a tile of 64x64 pixels has 64 chunks: the chunk field is 6 bits).
+// ------------------------------------------------------------------------------------------------
+
+// chunks of 64 fragments in the list of launch slot `slot` (0 past the frame)
+BB_DEV uint32_t slot_chunks(const FrameParams &fp, const uint32_t *__restrict__ frag_count, uint32_t slot, uint32_t n_slots, int grid_x) {
+  if (slot >= n_slots) return 0u;
+  const int gy = (int)(slot / (uint32_t)grid_x), tx = (int)(slot - (uint32_t)gy * (uint32_t)grid_x);
+  int ty, out_tile_row;
+  if (!tile_row(fp, gy, ty, out_tile_row)) return 0u;
+  return (frag_count[(uint32_t)ty * (uint32_t)fp.tiles_x + (uint32_t)tx] + 63u) >> 6;
+}
+
+// One workgroup per 256 launch slots, no communication between workgroups: the items in front of a workgroup's slots are
+// the sum of k_raster's per-group totals (eight independent loads per thread), its own 256 slots get a scan, then their items are
+// written.  (A single workgroup doing all of it took 25 us at C3 -- 70 000 scattered 4-byte stores through ONE compute
+// unit's address unit; every workgroup summing the raw counts in front of it took 13 us of dependent loads.)
+template <int TILE_W, int TILE_H>
+__global__ __launch_bounds__(kItemsThreads) void k_shade_items(FrameParams fp, const uint32_t *__restrict__ frag_count,
+                                                               const uint32_t *__restrict__ item_groups,
+                                                               uint32_t *__restrict__ items, int grid_x, int grid_y,
+                                                               uint32_t *__restrict__ host_count) {
+  __shared__ uint32_t s_wave[2][kItemsThreads / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t n_slots = (uint32_t)grid_x * (uint32_t)grid_y;
+  const uint32_t first = blockIdx.x * (uint32_t)kItemsThreads;
+  uint32_t before = 0u;  // (independent loads: one round trip)
+#pragma unroll
+  for (int q = 0; q < kItemGroups / kItemsThreads; ++q) {
+    const uint32_t g = (uint32_t)q * kItemsThreads + (uint32_t)tid;
+    before += g < first / kItemGroupSlots ? item_groups[g] : 0u;
+  }
+  const uint32_t chunks = slot_chunks(fp, frag_count, first + (uint32_t)tid, n_slots, grid_x);
+  uint32_t incl = chunks;  // inclusive scan of this workgroup's slots, wave level
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
+    if (lane >= d) incl += up;
+    before += (uint32_t)__shfl_xor((int)before, d);  // (butterfly sum: every lane ends with the wave's total)
+  }
+  if (lane == 63) s_wave[0][wave] = incl;
+  if (lane == 0) s_wave[1][wave] = before;
+  __syncthreads();
+  uint32_t at = 1u + incl - chunks;
+#pragma unroll
+  for (int w = 0; w < kItemsThreads / 64; ++w) {
+    at += s_wave[1][w];
+    if (w < wave) at += s_wave[0][w];
+  }
+  const uint32_t slot = first + (uint32_t)tid;
+  if (chunks != 0u) {
+    const uint32_t gy = slot / (uint32_t)grid_x, tx = slot - gy * (uint32_t)grid_x;
+    const uint32_t word = (gy << (kItemChunkBits + kItemTxBits)) | (tx << kItemChunkBits);
+    for (uint32_t c = 0; c < chunks; ++c) items[at + c] = word | c;
+  }
+  // the workgroup of the last slot knows the total
+  if (first + (uint32_t)kItemsThreads >= n_slots && tid == kItemsThreads - 1) {
+    items[0] = at + chunks - 1u;
+    if (host_count) *host_count = at + chunks - 1u;  // pinned host memory: sizes the launch of this slot's next frame
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_shade: forward_brdf.frag + brdf.glsl once per visible pixel.
+//
+// What bounded the first version of this kernel (one workgroup per 256 fragments of a tile) was not arithmetic but the
+// chain of dependent memory round trips in front of it -- kernel arguments -> fragment count -> fragment -> primitive
+// record -> clip slot -> texels, ~0.8 us each under load -- against ~0.9 us of issue time per 64 fragments: its
+// duration followed T = 66 us + 264 us / (waves per SIMD) at C3 (measured by padding LDS: 2, 3, 4, 7 waves -> 198,
+// 151, 132, 109 us), and a body that only loaded the fragment and stored a constant still took 52 us.  Hence:
+//  * PERSISTENT waves: a fixed grid of resident waves walks the work list of k_shade_items in a strided loop.  No wave
+//    is launched for an empty part of a tile, the cooked light table is built once per workgroup instead of once per
+//    256 fragments, and kernel arguments / list heads are read once per wave, not once per 64 fragments.
+//  * the chain is cut to two round trips per item: the fragment words of the NEXT item are prefetched during the light
+//    loop (k_raster pads every list to a multiple of 64, so they can be fetched before the count is known), and the
+//    fragment word carries the clip-arena slot of a clipped sub-triangle, so its planes are fetched together with the
+//    primitive record instead of after it.
+//  * many waves per SIMD rather than a deep software pipeline: a gfx950 wave issues at most one instruction of ANY
+//    kind every ~4 cycles (tools/microbench/issue_rate.hip), so the vector ALU (one instruction every 2 cycles) only
+//    fills up with four or more waves that are all busy issuing.
 // ------------------------------------------------------------------------------------------------
 #ifndef BB_SHADE_THREADS
 #define BB_SHADE_THREADS 256
 #endif
 constexpr int kShadeThreads = BB_SHADE_THREADS;
+#ifdef BB_STAMPS
+__device__ unsigned long long g_shade_stamps[4096 * 8];  // diagnostic build: per-wave phase cycles of k_shade
+#endif
+constexpr int kShadeWaves = kShadeThreads / 64;
+typedef const uint8_t __attribute__((address_space(1))) *GlobalBytes;  // a pointer known to point to global memory
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+typedef u32x3 __attribute__((aligned(1))) u32x3_any;  // 12 bytes at any byte address: one global_load_dwordx3
+typedef const u32x3_any __attribute__((address_space(1))) *GlobalTap;
 
-// One texel of a packed material: 9 bytes, unaligned (albedo.rgb metallic | normal.xyz roughness | ao), fetched as one
-// global_load_dwordx3 (the three bytes behind the record are the next texel's; the allocation is padded).
-struct PackedTaps {
-  uint32_t x[4], y[4], z[4];  // per tap: dword 0, dword 1, dword 2 of the record
+// one work item as the loop carries it: where its 64 fragments are (all uniform, held in scalar registers) and the
+// fragment word of this lane
+struct ItemFrag {
+  unsigned long long frag;
+  uint32_t n_frag;                  // fragments in the tile's list
+  int tx, ty, out_tile_row, chunk;
+  bool live;                        // the item exists
 };
 
 // PRESENT = true (option "present_fused"): the colour goes through present_pixel and is stored as RGBA8 -- the tone-map
 // subpass fused into the producing kernel: 4 bytes written per pixel instead of 16, and no k_present pass (16 B read +
 // 4 B written per pixel) afterwards.
-template <int TILE_W, int TILE_H, bool DEFERRED, bool PRESENT = false>
+// TAIL = false: one item per wave -- wave v of workgroup w shades item first_item + 4 w + v and exits; the host sizes the
+// grid from the item count of the frame this slot rendered before (frames are coherent), so nearly every wave launched
+// has an item.  TAIL = true: a small fixed grid loops over whatever lies behind the part the main launch covered (a
+// scene that suddenly grew); normally nothing.  Two instantiations because the loop form costs registers: the compiler
+// keeps 104 live around a loop where the straight-line body needs 68 -- four waves per SIMD instead of seven.
+template <int TILE_W, int TILE_H, bool DEFERRED, bool PRESENT = false, bool TAIL = false>
 __global__ __launch_bounds__(kShadeThreads) void k_shade(
     FrameParams fp, ShadeParams sp, const Light *__restrict__ lights, const ShadeRec *__restrict__ recs,
     const ClipSlot *__restrict__ clip_arena, const unsigned long long *__restrict__ frags,
-    const uint32_t *__restrict__ frag_count, const MaterialDesc *__restrict__ materials, float4 *__restrict__ out,
+    const uint32_t *__restrict__ frag_count, const uint32_t *__restrict__ items, uint32_t first_item,
+    const MaterialDesc *__restrict__ materials, float4 *__restrict__ out,
     uint2 *__restrict__ gbuffer, const SrgbTables *__restrict__ tables, uint32_t *__restrict__ out8,
-    Counters *__restrict__ ctr, Counters *__restrict__ ctr_done) {
+    Counters *__restrict__ ctr, Counters *__restrict__ ctr_done, uint32_t *__restrict__ item_groups) {
   constexpr int TILE_PIXELS = TILE_W * TILE_H;
-  constexpr int CHUNKS = TILE_PIXELS / kShadeThreads;
   __shared__ ShadeShared sh;
 #ifdef BB_EXP_LDS_PAD
   __shared__ char exp_pad[BB_EXP_LDS_PAD];  // experiment: fewer workgroups per CU
@@ -1509,90 +1660,128 @@ __global__ __launch_bounds__(kShadeThreads) void k_shade(
   // The frame's counter block has done its job (k_geometry filled it, k_raster read it): keep a copy for the host's
   // statistics / overflow check and clear the block for the next frame of this slot.  Frames of different slots
   // share nothing, so their kernels may overlap freely.
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < sizeof(Counters) / 4) {
+  if (blockIdx.x == 0 && threadIdx.x < sizeof(Counters) / 4) {
     reinterpret_cast<uint32_t *>(ctr_done)[threadIdx.x] = reinterpret_cast<uint32_t *>(ctr)[threadIdx.x];
     reinterpret_cast<uint32_t *>(ctr)[threadIdx.x] = 0u;
   }
-  const int tx = blockIdx.x / CHUNKS, chunk = blockIdx.x - tx * CHUNKS;
-  int ty, out_tile_row;
-  if (!tile_row(fp, blockIdx.y, ty, out_tile_row)) return;
-  const uint32_t tile = (uint32_t)ty * (uint32_t)fp.tiles_x + (uint32_t)tx;
-  const uint32_t n_frag = frag_count[tile];
-  if ((uint32_t)chunk * kShadeThreads >= n_frag) return;  // the whole workgroup (uniform): nothing of this chunk is covered
-  // Lanes past the end of the list shade the list's last fragment again and do not store; waves entirely past the end
-  // only wait at the barrier below (their workgroup still needs them there).
-  const uint32_t i_raw = (uint32_t)chunk * kShadeThreads + threadIdx.x;
-  const bool valid = i_raw < n_frag;
-  const bool wave_live = (uint32_t)chunk * kShadeThreads + (threadIdx.x & ~63u) < n_frag;
-  const uint32_t i = valid ? i_raw : n_frag - 1u;
-  const unsigned long long frag = frags[(size_t)tile * TILE_PIXELS + i];
+  if (!TAIL && blockIdx.x == 0 && item_groups)  // (k_shade_items is done with them)
+    for (uint32_t g = threadIdx.x; g < (uint32_t)kItemGroups; g += kShadeThreads) item_groups[g] = 0u;
+#ifdef BB_STAMPS
+  unsigned long long st_t[8];
+  st_t[0] = __builtin_amdgcn_s_memtime();
+#define BB_KSTAMP(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); st_t[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define BB_KSTAMP(i) do { } while (0)
+#endif
+  const int lane = (int)(threadIdx.x & 63u);
+  const uint32_t n_items = items[0];
+  if (first_item + blockIdx.x * (uint32_t)kShadeWaves >= n_items) return;  // the whole workgroup: nothing left for it
+  // this wave's (first) item: wave-uniform, everything derived from it lives in scalar registers
+  uint32_t j = first_item + (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (uint32_t)kShadeWaves + (threadIdx.x >> 6)));
   // The cooked light table is written now and only needed by the light loop: the barrier sits right in front of the
   // loop, so the light fetch overlaps the fragment's own memory round trips (fragment -> primitive record -> texels).
   stage_lights<kShadeThreads>(sp, lights, sh);
-  if (!wave_live) {
+  if (BB_ABLATE(2048u)) sp.num_lights = 0;
+  if (j >= n_items) {  // a wave without an item: its workgroup still needs it at the barrier
     __syncthreads();
     return;
   }
+  bool first_pass = true;
+  do {  // (a loop only in the TAIL instantiation)
+  const uint32_t item = items[1u + j];
+  const int chunk = (int)(item & 63u);
+  const int tx = (int)((item >> 6) & 8191u);
+  int ty, out_tile_row;
+  tile_row(fp, (int)(item >> 19), ty, out_tile_row);
+  const uint32_t tile = (uint32_t)ty * (uint32_t)fp.tiles_x + (uint32_t)tx;
+  const uint32_t n_frag = frag_count[tile];
+  const bool valid = (uint32_t)chunk * 64u + (uint32_t)lane < n_frag;
+  const unsigned long long frag = frags[(size_t)tile * TILE_PIXELS + (uint32_t)chunk * 64u + (uint32_t)lane];
+  BB_KSTAMP(1);  // item word, count and fragment arrived
   const uint32_t ref = (uint32_t)frag;
   uint32_t prim = BB_ABLATE(16u) ? 0u : (ref >> 3);
   if (BB_ABLATE(1024u)) prim = (uint32_t)__builtin_amdgcn_readfirstlane((int)prim);  // the record through the scalar cache
-  if (BB_ABLATE(2048u)) sp.num_lights = 0;
   int x, y;
   tile_pixel<TILE_W>((int)(frag >> 32) & (TILE_PIXELS - 1), x, y);
   const int gx = tx * TILE_W + x, gy = ty * TILE_H + y;
   const size_t o = (size_t)(out_tile_row * TILE_H + y) * (size_t)fp.width + (size_t)gx;
-  if (BB_ABLATE(2u)) {
-    if (!PRESENT && valid) out[o] = make_float4(1.f, 1.f, 1.f, 1.f);
-    __syncthreads();
-    return;
-  }
 
-  // One 224-byte record per fragment, gathered directly (neighbouring pixels share primitives, so most of these
-  // loads hit the same L1 lines).
-  const ShadeRec &pa = recs[prim];
-  // perspective-correct barycentrics from the screen-space planes of the (sub-)triangle
-  int X0 = pa.X0, Y0 = pa.Y0;
-  float l1dx = pa.l1dx, l1dy = pa.l1dy, l2dx = pa.l2dx, l2dy = pa.l2dy, rw0 = pa.rw0, rw1 = pa.rw1, rw2 = pa.rw2;
-  const uint32_t clip_base = pa.clip_base;
-  const bool clipped = clip_base != kNotClipped;
-  float cb[3][3];
-  if (clipped) {  // a sub-triangle of a clipped primitive (the ground plane, mostly): its own planes
-    const ClipSlot &cs = clip_arena[clip_base + (ref & 7u)];
-    X0 = cs.tri.X0; Y0 = cs.tri.Y0;
-    l1dx = cs.tri.l1dx; l1dy = cs.tri.l1dy; l2dx = cs.tri.l2dx; l2dy = cs.tri.l2dy;
-    rw0 = cs.tri.rw0; rw1 = cs.tri.rw1; rw2 = cs.tri.rw2;
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-      for (int k = 0; k < 3; ++k) cb[j][k] = cs.bary[j][k];
-  }
-  const int Xc = gx * 256 + 128, Yc = gy * 256 + 128;
-  const float dxp = (float)(Xc - X0), dyp = (float)(Yc - Y0);
-  const float l1 = fmaf(l1dx, dxp, l1dy * dyp);
-  const float l2 = fmaf(l2dx, dxp, l2dy * dyp);
-  const float l0 = (1.0f - l1) - l2;
-  const float u0 = l0 * rw0, u1 = l1 * rw1, u2 = l2 * rw2;
-  const float r = bb_rcp((u0 + u1) + u2);
-  float b0 = u0 * r, b1 = u1 * r, b2 = u2 * r;
-  if (clipped) {  // barycentrics with respect to the unclipped primitive
-    const float c0 = fmaf(b2, cb[2][0], fmaf(b1, cb[1][0], b0 * cb[0][0]));
-    const float c1 = fmaf(b2, cb[2][1], fmaf(b1, cb[1][1], b0 * cb[0][1]));
-    const float c2 = fmaf(b2, cb[2][2], fmaf(b1, cb[1][2], b0 * cb[0][2]));
-    b0 = c0; b1 = c1; b2 = c2;
-  }
-
+  // The primitive record (224 bytes) and, for a clipped primitive, its sub-triangle's clip slot: barycentrics and the
+  // fourteen varyings.  Two forms of the same statements:
+  //  * every fragment of the wave belongs to ONE (sub-)triangle -- the ground plane's waves, about half of C3's: the
+  //    record is fetched ONCE through the scalar cache (s_load) instead of 64 lanes gathering 16 x 16 bytes each.
+  //    That takes 20 of a wave's 26 vector loads -- 20 KB of register-file traffic through the texture-address unit
+  //    -- out of the memory pipeline, whose queues were what made a round trip cost 3-4 thousand cycles under load
+  //    (in-kernel stamps); the price is that operands coming from scalar registers halve the issue rate of the ~60
+  //    instructions that read them.
+  //  * otherwise each lane gathers the record of its own fragment's primitive (neighbouring pixels share primitives,
+  //    so the loads of a wave hit few L1 lines).
   float a[kNumVary];
+  uint32_t packed_dims, material;
+  const uint8_t *packed_texels;
+  auto interpolate = [&](const auto &pa, const auto *clips, uint32_t clip1, uint32_t sub) {
+    // perspective-correct barycentrics from the screen-space planes of the (sub-)triangle
+    int X0 = pa.X0, Y0 = pa.Y0;
+    float l1dx = pa.l1dx, l1dy = pa.l1dy, l2dx = pa.l2dx, l2dy = pa.l2dy, rw0 = pa.rw0, rw1 = pa.rw1, rw2 = pa.rw2;
+    // A sub-triangle of a clipped primitive (the ground plane, mostly) has its own planes, in the clip arena.  The
+    // fragment word usually carries the slot, so these loads go out together with the record's; when k_raster did not
+    // know it (more than 32 clipped sub-triangles on one tile) the slot comes from the record, one round trip later.
+    const uint32_t clip_base = pa.clip_base;
+    const bool clipped = clip1 != 0u || clip_base != kNotClipped;
+    float cb[3][3];
+    if (clipped) {
+      const auto &cs = clips[clip1 != 0u ? clip1 - 1u : clip_base + sub];
+      X0 = cs.tri.X0; Y0 = cs.tri.Y0;
+      l1dx = cs.tri.l1dx; l1dy = cs.tri.l1dy; l2dx = cs.tri.l2dx; l2dy = cs.tri.l2dy;
+      rw0 = cs.tri.rw0; rw1 = cs.tri.rw1; rw2 = cs.tri.rw2;
 #pragma unroll
-  for (int k = 0; k < kNumVary; ++k) a[k] = fmaf(b2, pa.vary[2][k], fmaf(b1, pa.vary[1][k], b0 * pa.vary[0][k]));
+      for (int jj = 0; jj < 3; ++jj)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) cb[jj][k] = cs.bary[jj][k];
+    }
+    const int Xc = gx * 256 + 128, Yc = gy * 256 + 128;
+    const float dxp = (float)(Xc - X0), dyp = (float)(Yc - Y0);
+    const float l1 = fmaf(l1dx, dxp, l1dy * dyp);
+    const float l2 = fmaf(l2dx, dxp, l2dy * dyp);
+    const float l0 = (1.0f - l1) - l2;
+    const float u0 = l0 * rw0, u1 = l1 * rw1, u2 = l2 * rw2;
+    const float r = bb_rcp((u0 + u1) + u2);
+    float b0 = u0 * r, b1 = u1 * r, b2 = u2 * r;
+    if (clipped) {  // barycentrics with respect to the unclipped primitive
+      const float c0 = fmaf(b2, cb[2][0], fmaf(b1, cb[1][0], b0 * cb[0][0]));
+      const float c1 = fmaf(b2, cb[2][1], fmaf(b1, cb[1][1], b0 * cb[0][1]));
+      const float c2 = fmaf(b2, cb[2][2], fmaf(b1, cb[1][2], b0 * cb[0][2]));
+      b0 = c0; b1 = c1; b2 = c2;
+    }
+#pragma unroll
+    for (int k = 0; k < kNumVary; ++k) a[k] = fmaf(b2, pa.vary[2][k], fmaf(b1, pa.vary[1][k], b0 * pa.vary[0][k]));
+    packed_dims = pa.packed_dims;
+    material = pa.material;
+    packed_texels = (const uint8_t *)pa.packed;
+  };
+  {
+    const uint32_t clip1 = (uint32_t)(frag >> (32 + kFragPixBits));
+    const uint32_t ref_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)ref);
+    if (__ballot(ref != ref_u) == 0ull && !BB_ABLATE(4096u)) {
+      // (the constant address space is what makes these scalar loads -- and keeps the compiler from merging the two
+      //  forms back into one that gathers: both buffers were written by k_geometry and are read-only here)
+      typedef const ShadeRec __attribute__((address_space(4))) *ConstRecs;
+      typedef const ClipSlot __attribute__((address_space(4))) *ConstClips;
+      interpolate(((ConstRecs)recs)[BB_ABLATE(16u) ? 0u : (ref_u >> 3)], (ConstClips)clip_arena,
+                  (uint32_t)__builtin_amdgcn_readfirstlane((int)clip1), ref_u & 7u);
+    } else {
+      interpolate(recs[prim], clip_arena, clip1, ref & 7u);
+    }
+  }
+
   // texture fetches, forward_brdf.frag:16-22
   const float u = BB_ABLATE(8u) ? 0.5f : a[0], v = BB_ABLATE(8u) ? 0.5f : a[1];
   f3 albedo, normal;
   float metallic, roughness, ao;
-  const uint32_t packed_dims = pa.packed_dims;
   if (packed_dims != 0u) {
     // packed material: one set of taps, four 12-byte loads of 9-byte records
     const BilinearTaps tp = bilinear_taps(u, v, (int)(packed_dims & 0xFFFFu), (int)(packed_dims >> 16));
-    const uint8_t *tb = pa.packed;
+    const uint8_t *tb = packed_texels;
     uint32_t t00[3], t10[3], t01[3], t11[3];
     __builtin_memcpy(t00, tb + kPackedTexelBytes * tp.o00, 12);
     __builtin_memcpy(t10, tb + kPackedTexelBytes * tp.o10, 12);
@@ -1617,7 +1806,7 @@ __global__ __launch_bounds__(kShadeThreads) void k_shade(
     }
   } else {
     // maps of different sizes: one set of taps per map
-    const MaterialDesc &md = materials[pa.material];
+    const MaterialDesc &md = materials[material];
     {
       const TexDesc &td = md.maps[kMapAlbedo];
       BilinearTaps tp = bilinear_taps(u, v, td.w, td.h);
@@ -1661,6 +1850,7 @@ __global__ __launch_bounds__(kShadeThreads) void k_shade(
     }
   }
 
+  BB_KSTAMP(3);  // varyings, taps arrived, filtered
   float4 color;
   if (DEFERRED) {
     // gbuffer.frag:24-32 into four RGBA16F attachments (binary16, round to nearest even), then brdf.frag:12-73 on
@@ -1670,7 +1860,7 @@ __global__ __launch_bounds__(kShadeThreads) void k_shade(
     albedo = mk3(bb_half_round(albedo.x), bb_half_round(albedo.y), bb_half_round(albedo.z));
     metallic = bb_half_round(metallic); roughness = bb_half_round(roughness); ao = bb_half_round(ao);
     if (gbuffer && valid) {
-      const MaterialDesc &md = materials[pa.material];
+      const MaterialDesc &md = materials[material];
       const TexDesc &td = md.maps[kMapHeight];
       BilinearTaps tp = bilinear_taps(u, v, td.w, td.h);
       const uint32_t *tx32 = reinterpret_cast<const uint32_t *>(td.texels);
@@ -1686,7 +1876,7 @@ __global__ __launch_bounds__(kShadeThreads) void k_shade(
       dst[0] = lo;
       dst[1] = hi;
     }
-    __syncthreads();  // cooked lights visible (the only barrier of the kernel; every wave of the workgroup reaches one)
+    if (first_pass) __syncthreads();  // cooked lights visible (the only barrier of the kernel; every wave reaches exactly one)
     if (fp.gbuffer_view >= 0) {
       // buffer_visualize.frag:8-12 instead of brdf.frag (recordCommand, src/main.cpp:96-121): the rgb of one attachment
       const f3 shown = fp.gbuffer_view == 0 ? P : (fp.gbuffer_view == 1 ? normal : (fp.gbuffer_view == 2 ? albedo : mk3(metallic, roughness, ao)));
@@ -1695,12 +1885,30 @@ __global__ __launch_bounds__(kShadeThreads) void k_shade(
       color = light_surface(sp, sh, P, normal, albedo, metallic, roughness, ao);
     }
   } else {
-    __syncthreads();  // cooked lights visible (the only barrier of the kernel; every wave of the workgroup reaches one)
+    if (first_pass) __syncthreads();  // cooked lights visible (the only barrier of the kernel; every wave reaches exactly one)
     color = light_surface(sp, sh, mk3(a[2], a[3], a[4]), normal, albedo, metallic, roughness, ao);
   }
-  if (!valid) return;
-  if (PRESENT) out8[o] = present_pixel(color.x, color.y, color.z, *tables, sp.tone_enable, sp.exposure, 1);
-  else out[o] = color;
+  BB_KSTAMP(4);  // light loop done
+  if (BB_ABLATE(2u)) color = make_float4(1.f, 1.f, 1.f, 1.f);
+  if (valid) {
+    if (PRESENT) out8[o] = present_pixel(color.x, color.y, color.z, *tables, sp.tone_enable, sp.exposure, 1);
+    else out[o] = color;
+  }
+#ifdef BB_STAMPS
+  {
+    BB_KSTAMP(5);
+    const uint32_t wv = blockIdx.x * (uint32_t)kShadeWaves + (threadIdx.x >> 6);
+    if (!TAIL && lane == 0 && wv < 4096u) {
+      unsigned long long *d = g_shade_stamps + (size_t)wv * 8;
+      for (int q = 0; q < 5; ++q) d[q] = st_t[q + 1] - st_t[q];
+      d[5] = 1;
+    }
+  }
+#endif
+  first_pass = false;
+  j += gridDim.x * (uint32_t)kShadeWaves;
+  asm volatile("" ::: "memory");
+  } while (TAIL && j < n_items);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -105,6 +105,8 @@ struct FrameSlot {
   DeviceBuffer<unsigned long long> d_frags;  // per tile: compacted (pixel << 32 | primitive ref) of covered pixels
   DeviceBuffer<uint32_t> d_frag_count;
   DeviceBuffer<uint32_t> d_tile_order;  // k_raster launch slots, heaviest tiles first
+  DeviceBuffer<uint32_t> d_items;       // k_shade's work list: [0] = count, then slot << 6 | chunk of 64 fragments
+  DeviceBuffer<uint32_t> d_item_groups; // 64-fragment chunks per group of 256 launch slots (k_raster -> k_shade_items)
   DeviceBuffer<float4> d_frame;
   DeviceBuffer<float4> d_background;  // deferred path: colour of the pixels no geometry covers
   DeviceBuffer<float> d_depth;        // option "overlays": the frame's resolved depth, for bbr_draw_overlays
@@ -120,7 +122,7 @@ struct FrameSlot {
     int32_t enable = 0, hdr16 = 1;
     float exposure = 1.f;
   } present;
-  hipEvent_t ev_geom_done = nullptr, ev_raster_done = nullptr, ev_shade_done = nullptr;
+  hipEvent_t ev_geom_done = nullptr, ev_raster_done = nullptr, ev_shade_done = nullptr, ev_tail_done = nullptr;
   bool in_flight = false;
   int32_t tone_enable = 0;  // FrameUniformBlock.EnableToneMapping / Exposure of the frame in this slot
   float tone_exposure = 1.f;
@@ -129,7 +131,7 @@ struct FrameSlot {
   uint32_t n_prims = 0;
 
   void release_tile_buffers() {
-    d_tile_count.release(); d_bins.release(); d_frags.release(); d_frag_count.release(); d_tile_order.release();
+    d_tile_count.release(); d_bins.release(); d_frags.release(); d_frag_count.release(); d_tile_order.release(); d_items.release(); d_item_groups.release();
   }
   void release_all() {
     d_staging.release(); d_tris.release(); d_attrs.release(); d_clip.release();
@@ -210,6 +212,7 @@ struct bbr_context {
   bool dump_gbuffer = false;
   DeviceBuffer<uint2> d_gbuffer;  // width*height*4 (four RGBA16F texels per pixel), only while bbr_read_gbuffer runs
   uint32_t ablate = 0;
+  int n_cus = 256;         // compute units of the device (hipDeviceProp_t::multiProcessorCount)
   int timing = 0;  // 0 off, 1 five events per frame, 2 only the two events around k_shade
   int timing_stride = 1;  // option "timing_stride": events on every n-th frame only (two events a frame cost ~4 % at C3)
   uint64_t timing_tick = 0;
@@ -365,6 +368,10 @@ int ensure_slot_buffers(bbr_context *c, FrameSlot &s) {
   HIP_TRY(c, s.d_frag_count.ensure(tiles, true));
 #endif
   HIP_TRY(c, s.d_tile_order.ensure(tiles * kOrderBuckets));
+  HIP_TRY(c, s.d_items.ensure(1 + tiles * (size_t)(c->tile_w() * c->tile_h() / 64), true));
+  if (tiles > (size_t)kItemGroupSlots * kItemGroups)  // 65536 launch slots: 8192 x 8192 pixels at 32 x 32 tiles
+    return fail(c, BBR_ERR_INVALID_ARGUMENT, "frame too large for this tile size: set option tile_mode to 0 (64 x 64 tiles)");
+  HIP_TRY(c, s.d_item_groups.ensure(kItemGroups, true));
   if (c->deferred) HIP_TRY(c, s.d_background.ensure(2));
   if (c->overlays && &s != &c->ov) HIP_TRY(c, s.d_depth.ensure((size_t)c->width * c->height));
   if (c->present_fused && &s != &c->ov) {
@@ -379,12 +386,13 @@ int ensure_slot_buffers(bbr_context *c, FrameSlot &s) {
     HIP_TRY(c, c->d_vis_depth.ensure((size_t)c->width * c->height));
   }
   if (!s.h_flags) {
-    HIP_TRY(c, hipHostMalloc((void **)&s.h_flags, 2 * sizeof(uint32_t), hipHostMallocDefault));
-    s.h_flags[0] = s.h_flags[1] = 0u;
+    HIP_TRY(c, hipHostMalloc((void **)&s.h_flags, 4 * sizeof(uint32_t), hipHostMallocDefault));
+    s.h_flags[0] = s.h_flags[1] = s.h_flags[2] = s.h_flags[3] = 0u;
   }
   if (!s.ev_geom_done) HIP_TRY(c, hipEventCreateWithFlags(&s.ev_geom_done, hipEventDisableTiming));
   if (!s.ev_raster_done) HIP_TRY(c, hipEventCreateWithFlags(&s.ev_raster_done, hipEventDisableTiming));
   if (!s.ev_shade_done) HIP_TRY(c, hipEventCreateWithFlags(&s.ev_shade_done, hipEventDisableTiming));
+  if (!s.ev_tail_done) HIP_TRY(c, hipEventCreateWithFlags(&s.ev_tail_done, hipEventDisableTiming));
   return BBR_OK;
 }
 
@@ -440,25 +448,41 @@ void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const Fra
                      s.d_frag_count.ptr, out, c->dump_vis ? c->d_vis_prim.ptr : nullptr,
                      c->dump_vis ? c->d_vis_depth.ptr : nullptr, ordered ? s.d_tile_order.ptr : nullptr,
                      fp.deferred ? s.d_background.ptr : nullptr, (c->overlays && c->world == 1) ? s.d_depth.ptr : nullptr,
-                     s.h_flags, out8);
+                     s.h_flags, out8, s.d_item_groups.ptr);
   s.has_depth = c->overlays && c->world == 1;
+  // k_shade is persistent: a fixed grid of resident waves walks the frame's work list (64 fragments per item), which a
+  // single workgroup builds from the per-tile fragment counts as soon as k_raster is done
+  hipLaunchKernelGGL((k_shade_items<TW, TH>), dim3((unsigned)((fp.tiles_x * grid_y + kItemsThreads - 1) / kItemsThreads)), dim3(kItemsThreads), 0, sr, fp, s.d_frag_count.ptr, s.d_item_groups.ptr, s.d_items.ptr,
+                     fp.tiles_x, grid_y, s.h_flags ? s.h_flags + 2 : nullptr);
   if (ev && c->timing == 1) (void)hipEventRecord(ev[2], sr);
   if (ss != sr) {
     (void)hipEventRecord(s.ev_raster_done, sr);
     (void)hipStreamWaitEvent(ss, s.ev_raster_done, 0);
   }
-  // one workgroup per (tile, 256-fragment chunk); empty ones exit after one load
   if (ev) (void)hipEventRecord(ev[3], ss);  // completes when the shade stream has seen "raster done"
-  // Workgroup -> tile mapping is the plain launch order, i.e. round-robin over the 8 XCDs.  XCD-aware remaps were
-  // measured and rejected: contiguous eighths of the screen put the sky on some XCDs and the geometry on others
-  // (k_shade 102 -> 169 us), interleaved 2-row bands still leave a 3:2 imbalance (132 us); the L2-miss traffic they
-  // save (FETCH_SIZE -20 %) does not matter to kernels that are issue- and latency-bound, not L2-bandwidth-bound.
-  constexpr int kChunks = TW * TH / kShadeThreads;
   uint2 *gbuf = (fp.deferred && c->dump_gbuffer) ? c->d_gbuffer.ptr : nullptr;
+  // Main launch: one item (64 fragments) per wave, four per workgroup, sized from the item count of the frame this slot
+  // rendered last (k_shade_items leaves it in pinned host memory) plus 3 %; tail launch: a small persistent grid for
+  // whatever lies behind that (a scene that suddenly grew; normally nothing, and its workgroups exit at once).
+  const uint32_t max_items = (uint32_t)(fp.tiles_x * grid_y) * (uint32_t)(TW * TH / 64);
+  const uint32_t seen = s.h_flags ? s.h_flags[2] : 0u;
+  uint32_t est = seen ? seen + seen / 32u + 64u : max_items;
+  if (est > max_items) est = max_items;
+  const uint32_t main_wgs = std::max(1u, (est + kShadeWaves - 1) / kShadeWaves);
+  // The tail runs on the raster stream, beside the main launch (their items are disjoint): in front of or behind it on
+  // one stream an empty tail would still cost the frame a kernel boundary (~4 us).
+  const bool tail = main_wgs * kShadeWaves < max_items;
   auto shade = [&](auto deferred, auto present) {
-    hipLaunchKernelGGL((k_shade<TW, TH, decltype(deferred)::value, decltype(present)::value>), dim3(fp.tiles_x * kChunks, grid_y),
+    if (tail) {
+      hipLaunchKernelGGL((k_shade<TW, TH, decltype(deferred)::value, decltype(present)::value, true>), dim3(32), dim3(kShadeThreads),
+                         0, sr, fp, sp, d_lights, s.d_attrs.ptr, s.d_clip.ptr, s.d_frags.ptr, s.d_frag_count.ptr, s.d_items.ptr,
+                         main_wgs * (uint32_t)kShadeWaves, c->d_materials.ptr, out, gbuf, tables, out8, ctr, ctr_done, nullptr);
+      if (ss != sr) (void)hipEventRecord(s.ev_tail_done, sr);
+    }
+    hipLaunchKernelGGL((k_shade<TW, TH, decltype(deferred)::value, decltype(present)::value, false>), dim3(main_wgs),
                        dim3(kShadeThreads), 0, ss, fp, sp, d_lights, s.d_attrs.ptr, s.d_clip.ptr, s.d_frags.ptr,
-                       s.d_frag_count.ptr, c->d_materials.ptr, out, gbuf, tables, out8, ctr, ctr_done);
+                       s.d_frag_count.ptr, s.d_items.ptr, 0u, c->d_materials.ptr, out, gbuf, tables, out8, ctr, ctr_done, s.d_item_groups.ptr);
+    if (tail && ss != sr) (void)hipStreamWaitEvent(ss, s.ev_tail_done, 0);
   };
   if (fp.deferred) {
     if (out8) shade(std::true_type{}, std::true_type{});
@@ -960,7 +984,7 @@ extern "C" int bbr_draw_overlays(bbr_context *c, int32_t gizmo_extent) {
       hipLaunchKernelGGL((k_raster<TW, TH, true>), dim3(fp.tiles_x, fp.tiles_y), dim3(kTileThreads), 0, st, fp, s.d_tris.ptr,
                          s.d_clip.ptr, ctr, s.d_tile_count.ptr, s.d_bins.ptr, s.d_broad.ptr, s.d_frags.ptr, s.d_frag_count.ptr,
                          (float4 *)nullptr, (uint32_t *)nullptr, (float *)nullptr, (const uint32_t *)nullptr,
-                         (const float4 *)nullptr, fs.d_depth.ptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
+                         (const float4 *)nullptr, fs.d_depth.ptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
       constexpr int kChunks = TW * TH / kShadeThreads;
       hipLaunchKernelGGL((k_shade_overlay<TW, TH>), dim3(fp.tiles_x * kChunks, fp.tiles_y), dim3(kShadeThreads), 0, st, fp,
                          s.d_attrs.ptr, s.d_clip.ptr, s.d_frags.ptr, s.d_frag_count.ptr, c->d_srgb_tables.ptr, fs.present.out);
@@ -1020,6 +1044,11 @@ int bbr_create(int32_t width, int32_t height, int32_t device, bbr_context **out_
   } while (0)
   CREATE_TRY(hipSetDevice(device));
   {
+    int cus = 0;
+    CREATE_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+    if (cus > 0) c->n_cus = cus;
+  }
+  {
     // geometry + raster are latency-bound and short: give them the high-priority queue so that their workgroups
     // slot in between the (ALU-bound, GPU-filling) shade kernel of the previous frame
     int prio_low = 0, prio_high = 0;
@@ -1073,6 +1102,7 @@ int bbr_destroy(bbr_context *c) {
     if (s.ev_geom_done) (void)hipEventDestroy(s.ev_geom_done);
     if (s.ev_raster_done) (void)hipEventDestroy(s.ev_raster_done);
     if (s.ev_shade_done) (void)hipEventDestroy(s.ev_shade_done);
+    if (s.ev_tail_done) (void)hipEventDestroy(s.ev_tail_done);
   }
   for (Mesh *m : {&c->marker_mesh, &c->gizmo_mesh}) {
     if (m->d_vertices) (void)hipFree(m->d_vertices);
@@ -1082,6 +1112,7 @@ int bbr_destroy(bbr_context *c) {
   if (c->ov.ev_geom_done) (void)hipEventDestroy(c->ov.ev_geom_done);
   if (c->ov.ev_raster_done) (void)hipEventDestroy(c->ov.ev_raster_done);
   if (c->ov.ev_shade_done) (void)hipEventDestroy(c->ov.ev_shade_done);
+  if (c->ov.ev_tail_done) (void)hipEventDestroy(c->ov.ev_tail_done);
   for (auto &e : c->ring)
     if (e) (void)hipEventDestroy(e);
   for (auto &e : c->present_ring)
@@ -1845,3 +1876,14 @@ int bbr_tone_map(bbr_context *c, int32_t enable, float exposure) {
 }
 
 }  // extern "C"
+
+#ifdef BB_STAMPS
+// diagnostic build only: per-wave phase cycles of the last k_shade launch (8 x u64 per wave, 4096 waves)
+extern "C" int bbr_debug_shade_stamps(bbr_context *c, unsigned long long *out) {
+  if (!c || !out) return BBR_ERR_INVALID_ARGUMENT;
+  int rc = drain(c);
+  if (rc) return rc;
+  HIP_TRY(c, hipMemcpyFromSymbol(out, HIP_SYMBOL(bbr::g_shade_stamps), sizeof(unsigned long long) * 4096 * 8));
+  return BBR_OK;
+}
+#endif

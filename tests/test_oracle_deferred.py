@@ -19,7 +19,9 @@ def _scene(cfg=configs.C2, size=(160, 90), **kw):
 def test_frozen_fixture():
     z = np.load(os.path.join(GOLDEN, "deferred.npz"))
     info = json.load(open(os.path.join(GOLDEN, "deferred.json")))
-    rgba, gbuf, prim, depth, st = bbo.render_deferred(_scene(), flags=bbo.FLAG_LITERAL)   # frozen: the literal light loop
+    rgba, gbuf, prim, depth, st = bbo.render_deferred(_scene())
+    lit = bbo.render_deferred(_scene(), flags=bbo.FLAG_LITERAL)[0]      # the statement-by-statement light loop, frozen too
+    assert np.array_equal(lit.view(np.uint32), z["c2_160x90_literal_rgba_bits"])
     assert st == info["c2_160x90"]
     assert np.array_equal(rgba.view(np.uint32), z["c2_160x90_rgba_bits"])
     assert np.array_equal(gbuf, z["c2_160x90_gbuffer_f16"].astype(np.float32))

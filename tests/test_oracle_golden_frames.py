@@ -23,14 +23,28 @@ def _check(prefix, rgba, prim, depth, st):
     assert st == stats[prefix]
 
 
+def _check_literal(prefix, scene):
+    """both forms of the light loop are frozen: the shipped evaluation order (default) and the statement-by-statement
+    one (BBO_FLAG_LITERAL); they share coverage and depth and agree within BASELINE's tolerance"""
+    g, _ = _g()
+    lit = bbo.render(scene, flags=bbo.FLAG_LITERAL)[0]
+    assert np.array_equal(lit.view(np.uint32), g[prefix + "_literal_rgba_bits"])
+    ref = g[prefix + "_rgba_bits"].view(np.float32)
+    with np.errstate(invalid="ignore"):
+        ok = np.abs(lit - ref) <= 1e-4 * np.maximum(1.0, np.abs(lit))
+    assert np.all(ok | (np.isnan(lit) & np.isnan(ref)))
+
+
 def test_triangle_scene_golden():
     _check("triangle64", *bbo.render(scenes.triangle_scene(64, 64)))
+    _check_literal("triangle64", scenes.triangle_scene(64, 64))
 
 
 def test_c2_small_golden():
     mat = bbo.MaterialData(textures.make_material(64))
-    # the frozen frame is the LITERAL form of the light loop (statement by statement as the GLSL is written)
-    _check("c2_160x90", *bbo.render(scenes.shaderball_scene(configs.C2.scaled(160, 90, 64), mat), flags=bbo.FLAG_LITERAL))
+    sc = scenes.shaderball_scene(configs.C2.scaled(160, 90, 64), mat)
+    _check("c2_160x90", *bbo.render(sc))
+    _check_literal("c2_160x90", sc)
 
 
 def gizmo_inputs():

@@ -153,6 +153,12 @@ def golden_frames():
     mat = bbo.MaterialData(textures.make_material(64))
     rgba, prim, depth, st2 = bbo.render(scenes.shaderball_scene(configs.C2.scaled(160, 90, 64), mat))
     out.update({f"c2_160x90_{k}": v for k, v in pack(rgba, prim, depth).items()})
+    # the same frames with the light loop evaluated statement by statement as the GLSL is written (BBO_FLAG_LITERAL);
+    # the default above is the shipped evaluation order, which the GPU reproduces bit for bit
+    lit, _, _, _ = bbo.render(scenes.triangle_scene(64, 64), flags=bbo.FLAG_LITERAL)
+    out["triangle64_literal_rgba_bits"] = lit.view(np.uint32)
+    lit, _, _, _ = bbo.render(scenes.shaderball_scene(configs.C2.scaled(160, 90, 64), mat), flags=bbo.FLAG_LITERAL)
+    out["c2_160x90_literal_rgba_bits"] = lit.view(np.uint32)
     g = np.load(os.path.join(GOLD, "gizmo.npz"))
     v = np.zeros(len(g["vertices"]), bbo.GIZMO_VERTEX_DTYPE)
     v["pos"], v["color"], v["normal"] = g["vertices"][:, 0:3], g["vertices"][:, 3:6], g["vertices"][:, 6:9]
@@ -278,8 +284,10 @@ def deferred():
     rgba, gbuf, prim, depth, st = bbo.render_deferred(scenes.shaderball_scene(configs.C2.scaled(160, 90, 64), mat))
     g16 = gbuf.astype(np.float16)
     assert np.array_equal(g16.astype(np.float32), gbuf)
+    lit = bbo.render_deferred(scenes.shaderball_scene(configs.C2.scaled(160, 90, 64), mat), flags=bbo.FLAG_LITERAL)[0]
     np.savez_compressed(os.path.join(GOLD, "deferred.npz"), c2_160x90_rgba_bits=rgba.view(np.uint32), c2_160x90_gbuffer_f16=g16,
-                        c2_160x90_prim=prim, c2_160x90_depth_bits=depth.view(np.uint32))
+                        c2_160x90_prim=prim, c2_160x90_depth_bits=depth.view(np.uint32),
+                        c2_160x90_literal_rgba_bits=lit.view(np.uint32))
     info = {"c2_160x90": st, "rgba_sha256": hashlib.sha256(rgba.tobytes()).hexdigest(),
             "gbuffer_sha256": hashlib.sha256(g16.tobytes()).hexdigest()}
     json.dump(info, open(os.path.join(GOLD, "deferred.json"), "w"), indent=1)
