@@ -1660,7 +1660,7 @@ __global__ __launch_bounds__(kShadeThreads) void k_shade(
   // The frame's counter block has done its job (k_geometry filled it, k_raster read it): keep a copy for the host's
   // statistics / overflow check and clear the block for the next frame of this slot.  Frames of different slots
   // share nothing, so their kernels may overlap freely.
-  if (blockIdx.x == 0 && threadIdx.x < sizeof(Counters) / 4) {
+  if (!TAIL && blockIdx.x == 0 && threadIdx.x < sizeof(Counters) / 4) {  // (the main launch only)
     reinterpret_cast<uint32_t *>(ctr_done)[threadIdx.x] = reinterpret_cast<uint32_t *>(ctr)[threadIdx.x];
     reinterpret_cast<uint32_t *>(ctr)[threadIdx.x] = 0u;
   }

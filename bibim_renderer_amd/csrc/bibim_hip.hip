@@ -236,29 +236,14 @@ struct bbr_context {
   //      nothing (each slot has its own buffers and counter block), so whole frames overlap and no event is needed
   //      inside a frame.  The four context streams double as the slot streams: a process that owns more than a
   //      handful of HIP streams gets slower as a whole -- with seven streams every layout lost 60 %
-  // Which one is fastest depends on whether the geometry -> raster chain, the kernels' tails or the vector ALUs set
-  // the frame rate (1080p, one ShaderBall: 65 / 44 / 34 us per frame; 4K, sixteen: 156 / 160 / 152 us).  The automatic
-  // setting therefore times them on the first frames of a workload: after kTuneWarm frames (clocks, caches),
-  // kTuneRounds rounds of one span per layout, kTuneSpan frames each after kTuneSkip frames for the switch to settle
-  // (24-frame spans flattered layout 2 by 5 % at 4K; 64-frame spans agree with steady-state runs to 1 %);
-  // two events per span on the frame's shade stream, polled without blocking.  Alternating the spans cancels what a
-  // single pass does not (the first span of a fresh context runs on a GPU that is still ramping up).  Until the answer
-  // is in, and unless another layout wins by 7 %, layout 0 is used.
+  // A plain option with a fixed default, 2: measured with three frames in flight (us per frame, layouts 0 / 1 / 2) it is
+  // the fastest everywhere -- C2 1080p 84.5 / 67.1 / 37.3, C3 4K 191.5 / 153.6 / 148.6 -- because a frame's chain of
+  // dependent kernels (copy -> geometry -> raster -> items -> shade) then only waits for itself.  (Round 1 timed the
+  // layouts on the first ~500 frames of every workload and switched by itself; the measurement was fragile and made
+  // the frame rate a function of history.)
   static constexpr int kLayouts = 3;
-  int layout_mode = -1;  // the option: -1 automatic
-  int layout = 0;        // layout of the frame being submitted
-  static constexpr int kTuneWarm = 32, kTuneSkip = 12, kTuneSpan = 64, kTuneRounds = 2, kTuneSpans = kLayouts * kTuneRounds;
-  struct {
-    int phase = 0;   // 0 not started, 1 .. kTuneSpans timing layout (phase - 1) % kLayouts, then waiting, then decided
-    int count = 0;   // frames submitted in the current phase
-    int best = 0;
-    hipEvent_t ev[2 * kTuneSpans] = {};  // begin / end of each span
-    uint32_t key_prims = 0;
-    int32_t key_lights = -1;
-    bool key_deferred = false;
-    float ms[kLayouts] = {0.f, 0.f, 0.f};
-  } tune;
-  static constexpr int kTuneWaiting = kTuneSpans + 1, kTuneDecided = kTuneSpans + 2;
+  int layout_mode = 2;  // the option
+  int layout = 2;       // layout of the frame being submitted
   bool pipelined() const { return !user_stream && frames_in_flight > 1; }
   hipStream_t slot_stream(int i) const { return i == 0 ? s_raster : (i == 1 ? s_shade : (i == 2 ? s_present : s_geom)); }
   hipStream_t frame_geom_stream(int slot) const { return (pipelined() && layout == 2) ? slot_stream(slot) : geom_stream(); }
@@ -514,7 +499,7 @@ int apply_growth(bbr_context *c, uint32_t overflow, uint32_t bin_need) {
   if (overflow & 4u) c->clip_cap *= 2;
   ++c->retries;
   for (FrameSlot &s : c->slots) {
-    if (s.h_flags) s.h_flags[0] = s.h_flags[1] = 0u;  // they describe frames rendered with the old capacities
+    if (s.h_flags) s.h_flags[0] = s.h_flags[1] = s.h_flags[2] = 0u;  // they describe frames rendered with the old capacities
     // tile counters may hold residue of references that did not fit
     if (s.d_tile_count.ptr) HIP_TRY(c, zero_fill_sync(s.d_tile_count.ptr, s.d_tile_count.cap * sizeof(uint32_t)));
   }
@@ -582,47 +567,7 @@ int submit_frame_into(bbr_context *c, int slot_index) {
   if (inst_bytes) std::memcpy((uint8_t *)s.h_staging + lights_bytes + draws_bytes, c->host_instances.data(), inst_bytes);
 
   const int n_lights = std::min(std::max(c->frame_u.num_lights, 0), kMaxNumLights);
-  int tune_mark = -1;  // which of tune.ev to record behind this frame's k_shade
-  if (c->layout_mode >= 0 || !c->pipelined()) {
-    c->layout = std::max(c->layout_mode, 0);
-  } else {
-    auto &t = c->tune;
-    const bool same_workload = t.key_lights == n_lights && t.key_deferred == c->deferred &&
-                               c->n_prims <= t.key_prims + t.key_prims / 4 && c->n_prims + c->n_prims / 4 >= t.key_prims;
-    if (t.phase == 0 || !same_workload) {
-      t.phase = 1;
-      t.count = 0;
-      t.key_prims = c->n_prims;
-      t.key_lights = n_lights;
-      t.key_deferred = c->deferred;
-      for (hipEvent_t &e : t.ev)
-        if (!e) HIP_TRY(c, hipEventCreate(&e));
-    }
-    if (t.phase >= 1 && t.phase <= bbr_context::kTuneSpans) {
-      c->layout = (t.phase - 1) % bbr_context::kLayouts;
-      const int skip = bbr_context::kTuneSkip + (t.phase == 1 ? bbr_context::kTuneWarm : 0);
-      if (t.count == skip) tune_mark = (t.phase - 1) * 2;
-      if (t.count == skip + bbr_context::kTuneSpan) tune_mark = (t.phase - 1) * 2 + 1;
-    } else if (t.phase == bbr_context::kTuneWaiting) {
-      c->layout = 0;
-      if (hipEventQuery(t.ev[2 * bbr_context::kTuneSpans - 1]) == hipSuccess) {
-        for (float &m : t.ms) m = 0.f;
-        for (int k = 0; k < bbr_context::kTuneSpans; ++k) {
-          float ms = 0.f;
-          (void)hipEventElapsedTime(&ms, t.ev[2 * k], t.ev[2 * k + 1]);
-          t.ms[k % bbr_context::kLayouts] += ms;
-        }
-        t.best = 0;
-        for (int l = 1; l < bbr_context::kLayouts; ++l)
-          if (t.ms[l] > 0.f && t.ms[l] < 0.93f * t.ms[0] && (t.best == 0 || t.ms[l] < t.ms[t.best])) t.best = l;
-        t.phase = bbr_context::kTuneDecided;
-        if (getenv("BBR_DEBUG"))
-          fprintf(stderr, "[bbr] stream layout: %d frames take %.3f / %.3f / %.3f ms -> layout %d\n",
-                  bbr_context::kTuneSpan * bbr_context::kTuneRounds, t.ms[0], t.ms[1], t.ms[2], t.best);
-      }
-    }
-    if (t.phase == bbr_context::kTuneDecided) c->layout = t.best;
-  }
+  c->layout = c->pipelined() ? c->layout_mode : 0;
   hipStream_t sg = c->frame_geom_stream(slot_index);
   for (hipEvent_t e : c->pending_waits) HIP_TRY(c, hipStreamWaitEvent(sg, e, 0));  // bbr_wait_event
   c->pending_waits.clear();
@@ -655,19 +600,6 @@ int submit_frame_into(bbr_context *c, int slot_index) {
   if (c->tile_mode == 0) launch_frame<64, 64>(c, s, prev, fp, pv, view, sp, d_lights, d_draws, c->n_live_draws, out);
   else launch_frame<32, 32>(c, s, prev, fp, pv, view, sp, d_lights, d_draws, c->n_live_draws, out);
   HIP_TRY(c, hipGetLastError());
-  if (c->layout_mode < 0 && c->pipelined() && c->tune.phase >= 1 && c->tune.phase <= bbr_context::kTuneSpans) {
-    auto &t = c->tune;
-    if (tune_mark >= 0) {
-      // "every frame up to this one is done": with one stream per slot frames may finish out of order
-      for (const FrameSlot &o : c->slots)
-        if (&o != &s && o.in_flight && o.stream_used != s.stream_used) HIP_TRY(c, hipStreamWaitEvent(s.stream_used, o.ev_shade_done, 0));
-      HIP_TRY(c, hipEventRecord(t.ev[tune_mark], s.stream_used));
-    }
-    if (t.count++ == bbr_context::kTuneSkip + bbr_context::kTuneSpan + (t.phase == 1 ? bbr_context::kTuneWarm : 0)) {
-      ++t.phase;
-      t.count = 0;
-    }
-  }
   s.in_flight = true;
   s.fused = c->present_fused;
   s.present.active = c->present_fused;  // fused presentation: the frame IS the presented image
@@ -1120,8 +1052,6 @@ int bbr_destroy(bbr_context *c) {
   c->d_srgb_tables.release();
   if (c->s_geom) (void)hipStreamDestroy(c->s_geom);
   if (c->s_raster) (void)hipStreamDestroy(c->s_raster);
-  for (hipEvent_t e : c->tune.ev)
-    if (e) (void)hipEventDestroy(e);
   if (c->s_shade) (void)hipStreamDestroy(c->s_shade);
   if (c->s_present) (void)hipStreamDestroy(c->s_present);
   delete c;
@@ -1421,7 +1351,6 @@ int bbr_set_partition(bbr_context *c, int32_t rank, int32_t world, int32_t band_
   c->rank = rank;
   c->world = world;
   c->band_rows = band_rows;
-  c->tune.phase = 0;
   if (c->ext_out) {
     uint64_t need = (uint64_t)c->width * (world > 1 ? c->shard_rows() : c->height) * 16;
     if (c->ext_out_bytes < need) {
@@ -1454,7 +1383,7 @@ int bbr_resize(bbr_context *c, int32_t width, int32_t height) {
     s.present.copy_to = nullptr;
     s.out_used = nullptr;
     s.in_flight = false;
-    if (s.h_flags) s.h_flags[0] = s.h_flags[1] = 0u;
+    if (s.h_flags) s.h_flags[0] = s.h_flags[1] = s.h_flags[2] = 0u;
   };
   for (FrameSlot &s : c->slots) drop(s);
   drop(c->ov);
@@ -1463,7 +1392,6 @@ int bbr_resize(bbr_context *c, int32_t width, int32_t height) {
   c->d_gbuffer.release();
   c->have_frame = false;
   c->last_slot = -1;
-  c->tune.phase = 0;
   // a caller-owned output buffer was sized for the old extent: the caller sets it again (bbr_set_output_device_ptr)
   c->ext_out = nullptr;
   c->ext_out_bytes = 0;
@@ -1472,12 +1400,10 @@ int bbr_resize(bbr_context *c, int32_t width, int32_t height) {
 
 int bbr_stream_layout_state(const bbr_context *c, int32_t *out_layout, int32_t *out_decided, float *out_ms) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
-  const bool fixed = c->layout_mode >= 0 || !c->pipelined();
-  const bool decided = fixed || c->tune.phase == bbr_context::kTuneDecided;
-  if (out_layout) *out_layout = fixed ? (c->pipelined() ? c->layout_mode : 0) : (decided ? c->tune.best : 0);
-  if (out_decided) *out_decided = decided;
+  if (out_layout) *out_layout = c->pipelined() ? c->layout_mode : 0;
+  if (out_decided) *out_decided = 1;  // (the layout is a plain option: nothing is timed or decided at run time)
   if (out_ms)
-    for (int l = 0; l < bbr_context::kLayouts; ++l) out_ms[l] = (fixed || !decided) ? 0.f : c->tune.ms[l];
+    for (int l = 0; l < bbr_context::kLayouts; ++l) out_ms[l] = 0.f;
   return BBR_OK;
 }
 
@@ -1675,13 +1601,11 @@ int bbr_set_option(bbr_context *c, const char *name, int64_t value) {
     if (value < 1 || value > bbr_context::kMaxSlots) return fail(c, BBR_ERR_INVALID_ARGUMENT, "frames_in_flight: 1 .. 4");
     c->frames_in_flight = (int)value;
     c->frame_counter = 0;
-    c->tune.phase = 0;
   } else if (n == "tile_mode") {
     if (value != 0 && value != 1) return fail(c, BBR_ERR_INVALID_ARGUMENT, "tile_mode: 0 (64x64) or 1 (32x32)");
     if (c->world > 1 && c->band_rows % (value == 0 ? 64 : 32))
       return fail(c, BBR_ERR_INVALID_ARGUMENT, "tile_mode: band_rows not a multiple of the new tile height");
     c->tile_mode = (int)value;
-    c->tune.phase = 0;
     // bins and fragment lists are laid out per tile: drop them so that ensure() re-zeroes the counters
     for (FrameSlot &s : c->slots) s.release_tile_buffers();
   } else if (n == "bin_cap") {
@@ -1701,9 +1625,8 @@ int bbr_set_option(bbr_context *c, const char *name, int64_t value) {
   } else if (n == "tile_order") {
     c->tile_order = value != 0;
   } else if (n == "stream_layout") {
-    if (value < -1 || value >= bbr_context::kLayouts) return fail(c, BBR_ERR_INVALID_ARGUMENT, "stream_layout: -1 (automatic), 0, 1 or 2");
+    if (value < 0 || value >= bbr_context::kLayouts) return fail(c, BBR_ERR_INVALID_ARGUMENT, "stream_layout: 0, 1 or 2");
     c->layout_mode = (int)value;
-    c->tune.phase = 0;
   } else if (n == "broad_threshold") {
     if (value < 1) return fail(c, BBR_ERR_INVALID_ARGUMENT, "broad_threshold must be >= 1");
     c->broad_threshold = (uint32_t)value;

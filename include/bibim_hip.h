@@ -192,19 +192,16 @@ int bbr_timing_summary(bbr_context *ctx, uint32_t *out_frames, float *out_avg_fr
  *   "overlays" 0|1           keep every frame's resolved depth for bbr_draw_overlays (default 0)
  *   "tile_order" 0|1         launch the heaviest raster tiles first (shorter single frame, lower pipelined
  *                            throughput; default 0)
- *   "stream_layout" -1|0|1|2 how the kernels of the frames in flight are spread over HIP streams.  Same pixels in every
- *                            layout; which is fastest depends on the workload.  0: geometry + raster on one stream,
- *                            shade on a second, present on a third.  1: as 0 with k_raster on a stream of its own (the
- *                            geometry of frame N+1 overlaps the raster of frame N).  2: every kernel of a frame on the
- *                            stream of its frame slot (frames share nothing, whole frames overlap).
- *                            1080p, one ShaderBall: 65 / 44 / 34 us per frame; 4K, sixteen: 156 / 160 / 152 us.
- *                            -1 (default): the context times the three, alternating, over the first 500 frames of a
- *                            workload (nothing blocks; layout 0 meanwhile, and kept unless another wins by 7 %);
- *                            bbr_stream_layout_state reports
- *   "ablate" bits            diagnostics only: skip parts of the pipeline (see bb_kernels.hip.h) */
+ *   "stream_layout" 0|1|2    how the kernels of the frames in flight are spread over HIP streams.  Same pixels in every
+ *                            layout.  0: geometry + raster on one stream, shade on a second, present on a third.
+ *                            1: as 0 with k_raster on a stream of its own (the geometry of frame N+1 overlaps the
+ *                            raster of frame N).  2 (default): every kernel of a frame on the stream of its frame slot
+ *                            (frames share nothing, whole frames overlap).  Three frames in flight, us per frame for
+ *                            0 / 1 / 2: 1080p, one ShaderBall 84.5 / 67.1 / 37.3; 4K, sixteen 191.5 / 153.6 / 148.6.
+ *   "ablate" bits            diagnostic builds only (make EXTRA=-DBB_ABLATE): skip parts of the pipeline */
 int bbr_set_option(bbr_context *ctx, const char *name, int64_t value);
-/* What option "stream_layout" resolved to: *out_decided = 0 while the automatic choice is still being measured;
- * out_ms[3] = the time the measured spans took per layout (0 when the layout was set by hand). */
+/* The stream layout in use (option "stream_layout"; 0 while only one frame is in flight).  *out_decided is always 1 and
+ * out_ms[3] all zero: the layout is a plain option, nothing is timed at run time (round 1 did). */
 int bbr_stream_layout_state(const bbr_context *ctx, int32_t *out_layout, int32_t *out_decided, float *out_ms);
 /* Self-test of the arithmetic contract on this device: the shader's reciprocal (v_rcp_f32 + one Newton step) against
  * the IEEE division for +x and -x of every float with bit pattern in [lo_bits, hi_bits); 0 mismatches expected.

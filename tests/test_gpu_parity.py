@@ -612,10 +612,10 @@ def test_resize_keeps_resources_and_renders_the_new_extent_exactly(maps64):
     r.close()
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, -1])
+@pytest.mark.parametrize("mode", [0, 1, 2, "switching"])
 def test_stream_layouts_render_the_same_frames(maps64, mode):
-    """option "stream_layout": stage streams, k_raster on its own stream, one stream per frame slot, or switched back and
-    forth while the context times the three (the automatic setting) -- the frames, their presented images and tone-mapped
+    """option "stream_layout": stage streams, k_raster on its own stream, one stream per frame slot (the default), or
+    switched by the caller every few frames with frames in flight -- the frames, their presented images and tone-mapped
     copies are the oracle's, bit for bit, throughout"""
     sc = scenes.shaderball_scene(configs.C3.scaled(640, 360, 64), bbo.MaterialData(maps64))
     sc.frame["enable_tone_mapping"], sc.frame["exposure"] = 1, 1.3
@@ -623,32 +623,57 @@ def test_stream_layouts_render_the_same_frames(maps64, mode):
     want8 = bbo.present(ref, 1, 1.3)
     r = Renderer(sc.width, sc.height)
     r.set_option("frames_in_flight", 3)
-    r.set_option("stream_layout", mode)
+    assert r.stream_layout_state() == (2, 1, [0, 0, 0])      # the documented default; nothing is timed at run time
+    if mode != "switching":
+        r.set_option("stream_layout", mode)
     h = None
-    for i in range(520):
+    for i in range(260):
+        if mode == "switching" and i % 7 == 0:
+            r.set_option("stream_layout", (i // 7) % 3)
         h = r.render_scene(sc, h)
         if i % 5 == 0:
             r.present()                  # queued behind the frame's k_shade, whichever stream that ran on
-        if i % 23 == 0 or i == 519:      # the read-back drains the pipeline: the switches happen at different depths
+        if i % 23 == 0 or i == 259:      # the read-back drains the pipeline: the switches happen at different depths
             assert np.array_equal(r.read_framebuffer().view(np.uint32), ref.view(np.uint32)), f"frame {i}"
             if i % 5 == 0:
                 assert np.array_equal(r.read_presented(), want8), f"presented frame {i}"
     layout, decided, ms = r.stream_layout_state()
-    if mode >= 0:
-        assert decided and layout == mode and ms == [0, 0, 0]
-    else:
-        for _ in range(4):
-            h = r.render_scene(sc, h)
-        layout, decided, ms = r.stream_layout_state()
-        assert decided and layout in (0, 1, 2) and min(ms) > 0
-        sc2 = scenes.shaderball_scene(configs.C2.scaled(640, 360, 64), sc.draws[0].material)   # another workload: timed afresh
-        r.render_scene(sc2, h)
-        assert not r.stream_layout_state()[1]
-        ref2, _, _, _ = bbo.render(sc2)
-        assert np.array_equal(r.read_framebuffer().view(np.uint32), ref2.view(np.uint32))
+    assert decided and ms == [0, 0, 0] and (layout == mode or mode == "switching")
+    sc2 = scenes.shaderball_scene(configs.C2.scaled(640, 360, 64), sc.draws[0].material)   # another workload, more fragments
+    r.render_scene(sc2, h)                                                                  # than the slots expect
+    ref2, _, _, _ = bbo.render(sc2)
+    assert np.array_equal(r.read_framebuffer().view(np.uint32), ref2.view(np.uint32))
     r.tone_map(1, 1.3)                   # in place, on the stream the frame's k_shade ran on
     with pytest.raises(BibimError):
         r.set_option("stream_layout", 3)
+    with pytest.raises(BibimError):
+        r.set_option("stream_layout", -1)
+    r.close()
+
+
+@pytest.mark.parametrize("layout", [0, 2])
+def test_a_frame_with_many_more_fragments_than_the_one_before(maps64, layout):
+    """k_shade's main launch is sized from the item count of the frame the slot rendered before; whatever lies behind it
+    is shaded by the small persistent tail launch.  A nearly empty frame followed by a full one (and back) in every
+    frame slot, with frames in flight: every frame is the oracle's, bit for bit"""
+    big = scenes.shaderball_scene(configs.C3.scaled(960, 540, 64), bbo.MaterialData(maps64))
+    small = scenes.triangle_scene(960, 540)
+    ref_big, _, _, st_big = bbo.render(big)
+    ref_small, _, _, st_small = bbo.render(small)
+    assert st_big["n_shaded"] > 10 * st_small["n_shaded"] > 0
+    r = Renderer(960, 540)
+    r.set_option("frames_in_flight", 3)
+    r.set_option("stream_layout", layout)
+    hb = hs = None
+    for rep in range(3):
+        for _ in range(4):                       # every slot has seen the small frame
+            hs = r.render_scene(small, hs)
+        assert np.array_equal(r.read_framebuffer().view(np.uint32), ref_small.view(np.uint32))
+        for i in range(4):                       # ... and now gets the big one: the tail shades nearly all of it
+            hb = r.render_scene(big, hb)
+            if i in (0, 3):
+                assert np.array_equal(r.read_framebuffer().view(np.uint32), ref_big.view(np.uint32)), (rep, i)
+        assert r.stats()["n_shaded"] == st_big["n_shaded"]
     r.close()
 
 

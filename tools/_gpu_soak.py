@@ -57,7 +57,7 @@ while time.time() < t_end:
         assert np.array_equal(r.read_presented(), last[1]), "presented image differs"
         n_checks += 1
     elif op == "layout":
-        r.set_option("stream_layout", rng.choice([-1, 0, 1, 2]))
+        r.set_option("stream_layout", rng.choice([0, 1, 2]))
     elif op == "fif":
         r.set_option("frames_in_flight", rng.choice([1, 2, 3, 4]))
     elif op == "resize":
