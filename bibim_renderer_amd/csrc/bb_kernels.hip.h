@@ -175,6 +175,10 @@ BB_DEV f3 normalize3(f3 a) { return scale3(a, bb_rsqrt(dot3(a, a))); }
 // maxNum with -0 < +0; k_selftest_rcp checks every bit pattern), and costs one instruction where the compiler, which
 // may not assume the -0 case, emits a compare and a select.
 BB_DEV float max0(float a) { return __builtin_fmaxf(a, 0.0f); }
+// saturate: clamp to [0, 1], NaN -> +0 (the `clamp` output modifier of the producing instruction under DX10_CLAMP, the
+// float mode HIP kernels run in: no instruction of its own, where v_max_f32 is a half-rate one that also breaks the
+// 2-cycle issue cadence of the fma / mul stream around it -- profiles/r02_issue_rate.txt)
+BB_DEV float sat01(float a) { return __builtin_amdgcn_fmed3f(a, 0.0f, 1.0f); }
 
 BB_DEV f4 mat4_mul(const Mat4 &m, f4 v) {
   f4 r;
@@ -1389,6 +1393,8 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
 //   D G / max(4 NdotV NdotL, .001) = (a2 NdotV NdotL) / ((q q) (PI dV dL) sden)   one reciprocal instead of four
 //   kD albedo / PI                 = (1 - F) ((1 - metallic) albedo / PI)         hoisted out of the loop
 //   radiance NdotL                 = (color intensity) (att NdotL)                color * intensity once per light
+//   max(N.V, 0), max(N.L, 0), max(H.V, 0) = saturate(...)   the three cosines that do not feed q: differs only where
+//                                                           rounding puts a cosine of unit vectors above 1 (<= 2 ulp)
 // Why the shape matters on gfx950 (tools/microbench/issue_rate.hip, profiles/r02_issue_rate.txt): v_fma/mul/add_f32 on
 // VGPR operands issue every 2 cycles per SIMD, but ANY scalar-register operand, v_max, v_cmp, every conversion and
 // v_pk_* cost 4, v_rcp 8.  Light data therefore reaches the loop through LDS (ds_read broadcasts cost no vector-ALU
@@ -1441,7 +1447,7 @@ BB_DEV float4 light_surface(const ShadeParams &sp, const ShadeShared &sh, f3 P, 
   // per-pixel invariants
   const f3 V = normalize3(sub3(mk3(sh.view_pos[0], sh.view_pos[1], sh.view_pos[2]), P));
   const f3 N = normalize3(normal);
-  const float NdotV = max0(dot3(V, N));
+  const float NdotV = sat01(dot3(V, N));
   const float rr = roughness + 1.0f;
   const float kk = (rr * rr) * 0.125f, omk = 1.0f - kk;
   const float pidV = kPi * fmaf(NdotV, omk, kk);
@@ -1486,10 +1492,10 @@ BB_DEV float4 light_surface(const ShadeParams &sp, const ShadeShared &sh, f3 P, 
     const f3 H = normalize3(add3(L, V));
     const float NdotH = max0(dot3(N, H));
     const float q = fmaf(NdotH * NdotH, a2m1, 1.0f);
-    const float x = 1.0f - max0(dot3(H, V));
+    const float x = 1.0f - sat01(dot3(H, V));
     const float x2 = x * x;
     const float p5 = (x2 * x2) * x;
-    const float NdotL = max0(dot3(N, L));
+    const float NdotL = sat01(dot3(N, L));
     const float dL = fmaf(NdotL, omk, kk);
     const float sden = __builtin_fmaxf(c4 * NdotL, 0.001f);  // NaN -> 0.001
     const float den = ((q * q) * (pidV * dL)) * sden;

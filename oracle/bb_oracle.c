@@ -343,6 +343,8 @@ static void light_surface(const bbo_frame_uniforms *fu, const bbo_view_uniforms 
  *       with dX = NdotX (1 - k) + k (geometrySchlickGGX's denominator), sden = max(4 NdotV NdotL, .001)
  *   kD albedo / PI                  =  (1 - F) ((1 - metallic) albedo (1/PI))         hoisted out of the loop
  *   radiance NdotL                  =  (color intensity) (att NdotL)                  color*intensity once per light
+ *   max(N.V,0), max(N.L,0), max(H.V,0) = saturate(...)  for the three cosines that do not feed q (N.H keeps max(.,0)):
+ *                                      differs only where rounding puts a cosine of unit vectors above 1 (<= 2 ulp)
  * The per-light constants (color*intensity, the normalised spot / directional direction, 1/epsilon) are
  * evaluated once per light and frame ("cooked" lights) -- the same operations as the literal form, hoisted.
  * The two forms agree to a few ulp of the result (tests/test_oracle_contract.py checks <= 1e-5 relative on
@@ -373,6 +375,7 @@ static void cook_light(const bbo_light *l, cooked_light *c) {
 }
 
 static inline float fmax_nan_lo(float a, float lo) { return a > lo ? a : lo; } /* max(a, lo), NaN -> lo */
+static inline float sat01(float a) { return a > 0.0f ? (a < 1.0f ? a : 1.0f) : 0.0f; } /* clamp to [0,1], NaN -> 0 */
 
 static void light_surface_contract(const bbo_frame_uniforms *fu, const bbo_view_uniforms *vu, const surface *s, float *out) {
   const v3 P = s->P, albedo = s->albedo;
@@ -382,7 +385,7 @@ static void light_surface_contract(const bbo_frame_uniforms *fu, const bbo_view_
   /* per-pixel invariants */
   const v3 V = normalize3(sub3(v3_ld(vu->view_pos), P));
   const v3 N = normalize3(s->normal);
-  const float NdotV = max0(dot3(V, N));
+  const float NdotV = sat01(dot3(V, N));
   const float rr = roughness + 1.0f;
   const float kk = (rr * rr) * 0.125f, omk = 1.0f - kk;
   const float pidV = BB_PI * fmaf(NdotV, omk, kk);
@@ -414,10 +417,10 @@ static void light_surface_contract(const bbo_frame_uniforms *fu, const bbo_view_
     const v3 H = normalize3(add3(L, V));
     const float NdotH = max0(dot3(N, H));
     const float q = fmaf(NdotH * NdotH, a2m1, 1.0f);
-    const float x = 1.0f - max0(dot3(H, V));
+    const float x = 1.0f - sat01(dot3(H, V));
     const float x2 = x * x;
     const float p5 = (x2 * x2) * x;
-    const float NdotL = max0(dot3(N, L));
+    const float NdotL = sat01(dot3(N, L));
     const float dL = fmaf(NdotL, omk, kk);
     const float sden = fmax_nan_lo(c4 * NdotL, 0.001f);
     const float den = ((q * q) * (pidV * dL)) * sden;

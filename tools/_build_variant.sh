@@ -6,5 +6,5 @@ name=$1; shift
 src=bibim_renderer_amd/csrc
 if [ -d "$1" ]; then src=$1; shift; fi
 mkdir -p tools/_tmp/variants
-/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fPIC -shared -Wno-unused-function \
+/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -fPIC -shared -Wno-unused-function \
   -Iinclude "$@" $src/bibim_hip.hip $src/bb_scene.cpp $src/bb_assets.cpp -o tools/_tmp/variants/$name.so -lz

@@ -208,6 +208,860 @@ constexpr int kIters = 2048;  // x 64 instructions = 131072 per wave
 #define X_DEF(NAME, T, M, PRE, N) DEF_OP(NAME, T, M, PRE)
 OPS(X_DEF)
 
+
+// ---- the light loop of k_shade (one point light, the hot path: 83 vector instructions copied from the compiled kernel) ----
+__global__ __launch_bounds__(1024) void k_lightloop(unsigned long long *__restrict__ stamps, float a, float b, float *sink) {
+  extern __shared__ char lds[];
+  if (threadIdx.x == 1023) lds[0] = 1;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < kIters; ++it) {
+    asm volatile(
+      "v_pk_add_f32 v[4:5], v[4:5], v[12:13] neg_lo:[0,1] neg_hi:[0,1]\n"
+      "v_sub_f32_e32 v23, v6, v14\n"
+      "v_mul_f32_e32 v38, v4, v4\n"
+      "v_fmac_f32_e32 v38, v5, v5\n"
+      "v_fmac_f32_e32 v38, v23, v23\n"
+      "v_lshrrev_b32_e32 v6, 1, v38\n"
+      "v_sub_u32_e32 v6, 0x5f375a86, v6\n"
+      "v_mul_f32_e32 v39, 0.5, v38\n"
+      "v_mul_f32_e64 v54, v39, -v6\n"
+      "v_fmaak_f32 v54, v54, v6, 0x3fc00000\n"
+      "v_mul_f32_e32 v6, v54, v6\n"
+      "v_mul_f32_e64 v54, v39, -v6\n"
+      "v_fmaak_f32 v54, v54, v6, 0x3fc00000\n"
+      "v_mul_f32_e32 v6, v6, v54\n"
+      "v_mul_f32_e64 v39, v39, -v6\n"
+      "v_fmaak_f32 v39, v39, v6, 0x3fc00000\n"
+      "v_mul_f32_e32 v6, v6, v39\n"
+      "v_cmp_class_f32_e32 vcc, v38, v51\n"
+      "v_add_f32_e32 v4, v11, v38\n"
+      "v_add_f32_e32 v5, v15, v39\n"
+      "v_mul_f32_e32 v55, v4, v4\n"
+      "v_add_f32_e32 v6, v43, v23\n"
+      "v_fmac_f32_e32 v55, v5, v5\n"
+      "v_fmac_f32_e32 v55, v6, v6\n"
+      "v_lshrrev_b32_e32 v56, 1, v55\n"
+      "v_sub_u32_e32 v56, 0x5f375a86, v56\n"
+      "v_mul_f32_e32 v57, 0.5, v55\n"
+      "v_mul_f32_e64 v58, v57, -v56\n"
+      "v_fmaak_f32 v58, v58, v56, 0x3fc00000\n"
+      "v_mul_f32_e32 v56, v58, v56\n"
+      "v_mul_f32_e64 v58, v57, -v56\n"
+      "v_fmaak_f32 v58, v58, v56, 0x3fc00000\n"
+      "v_mul_f32_e32 v56, v56, v58\n"
+      "v_mul_f32_e64 v57, v57, -v56\n"
+      "v_fmaak_f32 v57, v57, v56, 0x3fc00000\n"
+      "v_mul_f32_e32 v57, v56, v57\n"
+      "v_cmp_class_f32_e32 vcc, v55, v51\n"
+      "v_mul_f32_e32 v56, v4, v57\n"
+      "v_mul_f32_e32 v55, v5, v57\n"
+      "v_mul_f32_e32 v4, v20, v56\n"
+      "v_mul_f32_e32 v6, v6, v57\n"
+      "v_fmac_f32_e32 v4, v44, v55\n"
+      "v_fmac_f32_e32 v4, v45, v6\n"
+      "v_max_f32_e32 v4, 0, v4\n"
+      "v_mul_f32_e32 v5, v4, v4\n"
+      "v_mul_f32_e32 v4, v20, v38\n"
+      "v_fmac_f32_e32 v4, v44, v39\n"
+      "v_fmac_f32_e32 v4, v45, v23\n"
+      "v_max_f32_e32 v4, 0, v4\n"
+      "v_mul_f32_e32 v23, v47, v4\n"
+      "v_pk_fma_f32 v[38:39], v[4:5], v[18:19], v[16:17]\n"
+      "v_max_f32_e32 v57, 0x3a83126f, v23\n"
+      "v_mov_b32_e32 v23, v39\n"
+      "v_pk_mul_f32 v[38:39], v[22:23], v[38:39]\n"
+      "v_mul_f32_e32 v5, v38, v39\n"
+      "v_mul_f32_e32 v23, v57, v5\n"
+      "v_rcp_f32_e32 v5, v23\n"
+      "v_fma_f32 v38, -v23, v5, 1.0\n"
+      "v_cmp_class_f32_e32 vcc, v5, v53\n"
+      "v_fmac_f32_e32 v5, v5, v38\n"
+      "v_mul_f32_e32 v23, v11, v56\n"
+      "v_fmac_f32_e32 v23, v55, v15\n"
+      "v_fmac_f32_e32 v23, v6, v43\n"
+      "v_max_f32_e32 v6, 0, v23\n"
+      "v_sub_f32_e32 v6, 1.0, v6\n"
+      "v_mul_f32_e32 v23, v6, v6\n"
+      "v_mul_f32_e32 v23, v23, v23\n"
+      "v_mul_f32_e32 v6, v6, v23\n"
+      "v_mul_f32_e32 v23, v46, v4\n"
+      "v_mul_f32_e32 v38, v23, v5\n"
+      "v_pk_fma_f32 v[56:57], v[28:29], v[6:7], v[26:27] op_sel_hi:[1,0,1]\n"
+      "v_fma_f32 v5, v49, v6, v48\n"
+      "v_mul_f32_e32 v4, v54, v4\n"
+      "v_pk_add_f32 v[54:55], v[56:57], 1.0 op_sel_hi:[1,0] neg_lo:[1,0] neg_hi:[1,0]\n"
+      "v_pk_mul_f32 v[56:57], v[56:57], v[38:39] op_sel_hi:[1,0]\n"
+      "v_pk_mul_f32 v[8:9], v[8:9], v[4:5] op_sel_hi:[1,0]\n"
+      "v_sub_f32_e32 v6, 1.0, v5\n"
+      "v_mul_f32_e32 v5, v5, v38\n"
+      "v_pk_fma_f32 v[54:55], v[54:55], v[30:31], v[56:57]\n"
+      "v_fmac_f32_e32 v5, v6, v50\n"
+      "v_mul_f32_e32 v4, v10, v4\n"
+      "v_pk_fma_f32 v[24:25], v[54:55], v[8:9], v[24:25]\n"
+      "v_fmac_f32_e32 v2, v5, v4\n"
+      ::: "vcc", "scc", "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58");
+  }
+  asm volatile("s_nop 0" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = ((r1 - r0) << 32) | (t1 - t0);
+  if (t1 == 1) sink[0] = a + b;
+}
+constexpr int kLightLoopInstrs = 83;
+
+// ---- source operands drawn from a pool of registers (real code), not the same two for every instruction ----
+__global__ __launch_bounds__(1024) void k_operands_fma_3_distinct_srcs(unsigned long long *__restrict__ stamps, float a, float b, float *sink) {
+  extern __shared__ char lds[];
+  if (threadIdx.x == 1023) lds[0] = 1;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < kIters; ++it) {
+    asm volatile(
+      "v_fma_f32 v60, v68, v73, v78\n"
+      "v_fma_f32 v61, v71, v76, v81\n"
+      "v_fma_f32 v62, v74, v79, v60\n"
+      "v_fma_f32 v63, v77, v82, v63\n"
+      "v_fma_f32 v64, v80, v61, v66\n"
+      "v_fma_f32 v65, v83, v64, v69\n"
+      "v_fma_f32 v66, v62, v67, v72\n"
+      "v_fma_f32 v67, v65, v70, v75\n"
+      "v_fma_f32 v60, v68, v73, v78\n"
+      "v_fma_f32 v61, v71, v76, v81\n"
+      "v_fma_f32 v62, v74, v79, v60\n"
+      "v_fma_f32 v63, v77, v82, v63\n"
+      "v_fma_f32 v64, v80, v61, v66\n"
+      "v_fma_f32 v65, v83, v64, v69\n"
+      "v_fma_f32 v66, v62, v67, v72\n"
+      "v_fma_f32 v67, v65, v70, v75\n"
+      "v_fma_f32 v60, v68, v73, v78\n"
+      "v_fma_f32 v61, v71, v76, v81\n"
+      "v_fma_f32 v62, v74, v79, v60\n"
+      "v_fma_f32 v63, v77, v82, v63\n"
+      "v_fma_f32 v64, v80, v61, v66\n"
+      "v_fma_f32 v65, v83, v64, v69\n"
+      "v_fma_f32 v66, v62, v67, v72\n"
+      "v_fma_f32 v67, v65, v70, v75\n"
+      "v_fma_f32 v60, v68, v73, v78\n"
+      "v_fma_f32 v61, v71, v76, v81\n"
+      "v_fma_f32 v62, v74, v79, v60\n"
+      "v_fma_f32 v63, v77, v82, v63\n"
+      "v_fma_f32 v64, v80, v61, v66\n"
+      "v_fma_f32 v65, v83, v64, v69\n"
+      "v_fma_f32 v66, v62, v67, v72\n"
+      "v_fma_f32 v67, v65, v70, v75\n"
+      "v_fma_f32 v60, v68, v73, v78\n"
+      "v_fma_f32 v61, v71, v76, v81\n"
+      "v_fma_f32 v62, v74, v79, v60\n"
+      "v_fma_f32 v63, v77, v82, v63\n"
+      "v_fma_f32 v64, v80, v61, v66\n"
+      "v_fma_f32 v65, v83, v64, v69\n"
+      "v_fma_f32 v66, v62, v67, v72\n"
+      "v_fma_f32 v67, v65, v70, v75\n"
+      "v_fma_f32 v60, v68, v73, v78\n"
+      "v_fma_f32 v61, v71, v76, v81\n"
+      "v_fma_f32 v62, v74, v79, v60\n"
+      "v_fma_f32 v63, v77, v82, v63\n"
+      "v_fma_f32 v64, v80, v61, v66\n"
+      "v_fma_f32 v65, v83, v64, v69\n"
+      "v_fma_f32 v66, v62, v67, v72\n"
+      "v_fma_f32 v67, v65, v70, v75\n"
+      "v_fma_f32 v60, v68, v73, v78\n"
+      "v_fma_f32 v61, v71, v76, v81\n"
+      "v_fma_f32 v62, v74, v79, v60\n"
+      "v_fma_f32 v63, v77, v82, v63\n"
+      "v_fma_f32 v64, v80, v61, v66\n"
+      "v_fma_f32 v65, v83, v64, v69\n"
+      "v_fma_f32 v66, v62, v67, v72\n"
+      "v_fma_f32 v67, v65, v70, v75\n"
+      "v_fma_f32 v60, v68, v73, v78\n"
+      "v_fma_f32 v61, v71, v76, v81\n"
+      "v_fma_f32 v62, v74, v79, v60\n"
+      "v_fma_f32 v63, v77, v82, v63\n"
+      "v_fma_f32 v64, v80, v61, v66\n"
+      "v_fma_f32 v65, v83, v64, v69\n"
+      "v_fma_f32 v66, v62, v67, v72\n"
+      "v_fma_f32 v67, v65, v70, v75\n"
+      ::: "vcc", "scc", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83");
+  }
+  asm volatile("s_nop 0" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = ((r1 - r0) << 32) | (t1 - t0);
+  if (t1 == 1) sink[0] = a + b;
+}
+
+__global__ __launch_bounds__(1024) void k_operands_fma_2_distinct_srcs(unsigned long long *__restrict__ stamps, float a, float b, float *sink) {
+  extern __shared__ char lds[];
+  if (threadIdx.x == 1023) lds[0] = 1;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < kIters; ++it) {
+    asm volatile(
+      "v_fma_f32 v60, v68, v68, v73\n"
+      "v_fma_f32 v61, v71, v71, v76\n"
+      "v_fma_f32 v62, v74, v74, v79\n"
+      "v_fma_f32 v63, v77, v77, v82\n"
+      "v_fma_f32 v64, v80, v80, v61\n"
+      "v_fma_f32 v65, v83, v83, v64\n"
+      "v_fma_f32 v66, v62, v62, v67\n"
+      "v_fma_f32 v67, v65, v65, v70\n"
+      "v_fma_f32 v60, v68, v68, v73\n"
+      "v_fma_f32 v61, v71, v71, v76\n"
+      "v_fma_f32 v62, v74, v74, v79\n"
+      "v_fma_f32 v63, v77, v77, v82\n"
+      "v_fma_f32 v64, v80, v80, v61\n"
+      "v_fma_f32 v65, v83, v83, v64\n"
+      "v_fma_f32 v66, v62, v62, v67\n"
+      "v_fma_f32 v67, v65, v65, v70\n"
+      "v_fma_f32 v60, v68, v68, v73\n"
+      "v_fma_f32 v61, v71, v71, v76\n"
+      "v_fma_f32 v62, v74, v74, v79\n"
+      "v_fma_f32 v63, v77, v77, v82\n"
+      "v_fma_f32 v64, v80, v80, v61\n"
+      "v_fma_f32 v65, v83, v83, v64\n"
+      "v_fma_f32 v66, v62, v62, v67\n"
+      "v_fma_f32 v67, v65, v65, v70\n"
+      "v_fma_f32 v60, v68, v68, v73\n"
+      "v_fma_f32 v61, v71, v71, v76\n"
+      "v_fma_f32 v62, v74, v74, v79\n"
+      "v_fma_f32 v63, v77, v77, v82\n"
+      "v_fma_f32 v64, v80, v80, v61\n"
+      "v_fma_f32 v65, v83, v83, v64\n"
+      "v_fma_f32 v66, v62, v62, v67\n"
+      "v_fma_f32 v67, v65, v65, v70\n"
+      "v_fma_f32 v60, v68, v68, v73\n"
+      "v_fma_f32 v61, v71, v71, v76\n"
+      "v_fma_f32 v62, v74, v74, v79\n"
+      "v_fma_f32 v63, v77, v77, v82\n"
+      "v_fma_f32 v64, v80, v80, v61\n"
+      "v_fma_f32 v65, v83, v83, v64\n"
+      "v_fma_f32 v66, v62, v62, v67\n"
+      "v_fma_f32 v67, v65, v65, v70\n"
+      "v_fma_f32 v60, v68, v68, v73\n"
+      "v_fma_f32 v61, v71, v71, v76\n"
+      "v_fma_f32 v62, v74, v74, v79\n"
+      "v_fma_f32 v63, v77, v77, v82\n"
+      "v_fma_f32 v64, v80, v80, v61\n"
+      "v_fma_f32 v65, v83, v83, v64\n"
+      "v_fma_f32 v66, v62, v62, v67\n"
+      "v_fma_f32 v67, v65, v65, v70\n"
+      "v_fma_f32 v60, v68, v68, v73\n"
+      "v_fma_f32 v61, v71, v71, v76\n"
+      "v_fma_f32 v62, v74, v74, v79\n"
+      "v_fma_f32 v63, v77, v77, v82\n"
+      "v_fma_f32 v64, v80, v80, v61\n"
+      "v_fma_f32 v65, v83, v83, v64\n"
+      "v_fma_f32 v66, v62, v62, v67\n"
+      "v_fma_f32 v67, v65, v65, v70\n"
+      "v_fma_f32 v60, v68, v68, v73\n"
+      "v_fma_f32 v61, v71, v71, v76\n"
+      "v_fma_f32 v62, v74, v74, v79\n"
+      "v_fma_f32 v63, v77, v77, v82\n"
+      "v_fma_f32 v64, v80, v80, v61\n"
+      "v_fma_f32 v65, v83, v83, v64\n"
+      "v_fma_f32 v66, v62, v62, v67\n"
+      "v_fma_f32 v67, v65, v65, v70\n"
+      ::: "vcc", "scc", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83");
+  }
+  asm volatile("s_nop 0" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = ((r1 - r0) << 32) | (t1 - t0);
+  if (t1 == 1) sink[0] = a + b;
+}
+
+__global__ __launch_bounds__(1024) void k_operands_fmac_2_distinct_srcs(unsigned long long *__restrict__ stamps, float a, float b, float *sink) {
+  extern __shared__ char lds[];
+  if (threadIdx.x == 1023) lds[0] = 1;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < kIters; ++it) {
+    asm volatile(
+      "v_fmac_f32 v60, v68, v73\n"
+      "v_fmac_f32 v61, v71, v76\n"
+      "v_fmac_f32 v62, v74, v79\n"
+      "v_fmac_f32 v63, v77, v82\n"
+      "v_fmac_f32 v64, v80, v61\n"
+      "v_fmac_f32 v65, v83, v64\n"
+      "v_fmac_f32 v66, v62, v67\n"
+      "v_fmac_f32 v67, v65, v70\n"
+      "v_fmac_f32 v60, v68, v73\n"
+      "v_fmac_f32 v61, v71, v76\n"
+      "v_fmac_f32 v62, v74, v79\n"
+      "v_fmac_f32 v63, v77, v82\n"
+      "v_fmac_f32 v64, v80, v61\n"
+      "v_fmac_f32 v65, v83, v64\n"
+      "v_fmac_f32 v66, v62, v67\n"
+      "v_fmac_f32 v67, v65, v70\n"
+      "v_fmac_f32 v60, v68, v73\n"
+      "v_fmac_f32 v61, v71, v76\n"
+      "v_fmac_f32 v62, v74, v79\n"
+      "v_fmac_f32 v63, v77, v82\n"
+      "v_fmac_f32 v64, v80, v61\n"
+      "v_fmac_f32 v65, v83, v64\n"
+      "v_fmac_f32 v66, v62, v67\n"
+      "v_fmac_f32 v67, v65, v70\n"
+      "v_fmac_f32 v60, v68, v73\n"
+      "v_fmac_f32 v61, v71, v76\n"
+      "v_fmac_f32 v62, v74, v79\n"
+      "v_fmac_f32 v63, v77, v82\n"
+      "v_fmac_f32 v64, v80, v61\n"
+      "v_fmac_f32 v65, v83, v64\n"
+      "v_fmac_f32 v66, v62, v67\n"
+      "v_fmac_f32 v67, v65, v70\n"
+      "v_fmac_f32 v60, v68, v73\n"
+      "v_fmac_f32 v61, v71, v76\n"
+      "v_fmac_f32 v62, v74, v79\n"
+      "v_fmac_f32 v63, v77, v82\n"
+      "v_fmac_f32 v64, v80, v61\n"
+      "v_fmac_f32 v65, v83, v64\n"
+      "v_fmac_f32 v66, v62, v67\n"
+      "v_fmac_f32 v67, v65, v70\n"
+      "v_fmac_f32 v60, v68, v73\n"
+      "v_fmac_f32 v61, v71, v76\n"
+      "v_fmac_f32 v62, v74, v79\n"
+      "v_fmac_f32 v63, v77, v82\n"
+      "v_fmac_f32 v64, v80, v61\n"
+      "v_fmac_f32 v65, v83, v64\n"
+      "v_fmac_f32 v66, v62, v67\n"
+      "v_fmac_f32 v67, v65, v70\n"
+      "v_fmac_f32 v60, v68, v73\n"
+      "v_fmac_f32 v61, v71, v76\n"
+      "v_fmac_f32 v62, v74, v79\n"
+      "v_fmac_f32 v63, v77, v82\n"
+      "v_fmac_f32 v64, v80, v61\n"
+      "v_fmac_f32 v65, v83, v64\n"
+      "v_fmac_f32 v66, v62, v67\n"
+      "v_fmac_f32 v67, v65, v70\n"
+      "v_fmac_f32 v60, v68, v73\n"
+      "v_fmac_f32 v61, v71, v76\n"
+      "v_fmac_f32 v62, v74, v79\n"
+      "v_fmac_f32 v63, v77, v82\n"
+      "v_fmac_f32 v64, v80, v61\n"
+      "v_fmac_f32 v65, v83, v64\n"
+      "v_fmac_f32 v66, v62, v67\n"
+      "v_fmac_f32 v67, v65, v70\n"
+      ::: "vcc", "scc", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83");
+  }
+  asm volatile("s_nop 0" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = ((r1 - r0) << 32) | (t1 - t0);
+  if (t1 == 1) sink[0] = a + b;
+}
+
+__global__ __launch_bounds__(1024) void k_operands_mul_2_distinct_srcs(unsigned long long *__restrict__ stamps, float a, float b, float *sink) {
+  extern __shared__ char lds[];
+  if (threadIdx.x == 1023) lds[0] = 1;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < kIters; ++it) {
+    asm volatile(
+      "v_mul_f32 v60, v68, v73\n"
+      "v_mul_f32 v61, v71, v76\n"
+      "v_mul_f32 v62, v74, v79\n"
+      "v_mul_f32 v63, v77, v82\n"
+      "v_mul_f32 v64, v80, v61\n"
+      "v_mul_f32 v65, v83, v64\n"
+      "v_mul_f32 v66, v62, v67\n"
+      "v_mul_f32 v67, v65, v70\n"
+      "v_mul_f32 v60, v68, v73\n"
+      "v_mul_f32 v61, v71, v76\n"
+      "v_mul_f32 v62, v74, v79\n"
+      "v_mul_f32 v63, v77, v82\n"
+      "v_mul_f32 v64, v80, v61\n"
+      "v_mul_f32 v65, v83, v64\n"
+      "v_mul_f32 v66, v62, v67\n"
+      "v_mul_f32 v67, v65, v70\n"
+      "v_mul_f32 v60, v68, v73\n"
+      "v_mul_f32 v61, v71, v76\n"
+      "v_mul_f32 v62, v74, v79\n"
+      "v_mul_f32 v63, v77, v82\n"
+      "v_mul_f32 v64, v80, v61\n"
+      "v_mul_f32 v65, v83, v64\n"
+      "v_mul_f32 v66, v62, v67\n"
+      "v_mul_f32 v67, v65, v70\n"
+      "v_mul_f32 v60, v68, v73\n"
+      "v_mul_f32 v61, v71, v76\n"
+      "v_mul_f32 v62, v74, v79\n"
+      "v_mul_f32 v63, v77, v82\n"
+      "v_mul_f32 v64, v80, v61\n"
+      "v_mul_f32 v65, v83, v64\n"
+      "v_mul_f32 v66, v62, v67\n"
+      "v_mul_f32 v67, v65, v70\n"
+      "v_mul_f32 v60, v68, v73\n"
+      "v_mul_f32 v61, v71, v76\n"
+      "v_mul_f32 v62, v74, v79\n"
+      "v_mul_f32 v63, v77, v82\n"
+      "v_mul_f32 v64, v80, v61\n"
+      "v_mul_f32 v65, v83, v64\n"
+      "v_mul_f32 v66, v62, v67\n"
+      "v_mul_f32 v67, v65, v70\n"
+      "v_mul_f32 v60, v68, v73\n"
+      "v_mul_f32 v61, v71, v76\n"
+      "v_mul_f32 v62, v74, v79\n"
+      "v_mul_f32 v63, v77, v82\n"
+      "v_mul_f32 v64, v80, v61\n"
+      "v_mul_f32 v65, v83, v64\n"
+      "v_mul_f32 v66, v62, v67\n"
+      "v_mul_f32 v67, v65, v70\n"
+      "v_mul_f32 v60, v68, v73\n"
+      "v_mul_f32 v61, v71, v76\n"
+      "v_mul_f32 v62, v74, v79\n"
+      "v_mul_f32 v63, v77, v82\n"
+      "v_mul_f32 v64, v80, v61\n"
+      "v_mul_f32 v65, v83, v64\n"
+      "v_mul_f32 v66, v62, v67\n"
+      "v_mul_f32 v67, v65, v70\n"
+      "v_mul_f32 v60, v68, v73\n"
+      "v_mul_f32 v61, v71, v76\n"
+      "v_mul_f32 v62, v74, v79\n"
+      "v_mul_f32 v63, v77, v82\n"
+      "v_mul_f32 v64, v80, v61\n"
+      "v_mul_f32 v65, v83, v64\n"
+      "v_mul_f32 v66, v62, v67\n"
+      "v_mul_f32 v67, v65, v70\n"
+      ::: "vcc", "scc", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83");
+  }
+  asm volatile("s_nop 0" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = ((r1 - r0) << 32) | (t1 - t0);
+  if (t1 == 1) sink[0] = a + b;
+}
+
+__global__ __launch_bounds__(1024) void k_operands_mul_literal_1_src(unsigned long long *__restrict__ stamps, float a, float b, float *sink) {
+  extern __shared__ char lds[];
+  if (threadIdx.x == 1023) lds[0] = 1;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < kIters; ++it) {
+    asm volatile(
+      "v_mul_f32 v60, 0x3f8ccccd, v68\n"
+      "v_mul_f32 v61, 0x3f8ccccd, v71\n"
+      "v_mul_f32 v62, 0x3f8ccccd, v74\n"
+      "v_mul_f32 v63, 0x3f8ccccd, v77\n"
+      "v_mul_f32 v64, 0x3f8ccccd, v80\n"
+      "v_mul_f32 v65, 0x3f8ccccd, v83\n"
+      "v_mul_f32 v66, 0x3f8ccccd, v62\n"
+      "v_mul_f32 v67, 0x3f8ccccd, v65\n"
+      "v_mul_f32 v60, 0x3f8ccccd, v68\n"
+      "v_mul_f32 v61, 0x3f8ccccd, v71\n"
+      "v_mul_f32 v62, 0x3f8ccccd, v74\n"
+      "v_mul_f32 v63, 0x3f8ccccd, v77\n"
+      "v_mul_f32 v64, 0x3f8ccccd, v80\n"
+      "v_mul_f32 v65, 0x3f8ccccd, v83\n"
+      "v_mul_f32 v66, 0x3f8ccccd, v62\n"
+      "v_mul_f32 v67, 0x3f8ccccd, v65\n"
+      "v_mul_f32 v60, 0x3f8ccccd, v68\n"
+      "v_mul_f32 v61, 0x3f8ccccd, v71\n"
+      "v_mul_f32 v62, 0x3f8ccccd, v74\n"
+      "v_mul_f32 v63, 0x3f8ccccd, v77\n"
+      "v_mul_f32 v64, 0x3f8ccccd, v80\n"
+      "v_mul_f32 v65, 0x3f8ccccd, v83\n"
+      "v_mul_f32 v66, 0x3f8ccccd, v62\n"
+      "v_mul_f32 v67, 0x3f8ccccd, v65\n"
+      "v_mul_f32 v60, 0x3f8ccccd, v68\n"
+      "v_mul_f32 v61, 0x3f8ccccd, v71\n"
+      "v_mul_f32 v62, 0x3f8ccccd, v74\n"
+      "v_mul_f32 v63, 0x3f8ccccd, v77\n"
+      "v_mul_f32 v64, 0x3f8ccccd, v80\n"
+      "v_mul_f32 v65, 0x3f8ccccd, v83\n"
+      "v_mul_f32 v66, 0x3f8ccccd, v62\n"
+      "v_mul_f32 v67, 0x3f8ccccd, v65\n"
+      "v_mul_f32 v60, 0x3f8ccccd, v68\n"
+      "v_mul_f32 v61, 0x3f8ccccd, v71\n"
+      "v_mul_f32 v62, 0x3f8ccccd, v74\n"
+      "v_mul_f32 v63, 0x3f8ccccd, v77\n"
+      "v_mul_f32 v64, 0x3f8ccccd, v80\n"
+      "v_mul_f32 v65, 0x3f8ccccd, v83\n"
+      "v_mul_f32 v66, 0x3f8ccccd, v62\n"
+      "v_mul_f32 v67, 0x3f8ccccd, v65\n"
+      "v_mul_f32 v60, 0x3f8ccccd, v68\n"
+      "v_mul_f32 v61, 0x3f8ccccd, v71\n"
+      "v_mul_f32 v62, 0x3f8ccccd, v74\n"
+      "v_mul_f32 v63, 0x3f8ccccd, v77\n"
+      "v_mul_f32 v64, 0x3f8ccccd, v80\n"
+      "v_mul_f32 v65, 0x3f8ccccd, v83\n"
+      "v_mul_f32 v66, 0x3f8ccccd, v62\n"
+      "v_mul_f32 v67, 0x3f8ccccd, v65\n"
+      "v_mul_f32 v60, 0x3f8ccccd, v68\n"
+      "v_mul_f32 v61, 0x3f8ccccd, v71\n"
+      "v_mul_f32 v62, 0x3f8ccccd, v74\n"
+      "v_mul_f32 v63, 0x3f8ccccd, v77\n"
+      "v_mul_f32 v64, 0x3f8ccccd, v80\n"
+      "v_mul_f32 v65, 0x3f8ccccd, v83\n"
+      "v_mul_f32 v66, 0x3f8ccccd, v62\n"
+      "v_mul_f32 v67, 0x3f8ccccd, v65\n"
+      "v_mul_f32 v60, 0x3f8ccccd, v68\n"
+      "v_mul_f32 v61, 0x3f8ccccd, v71\n"
+      "v_mul_f32 v62, 0x3f8ccccd, v74\n"
+      "v_mul_f32 v63, 0x3f8ccccd, v77\n"
+      "v_mul_f32 v64, 0x3f8ccccd, v80\n"
+      "v_mul_f32 v65, 0x3f8ccccd, v83\n"
+      "v_mul_f32 v66, 0x3f8ccccd, v62\n"
+      "v_mul_f32 v67, 0x3f8ccccd, v65\n"
+      ::: "vcc", "scc", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83");
+  }
+  asm volatile("s_nop 0" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = ((r1 - r0) << 32) | (t1 - t0);
+  if (t1 == 1) sink[0] = a + b;
+}
+
+__global__ __launch_bounds__(1024) void k_operands_mov_1_src(unsigned long long *__restrict__ stamps, float a, float b, float *sink) {
+  extern __shared__ char lds[];
+  if (threadIdx.x == 1023) lds[0] = 1;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < kIters; ++it) {
+    asm volatile(
+      "v_mov_b32 v60, v68\n"
+      "v_mov_b32 v61, v71\n"
+      "v_mov_b32 v62, v74\n"
+      "v_mov_b32 v63, v77\n"
+      "v_mov_b32 v64, v80\n"
+      "v_mov_b32 v65, v83\n"
+      "v_mov_b32 v66, v62\n"
+      "v_mov_b32 v67, v65\n"
+      "v_mov_b32 v60, v68\n"
+      "v_mov_b32 v61, v71\n"
+      "v_mov_b32 v62, v74\n"
+      "v_mov_b32 v63, v77\n"
+      "v_mov_b32 v64, v80\n"
+      "v_mov_b32 v65, v83\n"
+      "v_mov_b32 v66, v62\n"
+      "v_mov_b32 v67, v65\n"
+      "v_mov_b32 v60, v68\n"
+      "v_mov_b32 v61, v71\n"
+      "v_mov_b32 v62, v74\n"
+      "v_mov_b32 v63, v77\n"
+      "v_mov_b32 v64, v80\n"
+      "v_mov_b32 v65, v83\n"
+      "v_mov_b32 v66, v62\n"
+      "v_mov_b32 v67, v65\n"
+      "v_mov_b32 v60, v68\n"
+      "v_mov_b32 v61, v71\n"
+      "v_mov_b32 v62, v74\n"
+      "v_mov_b32 v63, v77\n"
+      "v_mov_b32 v64, v80\n"
+      "v_mov_b32 v65, v83\n"
+      "v_mov_b32 v66, v62\n"
+      "v_mov_b32 v67, v65\n"
+      "v_mov_b32 v60, v68\n"
+      "v_mov_b32 v61, v71\n"
+      "v_mov_b32 v62, v74\n"
+      "v_mov_b32 v63, v77\n"
+      "v_mov_b32 v64, v80\n"
+      "v_mov_b32 v65, v83\n"
+      "v_mov_b32 v66, v62\n"
+      "v_mov_b32 v67, v65\n"
+      "v_mov_b32 v60, v68\n"
+      "v_mov_b32 v61, v71\n"
+      "v_mov_b32 v62, v74\n"
+      "v_mov_b32 v63, v77\n"
+      "v_mov_b32 v64, v80\n"
+      "v_mov_b32 v65, v83\n"
+      "v_mov_b32 v66, v62\n"
+      "v_mov_b32 v67, v65\n"
+      "v_mov_b32 v60, v68\n"
+      "v_mov_b32 v61, v71\n"
+      "v_mov_b32 v62, v74\n"
+      "v_mov_b32 v63, v77\n"
+      "v_mov_b32 v64, v80\n"
+      "v_mov_b32 v65, v83\n"
+      "v_mov_b32 v66, v62\n"
+      "v_mov_b32 v67, v65\n"
+      "v_mov_b32 v60, v68\n"
+      "v_mov_b32 v61, v71\n"
+      "v_mov_b32 v62, v74\n"
+      "v_mov_b32 v63, v77\n"
+      "v_mov_b32 v64, v80\n"
+      "v_mov_b32 v65, v83\n"
+      "v_mov_b32 v66, v62\n"
+      "v_mov_b32 v67, v65\n"
+      ::: "vcc", "scc", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83");
+  }
+  asm volatile("s_nop 0" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = ((r1 - r0) << 32) | (t1 - t0);
+  if (t1 == 1) sink[0] = a + b;
+}
+
+// ---- pieces of k_shade's light loop, as compiled ----
+__global__ __launch_bounds__(1024) void k_blk_rsqrt_block(unsigned long long *__restrict__ stamps, float a, float b, float *sink) {
+  extern __shared__ char lds[];
+  if (threadIdx.x == 1023) lds[0] = 1;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < kIters; ++it) {
+    asm volatile(
+      "v_pk_add_f32 v[4:5], v[4:5], v[12:13] neg_lo:[0,1] neg_hi:[0,1]\n"
+      "v_sub_f32_e32 v23, v6, v14\n"
+      "v_mul_f32_e32 v38, v4, v4\n"
+      "v_fmac_f32_e32 v38, v5, v5\n"
+      "v_fmac_f32_e32 v38, v23, v23\n"
+      "v_lshrrev_b32_e32 v6, 1, v38\n"
+      "v_sub_u32_e32 v6, 0x5f375a86, v6\n"
+      "v_mul_f32_e32 v39, 0.5, v38\n"
+      "v_mul_f32_e64 v54, v39, -v6\n"
+      "v_fmaak_f32 v54, v54, v6, 0x3fc00000\n"
+      "v_mul_f32_e32 v6, v54, v6\n"
+      "v_mul_f32_e64 v54, v39, -v6\n"
+      "v_fmaak_f32 v54, v54, v6, 0x3fc00000\n"
+      "v_mul_f32_e32 v6, v6, v54\n"
+      "v_mul_f32_e64 v39, v39, -v6\n"
+      "v_fmaak_f32 v39, v39, v6, 0x3fc00000\n"
+      "v_mul_f32_e32 v6, v6, v39\n"
+      "v_cmp_class_f32_e32 vcc, v38, v51\n"
+      ::: "vcc", "scc", "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54");
+  }
+  asm volatile("s_nop 0" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = ((r1 - r0) << 32) | (t1 - t0);
+  if (t1 == 1) sink[0] = a + b;
+}
+
+__global__ __launch_bounds__(1024) void k_blk_rsqrt_block_no_cmp_class(unsigned long long *__restrict__ stamps, float a, float b, float *sink) {
+  extern __shared__ char lds[];
+  if (threadIdx.x == 1023) lds[0] = 1;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < kIters; ++it) {
+    asm volatile(
+      "v_pk_add_f32 v[4:5], v[4:5], v[12:13] neg_lo:[0,1] neg_hi:[0,1]\n"
+      "v_sub_f32_e32 v23, v6, v14\n"
+      "v_mul_f32_e32 v38, v4, v4\n"
+      "v_fmac_f32_e32 v38, v5, v5\n"
+      "v_fmac_f32_e32 v38, v23, v23\n"
+      "v_lshrrev_b32_e32 v6, 1, v38\n"
+      "v_sub_u32_e32 v6, 0x5f375a86, v6\n"
+      "v_mul_f32_e32 v39, 0.5, v38\n"
+      "v_mul_f32_e64 v54, v39, -v6\n"
+      "v_fmaak_f32 v54, v54, v6, 0x3fc00000\n"
+      "v_mul_f32_e32 v6, v54, v6\n"
+      "v_mul_f32_e64 v54, v39, -v6\n"
+      "v_fmaak_f32 v54, v54, v6, 0x3fc00000\n"
+      "v_mul_f32_e32 v6, v6, v54\n"
+      "v_mul_f32_e64 v39, v39, -v6\n"
+      "v_fmaak_f32 v39, v39, v6, 0x3fc00000\n"
+      "v_mul_f32_e32 v6, v6, v39\n"
+      ::: "vcc", "scc", "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54");
+  }
+  asm volatile("s_nop 0" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = ((r1 - r0) << 32) | (t1 - t0);
+  if (t1 == 1) sink[0] = a + b;
+}
+
+__global__ __launch_bounds__(1024) void k_blk_rsqrt_block_no_pk(unsigned long long *__restrict__ stamps, float a, float b, float *sink) {
+  extern __shared__ char lds[];
+  if (threadIdx.x == 1023) lds[0] = 1;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < kIters; ++it) {
+    asm volatile(
+      "v_sub_f32_e32 v23, v6, v14\n"
+      "v_mul_f32_e32 v38, v4, v4\n"
+      "v_fmac_f32_e32 v38, v5, v5\n"
+      "v_fmac_f32_e32 v38, v23, v23\n"
+      "v_lshrrev_b32_e32 v6, 1, v38\n"
+      "v_sub_u32_e32 v6, 0x5f375a86, v6\n"
+      "v_mul_f32_e32 v39, 0.5, v38\n"
+      "v_mul_f32_e64 v54, v39, -v6\n"
+      "v_fmaak_f32 v54, v54, v6, 0x3fc00000\n"
+      "v_mul_f32_e32 v6, v54, v6\n"
+      "v_mul_f32_e64 v54, v39, -v6\n"
+      "v_fmaak_f32 v54, v54, v6, 0x3fc00000\n"
+      "v_mul_f32_e32 v6, v6, v54\n"
+      "v_mul_f32_e64 v39, v39, -v6\n"
+      "v_fmaak_f32 v39, v39, v6, 0x3fc00000\n"
+      "v_mul_f32_e32 v6, v6, v39\n"
+      "v_cmp_class_f32_e32 vcc, v38, v51\n"
+      ::: "vcc", "scc", "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54");
+  }
+  asm volatile("s_nop 0" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = ((r1 - r0) << 32) | (t1 - t0);
+  if (t1 == 1) sink[0] = a + b;
+}
+
+__global__ __launch_bounds__(1024) void k_blk_rsqrt_newton_only(unsigned long long *__restrict__ stamps, float a, float b, float *sink) {
+  extern __shared__ char lds[];
+  if (threadIdx.x == 1023) lds[0] = 1;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < kIters; ++it) {
+    asm volatile(
+      "v_lshrrev_b32_e32 v6, 1, v38\n"
+      "v_sub_u32_e32 v6, 0x5f375a86, v6\n"
+      "v_mul_f32_e32 v39, 0.5, v38\n"
+      "v_mul_f32_e64 v54, v39, -v6\n"
+      "v_fmaak_f32 v54, v54, v6, 0x3fc00000\n"
+      "v_mul_f32_e32 v6, v54, v6\n"
+      "v_mul_f32_e64 v54, v39, -v6\n"
+      "v_fmaak_f32 v54, v54, v6, 0x3fc00000\n"
+      "v_mul_f32_e32 v6, v6, v54\n"
+      "v_mul_f32_e64 v39, v39, -v6\n"
+      "v_fmaak_f32 v39, v39, v6, 0x3fc00000\n"
+      "v_mul_f32_e32 v6, v6, v39\n"
+      ::: "vcc", "scc", "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54");
+  }
+  asm volatile("s_nop 0" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = ((r1 - r0) << 32) | (t1 - t0);
+  if (t1 == 1) sink[0] = a + b;
+}
+
+__global__ __launch_bounds__(1024) void k_blk_ggx_block(unsigned long long *__restrict__ stamps, float a, float b, float *sink) {
+  extern __shared__ char lds[];
+  if (threadIdx.x == 1023) lds[0] = 1;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < kIters; ++it) {
+    asm volatile(
+      "v_mul_f32_e32 v56, v4, v57\n"
+      "v_mul_f32_e32 v55, v5, v57\n"
+      "v_mul_f32_e32 v4, v20, v56\n"
+      "v_mul_f32_e32 v6, v6, v57\n"
+      "v_fmac_f32_e32 v4, v44, v55\n"
+      "v_fmac_f32_e32 v4, v45, v6\n"
+      "v_max_f32_e32 v4, 0, v4\n"
+      "v_mul_f32_e32 v5, v4, v4\n"
+      "v_mul_f32_e32 v4, v20, v38\n"
+      "v_fmac_f32_e32 v4, v44, v39\n"
+      "v_fmac_f32_e32 v4, v45, v23\n"
+      "v_max_f32_e32 v4, 0, v4\n"
+      "v_mul_f32_e32 v23, v47, v4\n"
+      "v_pk_fma_f32 v[38:39], v[4:5], v[18:19], v[16:17]\n"
+      "v_max_f32_e32 v57, 0x3a83126f, v23\n"
+      "v_mov_b32_e32 v23, v39\n"
+      "v_pk_mul_f32 v[38:39], v[22:23], v[38:39]\n"
+      "v_mul_f32_e32 v5, v38, v39\n"
+      "v_mul_f32_e32 v23, v57, v5\n"
+      "v_rcp_f32_e32 v5, v23\n"
+      "v_fma_f32 v38, -v23, v5, 1.0\n"
+      "v_cmp_class_f32_e32 vcc, v5, v53\n"
+      "v_fmac_f32_e32 v5, v5, v38\n"
+      ::: "vcc", "scc", "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57");
+  }
+  asm volatile("s_nop 0" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = ((r1 - r0) << 32) | (t1 - t0);
+  if (t1 == 1) sink[0] = a + b;
+}
+
+__global__ __launch_bounds__(1024) void k_blk_ggx_block_no_trans_max_cmp_pk(unsigned long long *__restrict__ stamps, float a, float b, float *sink) {
+  extern __shared__ char lds[];
+  if (threadIdx.x == 1023) lds[0] = 1;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < kIters; ++it) {
+    asm volatile(
+      "v_mul_f32_e32 v56, v4, v57\n"
+      "v_mul_f32_e32 v55, v5, v57\n"
+      "v_mul_f32_e32 v4, v20, v56\n"
+      "v_mul_f32_e32 v6, v6, v57\n"
+      "v_fmac_f32_e32 v4, v44, v55\n"
+      "v_fmac_f32_e32 v4, v45, v6\n"
+      "v_mul_f32_e32 v5, v4, v4\n"
+      "v_mul_f32_e32 v4, v20, v38\n"
+      "v_fmac_f32_e32 v4, v44, v39\n"
+      "v_fmac_f32_e32 v4, v45, v23\n"
+      "v_mul_f32_e32 v23, v47, v4\n"
+      "v_mov_b32_e32 v23, v39\n"
+      "v_mul_f32_e32 v5, v38, v39\n"
+      "v_mul_f32_e32 v23, v57, v5\n"
+      "v_fma_f32 v38, -v23, v5, 1.0\n"
+      "v_fmac_f32_e32 v5, v5, v38\n"
+      ::: "vcc", "scc", "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57");
+  }
+  asm volatile("s_nop 0" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = ((r1 - r0) << 32) | (t1 - t0);
+  if (t1 == 1) sink[0] = a + b;
+}
+
+__global__ __launch_bounds__(1024) void k_blk_fresnel_block(unsigned long long *__restrict__ stamps, float a, float b, float *sink) {
+  extern __shared__ char lds[];
+  if (threadIdx.x == 1023) lds[0] = 1;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < kIters; ++it) {
+    asm volatile(
+      "v_mul_f32_e32 v23, v11, v56\n"
+      "v_fmac_f32_e32 v23, v55, v15\n"
+      "v_fmac_f32_e32 v23, v6, v43\n"
+      "v_max_f32_e32 v6, 0, v23\n"
+      "v_sub_f32_e32 v6, 1.0, v6\n"
+      "v_mul_f32_e32 v23, v6, v6\n"
+      "v_mul_f32_e32 v23, v23, v23\n"
+      "v_mul_f32_e32 v6, v6, v23\n"
+      "v_mul_f32_e32 v23, v46, v4\n"
+      "v_mul_f32_e32 v38, v23, v5\n"
+      "v_pk_fma_f32 v[56:57], v[28:29], v[6:7], v[26:27] op_sel_hi:[1,0,1]\n"
+      "v_fma_f32 v5, v49, v6, v48\n"
+      "v_mul_f32_e32 v4, v54, v4\n"
+      "v_pk_add_f32 v[54:55], v[56:57], 1.0 op_sel_hi:[1,0] neg_lo:[1,0] neg_hi:[1,0]\n"
+      "v_pk_mul_f32 v[56:57], v[56:57], v[38:39] op_sel_hi:[1,0]\n"
+      "v_pk_mul_f32 v[8:9], v[8:9], v[4:5] op_sel_hi:[1,0]\n"
+      "v_sub_f32_e32 v6, 1.0, v5\n"
+      "v_mul_f32_e32 v5, v5, v38\n"
+      "v_pk_fma_f32 v[54:55], v[54:55], v[30:31], v[56:57]\n"
+      "v_fmac_f32_e32 v5, v6, v50\n"
+      "v_mul_f32_e32 v4, v10, v4\n"
+      "v_pk_fma_f32 v[24:25], v[54:55], v[8:9], v[24:25]\n"
+      "v_fmac_f32_e32 v2, v5, v4\n"
+      ::: "vcc", "scc", "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57");
+  }
+  asm volatile("s_nop 0" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = ((r1 - r0) << 32) | (t1 - t0);
+  if (t1 == 1) sink[0] = a + b;
+}
+
+__global__ __launch_bounds__(1024) void k_blk_fresnel_block_no_pk_max(unsigned long long *__restrict__ stamps, float a, float b, float *sink) {
+  extern __shared__ char lds[];
+  if (threadIdx.x == 1023) lds[0] = 1;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < kIters; ++it) {
+    asm volatile(
+      "v_mul_f32_e32 v23, v11, v56\n"
+      "v_fmac_f32_e32 v23, v55, v15\n"
+      "v_fmac_f32_e32 v23, v6, v43\n"
+      "v_sub_f32_e32 v6, 1.0, v6\n"
+      "v_mul_f32_e32 v23, v6, v6\n"
+      "v_mul_f32_e32 v23, v23, v23\n"
+      "v_mul_f32_e32 v6, v6, v23\n"
+      "v_mul_f32_e32 v23, v46, v4\n"
+      "v_mul_f32_e32 v38, v23, v5\n"
+      "v_fma_f32 v5, v49, v6, v48\n"
+      "v_mul_f32_e32 v4, v54, v4\n"
+      "v_sub_f32_e32 v6, 1.0, v5\n"
+      "v_mul_f32_e32 v5, v5, v38\n"
+      "v_fmac_f32_e32 v5, v6, v50\n"
+      "v_mul_f32_e32 v4, v10, v4\n"
+      "v_fmac_f32_e32 v2, v5, v4\n"
+      ::: "vcc", "scc", "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56");
+  }
+  asm volatile("s_nop 0" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = ((r1 - r0) << 32) | (t1 - t0);
+  if (t1 == 1) sink[0] = a + b;
+}
+
 template <typename T>
 struct Init {
   static T a() { return (T)1.0000001f; }
@@ -230,7 +1084,7 @@ struct Result {
 };
 
 template <typename T, typename K>
-static Result run(K kernel, int waves_per_simd, unsigned long long *d_stamps, void *d_sink, int per_block_instrs) {
+static Result run(K kernel, int waves_per_simd, unsigned long long *d_stamps, void *d_sink, double per_block_instrs) {
   // W <= 4: ONE workgroup of 256 x W threads per CU (all of the CU's LDS, so a second one cannot join it);
   // W = 8: two workgroups of 1024 threads per CU (half the LDS each).  A workgroup's waves are dealt round-robin over
   // the four SIMDs, so every SIMD holds exactly W waves and all waves of the grid are resident together.
@@ -299,5 +1153,111 @@ int main(int argc, char **argv) {
     fflush(stdout);                                                                                   \
   }
   OPS(X_RUN)
+  if (selected("fma_3_distinct_srcs", argc, argv)) {
+    Result c[4];
+    int wi = 0;
+    for (int W : {1, 2, 4, 8}) c[wi++] = run<float>(k_operands_fma_3_distinct_srcs, W, d_stamps, d_sink, 1.0);
+    printf("%-26s %7.2f %7.2f %7.2f %7.2f %7s   %5.2f %5.2f\n", "fma_3_distinct_srcs", c[0].cyc, c[1].cyc, c[2].cyc, c[3].cyc, "-", c[3].ghz, c[3].wall);
+  }
+  if (selected("fma_2_distinct_srcs", argc, argv)) {
+    Result c[4];
+    int wi = 0;
+    for (int W : {1, 2, 4, 8}) c[wi++] = run<float>(k_operands_fma_2_distinct_srcs, W, d_stamps, d_sink, 1.0);
+    printf("%-26s %7.2f %7.2f %7.2f %7.2f %7s   %5.2f %5.2f\n", "fma_2_distinct_srcs", c[0].cyc, c[1].cyc, c[2].cyc, c[3].cyc, "-", c[3].ghz, c[3].wall);
+  }
+  if (selected("fmac_2_distinct_srcs", argc, argv)) {
+    Result c[4];
+    int wi = 0;
+    for (int W : {1, 2, 4, 8}) c[wi++] = run<float>(k_operands_fmac_2_distinct_srcs, W, d_stamps, d_sink, 1.0);
+    printf("%-26s %7.2f %7.2f %7.2f %7.2f %7s   %5.2f %5.2f\n", "fmac_2_distinct_srcs", c[0].cyc, c[1].cyc, c[2].cyc, c[3].cyc, "-", c[3].ghz, c[3].wall);
+  }
+  if (selected("mul_2_distinct_srcs", argc, argv)) {
+    Result c[4];
+    int wi = 0;
+    for (int W : {1, 2, 4, 8}) c[wi++] = run<float>(k_operands_mul_2_distinct_srcs, W, d_stamps, d_sink, 1.0);
+    printf("%-26s %7.2f %7.2f %7.2f %7.2f %7s   %5.2f %5.2f\n", "mul_2_distinct_srcs", c[0].cyc, c[1].cyc, c[2].cyc, c[3].cyc, "-", c[3].ghz, c[3].wall);
+  }
+  if (selected("mul_literal_1_src", argc, argv)) {
+    Result c[4];
+    int wi = 0;
+    for (int W : {1, 2, 4, 8}) c[wi++] = run<float>(k_operands_mul_literal_1_src, W, d_stamps, d_sink, 1.0);
+    printf("%-26s %7.2f %7.2f %7.2f %7.2f %7s   %5.2f %5.2f\n", "mul_literal_1_src", c[0].cyc, c[1].cyc, c[2].cyc, c[3].cyc, "-", c[3].ghz, c[3].wall);
+  }
+  if (selected("mov_1_src", argc, argv)) {
+    Result c[4];
+    int wi = 0;
+    for (int W : {1, 2, 4, 8}) c[wi++] = run<float>(k_operands_mov_1_src, W, d_stamps, d_sink, 1.0);
+    printf("%-26s %7.2f %7.2f %7.2f %7.2f %7s   %5.2f %5.2f\n", "mov_1_src", c[0].cyc, c[1].cyc, c[2].cyc, c[3].cyc, "-", c[3].ghz, c[3].wall);
+  }
+  if (selected("dep_chain_fma", argc, argv)) {
+    // ONE dependent chain per wave (every instruction waits for the previous one) at 1..8 waves per SIMD: do the other
+    // waves fill the gaps?
+    Result c[4];
+    int wi = 0;
+    for (int W : {1, 2, 4, 8}) c[wi++] = run<float>(k_fma_f32_dep, W, d_stamps, d_sink, 1.0);
+    printf("%-26s %7.2f %7.2f %7.2f %7.2f %7s   %5.2f %5.2f\n", "dep_chain_fma", c[0].cyc, c[1].cyc, c[2].cyc, c[3].cyc, "-", c[3].ghz, c[3].wall);
+    wi = 0;
+    for (int W : {1, 2, 4, 8}) c[wi++] = run<float>(k_mul_f32_dep, W, d_stamps, d_sink, 1.0);
+    printf("%-26s %7.2f %7.2f %7.2f %7.2f %7s   %5.2f %5.2f\n", "dep_chain_mul", c[0].cyc, c[1].cyc, c[2].cyc, c[3].cyc, "-", c[3].ghz, c[3].wall);
+    wi = 0;
+    for (int W : {1, 2, 4, 8}) c[wi++] = run<float>(k_mix_mul_add_dep, W, d_stamps, d_sink, 2.0);
+    printf("%-26s %7.2f %7.2f %7.2f %7.2f %7s   %5.2f %5.2f\n", "dep_chain_mul_add", c[0].cyc, c[1].cyc, c[2].cyc, c[3].cyc, "-", c[3].ghz, c[3].wall);
+  }
+  if (selected("blk_rsqrt_block", argc, argv)) {
+    Result c[4];
+    int wi = 0;
+    for (int W : {1, 2, 4, 8}) c[wi++] = run<float>(k_blk_rsqrt_block, W, d_stamps, d_sink, 18 / 64.0);
+    printf("%-26s %7.2f %7.2f %7.2f %7.2f %7s   %5.2f %5.2f  (18 instrs)\n", "blk_rsqrt_block", c[0].cyc, c[1].cyc, c[2].cyc, c[3].cyc, "-", c[3].ghz, c[3].wall);
+  }
+  if (selected("blk_rsqrt_block_no_cmp_class", argc, argv)) {
+    Result c[4];
+    int wi = 0;
+    for (int W : {1, 2, 4, 8}) c[wi++] = run<float>(k_blk_rsqrt_block_no_cmp_class, W, d_stamps, d_sink, 17 / 64.0);
+    printf("%-26s %7.2f %7.2f %7.2f %7.2f %7s   %5.2f %5.2f  (17 instrs)\n", "blk_rsqrt_block_no_cmp_cla", c[0].cyc, c[1].cyc, c[2].cyc, c[3].cyc, "-", c[3].ghz, c[3].wall);
+  }
+  if (selected("blk_rsqrt_block_no_pk", argc, argv)) {
+    Result c[4];
+    int wi = 0;
+    for (int W : {1, 2, 4, 8}) c[wi++] = run<float>(k_blk_rsqrt_block_no_pk, W, d_stamps, d_sink, 17 / 64.0);
+    printf("%-26s %7.2f %7.2f %7.2f %7.2f %7s   %5.2f %5.2f  (17 instrs)\n", "blk_rsqrt_block_no_pk", c[0].cyc, c[1].cyc, c[2].cyc, c[3].cyc, "-", c[3].ghz, c[3].wall);
+  }
+  if (selected("blk_rsqrt_newton_only", argc, argv)) {
+    Result c[4];
+    int wi = 0;
+    for (int W : {1, 2, 4, 8}) c[wi++] = run<float>(k_blk_rsqrt_newton_only, W, d_stamps, d_sink, 12 / 64.0);
+    printf("%-26s %7.2f %7.2f %7.2f %7.2f %7s   %5.2f %5.2f  (12 instrs)\n", "blk_rsqrt_newton_only", c[0].cyc, c[1].cyc, c[2].cyc, c[3].cyc, "-", c[3].ghz, c[3].wall);
+  }
+  if (selected("blk_ggx_block", argc, argv)) {
+    Result c[4];
+    int wi = 0;
+    for (int W : {1, 2, 4, 8}) c[wi++] = run<float>(k_blk_ggx_block, W, d_stamps, d_sink, 23 / 64.0);
+    printf("%-26s %7.2f %7.2f %7.2f %7.2f %7s   %5.2f %5.2f  (23 instrs)\n", "blk_ggx_block", c[0].cyc, c[1].cyc, c[2].cyc, c[3].cyc, "-", c[3].ghz, c[3].wall);
+  }
+  if (selected("blk_ggx_block_no_trans_max_cmp_pk", argc, argv)) {
+    Result c[4];
+    int wi = 0;
+    for (int W : {1, 2, 4, 8}) c[wi++] = run<float>(k_blk_ggx_block_no_trans_max_cmp_pk, W, d_stamps, d_sink, 16 / 64.0);
+    printf("%-26s %7.2f %7.2f %7.2f %7.2f %7s   %5.2f %5.2f  (16 instrs)\n", "blk_ggx_block_no_trans_max", c[0].cyc, c[1].cyc, c[2].cyc, c[3].cyc, "-", c[3].ghz, c[3].wall);
+  }
+  if (selected("blk_fresnel_block", argc, argv)) {
+    Result c[4];
+    int wi = 0;
+    for (int W : {1, 2, 4, 8}) c[wi++] = run<float>(k_blk_fresnel_block, W, d_stamps, d_sink, 23 / 64.0);
+    printf("%-26s %7.2f %7.2f %7.2f %7.2f %7s   %5.2f %5.2f  (23 instrs)\n", "blk_fresnel_block", c[0].cyc, c[1].cyc, c[2].cyc, c[3].cyc, "-", c[3].ghz, c[3].wall);
+  }
+  if (selected("blk_fresnel_block_no_pk_max", argc, argv)) {
+    Result c[4];
+    int wi = 0;
+    for (int W : {1, 2, 4, 8}) c[wi++] = run<float>(k_blk_fresnel_block_no_pk_max, W, d_stamps, d_sink, 16 / 64.0);
+    printf("%-26s %7.2f %7.2f %7.2f %7.2f %7s   %5.2f %5.2f  (16 instrs)\n", "blk_fresnel_block_no_pk_ma", c[0].cyc, c[1].cyc, c[2].cyc, c[3].cyc, "-", c[3].ghz, c[3].wall);
+  }
+  if (selected("k_shade_light_loop", argc, argv)) {
+    // 83 vector instructions of k_shade's light loop (one point light, hot path) exactly as compiled: what does the real
+    // mix cost per instruction?  (table prediction from the rows above: 66 at 2, 16 at 4, one at 8 = 2.46)
+    Result c[4];
+    int wi = 0;
+    for (int W : {1, 2, 4, 8}) c[wi++] = run<float>(k_lightloop, W, d_stamps, d_sink, kLightLoopInstrs / 64.0);
+    printf("%-26s %7.2f %7.2f %7.2f %7.2f %7s   %5.2f %5.2f\n", "k_shade_light_loop", c[0].cyc, c[1].cyc, c[2].cyc, c[3].cyc, "-", c[3].ghz, c[3].wall);
+  }
   return 0;
 }
