@@ -180,6 +180,14 @@ BB_DEV float max0(float a) { return __builtin_fmaxf(a, 0.0f); }
 // 2-cycle issue cadence of the fma / mul stream around it -- profiles/r02_issue_rate.txt)
 BB_DEV float sat01(float a) { return __builtin_amdgcn_fmed3f(a, 0.0f, 1.0f); }
 
+// 32-bit integer multiply that stays v_mul_lo_u32.  The 24-bit forms the compiler prefers for small operands (v_mul_u32_u24,
+// v_mad_i32_i24, ...) cost ~10 issue cycles each on gfx950 where v_mul_lo_u32 costs 3.5 (profiles/r02_issue_rate.txt, rows
+// iso_*): the empty asm hides the operand's known-zero bits from the instruction selector.
+BB_DEV int mul32(int a, int b) {
+  asm("" : "+v"(a));
+  return a * b;
+}
+
 BB_DEV f4 mat4_mul(const Mat4 &m, f4 v) {
   f4 r;
   r.x = fmaf(m.M[3][0], v.w, fmaf(m.M[2][0], v.z, fmaf(m.M[1][0], v.y, m.M[0][0] * v.x)));
@@ -754,8 +762,7 @@ BB_DEV BilinearTaps bilinear_taps(float u, float v, int w, int h) {
     x0 = wrap_repeat(ix, w); x1 = wrap_repeat(ix + 1, w);
     y0 = wrap_repeat(iy, h); y1 = wrap_repeat(iy + 1, h);
   }
-  // sizes are <= 16384 (checked at upload): 24-bit multiplies are exact and full rate
-  const uint32_t row0 = (uint32_t)__mul24(y0, w), row1 = (uint32_t)__mul24(y1, w);
+  const uint32_t row0 = (uint32_t)mul32(y0, w), row1 = (uint32_t)mul32(y1, w);
   t.o00 = row0 + (uint32_t)x0;
   t.o10 = row0 + (uint32_t)x1;
   t.o01 = row1 + (uint32_t)x0;
@@ -763,9 +770,26 @@ BB_DEV BilinearTaps bilinear_taps(float u, float v, int w, int h) {
   return t;
 }
 
+// byte k of a dword as a float: v_cvt_f32_ubyteN.  Spelled out, so that the compiler keeps the conversion: left to
+// itself it rewrites float(b) - float(a) as float(int(b) - int(a)) -- v_sub_u32_sdwa + v_cvt_f32_i32, two of the expensive
+// (non-fma-class) instructions where the float subtraction is a cheap one; 18 more of them per pixel.
+// byte offset of packed texel i (9-byte records): i * 8 + i as one v_lshl_add_u32, not the v_mad_i32_i24 the compiler picks
+BB_DEV uint32_t texel_offset(uint32_t i) {
+  static_assert(kPackedTexelBytes == 9, "texel_offset");
+  asm("" : "+v"(i));
+  return (i << 3) + i;
+}
+BB_DEV float byte_f32(uint32_t t, int shift) {
+  float f;
+  if (shift == 0) asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(f) : "v"(t));
+  else if (shift == 8) asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(f) : "v"(t));
+  else if (shift == 16) asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(f) : "v"(t));
+  else asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(f) : "v"(t));
+  return f;
+}
 BB_DEV float filter_channel(uint32_t t00, uint32_t t10, uint32_t t01, uint32_t t11, int shift, float fx, float fy) {
-  float a = (float)((t00 >> shift) & 0xFFu), b = (float)((t10 >> shift) & 0xFFu);
-  float c = (float)((t01 >> shift) & 0xFFu), d = (float)((t11 >> shift) & 0xFFu);
+  float a = byte_f32(t00, shift), b = byte_f32(t10, shift);
+  float c = byte_f32(t01, shift), d = byte_f32(t11, shift);
   float top = fmaf(fx, b - a, a);
   float bot = fmaf(fx, d - c, c);
   return fmaf(fy, bot - top, top) * (1.0f / 255.0f);
@@ -910,9 +934,9 @@ BB_DEV void raster_triangle_wave(const RasterTri &t, uint32_t ref, int tile_x0, 
         int x = bx + lx, y = by + ly;
         bool in = x < w && y < h;
         if (in && !all) {
-          int e0 = __mul24(x, sx[0]) + __mul24(y, sy[0]) + o[0];
-          int e1 = __mul24(x, sx[1]) + __mul24(y, sy[1]) + o[1];
-          int e2 = __mul24(x, sx[2]) + __mul24(y, sy[2]) + o[2];
+          int e0 = mul32(x, sx[0]) + mul32(y, sy[0]) + o[0];
+          int e1 = mul32(x, sx[1]) + mul32(y, sy[1]) + o[1];
+          int e2 = mul32(x, sx[2]) + mul32(y, sy[2]) + o[2];
           in = (e0 | e1 | e2) >= 0;
         }
         if (in) depth_max(t, px0 + x, py0 + y, ref, keys, tile_index<TILE_W>(px0 + x - tile_x0, py0 + y - tile_y0), zbias);
@@ -991,9 +1015,9 @@ BB_DEV void raster_triangle_group16(const RasterTri &t, uint32_t ref, int px0, i
   const int lx = gl & 3, ly = gl >> 2;
   // this lane's pixel of the first block; stepping a block to the right / down is an add (exact: same values as the
   // multiply-add form, all terms < 2^30)
-  int r0 = __mul24(lx, sx[0]) + __mul24(ly, sy[0]) + o[0];
-  int r1 = __mul24(lx, sx[1]) + __mul24(ly, sy[1]) + o[1];
-  int r2 = __mul24(lx, sx[2]) + __mul24(ly, sy[2]) + o[2];
+  int r0 = mul32(lx, sx[0]) + mul32(ly, sy[0]) + o[0];
+  int r1 = mul32(lx, sx[1]) + mul32(ly, sy[1]) + o[1];
+  int r2 = mul32(lx, sx[2]) + mul32(ly, sy[2]) + o[2];
   const int bx0 = 4 * sx[0], bx1 = 4 * sx[1], bx2 = 4 * sx[2];
   const int by0 = 4 * sy[0], by1 = 4 * sy[1], by2 = 4 * sy[2];
   for (int y = ly; y < h; y += 4) {
@@ -1789,10 +1813,10 @@ __global__ __launch_bounds__(kShadeThreads) void k_shade(
     const BilinearTaps tp = bilinear_taps(u, v, (int)(packed_dims & 0xFFFFu), (int)(packed_dims >> 16));
     const uint8_t *tb = packed_texels;
     uint32_t t00[3], t10[3], t01[3], t11[3];
-    __builtin_memcpy(t00, tb + kPackedTexelBytes * tp.o00, 12);
-    __builtin_memcpy(t10, tb + kPackedTexelBytes * tp.o10, 12);
-    __builtin_memcpy(t01, tb + kPackedTexelBytes * tp.o01, 12);
-    __builtin_memcpy(t11, tb + kPackedTexelBytes * tp.o11, 12);
+    __builtin_memcpy(t00, tb + texel_offset(tp.o00), 12);
+    __builtin_memcpy(t10, tb + texel_offset(tp.o10), 12);
+    __builtin_memcpy(t01, tb + texel_offset(tp.o01), 12);
+    __builtin_memcpy(t11, tb + texel_offset(tp.o11), 12);
     albedo.x = filter_channel(t00[0], t10[0], t01[0], t11[0], 0, tp.fx, tp.fy);
     albedo.y = filter_channel(t00[0], t10[0], t01[0], t11[0], 8, tp.fx, tp.fy);
     albedo.z = filter_channel(t00[0], t10[0], t01[0], t11[0], 16, tp.fx, tp.fy);

@@ -1062,6 +1062,2727 @@ __global__ __launch_bounds__(1024) void k_blk_fresnel_block_no_pk_max(unsigned l
   if (t1 == 1) sink[0] = a + b;
 }
 
+// ---- ONE instruction of a kind among seven plain v_fma_f32: what does it cost there? ----
+__global__ __launch_bounds__(1024) void k_iso_pk_add_f32(unsigned long long *__restrict__ stamps, float a, float b, float *sink) {
+  extern __shared__ char lds[];
+  if (threadIdx.x == 1023) lds[0] = 1;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < kIters; ++it) {
+    asm volatile(
+      "v_fma_f32 v60, v68, v69, v60\n"
+      "v_fma_f32 v61, v71, v74, v61\n"
+      "v_fma_f32 v62, v74, v79, v62\n"
+      "v_fma_f32 v63, v77, v84, v63\n"
+      "v_fma_f32 v64, v80, v73, v64\n"
+      "v_fma_f32 v65, v83, v78, v65\n"
+      "v_fma_f32 v66, v70, v83, v66\n"
+      "v_pk_add_f32 v[90:91], v[92:93], v[94:95]\n"
+      "v_fma_f32 v67, v68, v69, v67\n"
+      "v_fma_f32 v60, v71, v74, v60\n"
+      "v_fma_f32 v61, v74, v79, v61\n"
+      "v_fma_f32 v62, v77, v84, v62\n"
+      "v_fma_f32 v63, v80, v73, v63\n"
+      "v_fma_f32 v64, v83, v78, v64\n"
+      "v_fma_f32 v65, v70, v83, v65\n"
+      "v_pk_add_f32 v[90:91], v[92:93], v[94:95]\n"
+      "v_fma_f32 v66, v68, v69, v66\n"
+      "v_fma_f32 v67, v71, v74, v67\n"
+      "v_fma_f32 v60, v74, v79, v60\n"
+      "v_fma_f32 v61, v77, v84, v61\n"
+      "v_fma_f32 v62, v80, v73, v62\n"
+      "v_fma_f32 v63, v83, v78, v63\n"
+      "v_fma_f32 v64, v70, v83, v64\n"
+      "v_pk_add_f32 v[90:91], v[92:93], v[94:95]\n"
+      "v_fma_f32 v65, v68, v69, v65\n"
+      "v_fma_f32 v66, v71, v74, v66\n"
+      "v_fma_f32 v67, v74, v79, v67\n"
+      "v_fma_f32 v60, v77, v84, v60\n"
+      "v_fma_f32 v61, v80, v73, v61\n"
+      "v_fma_f32 v62, v83, v78, v62\n"
+      "v_fma_f32 v63, v70, v83, v63\n"
+      "v_pk_add_f32 v[90:91], v[92:93], v[94:95]\n"
+      "v_fma_f32 v64, v68, v69, v64\n"
+      "v_fma_f32 v65, v71, v74, v65\n"
+      "v_fma_f32 v66, v74, v79, v66\n"
+      "v_fma_f32 v67, v77, v84, v67\n"
+      "v_fma_f32 v60, v80, v73, v60\n"
+      "v_fma_f32 v61, v83, v78, v61\n"
+      "v_fma_f32 v62, v70, v83, v62\n"
+      "v_pk_add_f32 v[90:91], v[92:93], v[94:95]\n"
+      "v_fma_f32 v63, v68, v69, v63\n"
+      "v_fma_f32 v64, v71, v74, v64\n"
+      "v_fma_f32 v65, v74, v79, v65\n"
+      "v_fma_f32 v66, v77, v84, v66\n"
+      "v_fma_f32 v67, v80, v73, v67\n"
+      "v_fma_f32 v60, v83, v78, v60\n"
+      "v_fma_f32 v61, v70, v83, v61\n"
+      "v_pk_add_f32 v[90:91], v[92:93], v[94:95]\n"
+      "v_fma_f32 v62, v68, v69, v62\n"
+      "v_fma_f32 v63, v71, v74, v63\n"
+      "v_fma_f32 v64, v74, v79, v64\n"
+      "v_fma_f32 v65, v77, v84, v65\n"
+      "v_fma_f32 v66, v80, v73, v66\n"
+      "v_fma_f32 v67, v83, v78, v67\n"
+      "v_fma_f32 v60, v70, v83, v60\n"
+      "v_pk_add_f32 v[90:91], v[92:93], v[94:95]\n"
+      "v_fma_f32 v61, v68, v69, v61\n"
+      "v_fma_f32 v62, v71, v74, v62\n"
+      "v_fma_f32 v63, v74, v79, v63\n"
+      "v_fma_f32 v64, v77, v84, v64\n"
+      "v_fma_f32 v65, v80, v73, v65\n"
+      "v_fma_f32 v66, v83, v78, v66\n"
+      "v_fma_f32 v67, v70, v83, v67\n"
+      "v_pk_add_f32 v[90:91], v[92:93], v[94:95]\n"
+      ::: "vcc", "scc", "s20", "s21", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97");
+  }
+  asm volatile("s_nop 0" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = ((r1 - r0) << 32) | (t1 - t0);
+  if (t1 == 1) sink[0] = a + b;
+}
+
+__global__ __launch_bounds__(1024) void k_iso_pk_fma_f32(unsigned long long *__restrict__ stamps, float a, float b, float *sink) {
+  extern __shared__ char lds[];
+  if (threadIdx.x == 1023) lds[0] = 1;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < kIters; ++it) {
+    asm volatile(
+      "v_fma_f32 v60, v68, v69, v60\n"
+      "v_fma_f32 v61, v71, v74, v61\n"
+      "v_fma_f32 v62, v74, v79, v62\n"
+      "v_fma_f32 v63, v77, v84, v63\n"
+      "v_fma_f32 v64, v80, v73, v64\n"
+      "v_fma_f32 v65, v83, v78, v65\n"
+      "v_fma_f32 v66, v70, v83, v66\n"
+      "v_pk_fma_f32 v[90:91], v[92:93], v[94:95], v[96:97]\n"
+      "v_fma_f32 v67, v68, v69, v67\n"
+      "v_fma_f32 v60, v71, v74, v60\n"
+      "v_fma_f32 v61, v74, v79, v61\n"
+      "v_fma_f32 v62, v77, v84, v62\n"
+      "v_fma_f32 v63, v80, v73, v63\n"
+      "v_fma_f32 v64, v83, v78, v64\n"
+      "v_fma_f32 v65, v70, v83, v65\n"
+      "v_pk_fma_f32 v[90:91], v[92:93], v[94:95], v[96:97]\n"
+      "v_fma_f32 v66, v68, v69, v66\n"
+      "v_fma_f32 v67, v71, v74, v67\n"
+      "v_fma_f32 v60, v74, v79, v60\n"
+      "v_fma_f32 v61, v77, v84, v61\n"
+      "v_fma_f32 v62, v80, v73, v62\n"
+      "v_fma_f32 v63, v83, v78, v63\n"
+      "v_fma_f32 v64, v70, v83, v64\n"
+      "v_pk_fma_f32 v[90:91], v[92:93], v[94:95], v[96:97]\n"
+      "v_fma_f32 v65, v68, v69, v65\n"
+      "v_fma_f32 v66, v71, v74, v66\n"
+      "v_fma_f32 v67, v74, v79, v67\n"
+      "v_fma_f32 v60, v77, v84, v60\n"
+      "v_fma_f32 v61, v80, v73, v61\n"
+      "v_fma_f32 v62, v83, v78, v62\n"
+      "v_fma_f32 v63, v70, v83, v63\n"
+      "v_pk_fma_f32 v[90:91], v[92:93], v[94:95], v[96:97]\n"
+      "v_fma_f32 v64, v68, v69, v64\n"
+      "v_fma_f32 v65, v71, v74, v65\n"
+      "v_fma_f32 v66, v74, v79, v66\n"
+      "v_fma_f32 v67, v77, v84, v67\n"
+      "v_fma_f32 v60, v80, v73, v60\n"
+      "v_fma_f32 v61, v83, v78, v61\n"
+      "v_fma_f32 v62, v70, v83, v62\n"
+      "v_pk_fma_f32 v[90:91], v[92:93], v[94:95], v[96:97]\n"
+      "v_fma_f32 v63, v68, v69, v63\n"
+      "v_fma_f32 v64, v71, v74, v64\n"
+      "v_fma_f32 v65, v74, v79, v65\n"
+      "v_fma_f32 v66, v77, v84, v66\n"
+      "v_fma_f32 v67, v80, v73, v67\n"
+      "v_fma_f32 v60, v83, v78, v60\n"
+      "v_fma_f32 v61, v70, v83, v61\n"
+      "v_pk_fma_f32 v[90:91], v[92:93], v[94:95], v[96:97]\n"
+      "v_fma_f32 v62, v68, v69, v62\n"
+      "v_fma_f32 v63, v71, v74, v63\n"
+      "v_fma_f32 v64, v74, v79, v64\n"
+      "v_fma_f32 v65, v77, v84, v65\n"
+      "v_fma_f32 v66, v80, v73, v66\n"
+      "v_fma_f32 v67, v83, v78, v67\n"
+      "v_fma_f32 v60, v70, v83, v60\n"
+      "v_pk_fma_f32 v[90:91], v[92:93], v[94:95], v[96:97]\n"
+      "v_fma_f32 v61, v68, v69, v61\n"
+      "v_fma_f32 v62, v71, v74, v62\n"
+      "v_fma_f32 v63, v74, v79, v63\n"
+      "v_fma_f32 v64, v77, v84, v64\n"
+      "v_fma_f32 v65, v80, v73, v65\n"
+      "v_fma_f32 v66, v83, v78, v66\n"
+      "v_fma_f32 v67, v70, v83, v67\n"
+      "v_pk_fma_f32 v[90:91], v[92:93], v[94:95], v[96:97]\n"
+      ::: "vcc", "scc", "s20", "s21", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97");
+  }
+  asm volatile("s_nop 0" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = ((r1 - r0) << 32) | (t1 - t0);
+  if (t1 == 1) sink[0] = a + b;
+}
+
+__global__ __launch_bounds__(1024) void k_iso_cvt_f32_ubyte1(unsigned long long *__restrict__ stamps, float a, float b, float *sink) {
+  extern __shared__ char lds[];
+  if (threadIdx.x == 1023) lds[0] = 1;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < kIters; ++it) {
+    asm volatile(
+      "v_fma_f32 v60, v68, v69, v60\n"
+      "v_fma_f32 v61, v71, v74, v61\n"
+      "v_fma_f32 v62, v74, v79, v62\n"
+      "v_fma_f32 v63, v77, v84, v63\n"
+      "v_fma_f32 v64, v80, v73, v64\n"
+      "v_fma_f32 v65, v83, v78, v65\n"
+      "v_fma_f32 v66, v70, v83, v66\n"
+      "v_cvt_f32_ubyte1 v90, v92\n"
+      "v_fma_f32 v67, v68, v69, v67\n"
+      "v_fma_f32 v60, v71, v74, v60\n"
+      "v_fma_f32 v61, v74, v79, v61\n"
+      "v_fma_f32 v62, v77, v84, v62\n"
+      "v_fma_f32 v63, v80, v73, v63\n"
+      "v_fma_f32 v64, v83, v78, v64\n"
+      "v_fma_f32 v65, v70, v83, v65\n"
+      "v_cvt_f32_ubyte1 v90, v92\n"
+      "v_fma_f32 v66, v68, v69, v66\n"
+      "v_fma_f32 v67, v71, v74, v67\n"
+      "v_fma_f32 v60, v74, v79, v60\n"
+      "v_fma_f32 v61, v77, v84, v61\n"
+      "v_fma_f32 v62, v80, v73, v62\n"
+      "v_fma_f32 v63, v83, v78, v63\n"
+      "v_fma_f32 v64, v70, v83, v64\n"
+      "v_cvt_f32_ubyte1 v90, v92\n"
+      "v_fma_f32 v65, v68, v69, v65\n"
+      "v_fma_f32 v66, v71, v74, v66\n"
+      "v_fma_f32 v67, v74, v79, v67\n"
+      "v_fma_f32 v60, v77, v84, v60\n"
+      "v_fma_f32 v61, v80, v73, v61\n"
+      "v_fma_f32 v62, v83, v78, v62\n"
+      "v_fma_f32 v63, v70, v83, v63\n"
+      "v_cvt_f32_ubyte1 v90, v92\n"
+      "v_fma_f32 v64, v68, v69, v64\n"
+      "v_fma_f32 v65, v71, v74, v65\n"
+      "v_fma_f32 v66, v74, v79, v66\n"
+      "v_fma_f32 v67, v77, v84, v67\n"
+      "v_fma_f32 v60, v80, v73, v60\n"
+      "v_fma_f32 v61, v83, v78, v61\n"
+      "v_fma_f32 v62, v70, v83, v62\n"
+      "v_cvt_f32_ubyte1 v90, v92\n"
+      "v_fma_f32 v63, v68, v69, v63\n"
+      "v_fma_f32 v64, v71, v74, v64\n"
+      "v_fma_f32 v65, v74, v79, v65\n"
+      "v_fma_f32 v66, v77, v84, v66\n"
+      "v_fma_f32 v67, v80, v73, v67\n"
+      "v_fma_f32 v60, v83, v78, v60\n"
+      "v_fma_f32 v61, v70, v83, v61\n"
+      "v_cvt_f32_ubyte1 v90, v92\n"
+      "v_fma_f32 v62, v68, v69, v62\n"
+      "v_fma_f32 v63, v71, v74, v63\n"
+      "v_fma_f32 v64, v74, v79, v64\n"
+      "v_fma_f32 v65, v77, v84, v65\n"
+      "v_fma_f32 v66, v80, v73, v66\n"
+      "v_fma_f32 v67, v83, v78, v67\n"
+      "v_fma_f32 v60, v70, v83, v60\n"
+      "v_cvt_f32_ubyte1 v90, v92\n"
+      "v_fma_f32 v61, v68, v69, v61\n"
+      "v_fma_f32 v62, v71, v74, v62\n"
+      "v_fma_f32 v63, v74, v79, v63\n"
+      "v_fma_f32 v64, v77, v84, v64\n"
+      "v_fma_f32 v65, v80, v73, v65\n"
+      "v_fma_f32 v66, v83, v78, v66\n"
+      "v_fma_f32 v67, v70, v83, v67\n"
+      "v_cvt_f32_ubyte1 v90, v92\n"
+      ::: "vcc", "scc", "s20", "s21", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97");
+  }
+  asm volatile("s_nop 0" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = ((r1 - r0) << 32) | (t1 - t0);
+  if (t1 == 1) sink[0] = a + b;
+}
+
+__global__ __launch_bounds__(1024) void k_iso_cvt_f32_i32(unsigned long long *__restrict__ stamps, float a, float b, float *sink) {
+  extern __shared__ char lds[];
+  if (threadIdx.x == 1023) lds[0] = 1;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < kIters; ++it) {
+    asm volatile(
+      "v_fma_f32 v60, v68, v69, v60\n"
+      "v_fma_f32 v61, v71, v74, v61\n"
+      "v_fma_f32 v62, v74, v79, v62\n"
+      "v_fma_f32 v63, v77, v84, v63\n"
+      "v_fma_f32 v64, v80, v73, v64\n"
+      "v_fma_f32 v65, v83, v78, v65\n"
+      "v_fma_f32 v66, v70, v83, v66\n"
+      "v_cvt_f32_i32 v90, v92\n"
+      "v_fma_f32 v67, v68, v69, v67\n"
+      "v_fma_f32 v60, v71, v74, v60\n"
+      "v_fma_f32 v61, v74, v79, v61\n"
+      "v_fma_f32 v62, v77, v84, v62\n"
+      "v_fma_f32 v63, v80, v73, v63\n"
+      "v_fma_f32 v64, v83, v78, v64\n"
+      "v_fma_f32 v65, v70, v83, v65\n"
+      "v_cvt_f32_i32 v90, v92\n"
+      "v_fma_f32 v66, v68, v69, v66\n"
+      "v_fma_f32 v67, v71, v74, v67\n"
+      "v_fma_f32 v60, v74, v79, v60\n"
+      "v_fma_f32 v61, v77, v84, v61\n"
+      "v_fma_f32 v62, v80, v73, v62\n"
+      "v_fma_f32 v63, v83, v78, v63\n"
+      "v_fma_f32 v64, v70, v83, v64\n"
+      "v_cvt_f32_i32 v90, v92\n"
+      "v_fma_f32 v65, v68, v69, v65\n"
+      "v_fma_f32 v66, v71, v74, v66\n"
+      "v_fma_f32 v67, v74, v79, v67\n"
+      "v_fma_f32 v60, v77, v84, v60\n"
+      "v_fma_f32 v61, v80, v73, v61\n"
+      "v_fma_f32 v62, v83, v78, v62\n"
+      "v_fma_f32 v63, v70, v83, v63\n"
+      "v_cvt_f32_i32 v90, v92\n"
+      "v_fma_f32 v64, v68, v69, v64\n"
+      "v_fma_f32 v65, v71, v74, v65\n"
+      "v_fma_f32 v66, v74, v79, v66\n"
+      "v_fma_f32 v67, v77, v84, v67\n"
+      "v_fma_f32 v60, v80, v73, v60\n"
+      "v_fma_f32 v61, v83, v78, v61\n"
+      "v_fma_f32 v62, v70, v83, v62\n"
+      "v_cvt_f32_i32 v90, v92\n"
+      "v_fma_f32 v63, v68, v69, v63\n"
+      "v_fma_f32 v64, v71, v74, v64\n"
+      "v_fma_f32 v65, v74, v79, v65\n"
+      "v_fma_f32 v66, v77, v84, v66\n"
+      "v_fma_f32 v67, v80, v73, v67\n"
+      "v_fma_f32 v60, v83, v78, v60\n"
+      "v_fma_f32 v61, v70, v83, v61\n"
+      "v_cvt_f32_i32 v90, v92\n"
+      "v_fma_f32 v62, v68, v69, v62\n"
+      "v_fma_f32 v63, v71, v74, v63\n"
+      "v_fma_f32 v64, v74, v79, v64\n"
+      "v_fma_f32 v65, v77, v84, v65\n"
+      "v_fma_f32 v66, v80, v73, v66\n"
+      "v_fma_f32 v67, v83, v78, v67\n"
+      "v_fma_f32 v60, v70, v83, v60\n"
+      "v_cvt_f32_i32 v90, v92\n"
+      "v_fma_f32 v61, v68, v69, v61\n"
+      "v_fma_f32 v62, v71, v74, v62\n"
+      "v_fma_f32 v63, v74, v79, v63\n"
+      "v_fma_f32 v64, v77, v84, v64\n"
+      "v_fma_f32 v65, v80, v73, v65\n"
+      "v_fma_f32 v66, v83, v78, v66\n"
+      "v_fma_f32 v67, v70, v83, v67\n"
+      "v_cvt_f32_i32 v90, v92\n"
+      ::: "vcc", "scc", "s20", "s21", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97");
+  }
+  asm volatile("s_nop 0" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = ((r1 - r0) << 32) | (t1 - t0);
+  if (t1 == 1) sink[0] = a + b;
+}
+
+__global__ __launch_bounds__(1024) void k_iso_max_f32(unsigned long long *__restrict__ stamps, float a, float b, float *sink) {
+  extern __shared__ char lds[];
+  if (threadIdx.x == 1023) lds[0] = 1;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < kIters; ++it) {
+    asm volatile(
+      "v_fma_f32 v60, v68, v69, v60\n"
+      "v_fma_f32 v61, v71, v74, v61\n"
+      "v_fma_f32 v62, v74, v79, v62\n"
+      "v_fma_f32 v63, v77, v84, v63\n"
+      "v_fma_f32 v64, v80, v73, v64\n"
+      "v_fma_f32 v65, v83, v78, v65\n"
+      "v_fma_f32 v66, v70, v83, v66\n"
+      "v_max_f32 v90, v92, v94\n"
+      "v_fma_f32 v67, v68, v69, v67\n"
+      "v_fma_f32 v60, v71, v74, v60\n"
+      "v_fma_f32 v61, v74, v79, v61\n"
+      "v_fma_f32 v62, v77, v84, v62\n"
+      "v_fma_f32 v63, v80, v73, v63\n"
+      "v_fma_f32 v64, v83, v78, v64\n"
+      "v_fma_f32 v65, v70, v83, v65\n"
+      "v_max_f32 v90, v92, v94\n"
+      "v_fma_f32 v66, v68, v69, v66\n"
+      "v_fma_f32 v67, v71, v74, v67\n"
+      "v_fma_f32 v60, v74, v79, v60\n"
+      "v_fma_f32 v61, v77, v84, v61\n"
+      "v_fma_f32 v62, v80, v73, v62\n"
+      "v_fma_f32 v63, v83, v78, v63\n"
+      "v_fma_f32 v64, v70, v83, v64\n"
+      "v_max_f32 v90, v92, v94\n"
+      "v_fma_f32 v65, v68, v69, v65\n"
+      "v_fma_f32 v66, v71, v74, v66\n"
+      "v_fma_f32 v67, v74, v79, v67\n"
+      "v_fma_f32 v60, v77, v84, v60\n"
+      "v_fma_f32 v61, v80, v73, v61\n"
+      "v_fma_f32 v62, v83, v78, v62\n"
+      "v_fma_f32 v63, v70, v83, v63\n"
+      "v_max_f32 v90, v92, v94\n"
+      "v_fma_f32 v64, v68, v69, v64\n"
+      "v_fma_f32 v65, v71, v74, v65\n"
+      "v_fma_f32 v66, v74, v79, v66\n"
+      "v_fma_f32 v67, v77, v84, v67\n"
+      "v_fma_f32 v60, v80, v73, v60\n"
+      "v_fma_f32 v61, v83, v78, v61\n"
+      "v_fma_f32 v62, v70, v83, v62\n"
+      "v_max_f32 v90, v92, v94\n"
+      "v_fma_f32 v63, v68, v69, v63\n"
+      "v_fma_f32 v64, v71, v74, v64\n"
+      "v_fma_f32 v65, v74, v79, v65\n"
+      "v_fma_f32 v66, v77, v84, v66\n"
+      "v_fma_f32 v67, v80, v73, v67\n"
+      "v_fma_f32 v60, v83, v78, v60\n"
+      "v_fma_f32 v61, v70, v83, v61\n"
+      "v_max_f32 v90, v92, v94\n"
+      "v_fma_f32 v62, v68, v69, v62\n"
+      "v_fma_f32 v63, v71, v74, v63\n"
+      "v_fma_f32 v64, v74, v79, v64\n"
+      "v_fma_f32 v65, v77, v84, v65\n"
+      "v_fma_f32 v66, v80, v73, v66\n"
+      "v_fma_f32 v67, v83, v78, v67\n"
+      "v_fma_f32 v60, v70, v83, v60\n"
+      "v_max_f32 v90, v92, v94\n"
+      "v_fma_f32 v61, v68, v69, v61\n"
+      "v_fma_f32 v62, v71, v74, v62\n"
+      "v_fma_f32 v63, v74, v79, v63\n"
+      "v_fma_f32 v64, v77, v84, v64\n"
+      "v_fma_f32 v65, v80, v73, v65\n"
+      "v_fma_f32 v66, v83, v78, v66\n"
+      "v_fma_f32 v67, v70, v83, v67\n"
+      "v_max_f32 v90, v92, v94\n"
+      ::: "vcc", "scc", "s20", "s21", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97");
+  }
+  asm volatile("s_nop 0" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = ((r1 - r0) << 32) | (t1 - t0);
+  if (t1 == 1) sink[0] = a + b;
+}
+
+__global__ __launch_bounds__(1024) void k_iso_cmp_class_f32(unsigned long long *__restrict__ stamps, float a, float b, float *sink) {
+  extern __shared__ char lds[];
+  if (threadIdx.x == 1023) lds[0] = 1;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < kIters; ++it) {
+    asm volatile(
+      "v_fma_f32 v60, v68, v69, v60\n"
+      "v_fma_f32 v61, v71, v74, v61\n"
+      "v_fma_f32 v62, v74, v79, v62\n"
+      "v_fma_f32 v63, v77, v84, v63\n"
+      "v_fma_f32 v64, v80, v73, v64\n"
+      "v_fma_f32 v65, v83, v78, v65\n"
+      "v_fma_f32 v66, v70, v83, v66\n"
+      "v_cmp_class_f32 vcc, v92, v94\n"
+      "v_fma_f32 v67, v68, v69, v67\n"
+      "v_fma_f32 v60, v71, v74, v60\n"
+      "v_fma_f32 v61, v74, v79, v61\n"
+      "v_fma_f32 v62, v77, v84, v62\n"
+      "v_fma_f32 v63, v80, v73, v63\n"
+      "v_fma_f32 v64, v83, v78, v64\n"
+      "v_fma_f32 v65, v70, v83, v65\n"
+      "v_cmp_class_f32 vcc, v92, v94\n"
+      "v_fma_f32 v66, v68, v69, v66\n"
+      "v_fma_f32 v67, v71, v74, v67\n"
+      "v_fma_f32 v60, v74, v79, v60\n"
+      "v_fma_f32 v61, v77, v84, v61\n"
+      "v_fma_f32 v62, v80, v73, v62\n"
+      "v_fma_f32 v63, v83, v78, v63\n"
+      "v_fma_f32 v64, v70, v83, v64\n"
+      "v_cmp_class_f32 vcc, v92, v94\n"
+      "v_fma_f32 v65, v68, v69, v65\n"
+      "v_fma_f32 v66, v71, v74, v66\n"
+      "v_fma_f32 v67, v74, v79, v67\n"
+      "v_fma_f32 v60, v77, v84, v60\n"
+      "v_fma_f32 v61, v80, v73, v61\n"
+      "v_fma_f32 v62, v83, v78, v62\n"
+      "v_fma_f32 v63, v70, v83, v63\n"
+      "v_cmp_class_f32 vcc, v92, v94\n"
+      "v_fma_f32 v64, v68, v69, v64\n"
+      "v_fma_f32 v65, v71, v74, v65\n"
+      "v_fma_f32 v66, v74, v79, v66\n"
+      "v_fma_f32 v67, v77, v84, v67\n"
+      "v_fma_f32 v60, v80, v73, v60\n"
+      "v_fma_f32 v61, v83, v78, v61\n"
+      "v_fma_f32 v62, v70, v83, v62\n"
+      "v_cmp_class_f32 vcc, v92, v94\n"
+      "v_fma_f32 v63, v68, v69, v63\n"
+      "v_fma_f32 v64, v71, v74, v64\n"
+      "v_fma_f32 v65, v74, v79, v65\n"
+      "v_fma_f32 v66, v77, v84, v66\n"
+      "v_fma_f32 v67, v80, v73, v67\n"
+      "v_fma_f32 v60, v83, v78, v60\n"
+      "v_fma_f32 v61, v70, v83, v61\n"
+      "v_cmp_class_f32 vcc, v92, v94\n"
+      "v_fma_f32 v62, v68, v69, v62\n"
+      "v_fma_f32 v63, v71, v74, v63\n"
+      "v_fma_f32 v64, v74, v79, v64\n"
+      "v_fma_f32 v65, v77, v84, v65\n"
+      "v_fma_f32 v66, v80, v73, v66\n"
+      "v_fma_f32 v67, v83, v78, v67\n"
+      "v_fma_f32 v60, v70, v83, v60\n"
+      "v_cmp_class_f32 vcc, v92, v94\n"
+      "v_fma_f32 v61, v68, v69, v61\n"
+      "v_fma_f32 v62, v71, v74, v62\n"
+      "v_fma_f32 v63, v74, v79, v63\n"
+      "v_fma_f32 v64, v77, v84, v64\n"
+      "v_fma_f32 v65, v80, v73, v65\n"
+      "v_fma_f32 v66, v83, v78, v66\n"
+      "v_fma_f32 v67, v70, v83, v67\n"
+      "v_cmp_class_f32 vcc, v92, v94\n"
+      ::: "vcc", "scc", "s20", "s21", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97");
+  }
+  asm volatile("s_nop 0" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = ((r1 - r0) << 32) | (t1 - t0);
+  if (t1 == 1) sink[0] = a + b;
+}
+
+__global__ __launch_bounds__(1024) void k_iso_cndmask_b32(unsigned long long *__restrict__ stamps, float a, float b, float *sink) {
+  extern __shared__ char lds[];
+  if (threadIdx.x == 1023) lds[0] = 1;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < kIters; ++it) {
+    asm volatile(
+      "v_fma_f32 v60, v68, v69, v60\n"
+      "v_fma_f32 v61, v71, v74, v61\n"
+      "v_fma_f32 v62, v74, v79, v62\n"
+      "v_fma_f32 v63, v77, v84, v63\n"
+      "v_fma_f32 v64, v80, v73, v64\n"
+      "v_fma_f32 v65, v83, v78, v65\n"
+      "v_fma_f32 v66, v70, v83, v66\n"
+      "v_cndmask_b32 v90, v92, v94, vcc\n"
+      "v_fma_f32 v67, v68, v69, v67\n"
+      "v_fma_f32 v60, v71, v74, v60\n"
+      "v_fma_f32 v61, v74, v79, v61\n"
+      "v_fma_f32 v62, v77, v84, v62\n"
+      "v_fma_f32 v63, v80, v73, v63\n"
+      "v_fma_f32 v64, v83, v78, v64\n"
+      "v_fma_f32 v65, v70, v83, v65\n"
+      "v_cndmask_b32 v90, v92, v94, vcc\n"
+      "v_fma_f32 v66, v68, v69, v66\n"
+      "v_fma_f32 v67, v71, v74, v67\n"
+      "v_fma_f32 v60, v74, v79, v60\n"
+      "v_fma_f32 v61, v77, v84, v61\n"
+      "v_fma_f32 v62, v80, v73, v62\n"
+      "v_fma_f32 v63, v83, v78, v63\n"
+      "v_fma_f32 v64, v70, v83, v64\n"
+      "v_cndmask_b32 v90, v92, v94, vcc\n"
+      "v_fma_f32 v65, v68, v69, v65\n"
+      "v_fma_f32 v66, v71, v74, v66\n"
+      "v_fma_f32 v67, v74, v79, v67\n"
+      "v_fma_f32 v60, v77, v84, v60\n"
+      "v_fma_f32 v61, v80, v73, v61\n"
+      "v_fma_f32 v62, v83, v78, v62\n"
+      "v_fma_f32 v63, v70, v83, v63\n"
+      "v_cndmask_b32 v90, v92, v94, vcc\n"
+      "v_fma_f32 v64, v68, v69, v64\n"
+      "v_fma_f32 v65, v71, v74, v65\n"
+      "v_fma_f32 v66, v74, v79, v66\n"
+      "v_fma_f32 v67, v77, v84, v67\n"
+      "v_fma_f32 v60, v80, v73, v60\n"
+      "v_fma_f32 v61, v83, v78, v61\n"
+      "v_fma_f32 v62, v70, v83, v62\n"
+      "v_cndmask_b32 v90, v92, v94, vcc\n"
+      "v_fma_f32 v63, v68, v69, v63\n"
+      "v_fma_f32 v64, v71, v74, v64\n"
+      "v_fma_f32 v65, v74, v79, v65\n"
+      "v_fma_f32 v66, v77, v84, v66\n"
+      "v_fma_f32 v67, v80, v73, v67\n"
+      "v_fma_f32 v60, v83, v78, v60\n"
+      "v_fma_f32 v61, v70, v83, v61\n"
+      "v_cndmask_b32 v90, v92, v94, vcc\n"
+      "v_fma_f32 v62, v68, v69, v62\n"
+      "v_fma_f32 v63, v71, v74, v63\n"
+      "v_fma_f32 v64, v74, v79, v64\n"
+      "v_fma_f32 v65, v77, v84, v65\n"
+      "v_fma_f32 v66, v80, v73, v66\n"
+      "v_fma_f32 v67, v83, v78, v67\n"
+      "v_fma_f32 v60, v70, v83, v60\n"
+      "v_cndmask_b32 v90, v92, v94, vcc\n"
+      "v_fma_f32 v61, v68, v69, v61\n"
+      "v_fma_f32 v62, v71, v74, v62\n"
+      "v_fma_f32 v63, v74, v79, v63\n"
+      "v_fma_f32 v64, v77, v84, v64\n"
+      "v_fma_f32 v65, v80, v73, v65\n"
+      "v_fma_f32 v66, v83, v78, v66\n"
+      "v_fma_f32 v67, v70, v83, v67\n"
+      "v_cndmask_b32 v90, v92, v94, vcc\n"
+      ::: "vcc", "scc", "s20", "s21", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97");
+  }
+  asm volatile("s_nop 0" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = ((r1 - r0) << 32) | (t1 - t0);
+  if (t1 == 1) sink[0] = a + b;
+}
+
+__global__ __launch_bounds__(1024) void k_iso_rcp_f32(unsigned long long *__restrict__ stamps, float a, float b, float *sink) {
+  extern __shared__ char lds[];
+  if (threadIdx.x == 1023) lds[0] = 1;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < kIters; ++it) {
+    asm volatile(
+      "v_fma_f32 v60, v68, v69, v60\n"
+      "v_fma_f32 v61, v71, v74, v61\n"
+      "v_fma_f32 v62, v74, v79, v62\n"
+      "v_fma_f32 v63, v77, v84, v63\n"
+      "v_fma_f32 v64, v80, v73, v64\n"
+      "v_fma_f32 v65, v83, v78, v65\n"
+      "v_fma_f32 v66, v70, v83, v66\n"
+      "v_rcp_f32 v90, v92\n"
+      "v_fma_f32 v67, v68, v69, v67\n"
+      "v_fma_f32 v60, v71, v74, v60\n"
+      "v_fma_f32 v61, v74, v79, v61\n"
+      "v_fma_f32 v62, v77, v84, v62\n"
+      "v_fma_f32 v63, v80, v73, v63\n"
+      "v_fma_f32 v64, v83, v78, v64\n"
+      "v_fma_f32 v65, v70, v83, v65\n"
+      "v_rcp_f32 v90, v92\n"
+      "v_fma_f32 v66, v68, v69, v66\n"
+      "v_fma_f32 v67, v71, v74, v67\n"
+      "v_fma_f32 v60, v74, v79, v60\n"
+      "v_fma_f32 v61, v77, v84, v61\n"
+      "v_fma_f32 v62, v80, v73, v62\n"
+      "v_fma_f32 v63, v83, v78, v63\n"
+      "v_fma_f32 v64, v70, v83, v64\n"
+      "v_rcp_f32 v90, v92\n"
+      "v_fma_f32 v65, v68, v69, v65\n"
+      "v_fma_f32 v66, v71, v74, v66\n"
+      "v_fma_f32 v67, v74, v79, v67\n"
+      "v_fma_f32 v60, v77, v84, v60\n"
+      "v_fma_f32 v61, v80, v73, v61\n"
+      "v_fma_f32 v62, v83, v78, v62\n"
+      "v_fma_f32 v63, v70, v83, v63\n"
+      "v_rcp_f32 v90, v92\n"
+      "v_fma_f32 v64, v68, v69, v64\n"
+      "v_fma_f32 v65, v71, v74, v65\n"
+      "v_fma_f32 v66, v74, v79, v66\n"
+      "v_fma_f32 v67, v77, v84, v67\n"
+      "v_fma_f32 v60, v80, v73, v60\n"
+      "v_fma_f32 v61, v83, v78, v61\n"
+      "v_fma_f32 v62, v70, v83, v62\n"
+      "v_rcp_f32 v90, v92\n"
+      "v_fma_f32 v63, v68, v69, v63\n"
+      "v_fma_f32 v64, v71, v74, v64\n"
+      "v_fma_f32 v65, v74, v79, v65\n"
+      "v_fma_f32 v66, v77, v84, v66\n"
+      "v_fma_f32 v67, v80, v73, v67\n"
+      "v_fma_f32 v60, v83, v78, v60\n"
+      "v_fma_f32 v61, v70, v83, v61\n"
+      "v_rcp_f32 v90, v92\n"
+      "v_fma_f32 v62, v68, v69, v62\n"
+      "v_fma_f32 v63, v71, v74, v63\n"
+      "v_fma_f32 v64, v74, v79, v64\n"
+      "v_fma_f32 v65, v77, v84, v65\n"
+      "v_fma_f32 v66, v80, v73, v66\n"
+      "v_fma_f32 v67, v83, v78, v67\n"
+      "v_fma_f32 v60, v70, v83, v60\n"
+      "v_rcp_f32 v90, v92\n"
+      "v_fma_f32 v61, v68, v69, v61\n"
+      "v_fma_f32 v62, v71, v74, v62\n"
+      "v_fma_f32 v63, v74, v79, v63\n"
+      "v_fma_f32 v64, v77, v84, v64\n"
+      "v_fma_f32 v65, v80, v73, v65\n"
+      "v_fma_f32 v66, v83, v78, v66\n"
+      "v_fma_f32 v67, v70, v83, v67\n"
+      "v_rcp_f32 v90, v92\n"
+      ::: "vcc", "scc", "s20", "s21", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97");
+  }
+  asm volatile("s_nop 0" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = ((r1 - r0) << 32) | (t1 - t0);
+  if (t1 == 1) sink[0] = a + b;
+}
+
+__global__ __launch_bounds__(1024) void k_iso_floor_f32(unsigned long long *__restrict__ stamps, float a, float b, float *sink) {
+  extern __shared__ char lds[];
+  if (threadIdx.x == 1023) lds[0] = 1;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < kIters; ++it) {
+    asm volatile(
+      "v_fma_f32 v60, v68, v69, v60\n"
+      "v_fma_f32 v61, v71, v74, v61\n"
+      "v_fma_f32 v62, v74, v79, v62\n"
+      "v_fma_f32 v63, v77, v84, v63\n"
+      "v_fma_f32 v64, v80, v73, v64\n"
+      "v_fma_f32 v65, v83, v78, v65\n"
+      "v_fma_f32 v66, v70, v83, v66\n"
+      "v_floor_f32 v90, v92\n"
+      "v_fma_f32 v67, v68, v69, v67\n"
+      "v_fma_f32 v60, v71, v74, v60\n"
+      "v_fma_f32 v61, v74, v79, v61\n"
+      "v_fma_f32 v62, v77, v84, v62\n"
+      "v_fma_f32 v63, v80, v73, v63\n"
+      "v_fma_f32 v64, v83, v78, v64\n"
+      "v_fma_f32 v65, v70, v83, v65\n"
+      "v_floor_f32 v90, v92\n"
+      "v_fma_f32 v66, v68, v69, v66\n"
+      "v_fma_f32 v67, v71, v74, v67\n"
+      "v_fma_f32 v60, v74, v79, v60\n"
+      "v_fma_f32 v61, v77, v84, v61\n"
+      "v_fma_f32 v62, v80, v73, v62\n"
+      "v_fma_f32 v63, v83, v78, v63\n"
+      "v_fma_f32 v64, v70, v83, v64\n"
+      "v_floor_f32 v90, v92\n"
+      "v_fma_f32 v65, v68, v69, v65\n"
+      "v_fma_f32 v66, v71, v74, v66\n"
+      "v_fma_f32 v67, v74, v79, v67\n"
+      "v_fma_f32 v60, v77, v84, v60\n"
+      "v_fma_f32 v61, v80, v73, v61\n"
+      "v_fma_f32 v62, v83, v78, v62\n"
+      "v_fma_f32 v63, v70, v83, v63\n"
+      "v_floor_f32 v90, v92\n"
+      "v_fma_f32 v64, v68, v69, v64\n"
+      "v_fma_f32 v65, v71, v74, v65\n"
+      "v_fma_f32 v66, v74, v79, v66\n"
+      "v_fma_f32 v67, v77, v84, v67\n"
+      "v_fma_f32 v60, v80, v73, v60\n"
+      "v_fma_f32 v61, v83, v78, v61\n"
+      "v_fma_f32 v62, v70, v83, v62\n"
+      "v_floor_f32 v90, v92\n"
+      "v_fma_f32 v63, v68, v69, v63\n"
+      "v_fma_f32 v64, v71, v74, v64\n"
+      "v_fma_f32 v65, v74, v79, v65\n"
+      "v_fma_f32 v66, v77, v84, v66\n"
+      "v_fma_f32 v67, v80, v73, v67\n"
+      "v_fma_f32 v60, v83, v78, v60\n"
+      "v_fma_f32 v61, v70, v83, v61\n"
+      "v_floor_f32 v90, v92\n"
+      "v_fma_f32 v62, v68, v69, v62\n"
+      "v_fma_f32 v63, v71, v74, v63\n"
+      "v_fma_f32 v64, v74, v79, v64\n"
+      "v_fma_f32 v65, v77, v84, v65\n"
+      "v_fma_f32 v66, v80, v73, v66\n"
+      "v_fma_f32 v67, v83, v78, v67\n"
+      "v_fma_f32 v60, v70, v83, v60\n"
+      "v_floor_f32 v90, v92\n"
+      "v_fma_f32 v61, v68, v69, v61\n"
+      "v_fma_f32 v62, v71, v74, v62\n"
+      "v_fma_f32 v63, v74, v79, v63\n"
+      "v_fma_f32 v64, v77, v84, v64\n"
+      "v_fma_f32 v65, v80, v73, v65\n"
+      "v_fma_f32 v66, v83, v78, v66\n"
+      "v_fma_f32 v67, v70, v83, v67\n"
+      "v_floor_f32 v90, v92\n"
+      ::: "vcc", "scc", "s20", "s21", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97");
+  }
+  asm volatile("s_nop 0" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = ((r1 - r0) << 32) | (t1 - t0);
+  if (t1 == 1) sink[0] = a + b;
+}
+
+__global__ __launch_bounds__(1024) void k_iso_mul_u32_u24(unsigned long long *__restrict__ stamps, float a, float b, float *sink) {
+  extern __shared__ char lds[];
+  if (threadIdx.x == 1023) lds[0] = 1;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < kIters; ++it) {
+    asm volatile(
+      "v_fma_f32 v60, v68, v69, v60\n"
+      "v_fma_f32 v61, v71, v74, v61\n"
+      "v_fma_f32 v62, v74, v79, v62\n"
+      "v_fma_f32 v63, v77, v84, v63\n"
+      "v_fma_f32 v64, v80, v73, v64\n"
+      "v_fma_f32 v65, v83, v78, v65\n"
+      "v_fma_f32 v66, v70, v83, v66\n"
+      "v_mul_u32_u24 v90, v92, v94\n"
+      "v_fma_f32 v67, v68, v69, v67\n"
+      "v_fma_f32 v60, v71, v74, v60\n"
+      "v_fma_f32 v61, v74, v79, v61\n"
+      "v_fma_f32 v62, v77, v84, v62\n"
+      "v_fma_f32 v63, v80, v73, v63\n"
+      "v_fma_f32 v64, v83, v78, v64\n"
+      "v_fma_f32 v65, v70, v83, v65\n"
+      "v_mul_u32_u24 v90, v92, v94\n"
+      "v_fma_f32 v66, v68, v69, v66\n"
+      "v_fma_f32 v67, v71, v74, v67\n"
+      "v_fma_f32 v60, v74, v79, v60\n"
+      "v_fma_f32 v61, v77, v84, v61\n"
+      "v_fma_f32 v62, v80, v73, v62\n"
+      "v_fma_f32 v63, v83, v78, v63\n"
+      "v_fma_f32 v64, v70, v83, v64\n"
+      "v_mul_u32_u24 v90, v92, v94\n"
+      "v_fma_f32 v65, v68, v69, v65\n"
+      "v_fma_f32 v66, v71, v74, v66\n"
+      "v_fma_f32 v67, v74, v79, v67\n"
+      "v_fma_f32 v60, v77, v84, v60\n"
+      "v_fma_f32 v61, v80, v73, v61\n"
+      "v_fma_f32 v62, v83, v78, v62\n"
+      "v_fma_f32 v63, v70, v83, v63\n"
+      "v_mul_u32_u24 v90, v92, v94\n"
+      "v_fma_f32 v64, v68, v69, v64\n"
+      "v_fma_f32 v65, v71, v74, v65\n"
+      "v_fma_f32 v66, v74, v79, v66\n"
+      "v_fma_f32 v67, v77, v84, v67\n"
+      "v_fma_f32 v60, v80, v73, v60\n"
+      "v_fma_f32 v61, v83, v78, v61\n"
+      "v_fma_f32 v62, v70, v83, v62\n"
+      "v_mul_u32_u24 v90, v92, v94\n"
+      "v_fma_f32 v63, v68, v69, v63\n"
+      "v_fma_f32 v64, v71, v74, v64\n"
+      "v_fma_f32 v65, v74, v79, v65\n"
+      "v_fma_f32 v66, v77, v84, v66\n"
+      "v_fma_f32 v67, v80, v73, v67\n"
+      "v_fma_f32 v60, v83, v78, v60\n"
+      "v_fma_f32 v61, v70, v83, v61\n"
+      "v_mul_u32_u24 v90, v92, v94\n"
+      "v_fma_f32 v62, v68, v69, v62\n"
+      "v_fma_f32 v63, v71, v74, v63\n"
+      "v_fma_f32 v64, v74, v79, v64\n"
+      "v_fma_f32 v65, v77, v84, v65\n"
+      "v_fma_f32 v66, v80, v73, v66\n"
+      "v_fma_f32 v67, v83, v78, v67\n"
+      "v_fma_f32 v60, v70, v83, v60\n"
+      "v_mul_u32_u24 v90, v92, v94\n"
+      "v_fma_f32 v61, v68, v69, v61\n"
+      "v_fma_f32 v62, v71, v74, v62\n"
+      "v_fma_f32 v63, v74, v79, v63\n"
+      "v_fma_f32 v64, v77, v84, v64\n"
+      "v_fma_f32 v65, v80, v73, v65\n"
+      "v_fma_f32 v66, v83, v78, v66\n"
+      "v_fma_f32 v67, v70, v83, v67\n"
+      "v_mul_u32_u24 v90, v92, v94\n"
+      ::: "vcc", "scc", "s20", "s21", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97");
+  }
+  asm volatile("s_nop 0" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = ((r1 - r0) << 32) | (t1 - t0);
+  if (t1 == 1) sink[0] = a + b;
+}
+
+__global__ __launch_bounds__(1024) void k_iso_lshl_add_u32(unsigned long long *__restrict__ stamps, float a, float b, float *sink) {
+  extern __shared__ char lds[];
+  if (threadIdx.x == 1023) lds[0] = 1;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < kIters; ++it) {
+    asm volatile(
+      "v_fma_f32 v60, v68, v69, v60\n"
+      "v_fma_f32 v61, v71, v74, v61\n"
+      "v_fma_f32 v62, v74, v79, v62\n"
+      "v_fma_f32 v63, v77, v84, v63\n"
+      "v_fma_f32 v64, v80, v73, v64\n"
+      "v_fma_f32 v65, v83, v78, v65\n"
+      "v_fma_f32 v66, v70, v83, v66\n"
+      "v_lshl_add_u32 v90, v92, 3, v94\n"
+      "v_fma_f32 v67, v68, v69, v67\n"
+      "v_fma_f32 v60, v71, v74, v60\n"
+      "v_fma_f32 v61, v74, v79, v61\n"
+      "v_fma_f32 v62, v77, v84, v62\n"
+      "v_fma_f32 v63, v80, v73, v63\n"
+      "v_fma_f32 v64, v83, v78, v64\n"
+      "v_fma_f32 v65, v70, v83, v65\n"
+      "v_lshl_add_u32 v90, v92, 3, v94\n"
+      "v_fma_f32 v66, v68, v69, v66\n"
+      "v_fma_f32 v67, v71, v74, v67\n"
+      "v_fma_f32 v60, v74, v79, v60\n"
+      "v_fma_f32 v61, v77, v84, v61\n"
+      "v_fma_f32 v62, v80, v73, v62\n"
+      "v_fma_f32 v63, v83, v78, v63\n"
+      "v_fma_f32 v64, v70, v83, v64\n"
+      "v_lshl_add_u32 v90, v92, 3, v94\n"
+      "v_fma_f32 v65, v68, v69, v65\n"
+      "v_fma_f32 v66, v71, v74, v66\n"
+      "v_fma_f32 v67, v74, v79, v67\n"
+      "v_fma_f32 v60, v77, v84, v60\n"
+      "v_fma_f32 v61, v80, v73, v61\n"
+      "v_fma_f32 v62, v83, v78, v62\n"
+      "v_fma_f32 v63, v70, v83, v63\n"
+      "v_lshl_add_u32 v90, v92, 3, v94\n"
+      "v_fma_f32 v64, v68, v69, v64\n"
+      "v_fma_f32 v65, v71, v74, v65\n"
+      "v_fma_f32 v66, v74, v79, v66\n"
+      "v_fma_f32 v67, v77, v84, v67\n"
+      "v_fma_f32 v60, v80, v73, v60\n"
+      "v_fma_f32 v61, v83, v78, v61\n"
+      "v_fma_f32 v62, v70, v83, v62\n"
+      "v_lshl_add_u32 v90, v92, 3, v94\n"
+      "v_fma_f32 v63, v68, v69, v63\n"
+      "v_fma_f32 v64, v71, v74, v64\n"
+      "v_fma_f32 v65, v74, v79, v65\n"
+      "v_fma_f32 v66, v77, v84, v66\n"
+      "v_fma_f32 v67, v80, v73, v67\n"
+      "v_fma_f32 v60, v83, v78, v60\n"
+      "v_fma_f32 v61, v70, v83, v61\n"
+      "v_lshl_add_u32 v90, v92, 3, v94\n"
+      "v_fma_f32 v62, v68, v69, v62\n"
+      "v_fma_f32 v63, v71, v74, v63\n"
+      "v_fma_f32 v64, v74, v79, v64\n"
+      "v_fma_f32 v65, v77, v84, v65\n"
+      "v_fma_f32 v66, v80, v73, v66\n"
+      "v_fma_f32 v67, v83, v78, v67\n"
+      "v_fma_f32 v60, v70, v83, v60\n"
+      "v_lshl_add_u32 v90, v92, 3, v94\n"
+      "v_fma_f32 v61, v68, v69, v61\n"
+      "v_fma_f32 v62, v71, v74, v62\n"
+      "v_fma_f32 v63, v74, v79, v63\n"
+      "v_fma_f32 v64, v77, v84, v64\n"
+      "v_fma_f32 v65, v80, v73, v65\n"
+      "v_fma_f32 v66, v83, v78, v66\n"
+      "v_fma_f32 v67, v70, v83, v67\n"
+      "v_lshl_add_u32 v90, v92, 3, v94\n"
+      ::: "vcc", "scc", "s20", "s21", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97");
+  }
+  asm volatile("s_nop 0" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = ((r1 - r0) << 32) | (t1 - t0);
+  if (t1 == 1) sink[0] = a + b;
+}
+
+__global__ __launch_bounds__(1024) void k_iso_lshl_add_u64(unsigned long long *__restrict__ stamps, float a, float b, float *sink) {
+  extern __shared__ char lds[];
+  if (threadIdx.x == 1023) lds[0] = 1;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < kIters; ++it) {
+    asm volatile(
+      "v_fma_f32 v60, v68, v69, v60\n"
+      "v_fma_f32 v61, v71, v74, v61\n"
+      "v_fma_f32 v62, v74, v79, v62\n"
+      "v_fma_f32 v63, v77, v84, v63\n"
+      "v_fma_f32 v64, v80, v73, v64\n"
+      "v_fma_f32 v65, v83, v78, v65\n"
+      "v_fma_f32 v66, v70, v83, v66\n"
+      "v_lshl_add_u64 v[90:91], v[92:93], 0, v[94:95]\n"
+      "v_fma_f32 v67, v68, v69, v67\n"
+      "v_fma_f32 v60, v71, v74, v60\n"
+      "v_fma_f32 v61, v74, v79, v61\n"
+      "v_fma_f32 v62, v77, v84, v62\n"
+      "v_fma_f32 v63, v80, v73, v63\n"
+      "v_fma_f32 v64, v83, v78, v64\n"
+      "v_fma_f32 v65, v70, v83, v65\n"
+      "v_lshl_add_u64 v[90:91], v[92:93], 0, v[94:95]\n"
+      "v_fma_f32 v66, v68, v69, v66\n"
+      "v_fma_f32 v67, v71, v74, v67\n"
+      "v_fma_f32 v60, v74, v79, v60\n"
+      "v_fma_f32 v61, v77, v84, v61\n"
+      "v_fma_f32 v62, v80, v73, v62\n"
+      "v_fma_f32 v63, v83, v78, v63\n"
+      "v_fma_f32 v64, v70, v83, v64\n"
+      "v_lshl_add_u64 v[90:91], v[92:93], 0, v[94:95]\n"
+      "v_fma_f32 v65, v68, v69, v65\n"
+      "v_fma_f32 v66, v71, v74, v66\n"
+      "v_fma_f32 v67, v74, v79, v67\n"
+      "v_fma_f32 v60, v77, v84, v60\n"
+      "v_fma_f32 v61, v80, v73, v61\n"
+      "v_fma_f32 v62, v83, v78, v62\n"
+      "v_fma_f32 v63, v70, v83, v63\n"
+      "v_lshl_add_u64 v[90:91], v[92:93], 0, v[94:95]\n"
+      "v_fma_f32 v64, v68, v69, v64\n"
+      "v_fma_f32 v65, v71, v74, v65\n"
+      "v_fma_f32 v66, v74, v79, v66\n"
+      "v_fma_f32 v67, v77, v84, v67\n"
+      "v_fma_f32 v60, v80, v73, v60\n"
+      "v_fma_f32 v61, v83, v78, v61\n"
+      "v_fma_f32 v62, v70, v83, v62\n"
+      "v_lshl_add_u64 v[90:91], v[92:93], 0, v[94:95]\n"
+      "v_fma_f32 v63, v68, v69, v63\n"
+      "v_fma_f32 v64, v71, v74, v64\n"
+      "v_fma_f32 v65, v74, v79, v65\n"
+      "v_fma_f32 v66, v77, v84, v66\n"
+      "v_fma_f32 v67, v80, v73, v67\n"
+      "v_fma_f32 v60, v83, v78, v60\n"
+      "v_fma_f32 v61, v70, v83, v61\n"
+      "v_lshl_add_u64 v[90:91], v[92:93], 0, v[94:95]\n"
+      "v_fma_f32 v62, v68, v69, v62\n"
+      "v_fma_f32 v63, v71, v74, v63\n"
+      "v_fma_f32 v64, v74, v79, v64\n"
+      "v_fma_f32 v65, v77, v84, v65\n"
+      "v_fma_f32 v66, v80, v73, v66\n"
+      "v_fma_f32 v67, v83, v78, v67\n"
+      "v_fma_f32 v60, v70, v83, v60\n"
+      "v_lshl_add_u64 v[90:91], v[92:93], 0, v[94:95]\n"
+      "v_fma_f32 v61, v68, v69, v61\n"
+      "v_fma_f32 v62, v71, v74, v62\n"
+      "v_fma_f32 v63, v74, v79, v63\n"
+      "v_fma_f32 v64, v77, v84, v64\n"
+      "v_fma_f32 v65, v80, v73, v65\n"
+      "v_fma_f32 v66, v83, v78, v66\n"
+      "v_fma_f32 v67, v70, v83, v67\n"
+      "v_lshl_add_u64 v[90:91], v[92:93], 0, v[94:95]\n"
+      ::: "vcc", "scc", "s20", "s21", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97");
+  }
+  asm volatile("s_nop 0" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = ((r1 - r0) << 32) | (t1 - t0);
+  if (t1 == 1) sink[0] = a + b;
+}
+
+__global__ __launch_bounds__(1024) void k_iso_mad_u64_u32(unsigned long long *__restrict__ stamps, float a, float b, float *sink) {
+  extern __shared__ char lds[];
+  if (threadIdx.x == 1023) lds[0] = 1;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < kIters; ++it) {
+    asm volatile(
+      "v_fma_f32 v60, v68, v69, v60\n"
+      "v_fma_f32 v61, v71, v74, v61\n"
+      "v_fma_f32 v62, v74, v79, v62\n"
+      "v_fma_f32 v63, v77, v84, v63\n"
+      "v_fma_f32 v64, v80, v73, v64\n"
+      "v_fma_f32 v65, v83, v78, v65\n"
+      "v_fma_f32 v66, v70, v83, v66\n"
+      "v_mad_u64_u32 v[90:91], vcc, v92, v94, v[96:97]\n"
+      "v_fma_f32 v67, v68, v69, v67\n"
+      "v_fma_f32 v60, v71, v74, v60\n"
+      "v_fma_f32 v61, v74, v79, v61\n"
+      "v_fma_f32 v62, v77, v84, v62\n"
+      "v_fma_f32 v63, v80, v73, v63\n"
+      "v_fma_f32 v64, v83, v78, v64\n"
+      "v_fma_f32 v65, v70, v83, v65\n"
+      "v_mad_u64_u32 v[90:91], vcc, v92, v94, v[96:97]\n"
+      "v_fma_f32 v66, v68, v69, v66\n"
+      "v_fma_f32 v67, v71, v74, v67\n"
+      "v_fma_f32 v60, v74, v79, v60\n"
+      "v_fma_f32 v61, v77, v84, v61\n"
+      "v_fma_f32 v62, v80, v73, v62\n"
+      "v_fma_f32 v63, v83, v78, v63\n"
+      "v_fma_f32 v64, v70, v83, v64\n"
+      "v_mad_u64_u32 v[90:91], vcc, v92, v94, v[96:97]\n"
+      "v_fma_f32 v65, v68, v69, v65\n"
+      "v_fma_f32 v66, v71, v74, v66\n"
+      "v_fma_f32 v67, v74, v79, v67\n"
+      "v_fma_f32 v60, v77, v84, v60\n"
+      "v_fma_f32 v61, v80, v73, v61\n"
+      "v_fma_f32 v62, v83, v78, v62\n"
+      "v_fma_f32 v63, v70, v83, v63\n"
+      "v_mad_u64_u32 v[90:91], vcc, v92, v94, v[96:97]\n"
+      "v_fma_f32 v64, v68, v69, v64\n"
+      "v_fma_f32 v65, v71, v74, v65\n"
+      "v_fma_f32 v66, v74, v79, v66\n"
+      "v_fma_f32 v67, v77, v84, v67\n"
+      "v_fma_f32 v60, v80, v73, v60\n"
+      "v_fma_f32 v61, v83, v78, v61\n"
+      "v_fma_f32 v62, v70, v83, v62\n"
+      "v_mad_u64_u32 v[90:91], vcc, v92, v94, v[96:97]\n"
+      "v_fma_f32 v63, v68, v69, v63\n"
+      "v_fma_f32 v64, v71, v74, v64\n"
+      "v_fma_f32 v65, v74, v79, v65\n"
+      "v_fma_f32 v66, v77, v84, v66\n"
+      "v_fma_f32 v67, v80, v73, v67\n"
+      "v_fma_f32 v60, v83, v78, v60\n"
+      "v_fma_f32 v61, v70, v83, v61\n"
+      "v_mad_u64_u32 v[90:91], vcc, v92, v94, v[96:97]\n"
+      "v_fma_f32 v62, v68, v69, v62\n"
+      "v_fma_f32 v63, v71, v74, v63\n"
+      "v_fma_f32 v64, v74, v79, v64\n"
+      "v_fma_f32 v65, v77, v84, v65\n"
+      "v_fma_f32 v66, v80, v73, v66\n"
+      "v_fma_f32 v67, v83, v78, v67\n"
+      "v_fma_f32 v60, v70, v83, v60\n"
+      "v_mad_u64_u32 v[90:91], vcc, v92, v94, v[96:97]\n"
+      "v_fma_f32 v61, v68, v69, v61\n"
+      "v_fma_f32 v62, v71, v74, v62\n"
+      "v_fma_f32 v63, v74, v79, v63\n"
+      "v_fma_f32 v64, v77, v84, v64\n"
+      "v_fma_f32 v65, v80, v73, v65\n"
+      "v_fma_f32 v66, v83, v78, v66\n"
+      "v_fma_f32 v67, v70, v83, v67\n"
+      "v_mad_u64_u32 v[90:91], vcc, v92, v94, v[96:97]\n"
+      ::: "vcc", "scc", "s20", "s21", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97");
+  }
+  asm volatile("s_nop 0" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = ((r1 - r0) << 32) | (t1 - t0);
+  if (t1 == 1) sink[0] = a + b;
+}
+
+__global__ __launch_bounds__(1024) void k_iso_fma_sgpr_operand(unsigned long long *__restrict__ stamps, float a, float b, float *sink) {
+  extern __shared__ char lds[];
+  if (threadIdx.x == 1023) lds[0] = 1;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < kIters; ++it) {
+    asm volatile(
+      "v_fma_f32 v60, v68, v69, v60\n"
+      "v_fma_f32 v61, v71, v74, v61\n"
+      "v_fma_f32 v62, v74, v79, v62\n"
+      "v_fma_f32 v63, v77, v84, v63\n"
+      "v_fma_f32 v64, v80, v73, v64\n"
+      "v_fma_f32 v65, v83, v78, v65\n"
+      "v_fma_f32 v66, v70, v83, v66\n"
+      "v_fma_f32 v90, s20, v92, v94\n"
+      "v_fma_f32 v67, v68, v69, v67\n"
+      "v_fma_f32 v60, v71, v74, v60\n"
+      "v_fma_f32 v61, v74, v79, v61\n"
+      "v_fma_f32 v62, v77, v84, v62\n"
+      "v_fma_f32 v63, v80, v73, v63\n"
+      "v_fma_f32 v64, v83, v78, v64\n"
+      "v_fma_f32 v65, v70, v83, v65\n"
+      "v_fma_f32 v90, s20, v92, v94\n"
+      "v_fma_f32 v66, v68, v69, v66\n"
+      "v_fma_f32 v67, v71, v74, v67\n"
+      "v_fma_f32 v60, v74, v79, v60\n"
+      "v_fma_f32 v61, v77, v84, v61\n"
+      "v_fma_f32 v62, v80, v73, v62\n"
+      "v_fma_f32 v63, v83, v78, v63\n"
+      "v_fma_f32 v64, v70, v83, v64\n"
+      "v_fma_f32 v90, s20, v92, v94\n"
+      "v_fma_f32 v65, v68, v69, v65\n"
+      "v_fma_f32 v66, v71, v74, v66\n"
+      "v_fma_f32 v67, v74, v79, v67\n"
+      "v_fma_f32 v60, v77, v84, v60\n"
+      "v_fma_f32 v61, v80, v73, v61\n"
+      "v_fma_f32 v62, v83, v78, v62\n"
+      "v_fma_f32 v63, v70, v83, v63\n"
+      "v_fma_f32 v90, s20, v92, v94\n"
+      "v_fma_f32 v64, v68, v69, v64\n"
+      "v_fma_f32 v65, v71, v74, v65\n"
+      "v_fma_f32 v66, v74, v79, v66\n"
+      "v_fma_f32 v67, v77, v84, v67\n"
+      "v_fma_f32 v60, v80, v73, v60\n"
+      "v_fma_f32 v61, v83, v78, v61\n"
+      "v_fma_f32 v62, v70, v83, v62\n"
+      "v_fma_f32 v90, s20, v92, v94\n"
+      "v_fma_f32 v63, v68, v69, v63\n"
+      "v_fma_f32 v64, v71, v74, v64\n"
+      "v_fma_f32 v65, v74, v79, v65\n"
+      "v_fma_f32 v66, v77, v84, v66\n"
+      "v_fma_f32 v67, v80, v73, v67\n"
+      "v_fma_f32 v60, v83, v78, v60\n"
+      "v_fma_f32 v61, v70, v83, v61\n"
+      "v_fma_f32 v90, s20, v92, v94\n"
+      "v_fma_f32 v62, v68, v69, v62\n"
+      "v_fma_f32 v63, v71, v74, v63\n"
+      "v_fma_f32 v64, v74, v79, v64\n"
+      "v_fma_f32 v65, v77, v84, v65\n"
+      "v_fma_f32 v66, v80, v73, v66\n"
+      "v_fma_f32 v67, v83, v78, v67\n"
+      "v_fma_f32 v60, v70, v83, v60\n"
+      "v_fma_f32 v90, s20, v92, v94\n"
+      "v_fma_f32 v61, v68, v69, v61\n"
+      "v_fma_f32 v62, v71, v74, v62\n"
+      "v_fma_f32 v63, v74, v79, v63\n"
+      "v_fma_f32 v64, v77, v84, v64\n"
+      "v_fma_f32 v65, v80, v73, v65\n"
+      "v_fma_f32 v66, v83, v78, v66\n"
+      "v_fma_f32 v67, v70, v83, v67\n"
+      "v_fma_f32 v90, s20, v92, v94\n"
+      ::: "vcc", "scc", "s20", "s21", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97");
+  }
+  asm volatile("s_nop 0" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = ((r1 - r0) << 32) | (t1 - t0);
+  if (t1 == 1) sink[0] = a + b;
+}
+
+__global__ __launch_bounds__(1024) void k_iso_readfirstlane(unsigned long long *__restrict__ stamps, float a, float b, float *sink) {
+  extern __shared__ char lds[];
+  if (threadIdx.x == 1023) lds[0] = 1;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < kIters; ++it) {
+    asm volatile(
+      "v_fma_f32 v60, v68, v69, v60\n"
+      "v_fma_f32 v61, v71, v74, v61\n"
+      "v_fma_f32 v62, v74, v79, v62\n"
+      "v_fma_f32 v63, v77, v84, v63\n"
+      "v_fma_f32 v64, v80, v73, v64\n"
+      "v_fma_f32 v65, v83, v78, v65\n"
+      "v_fma_f32 v66, v70, v83, v66\n"
+      "v_readfirstlane_b32 s20, v92\n"
+      "v_fma_f32 v67, v68, v69, v67\n"
+      "v_fma_f32 v60, v71, v74, v60\n"
+      "v_fma_f32 v61, v74, v79, v61\n"
+      "v_fma_f32 v62, v77, v84, v62\n"
+      "v_fma_f32 v63, v80, v73, v63\n"
+      "v_fma_f32 v64, v83, v78, v64\n"
+      "v_fma_f32 v65, v70, v83, v65\n"
+      "v_readfirstlane_b32 s20, v92\n"
+      "v_fma_f32 v66, v68, v69, v66\n"
+      "v_fma_f32 v67, v71, v74, v67\n"
+      "v_fma_f32 v60, v74, v79, v60\n"
+      "v_fma_f32 v61, v77, v84, v61\n"
+      "v_fma_f32 v62, v80, v73, v62\n"
+      "v_fma_f32 v63, v83, v78, v63\n"
+      "v_fma_f32 v64, v70, v83, v64\n"
+      "v_readfirstlane_b32 s20, v92\n"
+      "v_fma_f32 v65, v68, v69, v65\n"
+      "v_fma_f32 v66, v71, v74, v66\n"
+      "v_fma_f32 v67, v74, v79, v67\n"
+      "v_fma_f32 v60, v77, v84, v60\n"
+      "v_fma_f32 v61, v80, v73, v61\n"
+      "v_fma_f32 v62, v83, v78, v62\n"
+      "v_fma_f32 v63, v70, v83, v63\n"
+      "v_readfirstlane_b32 s20, v92\n"
+      "v_fma_f32 v64, v68, v69, v64\n"
+      "v_fma_f32 v65, v71, v74, v65\n"
+      "v_fma_f32 v66, v74, v79, v66\n"
+      "v_fma_f32 v67, v77, v84, v67\n"
+      "v_fma_f32 v60, v80, v73, v60\n"
+      "v_fma_f32 v61, v83, v78, v61\n"
+      "v_fma_f32 v62, v70, v83, v62\n"
+      "v_readfirstlane_b32 s20, v92\n"
+      "v_fma_f32 v63, v68, v69, v63\n"
+      "v_fma_f32 v64, v71, v74, v64\n"
+      "v_fma_f32 v65, v74, v79, v65\n"
+      "v_fma_f32 v66, v77, v84, v66\n"
+      "v_fma_f32 v67, v80, v73, v67\n"
+      "v_fma_f32 v60, v83, v78, v60\n"
+      "v_fma_f32 v61, v70, v83, v61\n"
+      "v_readfirstlane_b32 s20, v92\n"
+      "v_fma_f32 v62, v68, v69, v62\n"
+      "v_fma_f32 v63, v71, v74, v63\n"
+      "v_fma_f32 v64, v74, v79, v64\n"
+      "v_fma_f32 v65, v77, v84, v65\n"
+      "v_fma_f32 v66, v80, v73, v66\n"
+      "v_fma_f32 v67, v83, v78, v67\n"
+      "v_fma_f32 v60, v70, v83, v60\n"
+      "v_readfirstlane_b32 s20, v92\n"
+      "v_fma_f32 v61, v68, v69, v61\n"
+      "v_fma_f32 v62, v71, v74, v62\n"
+      "v_fma_f32 v63, v74, v79, v63\n"
+      "v_fma_f32 v64, v77, v84, v64\n"
+      "v_fma_f32 v65, v80, v73, v65\n"
+      "v_fma_f32 v66, v83, v78, v66\n"
+      "v_fma_f32 v67, v70, v83, v67\n"
+      "v_readfirstlane_b32 s20, v92\n"
+      ::: "vcc", "scc", "s20", "s21", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97");
+  }
+  asm volatile("s_nop 0" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = ((r1 - r0) << 32) | (t1 - t0);
+  if (t1 == 1) sink[0] = a + b;
+}
+
+__global__ __launch_bounds__(1024) void k_iso_fma_f32_plain(unsigned long long *__restrict__ stamps, float a, float b, float *sink) {
+  extern __shared__ char lds[];
+  if (threadIdx.x == 1023) lds[0] = 1;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < kIters; ++it) {
+    asm volatile(
+      "v_fma_f32 v60, v68, v69, v60\n"
+      "v_fma_f32 v61, v71, v74, v61\n"
+      "v_fma_f32 v62, v74, v79, v62\n"
+      "v_fma_f32 v63, v77, v84, v63\n"
+      "v_fma_f32 v64, v80, v73, v64\n"
+      "v_fma_f32 v65, v83, v78, v65\n"
+      "v_fma_f32 v66, v70, v83, v66\n"
+      "v_fma_f32 v90, v91, v92, v94\n"
+      "v_fma_f32 v67, v68, v69, v67\n"
+      "v_fma_f32 v60, v71, v74, v60\n"
+      "v_fma_f32 v61, v74, v79, v61\n"
+      "v_fma_f32 v62, v77, v84, v62\n"
+      "v_fma_f32 v63, v80, v73, v63\n"
+      "v_fma_f32 v64, v83, v78, v64\n"
+      "v_fma_f32 v65, v70, v83, v65\n"
+      "v_fma_f32 v90, v91, v92, v94\n"
+      "v_fma_f32 v66, v68, v69, v66\n"
+      "v_fma_f32 v67, v71, v74, v67\n"
+      "v_fma_f32 v60, v74, v79, v60\n"
+      "v_fma_f32 v61, v77, v84, v61\n"
+      "v_fma_f32 v62, v80, v73, v62\n"
+      "v_fma_f32 v63, v83, v78, v63\n"
+      "v_fma_f32 v64, v70, v83, v64\n"
+      "v_fma_f32 v90, v91, v92, v94\n"
+      "v_fma_f32 v65, v68, v69, v65\n"
+      "v_fma_f32 v66, v71, v74, v66\n"
+      "v_fma_f32 v67, v74, v79, v67\n"
+      "v_fma_f32 v60, v77, v84, v60\n"
+      "v_fma_f32 v61, v80, v73, v61\n"
+      "v_fma_f32 v62, v83, v78, v62\n"
+      "v_fma_f32 v63, v70, v83, v63\n"
+      "v_fma_f32 v90, v91, v92, v94\n"
+      "v_fma_f32 v64, v68, v69, v64\n"
+      "v_fma_f32 v65, v71, v74, v65\n"
+      "v_fma_f32 v66, v74, v79, v66\n"
+      "v_fma_f32 v67, v77, v84, v67\n"
+      "v_fma_f32 v60, v80, v73, v60\n"
+      "v_fma_f32 v61, v83, v78, v61\n"
+      "v_fma_f32 v62, v70, v83, v62\n"
+      "v_fma_f32 v90, v91, v92, v94\n"
+      "v_fma_f32 v63, v68, v69, v63\n"
+      "v_fma_f32 v64, v71, v74, v64\n"
+      "v_fma_f32 v65, v74, v79, v65\n"
+      "v_fma_f32 v66, v77, v84, v66\n"
+      "v_fma_f32 v67, v80, v73, v67\n"
+      "v_fma_f32 v60, v83, v78, v60\n"
+      "v_fma_f32 v61, v70, v83, v61\n"
+      "v_fma_f32 v90, v91, v92, v94\n"
+      "v_fma_f32 v62, v68, v69, v62\n"
+      "v_fma_f32 v63, v71, v74, v63\n"
+      "v_fma_f32 v64, v74, v79, v64\n"
+      "v_fma_f32 v65, v77, v84, v65\n"
+      "v_fma_f32 v66, v80, v73, v66\n"
+      "v_fma_f32 v67, v83, v78, v67\n"
+      "v_fma_f32 v60, v70, v83, v60\n"
+      "v_fma_f32 v90, v91, v92, v94\n"
+      "v_fma_f32 v61, v68, v69, v61\n"
+      "v_fma_f32 v62, v71, v74, v62\n"
+      "v_fma_f32 v63, v74, v79, v63\n"
+      "v_fma_f32 v64, v77, v84, v64\n"
+      "v_fma_f32 v65, v80, v73, v65\n"
+      "v_fma_f32 v66, v83, v78, v66\n"
+      "v_fma_f32 v67, v70, v83, v67\n"
+      "v_fma_f32 v90, v91, v92, v94\n"
+      ::: "vcc", "scc", "s20", "s21", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97");
+  }
+  asm volatile("s_nop 0" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = ((r1 - r0) << 32) | (t1 - t0);
+  if (t1 == 1) sink[0] = a + b;
+}
+
+__global__ __launch_bounds__(1024) void k_iso_mul_lo_u32(unsigned long long *__restrict__ stamps, float a, float b, float *sink) {
+  extern __shared__ char lds[];
+  if (threadIdx.x == 1023) lds[0] = 1;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < kIters; ++it) {
+    asm volatile(
+      "v_fma_f32 v60, v68, v69, v60\n"
+      "v_fma_f32 v61, v71, v74, v61\n"
+      "v_fma_f32 v62, v74, v79, v62\n"
+      "v_fma_f32 v63, v77, v84, v63\n"
+      "v_fma_f32 v64, v80, v73, v64\n"
+      "v_fma_f32 v65, v83, v78, v65\n"
+      "v_fma_f32 v66, v70, v83, v66\n"
+      "v_mul_lo_u32 v90, v92, v94\n"
+      "v_fma_f32 v67, v68, v69, v67\n"
+      "v_fma_f32 v60, v71, v74, v60\n"
+      "v_fma_f32 v61, v74, v79, v61\n"
+      "v_fma_f32 v62, v77, v84, v62\n"
+      "v_fma_f32 v63, v80, v73, v63\n"
+      "v_fma_f32 v64, v83, v78, v64\n"
+      "v_fma_f32 v65, v70, v83, v65\n"
+      "v_mul_lo_u32 v90, v92, v94\n"
+      "v_fma_f32 v66, v68, v69, v66\n"
+      "v_fma_f32 v67, v71, v74, v67\n"
+      "v_fma_f32 v60, v74, v79, v60\n"
+      "v_fma_f32 v61, v77, v84, v61\n"
+      "v_fma_f32 v62, v80, v73, v62\n"
+      "v_fma_f32 v63, v83, v78, v63\n"
+      "v_fma_f32 v64, v70, v83, v64\n"
+      "v_mul_lo_u32 v90, v92, v94\n"
+      "v_fma_f32 v65, v68, v69, v65\n"
+      "v_fma_f32 v66, v71, v74, v66\n"
+      "v_fma_f32 v67, v74, v79, v67\n"
+      "v_fma_f32 v60, v77, v84, v60\n"
+      "v_fma_f32 v61, v80, v73, v61\n"
+      "v_fma_f32 v62, v83, v78, v62\n"
+      "v_fma_f32 v63, v70, v83, v63\n"
+      "v_mul_lo_u32 v90, v92, v94\n"
+      "v_fma_f32 v64, v68, v69, v64\n"
+      "v_fma_f32 v65, v71, v74, v65\n"
+      "v_fma_f32 v66, v74, v79, v66\n"
+      "v_fma_f32 v67, v77, v84, v67\n"
+      "v_fma_f32 v60, v80, v73, v60\n"
+      "v_fma_f32 v61, v83, v78, v61\n"
+      "v_fma_f32 v62, v70, v83, v62\n"
+      "v_mul_lo_u32 v90, v92, v94\n"
+      "v_fma_f32 v63, v68, v69, v63\n"
+      "v_fma_f32 v64, v71, v74, v64\n"
+      "v_fma_f32 v65, v74, v79, v65\n"
+      "v_fma_f32 v66, v77, v84, v66\n"
+      "v_fma_f32 v67, v80, v73, v67\n"
+      "v_fma_f32 v60, v83, v78, v60\n"
+      "v_fma_f32 v61, v70, v83, v61\n"
+      "v_mul_lo_u32 v90, v92, v94\n"
+      "v_fma_f32 v62, v68, v69, v62\n"
+      "v_fma_f32 v63, v71, v74, v63\n"
+      "v_fma_f32 v64, v74, v79, v64\n"
+      "v_fma_f32 v65, v77, v84, v65\n"
+      "v_fma_f32 v66, v80, v73, v66\n"
+      "v_fma_f32 v67, v83, v78, v67\n"
+      "v_fma_f32 v60, v70, v83, v60\n"
+      "v_mul_lo_u32 v90, v92, v94\n"
+      "v_fma_f32 v61, v68, v69, v61\n"
+      "v_fma_f32 v62, v71, v74, v62\n"
+      "v_fma_f32 v63, v74, v79, v63\n"
+      "v_fma_f32 v64, v77, v84, v64\n"
+      "v_fma_f32 v65, v80, v73, v65\n"
+      "v_fma_f32 v66, v83, v78, v66\n"
+      "v_fma_f32 v67, v70, v83, v67\n"
+      "v_mul_lo_u32 v90, v92, v94\n"
+      ::: "vcc", "scc", "s20", "s21", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97");
+  }
+  asm volatile("s_nop 0" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = ((r1 - r0) << 32) | (t1 - t0);
+  if (t1 == 1) sink[0] = a + b;
+}
+
+__global__ __launch_bounds__(1024) void k_iso_mul_hi_u32(unsigned long long *__restrict__ stamps, float a, float b, float *sink) {
+  extern __shared__ char lds[];
+  if (threadIdx.x == 1023) lds[0] = 1;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < kIters; ++it) {
+    asm volatile(
+      "v_fma_f32 v60, v68, v69, v60\n"
+      "v_fma_f32 v61, v71, v74, v61\n"
+      "v_fma_f32 v62, v74, v79, v62\n"
+      "v_fma_f32 v63, v77, v84, v63\n"
+      "v_fma_f32 v64, v80, v73, v64\n"
+      "v_fma_f32 v65, v83, v78, v65\n"
+      "v_fma_f32 v66, v70, v83, v66\n"
+      "v_mul_hi_u32 v90, v92, v94\n"
+      "v_fma_f32 v67, v68, v69, v67\n"
+      "v_fma_f32 v60, v71, v74, v60\n"
+      "v_fma_f32 v61, v74, v79, v61\n"
+      "v_fma_f32 v62, v77, v84, v62\n"
+      "v_fma_f32 v63, v80, v73, v63\n"
+      "v_fma_f32 v64, v83, v78, v64\n"
+      "v_fma_f32 v65, v70, v83, v65\n"
+      "v_mul_hi_u32 v90, v92, v94\n"
+      "v_fma_f32 v66, v68, v69, v66\n"
+      "v_fma_f32 v67, v71, v74, v67\n"
+      "v_fma_f32 v60, v74, v79, v60\n"
+      "v_fma_f32 v61, v77, v84, v61\n"
+      "v_fma_f32 v62, v80, v73, v62\n"
+      "v_fma_f32 v63, v83, v78, v63\n"
+      "v_fma_f32 v64, v70, v83, v64\n"
+      "v_mul_hi_u32 v90, v92, v94\n"
+      "v_fma_f32 v65, v68, v69, v65\n"
+      "v_fma_f32 v66, v71, v74, v66\n"
+      "v_fma_f32 v67, v74, v79, v67\n"
+      "v_fma_f32 v60, v77, v84, v60\n"
+      "v_fma_f32 v61, v80, v73, v61\n"
+      "v_fma_f32 v62, v83, v78, v62\n"
+      "v_fma_f32 v63, v70, v83, v63\n"
+      "v_mul_hi_u32 v90, v92, v94\n"
+      "v_fma_f32 v64, v68, v69, v64\n"
+      "v_fma_f32 v65, v71, v74, v65\n"
+      "v_fma_f32 v66, v74, v79, v66\n"
+      "v_fma_f32 v67, v77, v84, v67\n"
+      "v_fma_f32 v60, v80, v73, v60\n"
+      "v_fma_f32 v61, v83, v78, v61\n"
+      "v_fma_f32 v62, v70, v83, v62\n"
+      "v_mul_hi_u32 v90, v92, v94\n"
+      "v_fma_f32 v63, v68, v69, v63\n"
+      "v_fma_f32 v64, v71, v74, v64\n"
+      "v_fma_f32 v65, v74, v79, v65\n"
+      "v_fma_f32 v66, v77, v84, v66\n"
+      "v_fma_f32 v67, v80, v73, v67\n"
+      "v_fma_f32 v60, v83, v78, v60\n"
+      "v_fma_f32 v61, v70, v83, v61\n"
+      "v_mul_hi_u32 v90, v92, v94\n"
+      "v_fma_f32 v62, v68, v69, v62\n"
+      "v_fma_f32 v63, v71, v74, v63\n"
+      "v_fma_f32 v64, v74, v79, v64\n"
+      "v_fma_f32 v65, v77, v84, v65\n"
+      "v_fma_f32 v66, v80, v73, v66\n"
+      "v_fma_f32 v67, v83, v78, v67\n"
+      "v_fma_f32 v60, v70, v83, v60\n"
+      "v_mul_hi_u32 v90, v92, v94\n"
+      "v_fma_f32 v61, v68, v69, v61\n"
+      "v_fma_f32 v62, v71, v74, v62\n"
+      "v_fma_f32 v63, v74, v79, v63\n"
+      "v_fma_f32 v64, v77, v84, v64\n"
+      "v_fma_f32 v65, v80, v73, v65\n"
+      "v_fma_f32 v66, v83, v78, v66\n"
+      "v_fma_f32 v67, v70, v83, v67\n"
+      "v_mul_hi_u32 v90, v92, v94\n"
+      ::: "vcc", "scc", "s20", "s21", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97");
+  }
+  asm volatile("s_nop 0" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = ((r1 - r0) << 32) | (t1 - t0);
+  if (t1 == 1) sink[0] = a + b;
+}
+
+__global__ __launch_bounds__(1024) void k_iso_mad_u32_u24(unsigned long long *__restrict__ stamps, float a, float b, float *sink) {
+  extern __shared__ char lds[];
+  if (threadIdx.x == 1023) lds[0] = 1;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < kIters; ++it) {
+    asm volatile(
+      "v_fma_f32 v60, v68, v69, v60\n"
+      "v_fma_f32 v61, v71, v74, v61\n"
+      "v_fma_f32 v62, v74, v79, v62\n"
+      "v_fma_f32 v63, v77, v84, v63\n"
+      "v_fma_f32 v64, v80, v73, v64\n"
+      "v_fma_f32 v65, v83, v78, v65\n"
+      "v_fma_f32 v66, v70, v83, v66\n"
+      "v_mad_u32_u24 v90, v92, v94, v96\n"
+      "v_fma_f32 v67, v68, v69, v67\n"
+      "v_fma_f32 v60, v71, v74, v60\n"
+      "v_fma_f32 v61, v74, v79, v61\n"
+      "v_fma_f32 v62, v77, v84, v62\n"
+      "v_fma_f32 v63, v80, v73, v63\n"
+      "v_fma_f32 v64, v83, v78, v64\n"
+      "v_fma_f32 v65, v70, v83, v65\n"
+      "v_mad_u32_u24 v90, v92, v94, v96\n"
+      "v_fma_f32 v66, v68, v69, v66\n"
+      "v_fma_f32 v67, v71, v74, v67\n"
+      "v_fma_f32 v60, v74, v79, v60\n"
+      "v_fma_f32 v61, v77, v84, v61\n"
+      "v_fma_f32 v62, v80, v73, v62\n"
+      "v_fma_f32 v63, v83, v78, v63\n"
+      "v_fma_f32 v64, v70, v83, v64\n"
+      "v_mad_u32_u24 v90, v92, v94, v96\n"
+      "v_fma_f32 v65, v68, v69, v65\n"
+      "v_fma_f32 v66, v71, v74, v66\n"
+      "v_fma_f32 v67, v74, v79, v67\n"
+      "v_fma_f32 v60, v77, v84, v60\n"
+      "v_fma_f32 v61, v80, v73, v61\n"
+      "v_fma_f32 v62, v83, v78, v62\n"
+      "v_fma_f32 v63, v70, v83, v63\n"
+      "v_mad_u32_u24 v90, v92, v94, v96\n"
+      "v_fma_f32 v64, v68, v69, v64\n"
+      "v_fma_f32 v65, v71, v74, v65\n"
+      "v_fma_f32 v66, v74, v79, v66\n"
+      "v_fma_f32 v67, v77, v84, v67\n"
+      "v_fma_f32 v60, v80, v73, v60\n"
+      "v_fma_f32 v61, v83, v78, v61\n"
+      "v_fma_f32 v62, v70, v83, v62\n"
+      "v_mad_u32_u24 v90, v92, v94, v96\n"
+      "v_fma_f32 v63, v68, v69, v63\n"
+      "v_fma_f32 v64, v71, v74, v64\n"
+      "v_fma_f32 v65, v74, v79, v65\n"
+      "v_fma_f32 v66, v77, v84, v66\n"
+      "v_fma_f32 v67, v80, v73, v67\n"
+      "v_fma_f32 v60, v83, v78, v60\n"
+      "v_fma_f32 v61, v70, v83, v61\n"
+      "v_mad_u32_u24 v90, v92, v94, v96\n"
+      "v_fma_f32 v62, v68, v69, v62\n"
+      "v_fma_f32 v63, v71, v74, v63\n"
+      "v_fma_f32 v64, v74, v79, v64\n"
+      "v_fma_f32 v65, v77, v84, v65\n"
+      "v_fma_f32 v66, v80, v73, v66\n"
+      "v_fma_f32 v67, v83, v78, v67\n"
+      "v_fma_f32 v60, v70, v83, v60\n"
+      "v_mad_u32_u24 v90, v92, v94, v96\n"
+      "v_fma_f32 v61, v68, v69, v61\n"
+      "v_fma_f32 v62, v71, v74, v62\n"
+      "v_fma_f32 v63, v74, v79, v63\n"
+      "v_fma_f32 v64, v77, v84, v64\n"
+      "v_fma_f32 v65, v80, v73, v65\n"
+      "v_fma_f32 v66, v83, v78, v66\n"
+      "v_fma_f32 v67, v70, v83, v67\n"
+      "v_mad_u32_u24 v90, v92, v94, v96\n"
+      ::: "vcc", "scc", "s20", "s21", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97");
+  }
+  asm volatile("s_nop 0" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = ((r1 - r0) << 32) | (t1 - t0);
+  if (t1 == 1) sink[0] = a + b;
+}
+
+__global__ __launch_bounds__(1024) void k_iso_mad_i32_i24(unsigned long long *__restrict__ stamps, float a, float b, float *sink) {
+  extern __shared__ char lds[];
+  if (threadIdx.x == 1023) lds[0] = 1;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < kIters; ++it) {
+    asm volatile(
+      "v_fma_f32 v60, v68, v69, v60\n"
+      "v_fma_f32 v61, v71, v74, v61\n"
+      "v_fma_f32 v62, v74, v79, v62\n"
+      "v_fma_f32 v63, v77, v84, v63\n"
+      "v_fma_f32 v64, v80, v73, v64\n"
+      "v_fma_f32 v65, v83, v78, v65\n"
+      "v_fma_f32 v66, v70, v83, v66\n"
+      "v_mad_i32_i24 v90, v92, v94, v96\n"
+      "v_fma_f32 v67, v68, v69, v67\n"
+      "v_fma_f32 v60, v71, v74, v60\n"
+      "v_fma_f32 v61, v74, v79, v61\n"
+      "v_fma_f32 v62, v77, v84, v62\n"
+      "v_fma_f32 v63, v80, v73, v63\n"
+      "v_fma_f32 v64, v83, v78, v64\n"
+      "v_fma_f32 v65, v70, v83, v65\n"
+      "v_mad_i32_i24 v90, v92, v94, v96\n"
+      "v_fma_f32 v66, v68, v69, v66\n"
+      "v_fma_f32 v67, v71, v74, v67\n"
+      "v_fma_f32 v60, v74, v79, v60\n"
+      "v_fma_f32 v61, v77, v84, v61\n"
+      "v_fma_f32 v62, v80, v73, v62\n"
+      "v_fma_f32 v63, v83, v78, v63\n"
+      "v_fma_f32 v64, v70, v83, v64\n"
+      "v_mad_i32_i24 v90, v92, v94, v96\n"
+      "v_fma_f32 v65, v68, v69, v65\n"
+      "v_fma_f32 v66, v71, v74, v66\n"
+      "v_fma_f32 v67, v74, v79, v67\n"
+      "v_fma_f32 v60, v77, v84, v60\n"
+      "v_fma_f32 v61, v80, v73, v61\n"
+      "v_fma_f32 v62, v83, v78, v62\n"
+      "v_fma_f32 v63, v70, v83, v63\n"
+      "v_mad_i32_i24 v90, v92, v94, v96\n"
+      "v_fma_f32 v64, v68, v69, v64\n"
+      "v_fma_f32 v65, v71, v74, v65\n"
+      "v_fma_f32 v66, v74, v79, v66\n"
+      "v_fma_f32 v67, v77, v84, v67\n"
+      "v_fma_f32 v60, v80, v73, v60\n"
+      "v_fma_f32 v61, v83, v78, v61\n"
+      "v_fma_f32 v62, v70, v83, v62\n"
+      "v_mad_i32_i24 v90, v92, v94, v96\n"
+      "v_fma_f32 v63, v68, v69, v63\n"
+      "v_fma_f32 v64, v71, v74, v64\n"
+      "v_fma_f32 v65, v74, v79, v65\n"
+      "v_fma_f32 v66, v77, v84, v66\n"
+      "v_fma_f32 v67, v80, v73, v67\n"
+      "v_fma_f32 v60, v83, v78, v60\n"
+      "v_fma_f32 v61, v70, v83, v61\n"
+      "v_mad_i32_i24 v90, v92, v94, v96\n"
+      "v_fma_f32 v62, v68, v69, v62\n"
+      "v_fma_f32 v63, v71, v74, v63\n"
+      "v_fma_f32 v64, v74, v79, v64\n"
+      "v_fma_f32 v65, v77, v84, v65\n"
+      "v_fma_f32 v66, v80, v73, v66\n"
+      "v_fma_f32 v67, v83, v78, v67\n"
+      "v_fma_f32 v60, v70, v83, v60\n"
+      "v_mad_i32_i24 v90, v92, v94, v96\n"
+      "v_fma_f32 v61, v68, v69, v61\n"
+      "v_fma_f32 v62, v71, v74, v62\n"
+      "v_fma_f32 v63, v74, v79, v63\n"
+      "v_fma_f32 v64, v77, v84, v64\n"
+      "v_fma_f32 v65, v80, v73, v65\n"
+      "v_fma_f32 v66, v83, v78, v66\n"
+      "v_fma_f32 v67, v70, v83, v67\n"
+      "v_mad_i32_i24 v90, v92, v94, v96\n"
+      ::: "vcc", "scc", "s20", "s21", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97");
+  }
+  asm volatile("s_nop 0" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = ((r1 - r0) << 32) | (t1 - t0);
+  if (t1 == 1) sink[0] = a + b;
+}
+
+__global__ __launch_bounds__(1024) void k_iso_mul_i32_i24(unsigned long long *__restrict__ stamps, float a, float b, float *sink) {
+  extern __shared__ char lds[];
+  if (threadIdx.x == 1023) lds[0] = 1;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < kIters; ++it) {
+    asm volatile(
+      "v_fma_f32 v60, v68, v69, v60\n"
+      "v_fma_f32 v61, v71, v74, v61\n"
+      "v_fma_f32 v62, v74, v79, v62\n"
+      "v_fma_f32 v63, v77, v84, v63\n"
+      "v_fma_f32 v64, v80, v73, v64\n"
+      "v_fma_f32 v65, v83, v78, v65\n"
+      "v_fma_f32 v66, v70, v83, v66\n"
+      "v_mul_i32_i24 v90, v92, v94\n"
+      "v_fma_f32 v67, v68, v69, v67\n"
+      "v_fma_f32 v60, v71, v74, v60\n"
+      "v_fma_f32 v61, v74, v79, v61\n"
+      "v_fma_f32 v62, v77, v84, v62\n"
+      "v_fma_f32 v63, v80, v73, v63\n"
+      "v_fma_f32 v64, v83, v78, v64\n"
+      "v_fma_f32 v65, v70, v83, v65\n"
+      "v_mul_i32_i24 v90, v92, v94\n"
+      "v_fma_f32 v66, v68, v69, v66\n"
+      "v_fma_f32 v67, v71, v74, v67\n"
+      "v_fma_f32 v60, v74, v79, v60\n"
+      "v_fma_f32 v61, v77, v84, v61\n"
+      "v_fma_f32 v62, v80, v73, v62\n"
+      "v_fma_f32 v63, v83, v78, v63\n"
+      "v_fma_f32 v64, v70, v83, v64\n"
+      "v_mul_i32_i24 v90, v92, v94\n"
+      "v_fma_f32 v65, v68, v69, v65\n"
+      "v_fma_f32 v66, v71, v74, v66\n"
+      "v_fma_f32 v67, v74, v79, v67\n"
+      "v_fma_f32 v60, v77, v84, v60\n"
+      "v_fma_f32 v61, v80, v73, v61\n"
+      "v_fma_f32 v62, v83, v78, v62\n"
+      "v_fma_f32 v63, v70, v83, v63\n"
+      "v_mul_i32_i24 v90, v92, v94\n"
+      "v_fma_f32 v64, v68, v69, v64\n"
+      "v_fma_f32 v65, v71, v74, v65\n"
+      "v_fma_f32 v66, v74, v79, v66\n"
+      "v_fma_f32 v67, v77, v84, v67\n"
+      "v_fma_f32 v60, v80, v73, v60\n"
+      "v_fma_f32 v61, v83, v78, v61\n"
+      "v_fma_f32 v62, v70, v83, v62\n"
+      "v_mul_i32_i24 v90, v92, v94\n"
+      "v_fma_f32 v63, v68, v69, v63\n"
+      "v_fma_f32 v64, v71, v74, v64\n"
+      "v_fma_f32 v65, v74, v79, v65\n"
+      "v_fma_f32 v66, v77, v84, v66\n"
+      "v_fma_f32 v67, v80, v73, v67\n"
+      "v_fma_f32 v60, v83, v78, v60\n"
+      "v_fma_f32 v61, v70, v83, v61\n"
+      "v_mul_i32_i24 v90, v92, v94\n"
+      "v_fma_f32 v62, v68, v69, v62\n"
+      "v_fma_f32 v63, v71, v74, v63\n"
+      "v_fma_f32 v64, v74, v79, v64\n"
+      "v_fma_f32 v65, v77, v84, v65\n"
+      "v_fma_f32 v66, v80, v73, v66\n"
+      "v_fma_f32 v67, v83, v78, v67\n"
+      "v_fma_f32 v60, v70, v83, v60\n"
+      "v_mul_i32_i24 v90, v92, v94\n"
+      "v_fma_f32 v61, v68, v69, v61\n"
+      "v_fma_f32 v62, v71, v74, v62\n"
+      "v_fma_f32 v63, v74, v79, v63\n"
+      "v_fma_f32 v64, v77, v84, v64\n"
+      "v_fma_f32 v65, v80, v73, v65\n"
+      "v_fma_f32 v66, v83, v78, v66\n"
+      "v_fma_f32 v67, v70, v83, v67\n"
+      "v_mul_i32_i24 v90, v92, v94\n"
+      ::: "vcc", "scc", "s20", "s21", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97");
+  }
+  asm volatile("s_nop 0" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = ((r1 - r0) << 32) | (t1 - t0);
+  if (t1 == 1) sink[0] = a + b;
+}
+
+__global__ __launch_bounds__(1024) void k_iso_mad_i64_i32(unsigned long long *__restrict__ stamps, float a, float b, float *sink) {
+  extern __shared__ char lds[];
+  if (threadIdx.x == 1023) lds[0] = 1;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < kIters; ++it) {
+    asm volatile(
+      "v_fma_f32 v60, v68, v69, v60\n"
+      "v_fma_f32 v61, v71, v74, v61\n"
+      "v_fma_f32 v62, v74, v79, v62\n"
+      "v_fma_f32 v63, v77, v84, v63\n"
+      "v_fma_f32 v64, v80, v73, v64\n"
+      "v_fma_f32 v65, v83, v78, v65\n"
+      "v_fma_f32 v66, v70, v83, v66\n"
+      "v_mad_i64_i32 v[90:91], vcc, v92, v94, v[96:97]\n"
+      "v_fma_f32 v67, v68, v69, v67\n"
+      "v_fma_f32 v60, v71, v74, v60\n"
+      "v_fma_f32 v61, v74, v79, v61\n"
+      "v_fma_f32 v62, v77, v84, v62\n"
+      "v_fma_f32 v63, v80, v73, v63\n"
+      "v_fma_f32 v64, v83, v78, v64\n"
+      "v_fma_f32 v65, v70, v83, v65\n"
+      "v_mad_i64_i32 v[90:91], vcc, v92, v94, v[96:97]\n"
+      "v_fma_f32 v66, v68, v69, v66\n"
+      "v_fma_f32 v67, v71, v74, v67\n"
+      "v_fma_f32 v60, v74, v79, v60\n"
+      "v_fma_f32 v61, v77, v84, v61\n"
+      "v_fma_f32 v62, v80, v73, v62\n"
+      "v_fma_f32 v63, v83, v78, v63\n"
+      "v_fma_f32 v64, v70, v83, v64\n"
+      "v_mad_i64_i32 v[90:91], vcc, v92, v94, v[96:97]\n"
+      "v_fma_f32 v65, v68, v69, v65\n"
+      "v_fma_f32 v66, v71, v74, v66\n"
+      "v_fma_f32 v67, v74, v79, v67\n"
+      "v_fma_f32 v60, v77, v84, v60\n"
+      "v_fma_f32 v61, v80, v73, v61\n"
+      "v_fma_f32 v62, v83, v78, v62\n"
+      "v_fma_f32 v63, v70, v83, v63\n"
+      "v_mad_i64_i32 v[90:91], vcc, v92, v94, v[96:97]\n"
+      "v_fma_f32 v64, v68, v69, v64\n"
+      "v_fma_f32 v65, v71, v74, v65\n"
+      "v_fma_f32 v66, v74, v79, v66\n"
+      "v_fma_f32 v67, v77, v84, v67\n"
+      "v_fma_f32 v60, v80, v73, v60\n"
+      "v_fma_f32 v61, v83, v78, v61\n"
+      "v_fma_f32 v62, v70, v83, v62\n"
+      "v_mad_i64_i32 v[90:91], vcc, v92, v94, v[96:97]\n"
+      "v_fma_f32 v63, v68, v69, v63\n"
+      "v_fma_f32 v64, v71, v74, v64\n"
+      "v_fma_f32 v65, v74, v79, v65\n"
+      "v_fma_f32 v66, v77, v84, v66\n"
+      "v_fma_f32 v67, v80, v73, v67\n"
+      "v_fma_f32 v60, v83, v78, v60\n"
+      "v_fma_f32 v61, v70, v83, v61\n"
+      "v_mad_i64_i32 v[90:91], vcc, v92, v94, v[96:97]\n"
+      "v_fma_f32 v62, v68, v69, v62\n"
+      "v_fma_f32 v63, v71, v74, v63\n"
+      "v_fma_f32 v64, v74, v79, v64\n"
+      "v_fma_f32 v65, v77, v84, v65\n"
+      "v_fma_f32 v66, v80, v73, v66\n"
+      "v_fma_f32 v67, v83, v78, v67\n"
+      "v_fma_f32 v60, v70, v83, v60\n"
+      "v_mad_i64_i32 v[90:91], vcc, v92, v94, v[96:97]\n"
+      "v_fma_f32 v61, v68, v69, v61\n"
+      "v_fma_f32 v62, v71, v74, v62\n"
+      "v_fma_f32 v63, v74, v79, v63\n"
+      "v_fma_f32 v64, v77, v84, v64\n"
+      "v_fma_f32 v65, v80, v73, v65\n"
+      "v_fma_f32 v66, v83, v78, v66\n"
+      "v_fma_f32 v67, v70, v83, v67\n"
+      "v_mad_i64_i32 v[90:91], vcc, v92, v94, v[96:97]\n"
+      ::: "vcc", "scc", "s20", "s21", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97");
+  }
+  asm volatile("s_nop 0" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = ((r1 - r0) << 32) | (t1 - t0);
+  if (t1 == 1) sink[0] = a + b;
+}
+
+__global__ __launch_bounds__(1024) void k_iso_min_i32(unsigned long long *__restrict__ stamps, float a, float b, float *sink) {
+  extern __shared__ char lds[];
+  if (threadIdx.x == 1023) lds[0] = 1;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < kIters; ++it) {
+    asm volatile(
+      "v_fma_f32 v60, v68, v69, v60\n"
+      "v_fma_f32 v61, v71, v74, v61\n"
+      "v_fma_f32 v62, v74, v79, v62\n"
+      "v_fma_f32 v63, v77, v84, v63\n"
+      "v_fma_f32 v64, v80, v73, v64\n"
+      "v_fma_f32 v65, v83, v78, v65\n"
+      "v_fma_f32 v66, v70, v83, v66\n"
+      "v_min_i32 v90, v92, v94\n"
+      "v_fma_f32 v67, v68, v69, v67\n"
+      "v_fma_f32 v60, v71, v74, v60\n"
+      "v_fma_f32 v61, v74, v79, v61\n"
+      "v_fma_f32 v62, v77, v84, v62\n"
+      "v_fma_f32 v63, v80, v73, v63\n"
+      "v_fma_f32 v64, v83, v78, v64\n"
+      "v_fma_f32 v65, v70, v83, v65\n"
+      "v_min_i32 v90, v92, v94\n"
+      "v_fma_f32 v66, v68, v69, v66\n"
+      "v_fma_f32 v67, v71, v74, v67\n"
+      "v_fma_f32 v60, v74, v79, v60\n"
+      "v_fma_f32 v61, v77, v84, v61\n"
+      "v_fma_f32 v62, v80, v73, v62\n"
+      "v_fma_f32 v63, v83, v78, v63\n"
+      "v_fma_f32 v64, v70, v83, v64\n"
+      "v_min_i32 v90, v92, v94\n"
+      "v_fma_f32 v65, v68, v69, v65\n"
+      "v_fma_f32 v66, v71, v74, v66\n"
+      "v_fma_f32 v67, v74, v79, v67\n"
+      "v_fma_f32 v60, v77, v84, v60\n"
+      "v_fma_f32 v61, v80, v73, v61\n"
+      "v_fma_f32 v62, v83, v78, v62\n"
+      "v_fma_f32 v63, v70, v83, v63\n"
+      "v_min_i32 v90, v92, v94\n"
+      "v_fma_f32 v64, v68, v69, v64\n"
+      "v_fma_f32 v65, v71, v74, v65\n"
+      "v_fma_f32 v66, v74, v79, v66\n"
+      "v_fma_f32 v67, v77, v84, v67\n"
+      "v_fma_f32 v60, v80, v73, v60\n"
+      "v_fma_f32 v61, v83, v78, v61\n"
+      "v_fma_f32 v62, v70, v83, v62\n"
+      "v_min_i32 v90, v92, v94\n"
+      "v_fma_f32 v63, v68, v69, v63\n"
+      "v_fma_f32 v64, v71, v74, v64\n"
+      "v_fma_f32 v65, v74, v79, v65\n"
+      "v_fma_f32 v66, v77, v84, v66\n"
+      "v_fma_f32 v67, v80, v73, v67\n"
+      "v_fma_f32 v60, v83, v78, v60\n"
+      "v_fma_f32 v61, v70, v83, v61\n"
+      "v_min_i32 v90, v92, v94\n"
+      "v_fma_f32 v62, v68, v69, v62\n"
+      "v_fma_f32 v63, v71, v74, v63\n"
+      "v_fma_f32 v64, v74, v79, v64\n"
+      "v_fma_f32 v65, v77, v84, v65\n"
+      "v_fma_f32 v66, v80, v73, v66\n"
+      "v_fma_f32 v67, v83, v78, v67\n"
+      "v_fma_f32 v60, v70, v83, v60\n"
+      "v_min_i32 v90, v92, v94\n"
+      "v_fma_f32 v61, v68, v69, v61\n"
+      "v_fma_f32 v62, v71, v74, v62\n"
+      "v_fma_f32 v63, v74, v79, v63\n"
+      "v_fma_f32 v64, v77, v84, v64\n"
+      "v_fma_f32 v65, v80, v73, v65\n"
+      "v_fma_f32 v66, v83, v78, v66\n"
+      "v_fma_f32 v67, v70, v83, v67\n"
+      "v_min_i32 v90, v92, v94\n"
+      ::: "vcc", "scc", "s20", "s21", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97");
+  }
+  asm volatile("s_nop 0" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = ((r1 - r0) << 32) | (t1 - t0);
+  if (t1 == 1) sink[0] = a + b;
+}
+
+__global__ __launch_bounds__(1024) void k_iso_bfe_u32(unsigned long long *__restrict__ stamps, float a, float b, float *sink) {
+  extern __shared__ char lds[];
+  if (threadIdx.x == 1023) lds[0] = 1;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < kIters; ++it) {
+    asm volatile(
+      "v_fma_f32 v60, v68, v69, v60\n"
+      "v_fma_f32 v61, v71, v74, v61\n"
+      "v_fma_f32 v62, v74, v79, v62\n"
+      "v_fma_f32 v63, v77, v84, v63\n"
+      "v_fma_f32 v64, v80, v73, v64\n"
+      "v_fma_f32 v65, v83, v78, v65\n"
+      "v_fma_f32 v66, v70, v83, v66\n"
+      "v_bfe_u32 v90, v92, 8, 8\n"
+      "v_fma_f32 v67, v68, v69, v67\n"
+      "v_fma_f32 v60, v71, v74, v60\n"
+      "v_fma_f32 v61, v74, v79, v61\n"
+      "v_fma_f32 v62, v77, v84, v62\n"
+      "v_fma_f32 v63, v80, v73, v63\n"
+      "v_fma_f32 v64, v83, v78, v64\n"
+      "v_fma_f32 v65, v70, v83, v65\n"
+      "v_bfe_u32 v90, v92, 8, 8\n"
+      "v_fma_f32 v66, v68, v69, v66\n"
+      "v_fma_f32 v67, v71, v74, v67\n"
+      "v_fma_f32 v60, v74, v79, v60\n"
+      "v_fma_f32 v61, v77, v84, v61\n"
+      "v_fma_f32 v62, v80, v73, v62\n"
+      "v_fma_f32 v63, v83, v78, v63\n"
+      "v_fma_f32 v64, v70, v83, v64\n"
+      "v_bfe_u32 v90, v92, 8, 8\n"
+      "v_fma_f32 v65, v68, v69, v65\n"
+      "v_fma_f32 v66, v71, v74, v66\n"
+      "v_fma_f32 v67, v74, v79, v67\n"
+      "v_fma_f32 v60, v77, v84, v60\n"
+      "v_fma_f32 v61, v80, v73, v61\n"
+      "v_fma_f32 v62, v83, v78, v62\n"
+      "v_fma_f32 v63, v70, v83, v63\n"
+      "v_bfe_u32 v90, v92, 8, 8\n"
+      "v_fma_f32 v64, v68, v69, v64\n"
+      "v_fma_f32 v65, v71, v74, v65\n"
+      "v_fma_f32 v66, v74, v79, v66\n"
+      "v_fma_f32 v67, v77, v84, v67\n"
+      "v_fma_f32 v60, v80, v73, v60\n"
+      "v_fma_f32 v61, v83, v78, v61\n"
+      "v_fma_f32 v62, v70, v83, v62\n"
+      "v_bfe_u32 v90, v92, 8, 8\n"
+      "v_fma_f32 v63, v68, v69, v63\n"
+      "v_fma_f32 v64, v71, v74, v64\n"
+      "v_fma_f32 v65, v74, v79, v65\n"
+      "v_fma_f32 v66, v77, v84, v66\n"
+      "v_fma_f32 v67, v80, v73, v67\n"
+      "v_fma_f32 v60, v83, v78, v60\n"
+      "v_fma_f32 v61, v70, v83, v61\n"
+      "v_bfe_u32 v90, v92, 8, 8\n"
+      "v_fma_f32 v62, v68, v69, v62\n"
+      "v_fma_f32 v63, v71, v74, v63\n"
+      "v_fma_f32 v64, v74, v79, v64\n"
+      "v_fma_f32 v65, v77, v84, v65\n"
+      "v_fma_f32 v66, v80, v73, v66\n"
+      "v_fma_f32 v67, v83, v78, v67\n"
+      "v_fma_f32 v60, v70, v83, v60\n"
+      "v_bfe_u32 v90, v92, 8, 8\n"
+      "v_fma_f32 v61, v68, v69, v61\n"
+      "v_fma_f32 v62, v71, v74, v62\n"
+      "v_fma_f32 v63, v74, v79, v63\n"
+      "v_fma_f32 v64, v77, v84, v64\n"
+      "v_fma_f32 v65, v80, v73, v65\n"
+      "v_fma_f32 v66, v83, v78, v66\n"
+      "v_fma_f32 v67, v70, v83, v67\n"
+      "v_bfe_u32 v90, v92, 8, 8\n"
+      ::: "vcc", "scc", "s20", "s21", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97");
+  }
+  asm volatile("s_nop 0" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = ((r1 - r0) << 32) | (t1 - t0);
+  if (t1 == 1) sink[0] = a + b;
+}
+
+__global__ __launch_bounds__(1024) void k_iso_and_or_b32(unsigned long long *__restrict__ stamps, float a, float b, float *sink) {
+  extern __shared__ char lds[];
+  if (threadIdx.x == 1023) lds[0] = 1;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < kIters; ++it) {
+    asm volatile(
+      "v_fma_f32 v60, v68, v69, v60\n"
+      "v_fma_f32 v61, v71, v74, v61\n"
+      "v_fma_f32 v62, v74, v79, v62\n"
+      "v_fma_f32 v63, v77, v84, v63\n"
+      "v_fma_f32 v64, v80, v73, v64\n"
+      "v_fma_f32 v65, v83, v78, v65\n"
+      "v_fma_f32 v66, v70, v83, v66\n"
+      "v_and_or_b32 v90, v92, v94, v96\n"
+      "v_fma_f32 v67, v68, v69, v67\n"
+      "v_fma_f32 v60, v71, v74, v60\n"
+      "v_fma_f32 v61, v74, v79, v61\n"
+      "v_fma_f32 v62, v77, v84, v62\n"
+      "v_fma_f32 v63, v80, v73, v63\n"
+      "v_fma_f32 v64, v83, v78, v64\n"
+      "v_fma_f32 v65, v70, v83, v65\n"
+      "v_and_or_b32 v90, v92, v94, v96\n"
+      "v_fma_f32 v66, v68, v69, v66\n"
+      "v_fma_f32 v67, v71, v74, v67\n"
+      "v_fma_f32 v60, v74, v79, v60\n"
+      "v_fma_f32 v61, v77, v84, v61\n"
+      "v_fma_f32 v62, v80, v73, v62\n"
+      "v_fma_f32 v63, v83, v78, v63\n"
+      "v_fma_f32 v64, v70, v83, v64\n"
+      "v_and_or_b32 v90, v92, v94, v96\n"
+      "v_fma_f32 v65, v68, v69, v65\n"
+      "v_fma_f32 v66, v71, v74, v66\n"
+      "v_fma_f32 v67, v74, v79, v67\n"
+      "v_fma_f32 v60, v77, v84, v60\n"
+      "v_fma_f32 v61, v80, v73, v61\n"
+      "v_fma_f32 v62, v83, v78, v62\n"
+      "v_fma_f32 v63, v70, v83, v63\n"
+      "v_and_or_b32 v90, v92, v94, v96\n"
+      "v_fma_f32 v64, v68, v69, v64\n"
+      "v_fma_f32 v65, v71, v74, v65\n"
+      "v_fma_f32 v66, v74, v79, v66\n"
+      "v_fma_f32 v67, v77, v84, v67\n"
+      "v_fma_f32 v60, v80, v73, v60\n"
+      "v_fma_f32 v61, v83, v78, v61\n"
+      "v_fma_f32 v62, v70, v83, v62\n"
+      "v_and_or_b32 v90, v92, v94, v96\n"
+      "v_fma_f32 v63, v68, v69, v63\n"
+      "v_fma_f32 v64, v71, v74, v64\n"
+      "v_fma_f32 v65, v74, v79, v65\n"
+      "v_fma_f32 v66, v77, v84, v66\n"
+      "v_fma_f32 v67, v80, v73, v67\n"
+      "v_fma_f32 v60, v83, v78, v60\n"
+      "v_fma_f32 v61, v70, v83, v61\n"
+      "v_and_or_b32 v90, v92, v94, v96\n"
+      "v_fma_f32 v62, v68, v69, v62\n"
+      "v_fma_f32 v63, v71, v74, v63\n"
+      "v_fma_f32 v64, v74, v79, v64\n"
+      "v_fma_f32 v65, v77, v84, v65\n"
+      "v_fma_f32 v66, v80, v73, v66\n"
+      "v_fma_f32 v67, v83, v78, v67\n"
+      "v_fma_f32 v60, v70, v83, v60\n"
+      "v_and_or_b32 v90, v92, v94, v96\n"
+      "v_fma_f32 v61, v68, v69, v61\n"
+      "v_fma_f32 v62, v71, v74, v62\n"
+      "v_fma_f32 v63, v74, v79, v63\n"
+      "v_fma_f32 v64, v77, v84, v64\n"
+      "v_fma_f32 v65, v80, v73, v65\n"
+      "v_fma_f32 v66, v83, v78, v66\n"
+      "v_fma_f32 v67, v70, v83, v67\n"
+      "v_and_or_b32 v90, v92, v94, v96\n"
+      ::: "vcc", "scc", "s20", "s21", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97");
+  }
+  asm volatile("s_nop 0" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = ((r1 - r0) << 32) | (t1 - t0);
+  if (t1 == 1) sink[0] = a + b;
+}
+
+__global__ __launch_bounds__(1024) void k_iso_add3_u32(unsigned long long *__restrict__ stamps, float a, float b, float *sink) {
+  extern __shared__ char lds[];
+  if (threadIdx.x == 1023) lds[0] = 1;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < kIters; ++it) {
+    asm volatile(
+      "v_fma_f32 v60, v68, v69, v60\n"
+      "v_fma_f32 v61, v71, v74, v61\n"
+      "v_fma_f32 v62, v74, v79, v62\n"
+      "v_fma_f32 v63, v77, v84, v63\n"
+      "v_fma_f32 v64, v80, v73, v64\n"
+      "v_fma_f32 v65, v83, v78, v65\n"
+      "v_fma_f32 v66, v70, v83, v66\n"
+      "v_add3_u32 v90, v92, v94, v96\n"
+      "v_fma_f32 v67, v68, v69, v67\n"
+      "v_fma_f32 v60, v71, v74, v60\n"
+      "v_fma_f32 v61, v74, v79, v61\n"
+      "v_fma_f32 v62, v77, v84, v62\n"
+      "v_fma_f32 v63, v80, v73, v63\n"
+      "v_fma_f32 v64, v83, v78, v64\n"
+      "v_fma_f32 v65, v70, v83, v65\n"
+      "v_add3_u32 v90, v92, v94, v96\n"
+      "v_fma_f32 v66, v68, v69, v66\n"
+      "v_fma_f32 v67, v71, v74, v67\n"
+      "v_fma_f32 v60, v74, v79, v60\n"
+      "v_fma_f32 v61, v77, v84, v61\n"
+      "v_fma_f32 v62, v80, v73, v62\n"
+      "v_fma_f32 v63, v83, v78, v63\n"
+      "v_fma_f32 v64, v70, v83, v64\n"
+      "v_add3_u32 v90, v92, v94, v96\n"
+      "v_fma_f32 v65, v68, v69, v65\n"
+      "v_fma_f32 v66, v71, v74, v66\n"
+      "v_fma_f32 v67, v74, v79, v67\n"
+      "v_fma_f32 v60, v77, v84, v60\n"
+      "v_fma_f32 v61, v80, v73, v61\n"
+      "v_fma_f32 v62, v83, v78, v62\n"
+      "v_fma_f32 v63, v70, v83, v63\n"
+      "v_add3_u32 v90, v92, v94, v96\n"
+      "v_fma_f32 v64, v68, v69, v64\n"
+      "v_fma_f32 v65, v71, v74, v65\n"
+      "v_fma_f32 v66, v74, v79, v66\n"
+      "v_fma_f32 v67, v77, v84, v67\n"
+      "v_fma_f32 v60, v80, v73, v60\n"
+      "v_fma_f32 v61, v83, v78, v61\n"
+      "v_fma_f32 v62, v70, v83, v62\n"
+      "v_add3_u32 v90, v92, v94, v96\n"
+      "v_fma_f32 v63, v68, v69, v63\n"
+      "v_fma_f32 v64, v71, v74, v64\n"
+      "v_fma_f32 v65, v74, v79, v65\n"
+      "v_fma_f32 v66, v77, v84, v66\n"
+      "v_fma_f32 v67, v80, v73, v67\n"
+      "v_fma_f32 v60, v83, v78, v60\n"
+      "v_fma_f32 v61, v70, v83, v61\n"
+      "v_add3_u32 v90, v92, v94, v96\n"
+      "v_fma_f32 v62, v68, v69, v62\n"
+      "v_fma_f32 v63, v71, v74, v63\n"
+      "v_fma_f32 v64, v74, v79, v64\n"
+      "v_fma_f32 v65, v77, v84, v65\n"
+      "v_fma_f32 v66, v80, v73, v66\n"
+      "v_fma_f32 v67, v83, v78, v67\n"
+      "v_fma_f32 v60, v70, v83, v60\n"
+      "v_add3_u32 v90, v92, v94, v96\n"
+      "v_fma_f32 v61, v68, v69, v61\n"
+      "v_fma_f32 v62, v71, v74, v62\n"
+      "v_fma_f32 v63, v74, v79, v63\n"
+      "v_fma_f32 v64, v77, v84, v64\n"
+      "v_fma_f32 v65, v80, v73, v65\n"
+      "v_fma_f32 v66, v83, v78, v66\n"
+      "v_fma_f32 v67, v70, v83, v67\n"
+      "v_add3_u32 v90, v92, v94, v96\n"
+      ::: "vcc", "scc", "s20", "s21", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97");
+  }
+  asm volatile("s_nop 0" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = ((r1 - r0) << 32) | (t1 - t0);
+  if (t1 == 1) sink[0] = a + b;
+}
+
+__global__ __launch_bounds__(1024) void k_iso_lshlrev_b32(unsigned long long *__restrict__ stamps, float a, float b, float *sink) {
+  extern __shared__ char lds[];
+  if (threadIdx.x == 1023) lds[0] = 1;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < kIters; ++it) {
+    asm volatile(
+      "v_fma_f32 v60, v68, v69, v60\n"
+      "v_fma_f32 v61, v71, v74, v61\n"
+      "v_fma_f32 v62, v74, v79, v62\n"
+      "v_fma_f32 v63, v77, v84, v63\n"
+      "v_fma_f32 v64, v80, v73, v64\n"
+      "v_fma_f32 v65, v83, v78, v65\n"
+      "v_fma_f32 v66, v70, v83, v66\n"
+      "v_lshlrev_b32 v90, 3, v92\n"
+      "v_fma_f32 v67, v68, v69, v67\n"
+      "v_fma_f32 v60, v71, v74, v60\n"
+      "v_fma_f32 v61, v74, v79, v61\n"
+      "v_fma_f32 v62, v77, v84, v62\n"
+      "v_fma_f32 v63, v80, v73, v63\n"
+      "v_fma_f32 v64, v83, v78, v64\n"
+      "v_fma_f32 v65, v70, v83, v65\n"
+      "v_lshlrev_b32 v90, 3, v92\n"
+      "v_fma_f32 v66, v68, v69, v66\n"
+      "v_fma_f32 v67, v71, v74, v67\n"
+      "v_fma_f32 v60, v74, v79, v60\n"
+      "v_fma_f32 v61, v77, v84, v61\n"
+      "v_fma_f32 v62, v80, v73, v62\n"
+      "v_fma_f32 v63, v83, v78, v63\n"
+      "v_fma_f32 v64, v70, v83, v64\n"
+      "v_lshlrev_b32 v90, 3, v92\n"
+      "v_fma_f32 v65, v68, v69, v65\n"
+      "v_fma_f32 v66, v71, v74, v66\n"
+      "v_fma_f32 v67, v74, v79, v67\n"
+      "v_fma_f32 v60, v77, v84, v60\n"
+      "v_fma_f32 v61, v80, v73, v61\n"
+      "v_fma_f32 v62, v83, v78, v62\n"
+      "v_fma_f32 v63, v70, v83, v63\n"
+      "v_lshlrev_b32 v90, 3, v92\n"
+      "v_fma_f32 v64, v68, v69, v64\n"
+      "v_fma_f32 v65, v71, v74, v65\n"
+      "v_fma_f32 v66, v74, v79, v66\n"
+      "v_fma_f32 v67, v77, v84, v67\n"
+      "v_fma_f32 v60, v80, v73, v60\n"
+      "v_fma_f32 v61, v83, v78, v61\n"
+      "v_fma_f32 v62, v70, v83, v62\n"
+      "v_lshlrev_b32 v90, 3, v92\n"
+      "v_fma_f32 v63, v68, v69, v63\n"
+      "v_fma_f32 v64, v71, v74, v64\n"
+      "v_fma_f32 v65, v74, v79, v65\n"
+      "v_fma_f32 v66, v77, v84, v66\n"
+      "v_fma_f32 v67, v80, v73, v67\n"
+      "v_fma_f32 v60, v83, v78, v60\n"
+      "v_fma_f32 v61, v70, v83, v61\n"
+      "v_lshlrev_b32 v90, 3, v92\n"
+      "v_fma_f32 v62, v68, v69, v62\n"
+      "v_fma_f32 v63, v71, v74, v63\n"
+      "v_fma_f32 v64, v74, v79, v64\n"
+      "v_fma_f32 v65, v77, v84, v65\n"
+      "v_fma_f32 v66, v80, v73, v66\n"
+      "v_fma_f32 v67, v83, v78, v67\n"
+      "v_fma_f32 v60, v70, v83, v60\n"
+      "v_lshlrev_b32 v90, 3, v92\n"
+      "v_fma_f32 v61, v68, v69, v61\n"
+      "v_fma_f32 v62, v71, v74, v62\n"
+      "v_fma_f32 v63, v74, v79, v63\n"
+      "v_fma_f32 v64, v77, v84, v64\n"
+      "v_fma_f32 v65, v80, v73, v65\n"
+      "v_fma_f32 v66, v83, v78, v66\n"
+      "v_fma_f32 v67, v70, v83, v67\n"
+      "v_lshlrev_b32 v90, 3, v92\n"
+      ::: "vcc", "scc", "s20", "s21", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97");
+  }
+  asm volatile("s_nop 0" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = ((r1 - r0) << 32) | (t1 - t0);
+  if (t1 == 1) sink[0] = a + b;
+}
+
+__global__ __launch_bounds__(1024) void k_iso_ashrrev_i32(unsigned long long *__restrict__ stamps, float a, float b, float *sink) {
+  extern __shared__ char lds[];
+  if (threadIdx.x == 1023) lds[0] = 1;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < kIters; ++it) {
+    asm volatile(
+      "v_fma_f32 v60, v68, v69, v60\n"
+      "v_fma_f32 v61, v71, v74, v61\n"
+      "v_fma_f32 v62, v74, v79, v62\n"
+      "v_fma_f32 v63, v77, v84, v63\n"
+      "v_fma_f32 v64, v80, v73, v64\n"
+      "v_fma_f32 v65, v83, v78, v65\n"
+      "v_fma_f32 v66, v70, v83, v66\n"
+      "v_ashrrev_i32 v90, 3, v92\n"
+      "v_fma_f32 v67, v68, v69, v67\n"
+      "v_fma_f32 v60, v71, v74, v60\n"
+      "v_fma_f32 v61, v74, v79, v61\n"
+      "v_fma_f32 v62, v77, v84, v62\n"
+      "v_fma_f32 v63, v80, v73, v63\n"
+      "v_fma_f32 v64, v83, v78, v64\n"
+      "v_fma_f32 v65, v70, v83, v65\n"
+      "v_ashrrev_i32 v90, 3, v92\n"
+      "v_fma_f32 v66, v68, v69, v66\n"
+      "v_fma_f32 v67, v71, v74, v67\n"
+      "v_fma_f32 v60, v74, v79, v60\n"
+      "v_fma_f32 v61, v77, v84, v61\n"
+      "v_fma_f32 v62, v80, v73, v62\n"
+      "v_fma_f32 v63, v83, v78, v63\n"
+      "v_fma_f32 v64, v70, v83, v64\n"
+      "v_ashrrev_i32 v90, 3, v92\n"
+      "v_fma_f32 v65, v68, v69, v65\n"
+      "v_fma_f32 v66, v71, v74, v66\n"
+      "v_fma_f32 v67, v74, v79, v67\n"
+      "v_fma_f32 v60, v77, v84, v60\n"
+      "v_fma_f32 v61, v80, v73, v61\n"
+      "v_fma_f32 v62, v83, v78, v62\n"
+      "v_fma_f32 v63, v70, v83, v63\n"
+      "v_ashrrev_i32 v90, 3, v92\n"
+      "v_fma_f32 v64, v68, v69, v64\n"
+      "v_fma_f32 v65, v71, v74, v65\n"
+      "v_fma_f32 v66, v74, v79, v66\n"
+      "v_fma_f32 v67, v77, v84, v67\n"
+      "v_fma_f32 v60, v80, v73, v60\n"
+      "v_fma_f32 v61, v83, v78, v61\n"
+      "v_fma_f32 v62, v70, v83, v62\n"
+      "v_ashrrev_i32 v90, 3, v92\n"
+      "v_fma_f32 v63, v68, v69, v63\n"
+      "v_fma_f32 v64, v71, v74, v64\n"
+      "v_fma_f32 v65, v74, v79, v65\n"
+      "v_fma_f32 v66, v77, v84, v66\n"
+      "v_fma_f32 v67, v80, v73, v67\n"
+      "v_fma_f32 v60, v83, v78, v60\n"
+      "v_fma_f32 v61, v70, v83, v61\n"
+      "v_ashrrev_i32 v90, 3, v92\n"
+      "v_fma_f32 v62, v68, v69, v62\n"
+      "v_fma_f32 v63, v71, v74, v63\n"
+      "v_fma_f32 v64, v74, v79, v64\n"
+      "v_fma_f32 v65, v77, v84, v65\n"
+      "v_fma_f32 v66, v80, v73, v66\n"
+      "v_fma_f32 v67, v83, v78, v67\n"
+      "v_fma_f32 v60, v70, v83, v60\n"
+      "v_ashrrev_i32 v90, 3, v92\n"
+      "v_fma_f32 v61, v68, v69, v61\n"
+      "v_fma_f32 v62, v71, v74, v62\n"
+      "v_fma_f32 v63, v74, v79, v63\n"
+      "v_fma_f32 v64, v77, v84, v64\n"
+      "v_fma_f32 v65, v80, v73, v65\n"
+      "v_fma_f32 v66, v83, v78, v66\n"
+      "v_fma_f32 v67, v70, v83, v67\n"
+      "v_ashrrev_i32 v90, 3, v92\n"
+      ::: "vcc", "scc", "s20", "s21", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97");
+  }
+  asm volatile("s_nop 0" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = ((r1 - r0) << 32) | (t1 - t0);
+  if (t1 == 1) sink[0] = a + b;
+}
+
+__global__ __launch_bounds__(1024) void k_iso_cmp_lt_i32(unsigned long long *__restrict__ stamps, float a, float b, float *sink) {
+  extern __shared__ char lds[];
+  if (threadIdx.x == 1023) lds[0] = 1;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < kIters; ++it) {
+    asm volatile(
+      "v_fma_f32 v60, v68, v69, v60\n"
+      "v_fma_f32 v61, v71, v74, v61\n"
+      "v_fma_f32 v62, v74, v79, v62\n"
+      "v_fma_f32 v63, v77, v84, v63\n"
+      "v_fma_f32 v64, v80, v73, v64\n"
+      "v_fma_f32 v65, v83, v78, v65\n"
+      "v_fma_f32 v66, v70, v83, v66\n"
+      "v_cmp_lt_i32 vcc, v92, v94\n"
+      "v_fma_f32 v67, v68, v69, v67\n"
+      "v_fma_f32 v60, v71, v74, v60\n"
+      "v_fma_f32 v61, v74, v79, v61\n"
+      "v_fma_f32 v62, v77, v84, v62\n"
+      "v_fma_f32 v63, v80, v73, v63\n"
+      "v_fma_f32 v64, v83, v78, v64\n"
+      "v_fma_f32 v65, v70, v83, v65\n"
+      "v_cmp_lt_i32 vcc, v92, v94\n"
+      "v_fma_f32 v66, v68, v69, v66\n"
+      "v_fma_f32 v67, v71, v74, v67\n"
+      "v_fma_f32 v60, v74, v79, v60\n"
+      "v_fma_f32 v61, v77, v84, v61\n"
+      "v_fma_f32 v62, v80, v73, v62\n"
+      "v_fma_f32 v63, v83, v78, v63\n"
+      "v_fma_f32 v64, v70, v83, v64\n"
+      "v_cmp_lt_i32 vcc, v92, v94\n"
+      "v_fma_f32 v65, v68, v69, v65\n"
+      "v_fma_f32 v66, v71, v74, v66\n"
+      "v_fma_f32 v67, v74, v79, v67\n"
+      "v_fma_f32 v60, v77, v84, v60\n"
+      "v_fma_f32 v61, v80, v73, v61\n"
+      "v_fma_f32 v62, v83, v78, v62\n"
+      "v_fma_f32 v63, v70, v83, v63\n"
+      "v_cmp_lt_i32 vcc, v92, v94\n"
+      "v_fma_f32 v64, v68, v69, v64\n"
+      "v_fma_f32 v65, v71, v74, v65\n"
+      "v_fma_f32 v66, v74, v79, v66\n"
+      "v_fma_f32 v67, v77, v84, v67\n"
+      "v_fma_f32 v60, v80, v73, v60\n"
+      "v_fma_f32 v61, v83, v78, v61\n"
+      "v_fma_f32 v62, v70, v83, v62\n"
+      "v_cmp_lt_i32 vcc, v92, v94\n"
+      "v_fma_f32 v63, v68, v69, v63\n"
+      "v_fma_f32 v64, v71, v74, v64\n"
+      "v_fma_f32 v65, v74, v79, v65\n"
+      "v_fma_f32 v66, v77, v84, v66\n"
+      "v_fma_f32 v67, v80, v73, v67\n"
+      "v_fma_f32 v60, v83, v78, v60\n"
+      "v_fma_f32 v61, v70, v83, v61\n"
+      "v_cmp_lt_i32 vcc, v92, v94\n"
+      "v_fma_f32 v62, v68, v69, v62\n"
+      "v_fma_f32 v63, v71, v74, v63\n"
+      "v_fma_f32 v64, v74, v79, v64\n"
+      "v_fma_f32 v65, v77, v84, v65\n"
+      "v_fma_f32 v66, v80, v73, v66\n"
+      "v_fma_f32 v67, v83, v78, v67\n"
+      "v_fma_f32 v60, v70, v83, v60\n"
+      "v_cmp_lt_i32 vcc, v92, v94\n"
+      "v_fma_f32 v61, v68, v69, v61\n"
+      "v_fma_f32 v62, v71, v74, v62\n"
+      "v_fma_f32 v63, v74, v79, v63\n"
+      "v_fma_f32 v64, v77, v84, v64\n"
+      "v_fma_f32 v65, v80, v73, v65\n"
+      "v_fma_f32 v66, v83, v78, v66\n"
+      "v_fma_f32 v67, v70, v83, v67\n"
+      "v_cmp_lt_i32 vcc, v92, v94\n"
+      ::: "vcc", "scc", "s20", "s21", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97");
+  }
+  asm volatile("s_nop 0" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = ((r1 - r0) << 32) | (t1 - t0);
+  if (t1 == 1) sink[0] = a + b;
+}
+
+__global__ __launch_bounds__(1024) void k_iso_mov_dpp(unsigned long long *__restrict__ stamps, float a, float b, float *sink) {
+  extern __shared__ char lds[];
+  if (threadIdx.x == 1023) lds[0] = 1;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < kIters; ++it) {
+    asm volatile(
+      "v_fma_f32 v60, v68, v69, v60\n"
+      "v_fma_f32 v61, v71, v74, v61\n"
+      "v_fma_f32 v62, v74, v79, v62\n"
+      "v_fma_f32 v63, v77, v84, v63\n"
+      "v_fma_f32 v64, v80, v73, v64\n"
+      "v_fma_f32 v65, v83, v78, v65\n"
+      "v_fma_f32 v66, v70, v83, v66\n"
+      "v_mov_b32_dpp v90, v92 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+      "v_fma_f32 v67, v68, v69, v67\n"
+      "v_fma_f32 v60, v71, v74, v60\n"
+      "v_fma_f32 v61, v74, v79, v61\n"
+      "v_fma_f32 v62, v77, v84, v62\n"
+      "v_fma_f32 v63, v80, v73, v63\n"
+      "v_fma_f32 v64, v83, v78, v64\n"
+      "v_fma_f32 v65, v70, v83, v65\n"
+      "v_mov_b32_dpp v90, v92 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+      "v_fma_f32 v66, v68, v69, v66\n"
+      "v_fma_f32 v67, v71, v74, v67\n"
+      "v_fma_f32 v60, v74, v79, v60\n"
+      "v_fma_f32 v61, v77, v84, v61\n"
+      "v_fma_f32 v62, v80, v73, v62\n"
+      "v_fma_f32 v63, v83, v78, v63\n"
+      "v_fma_f32 v64, v70, v83, v64\n"
+      "v_mov_b32_dpp v90, v92 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+      "v_fma_f32 v65, v68, v69, v65\n"
+      "v_fma_f32 v66, v71, v74, v66\n"
+      "v_fma_f32 v67, v74, v79, v67\n"
+      "v_fma_f32 v60, v77, v84, v60\n"
+      "v_fma_f32 v61, v80, v73, v61\n"
+      "v_fma_f32 v62, v83, v78, v62\n"
+      "v_fma_f32 v63, v70, v83, v63\n"
+      "v_mov_b32_dpp v90, v92 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+      "v_fma_f32 v64, v68, v69, v64\n"
+      "v_fma_f32 v65, v71, v74, v65\n"
+      "v_fma_f32 v66, v74, v79, v66\n"
+      "v_fma_f32 v67, v77, v84, v67\n"
+      "v_fma_f32 v60, v80, v73, v60\n"
+      "v_fma_f32 v61, v83, v78, v61\n"
+      "v_fma_f32 v62, v70, v83, v62\n"
+      "v_mov_b32_dpp v90, v92 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+      "v_fma_f32 v63, v68, v69, v63\n"
+      "v_fma_f32 v64, v71, v74, v64\n"
+      "v_fma_f32 v65, v74, v79, v65\n"
+      "v_fma_f32 v66, v77, v84, v66\n"
+      "v_fma_f32 v67, v80, v73, v67\n"
+      "v_fma_f32 v60, v83, v78, v60\n"
+      "v_fma_f32 v61, v70, v83, v61\n"
+      "v_mov_b32_dpp v90, v92 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+      "v_fma_f32 v62, v68, v69, v62\n"
+      "v_fma_f32 v63, v71, v74, v63\n"
+      "v_fma_f32 v64, v74, v79, v64\n"
+      "v_fma_f32 v65, v77, v84, v65\n"
+      "v_fma_f32 v66, v80, v73, v66\n"
+      "v_fma_f32 v67, v83, v78, v67\n"
+      "v_fma_f32 v60, v70, v83, v60\n"
+      "v_mov_b32_dpp v90, v92 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+      "v_fma_f32 v61, v68, v69, v61\n"
+      "v_fma_f32 v62, v71, v74, v62\n"
+      "v_fma_f32 v63, v74, v79, v63\n"
+      "v_fma_f32 v64, v77, v84, v64\n"
+      "v_fma_f32 v65, v80, v73, v65\n"
+      "v_fma_f32 v66, v83, v78, v66\n"
+      "v_fma_f32 v67, v70, v83, v67\n"
+      "v_mov_b32_dpp v90, v92 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+      ::: "vcc", "scc", "s20", "s21", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97");
+  }
+  asm volatile("s_nop 0" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = ((r1 - r0) << 32) | (t1 - t0);
+  if (t1 == 1) sink[0] = a + b;
+}
+
+__global__ __launch_bounds__(1024) void k_iso_fma_mix_f32(unsigned long long *__restrict__ stamps, float a, float b, float *sink) {
+  extern __shared__ char lds[];
+  if (threadIdx.x == 1023) lds[0] = 1;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < kIters; ++it) {
+    asm volatile(
+      "v_fma_f32 v60, v68, v69, v60\n"
+      "v_fma_f32 v61, v71, v74, v61\n"
+      "v_fma_f32 v62, v74, v79, v62\n"
+      "v_fma_f32 v63, v77, v84, v63\n"
+      "v_fma_f32 v64, v80, v73, v64\n"
+      "v_fma_f32 v65, v83, v78, v65\n"
+      "v_fma_f32 v66, v70, v83, v66\n"
+      "v_fma_mix_f32 v90, v92, v94, v96 op_sel_hi:[0,1,1]\n"
+      "v_fma_f32 v67, v68, v69, v67\n"
+      "v_fma_f32 v60, v71, v74, v60\n"
+      "v_fma_f32 v61, v74, v79, v61\n"
+      "v_fma_f32 v62, v77, v84, v62\n"
+      "v_fma_f32 v63, v80, v73, v63\n"
+      "v_fma_f32 v64, v83, v78, v64\n"
+      "v_fma_f32 v65, v70, v83, v65\n"
+      "v_fma_mix_f32 v90, v92, v94, v96 op_sel_hi:[0,1,1]\n"
+      "v_fma_f32 v66, v68, v69, v66\n"
+      "v_fma_f32 v67, v71, v74, v67\n"
+      "v_fma_f32 v60, v74, v79, v60\n"
+      "v_fma_f32 v61, v77, v84, v61\n"
+      "v_fma_f32 v62, v80, v73, v62\n"
+      "v_fma_f32 v63, v83, v78, v63\n"
+      "v_fma_f32 v64, v70, v83, v64\n"
+      "v_fma_mix_f32 v90, v92, v94, v96 op_sel_hi:[0,1,1]\n"
+      "v_fma_f32 v65, v68, v69, v65\n"
+      "v_fma_f32 v66, v71, v74, v66\n"
+      "v_fma_f32 v67, v74, v79, v67\n"
+      "v_fma_f32 v60, v77, v84, v60\n"
+      "v_fma_f32 v61, v80, v73, v61\n"
+      "v_fma_f32 v62, v83, v78, v62\n"
+      "v_fma_f32 v63, v70, v83, v63\n"
+      "v_fma_mix_f32 v90, v92, v94, v96 op_sel_hi:[0,1,1]\n"
+      "v_fma_f32 v64, v68, v69, v64\n"
+      "v_fma_f32 v65, v71, v74, v65\n"
+      "v_fma_f32 v66, v74, v79, v66\n"
+      "v_fma_f32 v67, v77, v84, v67\n"
+      "v_fma_f32 v60, v80, v73, v60\n"
+      "v_fma_f32 v61, v83, v78, v61\n"
+      "v_fma_f32 v62, v70, v83, v62\n"
+      "v_fma_mix_f32 v90, v92, v94, v96 op_sel_hi:[0,1,1]\n"
+      "v_fma_f32 v63, v68, v69, v63\n"
+      "v_fma_f32 v64, v71, v74, v64\n"
+      "v_fma_f32 v65, v74, v79, v65\n"
+      "v_fma_f32 v66, v77, v84, v66\n"
+      "v_fma_f32 v67, v80, v73, v67\n"
+      "v_fma_f32 v60, v83, v78, v60\n"
+      "v_fma_f32 v61, v70, v83, v61\n"
+      "v_fma_mix_f32 v90, v92, v94, v96 op_sel_hi:[0,1,1]\n"
+      "v_fma_f32 v62, v68, v69, v62\n"
+      "v_fma_f32 v63, v71, v74, v63\n"
+      "v_fma_f32 v64, v74, v79, v64\n"
+      "v_fma_f32 v65, v77, v84, v65\n"
+      "v_fma_f32 v66, v80, v73, v66\n"
+      "v_fma_f32 v67, v83, v78, v67\n"
+      "v_fma_f32 v60, v70, v83, v60\n"
+      "v_fma_mix_f32 v90, v92, v94, v96 op_sel_hi:[0,1,1]\n"
+      "v_fma_f32 v61, v68, v69, v61\n"
+      "v_fma_f32 v62, v71, v74, v62\n"
+      "v_fma_f32 v63, v74, v79, v63\n"
+      "v_fma_f32 v64, v77, v84, v64\n"
+      "v_fma_f32 v65, v80, v73, v65\n"
+      "v_fma_f32 v66, v83, v78, v66\n"
+      "v_fma_f32 v67, v70, v83, v67\n"
+      "v_fma_mix_f32 v90, v92, v94, v96 op_sel_hi:[0,1,1]\n"
+      ::: "vcc", "scc", "s20", "s21", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97");
+  }
+  asm volatile("s_nop 0" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = ((r1 - r0) << 32) | (t1 - t0);
+  if (t1 == 1) sink[0] = a + b;
+}
+
+__global__ __launch_bounds__(1024) void k_iso_rsq_f32(unsigned long long *__restrict__ stamps, float a, float b, float *sink) {
+  extern __shared__ char lds[];
+  if (threadIdx.x == 1023) lds[0] = 1;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < kIters; ++it) {
+    asm volatile(
+      "v_fma_f32 v60, v68, v69, v60\n"
+      "v_fma_f32 v61, v71, v74, v61\n"
+      "v_fma_f32 v62, v74, v79, v62\n"
+      "v_fma_f32 v63, v77, v84, v63\n"
+      "v_fma_f32 v64, v80, v73, v64\n"
+      "v_fma_f32 v65, v83, v78, v65\n"
+      "v_fma_f32 v66, v70, v83, v66\n"
+      "v_rsq_f32 v90, v92\n"
+      "v_fma_f32 v67, v68, v69, v67\n"
+      "v_fma_f32 v60, v71, v74, v60\n"
+      "v_fma_f32 v61, v74, v79, v61\n"
+      "v_fma_f32 v62, v77, v84, v62\n"
+      "v_fma_f32 v63, v80, v73, v63\n"
+      "v_fma_f32 v64, v83, v78, v64\n"
+      "v_fma_f32 v65, v70, v83, v65\n"
+      "v_rsq_f32 v90, v92\n"
+      "v_fma_f32 v66, v68, v69, v66\n"
+      "v_fma_f32 v67, v71, v74, v67\n"
+      "v_fma_f32 v60, v74, v79, v60\n"
+      "v_fma_f32 v61, v77, v84, v61\n"
+      "v_fma_f32 v62, v80, v73, v62\n"
+      "v_fma_f32 v63, v83, v78, v63\n"
+      "v_fma_f32 v64, v70, v83, v64\n"
+      "v_rsq_f32 v90, v92\n"
+      "v_fma_f32 v65, v68, v69, v65\n"
+      "v_fma_f32 v66, v71, v74, v66\n"
+      "v_fma_f32 v67, v74, v79, v67\n"
+      "v_fma_f32 v60, v77, v84, v60\n"
+      "v_fma_f32 v61, v80, v73, v61\n"
+      "v_fma_f32 v62, v83, v78, v62\n"
+      "v_fma_f32 v63, v70, v83, v63\n"
+      "v_rsq_f32 v90, v92\n"
+      "v_fma_f32 v64, v68, v69, v64\n"
+      "v_fma_f32 v65, v71, v74, v65\n"
+      "v_fma_f32 v66, v74, v79, v66\n"
+      "v_fma_f32 v67, v77, v84, v67\n"
+      "v_fma_f32 v60, v80, v73, v60\n"
+      "v_fma_f32 v61, v83, v78, v61\n"
+      "v_fma_f32 v62, v70, v83, v62\n"
+      "v_rsq_f32 v90, v92\n"
+      "v_fma_f32 v63, v68, v69, v63\n"
+      "v_fma_f32 v64, v71, v74, v64\n"
+      "v_fma_f32 v65, v74, v79, v65\n"
+      "v_fma_f32 v66, v77, v84, v66\n"
+      "v_fma_f32 v67, v80, v73, v67\n"
+      "v_fma_f32 v60, v83, v78, v60\n"
+      "v_fma_f32 v61, v70, v83, v61\n"
+      "v_rsq_f32 v90, v92\n"
+      "v_fma_f32 v62, v68, v69, v62\n"
+      "v_fma_f32 v63, v71, v74, v63\n"
+      "v_fma_f32 v64, v74, v79, v64\n"
+      "v_fma_f32 v65, v77, v84, v65\n"
+      "v_fma_f32 v66, v80, v73, v66\n"
+      "v_fma_f32 v67, v83, v78, v67\n"
+      "v_fma_f32 v60, v70, v83, v60\n"
+      "v_rsq_f32 v90, v92\n"
+      "v_fma_f32 v61, v68, v69, v61\n"
+      "v_fma_f32 v62, v71, v74, v62\n"
+      "v_fma_f32 v63, v74, v79, v63\n"
+      "v_fma_f32 v64, v77, v84, v64\n"
+      "v_fma_f32 v65, v80, v73, v65\n"
+      "v_fma_f32 v66, v83, v78, v66\n"
+      "v_fma_f32 v67, v70, v83, v67\n"
+      "v_rsq_f32 v90, v92\n"
+      ::: "vcc", "scc", "s20", "s21", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97");
+  }
+  asm volatile("s_nop 0" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = ((r1 - r0) << 32) | (t1 - t0);
+  if (t1 == 1) sink[0] = a + b;
+}
+
+__global__ __launch_bounds__(1024) void k_iso_cvt_f16_f32(unsigned long long *__restrict__ stamps, float a, float b, float *sink) {
+  extern __shared__ char lds[];
+  if (threadIdx.x == 1023) lds[0] = 1;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < kIters; ++it) {
+    asm volatile(
+      "v_fma_f32 v60, v68, v69, v60\n"
+      "v_fma_f32 v61, v71, v74, v61\n"
+      "v_fma_f32 v62, v74, v79, v62\n"
+      "v_fma_f32 v63, v77, v84, v63\n"
+      "v_fma_f32 v64, v80, v73, v64\n"
+      "v_fma_f32 v65, v83, v78, v65\n"
+      "v_fma_f32 v66, v70, v83, v66\n"
+      "v_cvt_f16_f32 v90, v92\n"
+      "v_fma_f32 v67, v68, v69, v67\n"
+      "v_fma_f32 v60, v71, v74, v60\n"
+      "v_fma_f32 v61, v74, v79, v61\n"
+      "v_fma_f32 v62, v77, v84, v62\n"
+      "v_fma_f32 v63, v80, v73, v63\n"
+      "v_fma_f32 v64, v83, v78, v64\n"
+      "v_fma_f32 v65, v70, v83, v65\n"
+      "v_cvt_f16_f32 v90, v92\n"
+      "v_fma_f32 v66, v68, v69, v66\n"
+      "v_fma_f32 v67, v71, v74, v67\n"
+      "v_fma_f32 v60, v74, v79, v60\n"
+      "v_fma_f32 v61, v77, v84, v61\n"
+      "v_fma_f32 v62, v80, v73, v62\n"
+      "v_fma_f32 v63, v83, v78, v63\n"
+      "v_fma_f32 v64, v70, v83, v64\n"
+      "v_cvt_f16_f32 v90, v92\n"
+      "v_fma_f32 v65, v68, v69, v65\n"
+      "v_fma_f32 v66, v71, v74, v66\n"
+      "v_fma_f32 v67, v74, v79, v67\n"
+      "v_fma_f32 v60, v77, v84, v60\n"
+      "v_fma_f32 v61, v80, v73, v61\n"
+      "v_fma_f32 v62, v83, v78, v62\n"
+      "v_fma_f32 v63, v70, v83, v63\n"
+      "v_cvt_f16_f32 v90, v92\n"
+      "v_fma_f32 v64, v68, v69, v64\n"
+      "v_fma_f32 v65, v71, v74, v65\n"
+      "v_fma_f32 v66, v74, v79, v66\n"
+      "v_fma_f32 v67, v77, v84, v67\n"
+      "v_fma_f32 v60, v80, v73, v60\n"
+      "v_fma_f32 v61, v83, v78, v61\n"
+      "v_fma_f32 v62, v70, v83, v62\n"
+      "v_cvt_f16_f32 v90, v92\n"
+      "v_fma_f32 v63, v68, v69, v63\n"
+      "v_fma_f32 v64, v71, v74, v64\n"
+      "v_fma_f32 v65, v74, v79, v65\n"
+      "v_fma_f32 v66, v77, v84, v66\n"
+      "v_fma_f32 v67, v80, v73, v67\n"
+      "v_fma_f32 v60, v83, v78, v60\n"
+      "v_fma_f32 v61, v70, v83, v61\n"
+      "v_cvt_f16_f32 v90, v92\n"
+      "v_fma_f32 v62, v68, v69, v62\n"
+      "v_fma_f32 v63, v71, v74, v63\n"
+      "v_fma_f32 v64, v74, v79, v64\n"
+      "v_fma_f32 v65, v77, v84, v65\n"
+      "v_fma_f32 v66, v80, v73, v66\n"
+      "v_fma_f32 v67, v83, v78, v67\n"
+      "v_fma_f32 v60, v70, v83, v60\n"
+      "v_cvt_f16_f32 v90, v92\n"
+      "v_fma_f32 v61, v68, v69, v61\n"
+      "v_fma_f32 v62, v71, v74, v62\n"
+      "v_fma_f32 v63, v74, v79, v63\n"
+      "v_fma_f32 v64, v77, v84, v64\n"
+      "v_fma_f32 v65, v80, v73, v65\n"
+      "v_fma_f32 v66, v83, v78, v66\n"
+      "v_fma_f32 v67, v70, v83, v67\n"
+      "v_cvt_f16_f32 v90, v92\n"
+      ::: "vcc", "scc", "s20", "s21", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97");
+  }
+  asm volatile("s_nop 0" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = ((r1 - r0) << 32) | (t1 - t0);
+  if (t1 == 1) sink[0] = a + b;
+}
+
+__global__ __launch_bounds__(1024) void k_iso_mbcnt_lo(unsigned long long *__restrict__ stamps, float a, float b, float *sink) {
+  extern __shared__ char lds[];
+  if (threadIdx.x == 1023) lds[0] = 1;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < kIters; ++it) {
+    asm volatile(
+      "v_fma_f32 v60, v68, v69, v60\n"
+      "v_fma_f32 v61, v71, v74, v61\n"
+      "v_fma_f32 v62, v74, v79, v62\n"
+      "v_fma_f32 v63, v77, v84, v63\n"
+      "v_fma_f32 v64, v80, v73, v64\n"
+      "v_fma_f32 v65, v83, v78, v65\n"
+      "v_fma_f32 v66, v70, v83, v66\n"
+      "v_mbcnt_lo_u32_b32 v90, v92, v94\n"
+      "v_fma_f32 v67, v68, v69, v67\n"
+      "v_fma_f32 v60, v71, v74, v60\n"
+      "v_fma_f32 v61, v74, v79, v61\n"
+      "v_fma_f32 v62, v77, v84, v62\n"
+      "v_fma_f32 v63, v80, v73, v63\n"
+      "v_fma_f32 v64, v83, v78, v64\n"
+      "v_fma_f32 v65, v70, v83, v65\n"
+      "v_mbcnt_lo_u32_b32 v90, v92, v94\n"
+      "v_fma_f32 v66, v68, v69, v66\n"
+      "v_fma_f32 v67, v71, v74, v67\n"
+      "v_fma_f32 v60, v74, v79, v60\n"
+      "v_fma_f32 v61, v77, v84, v61\n"
+      "v_fma_f32 v62, v80, v73, v62\n"
+      "v_fma_f32 v63, v83, v78, v63\n"
+      "v_fma_f32 v64, v70, v83, v64\n"
+      "v_mbcnt_lo_u32_b32 v90, v92, v94\n"
+      "v_fma_f32 v65, v68, v69, v65\n"
+      "v_fma_f32 v66, v71, v74, v66\n"
+      "v_fma_f32 v67, v74, v79, v67\n"
+      "v_fma_f32 v60, v77, v84, v60\n"
+      "v_fma_f32 v61, v80, v73, v61\n"
+      "v_fma_f32 v62, v83, v78, v62\n"
+      "v_fma_f32 v63, v70, v83, v63\n"
+      "v_mbcnt_lo_u32_b32 v90, v92, v94\n"
+      "v_fma_f32 v64, v68, v69, v64\n"
+      "v_fma_f32 v65, v71, v74, v65\n"
+      "v_fma_f32 v66, v74, v79, v66\n"
+      "v_fma_f32 v67, v77, v84, v67\n"
+      "v_fma_f32 v60, v80, v73, v60\n"
+      "v_fma_f32 v61, v83, v78, v61\n"
+      "v_fma_f32 v62, v70, v83, v62\n"
+      "v_mbcnt_lo_u32_b32 v90, v92, v94\n"
+      "v_fma_f32 v63, v68, v69, v63\n"
+      "v_fma_f32 v64, v71, v74, v64\n"
+      "v_fma_f32 v65, v74, v79, v65\n"
+      "v_fma_f32 v66, v77, v84, v66\n"
+      "v_fma_f32 v67, v80, v73, v67\n"
+      "v_fma_f32 v60, v83, v78, v60\n"
+      "v_fma_f32 v61, v70, v83, v61\n"
+      "v_mbcnt_lo_u32_b32 v90, v92, v94\n"
+      "v_fma_f32 v62, v68, v69, v62\n"
+      "v_fma_f32 v63, v71, v74, v63\n"
+      "v_fma_f32 v64, v74, v79, v64\n"
+      "v_fma_f32 v65, v77, v84, v65\n"
+      "v_fma_f32 v66, v80, v73, v66\n"
+      "v_fma_f32 v67, v83, v78, v67\n"
+      "v_fma_f32 v60, v70, v83, v60\n"
+      "v_mbcnt_lo_u32_b32 v90, v92, v94\n"
+      "v_fma_f32 v61, v68, v69, v61\n"
+      "v_fma_f32 v62, v71, v74, v62\n"
+      "v_fma_f32 v63, v74, v79, v63\n"
+      "v_fma_f32 v64, v77, v84, v64\n"
+      "v_fma_f32 v65, v80, v73, v65\n"
+      "v_fma_f32 v66, v83, v78, v66\n"
+      "v_fma_f32 v67, v70, v83, v67\n"
+      "v_mbcnt_lo_u32_b32 v90, v92, v94\n"
+      ::: "vcc", "scc", "s20", "s21", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97");
+  }
+  asm volatile("s_nop 0" ::: "memory");
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+  if ((threadIdx.x & 63) == 0) stamps[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = ((r1 - r0) << 32) | (t1 - t0);
+  if (t1 == 1) sink[0] = a + b;
+}
+
 template <typename T>
 struct Init {
   static T a() { return (T)1.0000001f; }
@@ -1188,6 +3909,226 @@ int main(int argc, char **argv) {
     int wi = 0;
     for (int W : {1, 2, 4, 8}) c[wi++] = run<float>(k_operands_mov_1_src, W, d_stamps, d_sink, 1.0);
     printf("%-26s %7.2f %7.2f %7.2f %7.2f %7s   %5.2f %5.2f\n", "mov_1_src", c[0].cyc, c[1].cyc, c[2].cyc, c[3].cyc, "-", c[3].ghz, c[3].wall);
+  }
+  if (selected("iso_pk_add_f32", argc, argv)) {
+    // one such instruction after every seven v_fma_f32: cost of the group of eight minus seven plain fma (2.37 cycles each, row iso_fma_f32_plain)
+    Result c[4];
+    int wi = 0;
+    for (int W : {1, 2, 4, 8}) c[wi++] = run<float>(k_iso_pk_add_f32, W, d_stamps, d_sink, 1.0);
+    printf("%-26s %7.2f %7.2f %7.2f %7.2f %7s   cost of the one in eight at W=8: %5.1f cycles\n", "iso_pk_add_f32", c[0].cyc, c[1].cyc, c[2].cyc, c[3].cyc, "-", 8.0 * c[3].cyc - 7.0 * 2.37);
+  }
+  if (selected("iso_pk_fma_f32", argc, argv)) {
+    // one such instruction after every seven v_fma_f32: cost of the group of eight minus seven plain fma (2.37 cycles each, row iso_fma_f32_plain)
+    Result c[4];
+    int wi = 0;
+    for (int W : {1, 2, 4, 8}) c[wi++] = run<float>(k_iso_pk_fma_f32, W, d_stamps, d_sink, 1.0);
+    printf("%-26s %7.2f %7.2f %7.2f %7.2f %7s   cost of the one in eight at W=8: %5.1f cycles\n", "iso_pk_fma_f32", c[0].cyc, c[1].cyc, c[2].cyc, c[3].cyc, "-", 8.0 * c[3].cyc - 7.0 * 2.37);
+  }
+  if (selected("iso_cvt_f32_ubyte1", argc, argv)) {
+    // one such instruction after every seven v_fma_f32: cost of the group of eight minus seven plain fma (2.37 cycles each, row iso_fma_f32_plain)
+    Result c[4];
+    int wi = 0;
+    for (int W : {1, 2, 4, 8}) c[wi++] = run<float>(k_iso_cvt_f32_ubyte1, W, d_stamps, d_sink, 1.0);
+    printf("%-26s %7.2f %7.2f %7.2f %7.2f %7s   cost of the one in eight at W=8: %5.1f cycles\n", "iso_cvt_f32_ubyte1", c[0].cyc, c[1].cyc, c[2].cyc, c[3].cyc, "-", 8.0 * c[3].cyc - 7.0 * 2.37);
+  }
+  if (selected("iso_cvt_f32_i32", argc, argv)) {
+    // one such instruction after every seven v_fma_f32: cost of the group of eight minus seven plain fma (2.37 cycles each, row iso_fma_f32_plain)
+    Result c[4];
+    int wi = 0;
+    for (int W : {1, 2, 4, 8}) c[wi++] = run<float>(k_iso_cvt_f32_i32, W, d_stamps, d_sink, 1.0);
+    printf("%-26s %7.2f %7.2f %7.2f %7.2f %7s   cost of the one in eight at W=8: %5.1f cycles\n", "iso_cvt_f32_i32", c[0].cyc, c[1].cyc, c[2].cyc, c[3].cyc, "-", 8.0 * c[3].cyc - 7.0 * 2.37);
+  }
+  if (selected("iso_max_f32", argc, argv)) {
+    // one such instruction after every seven v_fma_f32: cost of the group of eight minus seven plain fma (2.37 cycles each, row iso_fma_f32_plain)
+    Result c[4];
+    int wi = 0;
+    for (int W : {1, 2, 4, 8}) c[wi++] = run<float>(k_iso_max_f32, W, d_stamps, d_sink, 1.0);
+    printf("%-26s %7.2f %7.2f %7.2f %7.2f %7s   cost of the one in eight at W=8: %5.1f cycles\n", "iso_max_f32", c[0].cyc, c[1].cyc, c[2].cyc, c[3].cyc, "-", 8.0 * c[3].cyc - 7.0 * 2.37);
+  }
+  if (selected("iso_cmp_class_f32", argc, argv)) {
+    // one such instruction after every seven v_fma_f32: cost of the group of eight minus seven plain fma (2.37 cycles each, row iso_fma_f32_plain)
+    Result c[4];
+    int wi = 0;
+    for (int W : {1, 2, 4, 8}) c[wi++] = run<float>(k_iso_cmp_class_f32, W, d_stamps, d_sink, 1.0);
+    printf("%-26s %7.2f %7.2f %7.2f %7.2f %7s   cost of the one in eight at W=8: %5.1f cycles\n", "iso_cmp_class_f32", c[0].cyc, c[1].cyc, c[2].cyc, c[3].cyc, "-", 8.0 * c[3].cyc - 7.0 * 2.37);
+  }
+  if (selected("iso_cndmask_b32", argc, argv)) {
+    // one such instruction after every seven v_fma_f32: cost of the group of eight minus seven plain fma (2.37 cycles each, row iso_fma_f32_plain)
+    Result c[4];
+    int wi = 0;
+    for (int W : {1, 2, 4, 8}) c[wi++] = run<float>(k_iso_cndmask_b32, W, d_stamps, d_sink, 1.0);
+    printf("%-26s %7.2f %7.2f %7.2f %7.2f %7s   cost of the one in eight at W=8: %5.1f cycles\n", "iso_cndmask_b32", c[0].cyc, c[1].cyc, c[2].cyc, c[3].cyc, "-", 8.0 * c[3].cyc - 7.0 * 2.37);
+  }
+  if (selected("iso_rcp_f32", argc, argv)) {
+    // one such instruction after every seven v_fma_f32: cost of the group of eight minus seven plain fma (2.37 cycles each, row iso_fma_f32_plain)
+    Result c[4];
+    int wi = 0;
+    for (int W : {1, 2, 4, 8}) c[wi++] = run<float>(k_iso_rcp_f32, W, d_stamps, d_sink, 1.0);
+    printf("%-26s %7.2f %7.2f %7.2f %7.2f %7s   cost of the one in eight at W=8: %5.1f cycles\n", "iso_rcp_f32", c[0].cyc, c[1].cyc, c[2].cyc, c[3].cyc, "-", 8.0 * c[3].cyc - 7.0 * 2.37);
+  }
+  if (selected("iso_floor_f32", argc, argv)) {
+    // one such instruction after every seven v_fma_f32: cost of the group of eight minus seven plain fma (2.37 cycles each, row iso_fma_f32_plain)
+    Result c[4];
+    int wi = 0;
+    for (int W : {1, 2, 4, 8}) c[wi++] = run<float>(k_iso_floor_f32, W, d_stamps, d_sink, 1.0);
+    printf("%-26s %7.2f %7.2f %7.2f %7.2f %7s   cost of the one in eight at W=8: %5.1f cycles\n", "iso_floor_f32", c[0].cyc, c[1].cyc, c[2].cyc, c[3].cyc, "-", 8.0 * c[3].cyc - 7.0 * 2.37);
+  }
+  if (selected("iso_mul_u32_u24", argc, argv)) {
+    // one such instruction after every seven v_fma_f32: cost of the group of eight minus seven plain fma (2.37 cycles each, row iso_fma_f32_plain)
+    Result c[4];
+    int wi = 0;
+    for (int W : {1, 2, 4, 8}) c[wi++] = run<float>(k_iso_mul_u32_u24, W, d_stamps, d_sink, 1.0);
+    printf("%-26s %7.2f %7.2f %7.2f %7.2f %7s   cost of the one in eight at W=8: %5.1f cycles\n", "iso_mul_u32_u24", c[0].cyc, c[1].cyc, c[2].cyc, c[3].cyc, "-", 8.0 * c[3].cyc - 7.0 * 2.37);
+  }
+  if (selected("iso_lshl_add_u32", argc, argv)) {
+    // one such instruction after every seven v_fma_f32: cost of the group of eight minus seven plain fma (2.37 cycles each, row iso_fma_f32_plain)
+    Result c[4];
+    int wi = 0;
+    for (int W : {1, 2, 4, 8}) c[wi++] = run<float>(k_iso_lshl_add_u32, W, d_stamps, d_sink, 1.0);
+    printf("%-26s %7.2f %7.2f %7.2f %7.2f %7s   cost of the one in eight at W=8: %5.1f cycles\n", "iso_lshl_add_u32", c[0].cyc, c[1].cyc, c[2].cyc, c[3].cyc, "-", 8.0 * c[3].cyc - 7.0 * 2.37);
+  }
+  if (selected("iso_lshl_add_u64", argc, argv)) {
+    // one such instruction after every seven v_fma_f32: cost of the group of eight minus seven plain fma (2.37 cycles each, row iso_fma_f32_plain)
+    Result c[4];
+    int wi = 0;
+    for (int W : {1, 2, 4, 8}) c[wi++] = run<float>(k_iso_lshl_add_u64, W, d_stamps, d_sink, 1.0);
+    printf("%-26s %7.2f %7.2f %7.2f %7.2f %7s   cost of the one in eight at W=8: %5.1f cycles\n", "iso_lshl_add_u64", c[0].cyc, c[1].cyc, c[2].cyc, c[3].cyc, "-", 8.0 * c[3].cyc - 7.0 * 2.37);
+  }
+  if (selected("iso_mad_u64_u32", argc, argv)) {
+    // one such instruction after every seven v_fma_f32: cost of the group of eight minus seven plain fma (2.37 cycles each, row iso_fma_f32_plain)
+    Result c[4];
+    int wi = 0;
+    for (int W : {1, 2, 4, 8}) c[wi++] = run<float>(k_iso_mad_u64_u32, W, d_stamps, d_sink, 1.0);
+    printf("%-26s %7.2f %7.2f %7.2f %7.2f %7s   cost of the one in eight at W=8: %5.1f cycles\n", "iso_mad_u64_u32", c[0].cyc, c[1].cyc, c[2].cyc, c[3].cyc, "-", 8.0 * c[3].cyc - 7.0 * 2.37);
+  }
+  if (selected("iso_fma_sgpr_operand", argc, argv)) {
+    // one such instruction after every seven v_fma_f32: cost of the group of eight minus seven plain fma (2.37 cycles each, row iso_fma_f32_plain)
+    Result c[4];
+    int wi = 0;
+    for (int W : {1, 2, 4, 8}) c[wi++] = run<float>(k_iso_fma_sgpr_operand, W, d_stamps, d_sink, 1.0);
+    printf("%-26s %7.2f %7.2f %7.2f %7.2f %7s   cost of the one in eight at W=8: %5.1f cycles\n", "iso_fma_sgpr_operand", c[0].cyc, c[1].cyc, c[2].cyc, c[3].cyc, "-", 8.0 * c[3].cyc - 7.0 * 2.37);
+  }
+  if (selected("iso_readfirstlane", argc, argv)) {
+    // one such instruction after every seven v_fma_f32: cost of the group of eight minus seven plain fma (2.37 cycles each, row iso_fma_f32_plain)
+    Result c[4];
+    int wi = 0;
+    for (int W : {1, 2, 4, 8}) c[wi++] = run<float>(k_iso_readfirstlane, W, d_stamps, d_sink, 1.0);
+    printf("%-26s %7.2f %7.2f %7.2f %7.2f %7s   cost of the one in eight at W=8: %5.1f cycles\n", "iso_readfirstlane", c[0].cyc, c[1].cyc, c[2].cyc, c[3].cyc, "-", 8.0 * c[3].cyc - 7.0 * 2.37);
+  }
+  if (selected("iso_fma_f32_plain", argc, argv)) {
+    // one such instruction after every seven v_fma_f32: cost of the group of eight minus seven plain fma (2.37 cycles each, row iso_fma_f32_plain)
+    Result c[4];
+    int wi = 0;
+    for (int W : {1, 2, 4, 8}) c[wi++] = run<float>(k_iso_fma_f32_plain, W, d_stamps, d_sink, 1.0);
+    printf("%-26s %7.2f %7.2f %7.2f %7.2f %7s   cost of the one in eight at W=8: %5.1f cycles\n", "iso_fma_f32_plain", c[0].cyc, c[1].cyc, c[2].cyc, c[3].cyc, "-", 8.0 * c[3].cyc - 7.0 * 2.37);
+  }
+  if (selected("iso_mul_lo_u32", argc, argv)) {
+    Result c[4];
+    int wi = 0;
+    for (int W : {1, 2, 4, 8}) c[wi++] = run<float>(k_iso_mul_lo_u32, W, d_stamps, d_sink, 1.0);
+    printf("%-26s %7.2f %7.2f %7.2f %7.2f %7s   cost of the one in eight at W=8: %5.1f cycles\n", "iso_mul_lo_u32", c[0].cyc, c[1].cyc, c[2].cyc, c[3].cyc, "-", 8.0 * c[3].cyc - 7.0 * 2.37);
+  }
+  if (selected("iso_mul_hi_u32", argc, argv)) {
+    Result c[4];
+    int wi = 0;
+    for (int W : {1, 2, 4, 8}) c[wi++] = run<float>(k_iso_mul_hi_u32, W, d_stamps, d_sink, 1.0);
+    printf("%-26s %7.2f %7.2f %7.2f %7.2f %7s   cost of the one in eight at W=8: %5.1f cycles\n", "iso_mul_hi_u32", c[0].cyc, c[1].cyc, c[2].cyc, c[3].cyc, "-", 8.0 * c[3].cyc - 7.0 * 2.37);
+  }
+  if (selected("iso_mad_u32_u24", argc, argv)) {
+    Result c[4];
+    int wi = 0;
+    for (int W : {1, 2, 4, 8}) c[wi++] = run<float>(k_iso_mad_u32_u24, W, d_stamps, d_sink, 1.0);
+    printf("%-26s %7.2f %7.2f %7.2f %7.2f %7s   cost of the one in eight at W=8: %5.1f cycles\n", "iso_mad_u32_u24", c[0].cyc, c[1].cyc, c[2].cyc, c[3].cyc, "-", 8.0 * c[3].cyc - 7.0 * 2.37);
+  }
+  if (selected("iso_mad_i32_i24", argc, argv)) {
+    Result c[4];
+    int wi = 0;
+    for (int W : {1, 2, 4, 8}) c[wi++] = run<float>(k_iso_mad_i32_i24, W, d_stamps, d_sink, 1.0);
+    printf("%-26s %7.2f %7.2f %7.2f %7.2f %7s   cost of the one in eight at W=8: %5.1f cycles\n", "iso_mad_i32_i24", c[0].cyc, c[1].cyc, c[2].cyc, c[3].cyc, "-", 8.0 * c[3].cyc - 7.0 * 2.37);
+  }
+  if (selected("iso_mul_i32_i24", argc, argv)) {
+    Result c[4];
+    int wi = 0;
+    for (int W : {1, 2, 4, 8}) c[wi++] = run<float>(k_iso_mul_i32_i24, W, d_stamps, d_sink, 1.0);
+    printf("%-26s %7.2f %7.2f %7.2f %7.2f %7s   cost of the one in eight at W=8: %5.1f cycles\n", "iso_mul_i32_i24", c[0].cyc, c[1].cyc, c[2].cyc, c[3].cyc, "-", 8.0 * c[3].cyc - 7.0 * 2.37);
+  }
+  if (selected("iso_mad_i64_i32", argc, argv)) {
+    Result c[4];
+    int wi = 0;
+    for (int W : {1, 2, 4, 8}) c[wi++] = run<float>(k_iso_mad_i64_i32, W, d_stamps, d_sink, 1.0);
+    printf("%-26s %7.2f %7.2f %7.2f %7.2f %7s   cost of the one in eight at W=8: %5.1f cycles\n", "iso_mad_i64_i32", c[0].cyc, c[1].cyc, c[2].cyc, c[3].cyc, "-", 8.0 * c[3].cyc - 7.0 * 2.37);
+  }
+  if (selected("iso_min_i32", argc, argv)) {
+    Result c[4];
+    int wi = 0;
+    for (int W : {1, 2, 4, 8}) c[wi++] = run<float>(k_iso_min_i32, W, d_stamps, d_sink, 1.0);
+    printf("%-26s %7.2f %7.2f %7.2f %7.2f %7s   cost of the one in eight at W=8: %5.1f cycles\n", "iso_min_i32", c[0].cyc, c[1].cyc, c[2].cyc, c[3].cyc, "-", 8.0 * c[3].cyc - 7.0 * 2.37);
+  }
+  if (selected("iso_bfe_u32", argc, argv)) {
+    Result c[4];
+    int wi = 0;
+    for (int W : {1, 2, 4, 8}) c[wi++] = run<float>(k_iso_bfe_u32, W, d_stamps, d_sink, 1.0);
+    printf("%-26s %7.2f %7.2f %7.2f %7.2f %7s   cost of the one in eight at W=8: %5.1f cycles\n", "iso_bfe_u32", c[0].cyc, c[1].cyc, c[2].cyc, c[3].cyc, "-", 8.0 * c[3].cyc - 7.0 * 2.37);
+  }
+  if (selected("iso_and_or_b32", argc, argv)) {
+    Result c[4];
+    int wi = 0;
+    for (int W : {1, 2, 4, 8}) c[wi++] = run<float>(k_iso_and_or_b32, W, d_stamps, d_sink, 1.0);
+    printf("%-26s %7.2f %7.2f %7.2f %7.2f %7s   cost of the one in eight at W=8: %5.1f cycles\n", "iso_and_or_b32", c[0].cyc, c[1].cyc, c[2].cyc, c[3].cyc, "-", 8.0 * c[3].cyc - 7.0 * 2.37);
+  }
+  if (selected("iso_add3_u32", argc, argv)) {
+    Result c[4];
+    int wi = 0;
+    for (int W : {1, 2, 4, 8}) c[wi++] = run<float>(k_iso_add3_u32, W, d_stamps, d_sink, 1.0);
+    printf("%-26s %7.2f %7.2f %7.2f %7.2f %7s   cost of the one in eight at W=8: %5.1f cycles\n", "iso_add3_u32", c[0].cyc, c[1].cyc, c[2].cyc, c[3].cyc, "-", 8.0 * c[3].cyc - 7.0 * 2.37);
+  }
+  if (selected("iso_lshlrev_b32", argc, argv)) {
+    Result c[4];
+    int wi = 0;
+    for (int W : {1, 2, 4, 8}) c[wi++] = run<float>(k_iso_lshlrev_b32, W, d_stamps, d_sink, 1.0);
+    printf("%-26s %7.2f %7.2f %7.2f %7.2f %7s   cost of the one in eight at W=8: %5.1f cycles\n", "iso_lshlrev_b32", c[0].cyc, c[1].cyc, c[2].cyc, c[3].cyc, "-", 8.0 * c[3].cyc - 7.0 * 2.37);
+  }
+  if (selected("iso_ashrrev_i32", argc, argv)) {
+    Result c[4];
+    int wi = 0;
+    for (int W : {1, 2, 4, 8}) c[wi++] = run<float>(k_iso_ashrrev_i32, W, d_stamps, d_sink, 1.0);
+    printf("%-26s %7.2f %7.2f %7.2f %7.2f %7s   cost of the one in eight at W=8: %5.1f cycles\n", "iso_ashrrev_i32", c[0].cyc, c[1].cyc, c[2].cyc, c[3].cyc, "-", 8.0 * c[3].cyc - 7.0 * 2.37);
+  }
+  if (selected("iso_cmp_lt_i32", argc, argv)) {
+    Result c[4];
+    int wi = 0;
+    for (int W : {1, 2, 4, 8}) c[wi++] = run<float>(k_iso_cmp_lt_i32, W, d_stamps, d_sink, 1.0);
+    printf("%-26s %7.2f %7.2f %7.2f %7.2f %7s   cost of the one in eight at W=8: %5.1f cycles\n", "iso_cmp_lt_i32", c[0].cyc, c[1].cyc, c[2].cyc, c[3].cyc, "-", 8.0 * c[3].cyc - 7.0 * 2.37);
+  }
+  if (selected("iso_mov_dpp", argc, argv)) {
+    Result c[4];
+    int wi = 0;
+    for (int W : {1, 2, 4, 8}) c[wi++] = run<float>(k_iso_mov_dpp, W, d_stamps, d_sink, 1.0);
+    printf("%-26s %7.2f %7.2f %7.2f %7.2f %7s   cost of the one in eight at W=8: %5.1f cycles\n", "iso_mov_dpp", c[0].cyc, c[1].cyc, c[2].cyc, c[3].cyc, "-", 8.0 * c[3].cyc - 7.0 * 2.37);
+  }
+  if (selected("iso_fma_mix_f32", argc, argv)) {
+    Result c[4];
+    int wi = 0;
+    for (int W : {1, 2, 4, 8}) c[wi++] = run<float>(k_iso_fma_mix_f32, W, d_stamps, d_sink, 1.0);
+    printf("%-26s %7.2f %7.2f %7.2f %7.2f %7s   cost of the one in eight at W=8: %5.1f cycles\n", "iso_fma_mix_f32", c[0].cyc, c[1].cyc, c[2].cyc, c[3].cyc, "-", 8.0 * c[3].cyc - 7.0 * 2.37);
+  }
+  if (selected("iso_rsq_f32", argc, argv)) {
+    Result c[4];
+    int wi = 0;
+    for (int W : {1, 2, 4, 8}) c[wi++] = run<float>(k_iso_rsq_f32, W, d_stamps, d_sink, 1.0);
+    printf("%-26s %7.2f %7.2f %7.2f %7.2f %7s   cost of the one in eight at W=8: %5.1f cycles\n", "iso_rsq_f32", c[0].cyc, c[1].cyc, c[2].cyc, c[3].cyc, "-", 8.0 * c[3].cyc - 7.0 * 2.37);
+  }
+  if (selected("iso_cvt_f16_f32", argc, argv)) {
+    Result c[4];
+    int wi = 0;
+    for (int W : {1, 2, 4, 8}) c[wi++] = run<float>(k_iso_cvt_f16_f32, W, d_stamps, d_sink, 1.0);
+    printf("%-26s %7.2f %7.2f %7.2f %7.2f %7s   cost of the one in eight at W=8: %5.1f cycles\n", "iso_cvt_f16_f32", c[0].cyc, c[1].cyc, c[2].cyc, c[3].cyc, "-", 8.0 * c[3].cyc - 7.0 * 2.37);
+  }
+  if (selected("iso_mbcnt_lo", argc, argv)) {
+    Result c[4];
+    int wi = 0;
+    for (int W : {1, 2, 4, 8}) c[wi++] = run<float>(k_iso_mbcnt_lo, W, d_stamps, d_sink, 1.0);
+    printf("%-26s %7.2f %7.2f %7.2f %7.2f %7s   cost of the one in eight at W=8: %5.1f cycles\n", "iso_mbcnt_lo", c[0].cyc, c[1].cyc, c[2].cyc, c[3].cyc, "-", 8.0 * c[3].cyc - 7.0 * 2.37);
   }
   if (selected("dep_chain_fma", argc, argv)) {
     // ONE dependent chain per wave (every instruction waits for the previous one) at 1..8 waves per SIMD: do the other
