@@ -1140,11 +1140,14 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
   __shared__ uint32_t s_count;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // {overflow bits, bin_need} of this frame straight into pinned host memory (final since k_geometry ended): the host
-  // looks at them when it reuses the frame's slot -- two stores instead of a copy kernel on the stream
+  // {overflow bits, bin_need, -, every-tile entries asked for, clip slots asked for} of this frame straight into pinned host
+  // memory (final since k_geometry ended): the host looks at them when it reuses the frame's slot -- a few stores instead
+  // of a copy kernel on the stream.  (Word 2 is the frame's shade item count, stored by k_shade_items.)
   if (host_flags && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
     host_flags[0] = ctr->overflow;
     host_flags[1] = ctr->bin_need;
+    host_flags[3] = ctr->n_broad;
+    host_flags[4] = ctr->n_clip_slots;
   }
   // launch slot -> tile: plain row order, or heaviest tiles first (k_tile_order)
   uint32_t slot = blockIdx.y * gridDim.x + blockIdx.x;
@@ -1188,7 +1191,10 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
   __shared__ unsigned long long s_pad_frag;
   if (tid < (int)kBinClasses)
     s_n_cls[tid] = BB_ABLATE(1u | (256u << tid)) ? 0u : min(tile_count[tile * kBinClasses + tid], fp.bin_cap);
-  const uint32_t n_broad = BB_ABLATE(5u) ? 0u : min(ctr->n_broad, fp.broad_cap);
+  // A frame whose every-tile list overflowed (bit 1 of ctr->overflow, final since k_geometry ended) is rendered again after
+  // the host has grown the list: the clip path reserves a run of entries and writes none of them when the run does not
+  // fit, so a prefix of the list may hold entries never written this frame -- the overflowed frame takes none of it.
+  const uint32_t n_broad = (BB_ABLATE(5u) || (ctr->overflow & 2u)) ? 0u : min(ctr->n_broad, fp.broad_cap);
   for (int p = tid; p < TILE_PIXELS; p += kTileThreads) {
     unsigned long long k0 = 0ull;
     if (OVERLAY) {  // depth test against what the scene left behind; low word 0 = "no overlay primitive here"

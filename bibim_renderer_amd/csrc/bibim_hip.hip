@@ -90,7 +90,8 @@ struct DeviceBuffer {
 // Everything one frame in flight owns.
 struct FrameSlot {
   void *h_staging = nullptr;  // pinned: lights, draw descriptors, instances
-  uint32_t *h_flags = nullptr;  // pinned, device-visible {overflow bits, bin_need} of the frame last rendered in this
+  static constexpr int kHostFlagWords = 8;
+  uint32_t *h_flags = nullptr;  // pinned, device-visible {overflow bits, bin_need, shade items, every-tile entries, clip slots} of the frame last rendered in this
                                 // slot (stored by its k_raster): lets a host that never synchronises still grow capacities
   size_t staging_cap = 0;
   DeviceBuffer<uint8_t> d_staging;
@@ -275,6 +276,14 @@ int fail(bbr_context *ctx, int code, const std::string &msg) {
   return code;
 }
 
+// Every entry point that can allocate, copy or launch makes the context's device current first: a process that drives
+// several GPUs (one context each) may call with another device current.
+#define BBR_ON_DEVICE(ctx)                                                                                     \
+  do {                                                                                                         \
+    hipError_t _e = hipSetDevice((ctx)->device);                                                               \
+    if (_e != hipSuccess) return fail(ctx, BBR_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(_e)); \
+  } while (0)
+
 #define HIP_TRY(ctx, expr)                                                                                     \
   do {                                                                                                         \
     hipError_t _e = (expr);                                                                                    \
@@ -345,7 +354,7 @@ int ensure_slot_buffers(bbr_context *c, FrameSlot &s) {
   HIP_TRY(c, s.d_block_stats.ensure(std::max<size_t>((c->n_prims + 255) / 256, 1), true));
   HIP_TRY(c, s.d_tile_count.ensure(tiles * kBinClasses, true));
   HIP_TRY(c, s.d_bins.ensure(tiles * kBinClasses * c->bin_cap));
-  HIP_TRY(c, s.d_broad.ensure(c->broad_cap));
+  HIP_TRY(c, s.d_broad.ensure(c->broad_cap, true));
   HIP_TRY(c, s.d_frags.ensure(tiles * (size_t)(c->tile_w() * c->tile_h())));
 #ifdef BB_STAMPS
   HIP_TRY(c, s.d_frag_count.ensure(tiles * 17, true));  // diagnostic build: 8 x u64 raster stamps per tile behind the counts
@@ -371,8 +380,8 @@ int ensure_slot_buffers(bbr_context *c, FrameSlot &s) {
     HIP_TRY(c, c->d_vis_depth.ensure((size_t)c->width * c->height));
   }
   if (!s.h_flags) {
-    HIP_TRY(c, hipHostMalloc((void **)&s.h_flags, 4 * sizeof(uint32_t), hipHostMallocDefault));
-    s.h_flags[0] = s.h_flags[1] = s.h_flags[2] = s.h_flags[3] = 0u;
+    HIP_TRY(c, hipHostMalloc((void **)&s.h_flags, FrameSlot::kHostFlagWords * sizeof(uint32_t), hipHostMallocDefault));
+    for (int i = 0; i < FrameSlot::kHostFlagWords; ++i) s.h_flags[i] = 0u;
   }
   if (!s.ev_geom_done) HIP_TRY(c, hipEventCreateWithFlags(&s.ev_geom_done, hipEventDisableTiming));
   if (!s.ev_raster_done) HIP_TRY(c, hipEventCreateWithFlags(&s.ev_raster_done, hipEventDisableTiming));
@@ -485,7 +494,7 @@ void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const Fra
 }
 
 // A capacity overflowed (bit0 bins, bit1 every-tile list, bit2 clip arena): grow it.  Everything must have left the GPU.
-int apply_growth(bbr_context *c, uint32_t overflow, uint32_t bin_need) {
+int apply_growth(bbr_context *c, uint32_t overflow, uint32_t bin_need, uint32_t broad_need, uint32_t clip_need) {
   if (getenv("BBR_DEBUG"))
     fprintf(stderr, "[bbr] capacity growth: overflow bits %u, bin_need %u (bin_cap %u, broad_cap %u, clip_cap %u), frame %llu\n", overflow,
             bin_need, c->bin_cap, c->broad_cap, c->clip_cap, (unsigned long long)c->frame_counter);
@@ -495,11 +504,14 @@ int apply_growth(bbr_context *c, uint32_t overflow, uint32_t bin_need) {
     c->bin_cap = (need + 255u) & ~255u;
     for (FrameSlot &s : c->slots) s.d_bins.release();
   }
-  if (overflow & 2u) c->broad_cap *= 2;
-  if (overflow & 4u) c->clip_cap *= 2;
+  // the every-tile list and the clip arena: what the overflowed frame asked for (a lower bound: primitives dropped by a
+  // full clip arena asked for no list entry) with headroom, at least double
+  auto grown = [](uint32_t cap, uint32_t need) { return std::max(cap * 2u, (need + need / 4u + 255u) & ~255u); };
+  if (overflow & 2u) c->broad_cap = grown(c->broad_cap, broad_need);
+  if (overflow & 4u) c->clip_cap = grown(c->clip_cap, clip_need);
   ++c->retries;
   for (FrameSlot &s : c->slots) {
-    if (s.h_flags) s.h_flags[0] = s.h_flags[1] = s.h_flags[2] = 0u;  // they describe frames rendered with the old capacities
+    if (s.h_flags) s.h_flags[0] = s.h_flags[1] = s.h_flags[2] = s.h_flags[3] = s.h_flags[4] = 0u;  // they describe frames rendered with the old capacities
     // tile counters may hold residue of references that did not fit
     if (s.d_tile_count.ptr) HIP_TRY(c, zero_fill_sync(s.d_tile_count.ptr, s.d_tile_count.cap * sizeof(uint32_t)));
   }
@@ -521,10 +533,10 @@ int submit_frame_into(bbr_context *c, int slot_index) {
   // pixels (and those of the frames queued since) are incomplete and already handed out; from this frame on the
   // capacities fit.  (Synchronising calls do better: they re-render the overflowed frame, sync_and_fix.)
   if (s.h_flags && s.h_flags[0]) {
-    const uint32_t overflow = s.h_flags[0], bin_need = s.h_flags[1];
+    const uint32_t overflow = s.h_flags[0], bin_need = s.h_flags[1], broad_need = s.h_flags[3], clip_need = s.h_flags[4];
     rc = drain(c);
     if (rc) return rc;
-    rc = apply_growth(c, overflow, bin_need);
+    rc = apply_growth(c, overflow, bin_need, broad_need, clip_need);
     if (rc) return rc;
   }
   rc = ensure_slot_buffers(c, s);
@@ -690,6 +702,28 @@ int submit_frame(bbr_context *c) {
 }
 
 // Synchronise and, if a capacity overflowed in the most recent frame, grow it and render that frame again.
+// Render the recorded frame once more into the slot it was last rendered in (after a capacity growth, or for a diagnostic
+// dump) and put the slot's presentation state back: the presented image is made again from the new frame, a caller's
+// copy of it is refreshed, and bbr_read_presented / bbr_draw_overlays keep working afterwards.
+int resubmit_last_frame(bbr_context *c) {
+  FrameSlot &s = c->slots[c->last_slot];
+  const auto present = s.present;
+  int rc = submit_frame_into(c, c->last_slot);
+  if (rc) return rc;
+  if (present.active && !s.fused) {
+    s.present = present;
+    rc = queue_present(c, s);
+    if (rc) return rc;
+  } else if (s.fused && present.copy_to) {  // fused: the re-rendered frame is the image; redo the caller's copy
+    const size_t n = (size_t)c->width * (c->world > 1 ? c->shard_rows() : c->height);
+    s.present.copy_to = present.copy_to;
+    HIP_TRY(c, hipStreamWaitEvent(c->present_stream(), s.ev_shade_done, 0));
+    HIP_TRY(c, hipMemcpyAsync(present.copy_to, s.d_present.ptr, n * 4, hipMemcpyDeviceToDevice, c->present_stream()));
+    HIP_TRY(c, hipEventRecord(s.ev_shade_done, c->present_stream()));
+  }
+  return BBR_OK;
+}
+
 int sync_and_fix(bbr_context *c, Counters *out_counters) {
   for (int attempt = 0; attempt < 8; ++attempt) {
     int rc = drain(c);
@@ -699,23 +733,10 @@ int sync_and_fix(bbr_context *c, Counters *out_counters) {
       HIP_TRY(c, hipMemcpy(&h, c->d_counters_done.ptr + c->slots[c->last_slot].ctr_index, sizeof h, hipMemcpyDeviceToHost));
     if (out_counters) *out_counters = h;
     if (!h.overflow) return BBR_OK;
-    rc = apply_growth(c, h.overflow, h.bin_need);
+    rc = apply_growth(c, h.overflow, h.bin_need, h.n_broad, h.n_clip_slots);
     if (rc) return rc;
-    FrameSlot &s = c->slots[c->last_slot];
-    const auto present = s.present;
-    rc = submit_frame_into(c, c->last_slot);
+    rc = resubmit_last_frame(c);
     if (rc) return rc;
-    if (present.active && !s.fused) {  // the presented image was made from the overflowed frame: make it again
-      s.present = present;
-      rc = queue_present(c, s);
-      if (rc) return rc;
-    } else if (s.fused && present.copy_to) {  // fused: the re-rendered frame is the image; redo the caller's copy
-      const size_t n = (size_t)c->width * (c->world > 1 ? c->shard_rows() : c->height);
-      s.present.copy_to = present.copy_to;
-      HIP_TRY(c, hipStreamWaitEvent(c->present_stream(), s.ev_shade_done, 0));
-      HIP_TRY(c, hipMemcpyAsync(present.copy_to, s.d_present.ptr, n * 4, hipMemcpyDeviceToDevice, c->present_stream()));
-      HIP_TRY(c, hipEventRecord(s.ev_shade_done, c->present_stream()));
-    }
   }
   return fail(c, BBR_ERR_CAPACITY, "bin capacity still exceeded after 8 growth steps");
 }
@@ -788,7 +809,6 @@ extern "C" int bbr_upload_gizmo(bbr_context *c, const void *gizmo_vertices, uint
                                 uint32_t n_indices) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
   if (!gizmo_vertices || !n_vertices) return fail(c, BBR_ERR_INVALID_ARGUMENT, "upload_gizmo: null/empty input");
-  HIP_TRY(c, hipSetDevice(c->device));
   int rc = drain(c);
   if (rc) return rc;
   // bb::GizmoVertex {Pos, Color, Normal} (src/render.h:122-126) -> Vertex {pos, uv, normal, tangent := colour}
@@ -816,6 +836,7 @@ extern "C" int bbr_upload_gizmo(bbr_context *c, const void *gizmo_vertices, uint
 
 extern "C" int bbr_draw_overlays(bbr_context *c, int32_t gizmo_extent) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  BBR_ON_DEVICE(c);
   if (!c->have_frame || c->last_slot < 0) return fail(c, BBR_ERR_NOT_IN_FRAME, "draw_overlays: nothing rendered");
   if (c->world > 1) return fail(c, BBR_ERR_INVALID_ARGUMENT, "draw_overlays: not available with a partition");
   int rc = sync_and_fix(c, nullptr);  // the overlay pass is synchronous: it is a debugging aid, not part of the hot path
@@ -892,7 +913,7 @@ extern "C" int bbr_draw_overlays(bbr_context *c, int32_t gizmo_extent) {
     HIP_TRY(c, s.d_block_stats.ensure((n_prims + 255) / 256, true));
     HIP_TRY(c, s.d_tile_count.ensure(tiles * kBinClasses, true));
     HIP_TRY(c, s.d_bins.ensure(tiles * kBinClasses * c->bin_cap));
-    HIP_TRY(c, s.d_broad.ensure(c->broad_cap));
+    HIP_TRY(c, s.d_broad.ensure(c->broad_cap, true));
     HIP_TRY(c, s.d_frags.ensure(tiles * (size_t)(c->tile_w() * c->tile_h())));
     HIP_TRY(c, s.d_frag_count.ensure(tiles, true));
     FrameParams fp = make_params(c);
@@ -931,7 +952,7 @@ extern "C" int bbr_draw_overlays(bbr_context *c, int32_t gizmo_extent) {
     if (!h.overflow) return BBR_OK;
     // an overlay triangle did not fit: the presented pixels it already wrote are a subset of the right ones (same
     // colours), so growing and drawing again on top is correct
-    rc = apply_growth(c, h.overflow, h.bin_need);
+    rc = apply_growth(c, h.overflow, h.bin_need, h.n_broad, h.n_clip_slots);
     if (rc) return rc;
     if (s.d_tile_count.ptr) HIP_TRY(c, zero_fill_sync(s.d_tile_count.ptr, s.d_tile_count.cap * sizeof(uint32_t)));
   }
@@ -952,6 +973,54 @@ int bbr_device_count(void) {
 
 const char *bbr_last_error(const bbr_context *ctx) { return ctx ? ctx->last_error.c_str() : g_create_error.c_str(); }
 
+// Everything a context owns, whatever state its construction reached (bbr_destroy, and bbr_create when a step fails).
+static void release_context(bbr_context *c) {
+  (void)hipSetDevice(c->device);
+  (void)drain(c);
+  for (Mesh &m : c->meshes) {
+    if (m.d_vertices) (void)hipFree(m.d_vertices);
+    if (m.d_indices) (void)hipFree(m.d_indices);
+  }
+  for (Material &m : c->materials) {
+    for (auto &p : m.d_texels)
+      if (p) (void)hipFree(p);
+    if (m.d_packed) (void)hipFree(m.d_packed);
+  }
+  if (c->d_default_texels) (void)hipFree(c->d_default_texels);
+  c->d_materials.release();
+  c->d_counters.release();
+  c->d_counters_done.release();
+  c->d_vis_prim.release();
+  c->d_vis_depth.release();
+  c->d_gbuffer.release();
+  for (FrameSlot &s : c->slots) {
+    s.release_all();
+    if (s.ev_geom_done) (void)hipEventDestroy(s.ev_geom_done);
+    if (s.ev_raster_done) (void)hipEventDestroy(s.ev_raster_done);
+    if (s.ev_shade_done) (void)hipEventDestroy(s.ev_shade_done);
+    if (s.ev_tail_done) (void)hipEventDestroy(s.ev_tail_done);
+  }
+  for (Mesh *m : {&c->marker_mesh, &c->gizmo_mesh}) {
+    if (m->d_vertices) (void)hipFree(m->d_vertices);
+    if (m->d_indices) (void)hipFree(m->d_indices);
+  }
+  c->ov.release_all();
+  if (c->ov.ev_geom_done) (void)hipEventDestroy(c->ov.ev_geom_done);
+  if (c->ov.ev_raster_done) (void)hipEventDestroy(c->ov.ev_raster_done);
+  if (c->ov.ev_shade_done) (void)hipEventDestroy(c->ov.ev_shade_done);
+  if (c->ov.ev_tail_done) (void)hipEventDestroy(c->ov.ev_tail_done);
+  for (auto &e : c->ring)
+    if (e) (void)hipEventDestroy(e);
+  for (auto &e : c->present_ring)
+    if (e) (void)hipEventDestroy(e);
+  c->d_srgb_tables.release();
+  if (c->s_geom) (void)hipStreamDestroy(c->s_geom);
+  if (c->s_raster) (void)hipStreamDestroy(c->s_raster);
+  if (c->s_shade) (void)hipStreamDestroy(c->s_shade);
+  if (c->s_present) (void)hipStreamDestroy(c->s_present);
+  delete c;
+}
+
 int bbr_create(int32_t width, int32_t height, int32_t device, bbr_context **out_ctx) {
   if (!out_ctx) return fail(nullptr, BBR_ERR_INVALID_ARGUMENT, "out_ctx is NULL");
   *out_ctx = nullptr;
@@ -970,7 +1039,7 @@ int bbr_create(int32_t width, int32_t height, int32_t device, bbr_context **out_
     hipError_t _e = (expr);                                                                    \
     if (_e != hipSuccess) {                                                                    \
       g_create_error = std::string(#expr) + ": " + hipGetErrorString(_e);                      \
-      delete c;                                                                                \
+      release_context(c);                                                                      \
       return _e == hipErrorOutOfMemory ? BBR_ERR_OUT_OF_MEMORY : BBR_ERR_HIP;                  \
     }                                                                                          \
   } while (0)
@@ -1012,55 +1081,14 @@ int bbr_destroy(bbr_context *c) {
     std::lock_guard<std::mutex> lock(g_live_mutex);
     if (!g_live.erase(c)) return BBR_ERR_BAD_HANDLE;  // never created, or destroyed already
   }
-  (void)hipSetDevice(c->device);
-  (void)drain(c);
-  for (Mesh &m : c->meshes) {
-    if (m.d_vertices) (void)hipFree(m.d_vertices);
-    if (m.d_indices) (void)hipFree(m.d_indices);
-  }
-  for (Material &m : c->materials) {
-    for (auto &p : m.d_texels)
-      if (p) (void)hipFree(p);
-    if (m.d_packed) (void)hipFree(m.d_packed);
-  }
-  if (c->d_default_texels) (void)hipFree(c->d_default_texels);
-  c->d_materials.release();
-  c->d_counters.release();
-  c->d_counters_done.release();
-  c->d_vis_prim.release();
-  c->d_vis_depth.release();
-  for (FrameSlot &s : c->slots) {
-    s.release_all();
-    if (s.ev_geom_done) (void)hipEventDestroy(s.ev_geom_done);
-    if (s.ev_raster_done) (void)hipEventDestroy(s.ev_raster_done);
-    if (s.ev_shade_done) (void)hipEventDestroy(s.ev_shade_done);
-    if (s.ev_tail_done) (void)hipEventDestroy(s.ev_tail_done);
-  }
-  for (Mesh *m : {&c->marker_mesh, &c->gizmo_mesh}) {
-    if (m->d_vertices) (void)hipFree(m->d_vertices);
-    if (m->d_indices) (void)hipFree(m->d_indices);
-  }
-  c->ov.release_all();
-  if (c->ov.ev_geom_done) (void)hipEventDestroy(c->ov.ev_geom_done);
-  if (c->ov.ev_raster_done) (void)hipEventDestroy(c->ov.ev_raster_done);
-  if (c->ov.ev_shade_done) (void)hipEventDestroy(c->ov.ev_shade_done);
-  if (c->ov.ev_tail_done) (void)hipEventDestroy(c->ov.ev_tail_done);
-  for (auto &e : c->ring)
-    if (e) (void)hipEventDestroy(e);
-  for (auto &e : c->present_ring)
-    if (e) (void)hipEventDestroy(e);
-  c->d_srgb_tables.release();
-  if (c->s_geom) (void)hipStreamDestroy(c->s_geom);
-  if (c->s_raster) (void)hipStreamDestroy(c->s_raster);
-  if (c->s_shade) (void)hipStreamDestroy(c->s_shade);
-  if (c->s_present) (void)hipStreamDestroy(c->s_present);
-  delete c;
+  release_context(c);
   return BBR_OK;
 }
 
 int bbr_upload_mesh(bbr_context *c, const void *vertices, uint32_t n_vertices, const uint32_t *indices,
                     uint32_t n_indices, int32_t *out_mesh) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  BBR_ON_DEVICE(c);
   if (!vertices || !n_vertices || !out_mesh) return fail(c, BBR_ERR_INVALID_ARGUMENT, "upload_mesh: null/empty input");
   if (indices) {
     for (uint32_t i = 0; i < n_indices; ++i)
@@ -1068,7 +1096,6 @@ int bbr_upload_mesh(bbr_context *c, const void *vertices, uint32_t n_vertices, c
   } else if (n_indices) {
     return fail(c, BBR_ERR_INVALID_ARGUMENT, "upload_mesh: n_indices without indices");
   }
-  HIP_TRY(c, hipSetDevice(c->device));
   Mesh m;
   m.n_vertices = n_vertices;
   m.n_indices = indices ? n_indices : 0;
@@ -1086,7 +1113,8 @@ int bbr_upload_mesh(bbr_context *c, const void *vertices, uint32_t n_vertices, c
 
 int bbr_free_mesh(bbr_context *c, int32_t mesh) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
-  if (!is_live(c)) return BBR_ERR_BAD_HANDLE;  // the context is gone and took the mesh with it
+  if (!is_live(c)) return BBR_ERR_BAD_HANDLE;  // the context is gone and took the mesh with it (checked before c is touched)
+  BBR_ON_DEVICE(c);
   if (mesh < 0 || mesh >= (int32_t)c->meshes.size() || !c->meshes[mesh].alive)
     return fail(c, BBR_ERR_BAD_HANDLE, "free_mesh: bad handle");
   int rc = drain(c);
@@ -1101,8 +1129,8 @@ int bbr_free_mesh(bbr_context *c, int32_t mesh) {
 
 int bbr_upload_material(bbr_context *c, const bbr_image maps[BBR_MAP_COUNT], int32_t *out_material) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  BBR_ON_DEVICE(c);
   if (!maps || !out_material) return fail(c, BBR_ERR_INVALID_ARGUMENT, "upload_material: null input");
-  HIP_TRY(c, hipSetDevice(c->device));
   Material m;
   struct Guard {  // frees what a failed upload had already allocated
     Material *m;
@@ -1176,7 +1204,8 @@ int bbr_upload_material(bbr_context *c, const bbr_image maps[BBR_MAP_COUNT], int
 
 int bbr_free_material(bbr_context *c, int32_t material) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
-  if (!is_live(c)) return BBR_ERR_BAD_HANDLE;  // the context is gone and took the material with it
+  if (!is_live(c)) return BBR_ERR_BAD_HANDLE;  // the context is gone and took the material with it (checked before c is touched)
+  BBR_ON_DEVICE(c);
   if (material < 0 || material >= (int32_t)c->materials.size() || !c->materials[material].alive)
     return fail(c, BBR_ERR_BAD_HANDLE, "free_material: bad handle");
   int rc = drain(c);
@@ -1193,6 +1222,7 @@ int bbr_free_material(bbr_context *c, int32_t material) {
 
 int bbr_set_frame_uniforms(bbr_context *c, const void *block) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  BBR_ON_DEVICE(c);
   if (!block) return fail(c, BBR_ERR_INVALID_ARGUMENT, "set_frame_uniforms: NULL");
   std::memcpy(&c->frame_u, block, sizeof(FrameUniformBlock));
   // the reference asserts NumLights < MAX_NUM_LIGHTS (src/main.cpp:1289-1290)
@@ -1203,6 +1233,7 @@ int bbr_set_frame_uniforms(bbr_context *c, const void *block) {
 
 int bbr_set_view_uniforms(bbr_context *c, const void *block) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  BBR_ON_DEVICE(c);
   if (!block) return fail(c, BBR_ERR_INVALID_ARGUMENT, "set_view_uniforms: NULL");
   std::memcpy(&c->view_u, block, sizeof(ViewUniformBlock));
   return BBR_OK;
@@ -1210,6 +1241,7 @@ int bbr_set_view_uniforms(bbr_context *c, const void *block) {
 
 int bbr_begin_frame(bbr_context *c) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  BBR_ON_DEVICE(c);
   c->draws.clear();
   c->host_instances.clear();
   c->n_prims = 0;
@@ -1220,6 +1252,7 @@ int bbr_begin_frame(bbr_context *c) {
 
 int bbr_draw(bbr_context *c, int32_t mesh, int32_t material, const void *instance_blocks, uint32_t n_instances) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  BBR_ON_DEVICE(c);
   if (!c->in_frame) return fail(c, BBR_ERR_NOT_IN_FRAME, "draw outside begin_frame/end_frame");
   if (mesh < 0 || mesh >= (int32_t)c->meshes.size() || !c->meshes[mesh].alive)
     return fail(c, BBR_ERR_BAD_HANDLE, "draw: bad mesh handle");
@@ -1246,26 +1279,29 @@ int bbr_draw(bbr_context *c, int32_t mesh, int32_t material, const void *instanc
 
 int bbr_end_frame(bbr_context *c) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  BBR_ON_DEVICE(c);
   if (!c->in_frame) return fail(c, BBR_ERR_NOT_IN_FRAME, "end_frame without begin_frame");
   c->in_frame = false;
   c->have_frame = true;
-  HIP_TRY(c, hipSetDevice(c->device));
   return submit_frame(c);
 }
 
 int bbr_replay_frame(bbr_context *c) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  BBR_ON_DEVICE(c);
   if (!c->have_frame) return fail(c, BBR_ERR_NOT_IN_FRAME, "replay_frame: no recorded frame");
   return submit_frame(c);
 }
 
 int bbr_synchronize(bbr_context *c) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  BBR_ON_DEVICE(c);
   return sync_and_fix(c, nullptr);
 }
 
 int bbr_read_framebuffer(bbr_context *c, float *host) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  BBR_ON_DEVICE(c);
   if (!host) return fail(c, BBR_ERR_INVALID_ARGUMENT, "read_framebuffer: NULL");
   if (c->world > 1) return fail(c, BBR_ERR_INVALID_ARGUMENT, "read_framebuffer on a partitioned context: use bbr_read_shard");
   if (!c->have_frame) return fail(c, BBR_ERR_NOT_IN_FRAME, "read_framebuffer: nothing rendered");
@@ -1279,6 +1315,7 @@ int bbr_read_framebuffer(bbr_context *c, float *host) {
 
 int bbr_read_shard(bbr_context *c, float *host) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  BBR_ON_DEVICE(c);
   if (!host) return fail(c, BBR_ERR_INVALID_ARGUMENT, "read_shard: NULL");
   if (!c->have_frame) return fail(c, BBR_ERR_NOT_IN_FRAME, "read_shard: nothing rendered");
   if (c->last_slot >= 0 && c->slots[c->last_slot].fused)
@@ -1291,6 +1328,7 @@ int bbr_read_shard(bbr_context *c, float *host) {
 
 int bbr_framebuffer_device_ptr(bbr_context *c, void **out_ptr, uint64_t *out_bytes) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  BBR_ON_DEVICE(c);
   if (!out_ptr) return fail(c, BBR_ERR_INVALID_ARGUMENT, "framebuffer_device_ptr: NULL");
   if (!c->have_frame || c->last_slot < 0) return fail(c, BBR_ERR_NOT_IN_FRAME, "framebuffer_device_ptr: nothing rendered");
   *out_ptr = (void *)c->slots[c->last_slot].out_used;
@@ -1301,6 +1339,7 @@ int bbr_framebuffer_device_ptr(bbr_context *c, void **out_ptr, uint64_t *out_byt
 
 int bbr_set_output_device_ptr(bbr_context *c, void *device_ptr, uint64_t bytes) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  BBR_ON_DEVICE(c);
   if (device_ptr) {
     uint64_t need = (uint64_t)c->width * (c->world > 1 ? c->shard_rows() : c->height) * 16;
     if (bytes < need) return fail(c, BBR_ERR_INVALID_ARGUMENT, "set_output_device_ptr: buffer too small");
@@ -1313,6 +1352,7 @@ int bbr_set_output_device_ptr(bbr_context *c, void *device_ptr, uint64_t bytes) 
 
 int bbr_set_stream(bbr_context *c, void *stream) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  BBR_ON_DEVICE(c);
   int rc = drain(c);
   if (rc) return rc;
   c->user_stream = (hipStream_t)stream;
@@ -1322,6 +1362,7 @@ int bbr_set_stream(bbr_context *c, void *stream) {
 
 int bbr_wait_event(bbr_context *c, void *hip_event) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  BBR_ON_DEVICE(c);
   if (!hip_event) return fail(c, BBR_ERR_INVALID_ARGUMENT, "wait_event: NULL");
   c->pending_waits.push_back((hipEvent_t)hip_event);  // the next frame's first stream waits for it (which stream that is
                                                       // depends on the stream layout)
@@ -1330,6 +1371,7 @@ int bbr_wait_event(bbr_context *c, void *hip_event) {
 
 int bbr_stream_wait_frame(bbr_context *c, void *stream) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  BBR_ON_DEVICE(c);
   if (!c->have_frame || c->last_slot < 0) return fail(c, BBR_ERR_NOT_IN_FRAME, "stream_wait_frame: nothing rendered");
   HIP_TRY(c, hipStreamWaitEvent((hipStream_t)stream, c->slots[c->last_slot].ev_shade_done, 0));
   return BBR_OK;
@@ -1343,6 +1385,7 @@ int bbr_tile_height(const bbr_context *c, int32_t *out) {
 
 int bbr_set_partition(bbr_context *c, int32_t rank, int32_t world, int32_t band_rows) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  BBR_ON_DEVICE(c);
   if (world < 1 || rank < 0 || rank >= world) return fail(c, BBR_ERR_INVALID_ARGUMENT, "set_partition: bad rank/world");
   if (band_rows <= 0) band_rows = c->tile_h();
   if (band_rows % c->tile_h()) return fail(c, BBR_ERR_INVALID_ARGUMENT, "set_partition: band_rows must be a multiple of the tile height");
@@ -1365,6 +1408,7 @@ int bbr_set_partition(bbr_context *c, int32_t rank, int32_t world, int32_t band_
 // extent, keep meshes, materials and options.  Buffers come back lazily with the next frame.
 int bbr_resize(bbr_context *c, int32_t width, int32_t height) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  BBR_ON_DEVICE(c);
   if (width <= 0 || height <= 0 || width > 32768 || height > 32768)
     return fail(c, BBR_ERR_INVALID_ARGUMENT, "resize: width/height out of range");
   if (c->in_frame) return fail(c, BBR_ERR_INVALID_ARGUMENT, "resize: between begin_frame and end_frame");
@@ -1415,6 +1459,7 @@ int bbr_shard_rows(const bbr_context *c, int32_t *out_rows) {
 
 int bbr_unpack_gathered(bbr_context *c, const void *gathered, void *frame, void *stream) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  BBR_ON_DEVICE(c);
   if (!gathered || !frame) return fail(c, BBR_ERR_INVALID_ARGUMENT, "unpack_gathered: NULL");
   size_t n = (size_t)c->width * c->height;
   hipStream_t st = stream ? (hipStream_t)stream : c->shade_stream();
@@ -1426,6 +1471,7 @@ int bbr_unpack_gathered(bbr_context *c, const void *gathered, void *frame, void 
 
 int bbr_get_stats(bbr_context *c, bbr_stats *out) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  BBR_ON_DEVICE(c);
   if (!out) return fail(c, BBR_ERR_INVALID_ARGUMENT, "get_stats: NULL");
   if (!c->have_frame) return fail(c, BBR_ERR_NOT_IN_FRAME, "get_stats: nothing rendered");
   Counters h;
@@ -1465,12 +1511,13 @@ int bbr_get_stats(bbr_context *c, bbr_stats *out) {
 
 int bbr_read_visibility(bbr_context *c, uint32_t *prim_host, float *depth_host) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  BBR_ON_DEVICE(c);
   if (!c->have_frame) return fail(c, BBR_ERR_NOT_IN_FRAME, "read_visibility: nothing rendered");
   if (c->world > 1) return fail(c, BBR_ERR_INVALID_ARGUMENT, "read_visibility: not available on a partitioned context");
   int rc = sync_and_fix(c, nullptr);
   if (rc) return rc;
   c->dump_vis = true;
-  rc = submit_frame_into(c, c->last_slot);
+  rc = resubmit_last_frame(c);
   if (!rc) rc = sync_and_fix(c, nullptr);
   c->dump_vis = false;
   if (rc) return rc;
@@ -1482,6 +1529,7 @@ int bbr_read_visibility(bbr_context *c, uint32_t *prim_host, float *depth_host) 
 
 int bbr_read_gbuffer(bbr_context *c, float *host) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  BBR_ON_DEVICE(c);
   if (!host) return fail(c, BBR_ERR_INVALID_ARGUMENT, "read_gbuffer: NULL");
   if (!c->have_frame || c->last_slot < 0) return fail(c, BBR_ERR_NOT_IN_FRAME, "read_gbuffer: nothing rendered");
   if (!c->deferred) return fail(c, BBR_ERR_INVALID_ARGUMENT, "read_gbuffer: option render_pass is not 1 (deferred)");
@@ -1490,7 +1538,7 @@ int bbr_read_gbuffer(bbr_context *c, float *host) {
   if (rc) return rc;
   // the fused deferred kernel keeps the G-buffer in registers; render the frame once more with the dump enabled
   c->dump_gbuffer = true;
-  rc = submit_frame_into(c, c->last_slot);
+  rc = resubmit_last_frame(c);
   if (rc == BBR_OK) rc = sync_and_fix(c, nullptr);
   c->dump_gbuffer = false;
   if (rc) return rc;
@@ -1504,6 +1552,7 @@ int bbr_read_gbuffer(bbr_context *c, float *host) {
 
 int bbr_last_frame_time_ms(bbr_context *c, float *out_frame_ms, float *out_shade_ms) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  BBR_ON_DEVICE(c);
   if (!c->timing) return fail(c, BBR_ERR_INVALID_ARGUMENT, "last_frame_time_ms: enable option \"timing\" first");
   if (!c->ring_frames) return fail(c, BBR_ERR_NOT_IN_FRAME, "last_frame_time_ms: no timed frame yet");
   int rc = drain(c);
@@ -1519,6 +1568,7 @@ int bbr_last_frame_time_ms(bbr_context *c, float *out_frame_ms, float *out_shade
 
 int bbr_timing_reset(bbr_context *c) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  BBR_ON_DEVICE(c);
   int rc = drain(c);
   if (rc) return rc;
   c->ring_frames = 0;
@@ -1529,6 +1579,7 @@ int bbr_timing_reset(bbr_context *c) {
 int bbr_timing_summary(bbr_context *c, uint32_t *out_frames, float *out_avg_frame_ms, float *out_avg_geometry_ms,
                        float *out_avg_raster_ms, float *out_avg_shade_ms) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  BBR_ON_DEVICE(c);
   if (!c->timing) return fail(c, BBR_ERR_INVALID_ARGUMENT, "timing_summary: enable option \"timing\" first");
   int rc = drain(c);
   if (rc) return rc;
@@ -1555,6 +1606,7 @@ int bbr_timing_summary(bbr_context *c, uint32_t *out_frames, float *out_avg_fram
 
 int bbr_present_timing(bbr_context *c, uint32_t *out_launches, float *out_avg_ms) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  BBR_ON_DEVICE(c);
   if (!c->timing) return fail(c, BBR_ERR_INVALID_ARGUMENT, "present_timing: enable option \"timing\" first");
   int rc = drain(c);
   if (rc) return rc;
@@ -1572,6 +1624,7 @@ int bbr_present_timing(bbr_context *c, uint32_t *out_launches, float *out_avg_ms
 
 int bbr_set_option(bbr_context *c, const char *name, int64_t value) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  BBR_ON_DEVICE(c);
   if (!name) return fail(c, BBR_ERR_INVALID_ARGUMENT, "set_option: NULL name");
   std::string n(name);
   if (n == "gbuffer_view") {  // like render_pass: takes effect with the next submitted frame
@@ -1627,6 +1680,18 @@ int bbr_set_option(bbr_context *c, const char *name, int64_t value) {
   } else if (n == "stream_layout") {
     if (value < 0 || value >= bbr_context::kLayouts) return fail(c, BBR_ERR_INVALID_ARGUMENT, "stream_layout: 0, 1 or 2");
     c->layout_mode = (int)value;
+  } else if (n == "broad_cap" || n == "clip_cap") {
+    // starting capacity of the every-tile list / the clip arena (entries); both double when a frame overflows them
+    if (value < 1 || value > (1 << 24)) return fail(c, BBR_ERR_INVALID_ARGUMENT, n + " out of range (1 .. 2^24)");
+    int rc = drain(c);
+    if (rc) return rc;
+    (n == "broad_cap" ? c->broad_cap : c->clip_cap) = (uint32_t)value;
+    for (FrameSlot &s : c->slots) {
+      if (n == "broad_cap") s.d_broad.release();
+      else s.d_clip.release();
+    }
+    if (n == "broad_cap") c->ov.d_broad.release();
+    else c->ov.d_clip.release();
   } else if (n == "broad_threshold") {
     if (value < 1) return fail(c, BBR_ERR_INVALID_ARGUMENT, "broad_threshold must be >= 1");
     c->broad_threshold = (uint32_t)value;
@@ -1657,6 +1722,7 @@ int bbr_debug_stamps(bbr_context *c, unsigned long long *out, uint32_t n_blocks)
 
 int bbr_present(bbr_context *c, void *rgba8_device, int32_t hdr16) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  BBR_ON_DEVICE(c);
   if (!c->have_frame || c->last_slot < 0) return fail(c, BBR_ERR_NOT_IN_FRAME, "present: nothing rendered");
   FrameSlot &s = c->slots[c->last_slot];
   const size_t n = (size_t)c->width * (c->world > 1 ? c->shard_rows() : c->height);
@@ -1683,6 +1749,7 @@ int bbr_present(bbr_context *c, void *rgba8_device, int32_t hdr16) {
 int bbr_present_buffer(bbr_context *c, const void *rgba32f_device, void *rgba8_device, uint64_t n_pixels, int32_t enable,
                        float exposure, int32_t hdr16, void *stream) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  BBR_ON_DEVICE(c);
   if (!rgba32f_device || !rgba8_device) return fail(c, BBR_ERR_INVALID_ARGUMENT, "present_buffer: NULL");
   if (!n_pixels) return BBR_OK;
   int rc = ensure_srgb_tables(c);
@@ -1697,6 +1764,7 @@ int bbr_present_buffer(bbr_context *c, const void *rgba32f_device, void *rgba8_d
 
 int bbr_read_presented(bbr_context *c, uint8_t *host) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  BBR_ON_DEVICE(c);
   if (!host) return fail(c, BBR_ERR_INVALID_ARGUMENT, "read_presented: NULL");
   if (!c->have_frame || c->last_slot < 0 || !c->slots[c->last_slot].present.active)
     return fail(c, BBR_ERR_NOT_IN_FRAME, "read_presented: bbr_present was not called for the last frame");
@@ -1709,6 +1777,7 @@ int bbr_read_presented(bbr_context *c, uint8_t *host) {
 
 int bbr_presented_device_ptr(bbr_context *c, void **out_ptr, uint64_t *out_bytes) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  BBR_ON_DEVICE(c);
   if (!out_ptr) return fail(c, BBR_ERR_INVALID_ARGUMENT, "presented_device_ptr: NULL");
   if (!c->have_frame || c->last_slot < 0 || !c->slots[c->last_slot].present.active)
     return fail(c, BBR_ERR_NOT_IN_FRAME, "presented_device_ptr: bbr_present was not called for the last frame");
@@ -1719,6 +1788,7 @@ int bbr_presented_device_ptr(bbr_context *c, void **out_ptr, uint64_t *out_bytes
 
 int bbr_unpack_gathered_rgba8(bbr_context *c, const void *gathered, void *frame, void *stream) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  BBR_ON_DEVICE(c);
   if (!gathered || !frame) return fail(c, BBR_ERR_INVALID_ARGUMENT, "unpack_gathered_rgba8: NULL");
   size_t n = (size_t)c->width * c->height;
   hipStream_t st = stream ? (hipStream_t)stream : c->shade_stream();
@@ -1746,6 +1816,7 @@ int bbr_packed_shard_bytes(const bbr_context *c, uint64_t *out_bytes) {
 
 int bbr_pack_shard(bbr_context *c, void *packed, void *stream) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  BBR_ON_DEVICE(c);
   if (!packed) return fail(c, BBR_ERR_INVALID_ARGUMENT, "pack_shard: NULL");
   if (!c->have_frame || c->last_slot < 0) return fail(c, BBR_ERR_NOT_IN_FRAME, "pack_shard: nothing rendered");
   const FrameSlot &s = c->slots[c->last_slot];
@@ -1760,6 +1831,7 @@ int bbr_pack_shard(bbr_context *c, void *packed, void *stream) {
 
 int bbr_unpack_gathered_packed(bbr_context *c, const void *gathered, void *frame, void *stream) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  BBR_ON_DEVICE(c);
   if (!gathered || !frame) return fail(c, BBR_ERR_INVALID_ARGUMENT, "unpack_gathered_packed: NULL");
   size_t n = (size_t)c->width * c->height;
   hipStream_t st = stream ? (hipStream_t)stream : c->shade_stream();
@@ -1772,6 +1844,7 @@ int bbr_unpack_gathered_packed(bbr_context *c, const void *gathered, void *frame
 
 int bbr_selftest_rcp(bbr_context *c, uint32_t lo_bits, uint32_t hi_bits, uint64_t *out_mismatches) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  BBR_ON_DEVICE(c);
   if (!out_mismatches || hi_bits < lo_bits) return fail(c, BBR_ERR_INVALID_ARGUMENT, "selftest_rcp: bad arguments");
   int rc = drain(c);
   if (rc) return rc;
@@ -1788,6 +1861,7 @@ int bbr_selftest_rcp(bbr_context *c, uint32_t lo_bits, uint32_t hi_bits, uint64_
 
 int bbr_tone_map(bbr_context *c, int32_t enable, float exposure) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  BBR_ON_DEVICE(c);
   if (!c->have_frame || c->last_slot < 0) return fail(c, BBR_ERR_NOT_IN_FRAME, "tone_map: nothing rendered");
   if (c->slots[c->last_slot].fused) return fail(c, BBR_ERR_INVALID_ARGUMENT, "tone_map: no fp32 frame with option present_fused");
   float4 *frame = c->slots[c->last_slot].out_used;

@@ -181,6 +181,8 @@ int bbr_timing_summary(bbr_context *ctx, uint32_t *out_frames, float *out_avg_fr
  *   "tile_mode" 0|1          0: 64x64 tiles, 1: 32x32 tiles (default)
  *   "bin_cap" n              initial references per (tile, raster class); grows by itself on overflow
  *   "broad_threshold" n      triangles touching more than n x n tiles go to the every-tile list
+ *   "broad_cap" n            initial entries of the every-tile list (default 4096); doubles when a frame overflows it
+ *   "clip_cap" n             initial sub-triangle slots of the clip arena (default 4096); doubles likewise
  *   "gbuffer_view" -1..3      deferred path only: instead of brdf.frag, buffer_visualize.frag shows the rgb of one G-buffer
  *                            attachment (GBufferVisualizingOption, src/scene.h:27-35; recordCommand src/main.cpp:96-121):
  *                            0 position, 1 normal, 2 albedo, 3 metallic / roughness / ao; -1 (default) the lit scene.

@@ -236,6 +236,30 @@ def test_broad_list_threshold_extremes(maps64):
     check(sc, broad_threshold=100000)  # nothing does: the ground plane is binned into every tile it touches
 
 
+@pytest.mark.parametrize("caps", [{"broad_cap": 1}, {"clip_cap": 1}, {"broad_cap": 2, "clip_cap": 2, "broad_threshold": 1}])
+def test_every_tile_list_and_clip_arena_overflow_through_a_clipped_primitive(maps64, caps):
+    """The clip path reserves a RUN of list entries / arena slots per primitive and writes none of them when the run
+    does not fit: the overflowed frame must not consume the unwritten part (it takes no every-tile entry at all), and the
+    frame rendered after the growth is the oracle's.  Once with a synchronising call right after the first frame, once
+    streaming frames with no synchronising call in between (the capacities then grow from the pinned overflow words)."""
+    sc = scenes.shaderball_scene(configs.C3.scaled(400, 225, 64), bbo.MaterialData(maps64))
+    ref, rprim, _, rst = bbo.render(sc)
+    assert rst["n_clipped_prims"] > 0, "the scene must send a primitive through the clip path"
+    _, _, st = check(sc, **caps)
+    assert st["bin_overflow"] >= 1
+    r = Renderer(sc.width, sc.height)
+    for k, v in caps.items():
+        r.set_option(k, v)
+    h = None
+    for _ in range(12):  # no synchronising call: overflowed frames are incomplete, later ones must be right
+        h = r.render_scene(sc, h)
+    img = r.read_framebuffer()
+    prim, _ = r.read_visibility()
+    r.close()
+    assert np.array_equal(prim, rprim)
+    assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+
+
 @pytest.mark.parametrize("tile_mode", [0, 1])
 def test_heaviest_first_tile_order_changes_nothing(maps64, tile_mode):
     """option tile_order: k_raster takes its tiles from the bucketed order of k_tile_order; same image, same bits"""
@@ -437,6 +461,34 @@ def test_present_after_an_overflow_replay_and_into_a_caller_buffer(maps64):
     torch.cuda.synchronize()
     assert np.array_equal(got, want) and np.array_equal(out.cpu().numpy(), want)
     r.close()
+
+
+def test_diagnostic_reads_keep_the_presented_image(maps64):
+    """bbr_read_visibility / bbr_read_gbuffer render the frame once more: the slot's presentation state must survive it
+    (bbr_read_presented afterwards, and a caller's presented buffer refreshed with the same pixels)."""
+    import torch
+    sc = scenes.shaderball_scene(configs.C2.scaled(256, 144, 64), bbo.MaterialData(maps64))
+    sc.frame["enable_tone_mapping"], sc.frame["exposure"] = 1, 1.5
+    ref, rprim, _, _ = bbo.render(sc)
+    want = bbo.present(ref, 1, 1.5)
+    for deferred in (0, 1):
+        r = Renderer(sc.width, sc.height)
+        r.set_option("render_pass", deferred)
+        out = torch.zeros((sc.height, sc.width, 4), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        r.render_scene(sc)
+        r.present(out.data_ptr())
+        prim, _ = r.read_visibility()
+        if deferred:
+            r.read_gbuffer()
+        else:
+            assert np.array_equal(prim, rprim)
+            assert np.array_equal(r.read_presented(), want)
+            torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy(), want)
+        first = r.read_presented()
+        assert np.array_equal(first, r.read_presented())
+        r.close()
 
 
 def test_api_lifecycle_user_stream_frees_and_timing(maps64):
