@@ -125,6 +125,13 @@ def main():
     ap.add_argument("--gather", default="packed", choices=["packed", "rgba32f"],
                     help="N > 1: what the all-gather moves -- the shard as rgb + one alpha bit per pixel (lossless, 12.1 B per "
                          "pixel; default) or as plain RGBA32F (16 B); the reassembled frame is the same, bit for bit")
+    ap.add_argument("--exchange", default="torch", choices=["torch", "native", "peer"],
+                    help="N > 1: who runs the exchange.  torch (default): torch.distributed all_gather_into_tensor (RCCL) on "
+                         "a stream of the harness + the library's un-interleave kernel.  native: bbr_allgather_frame -- the "
+                         "library packs, calls ncclAllGather on the frame's own stream and un-interleaves (the id travels "
+                         "through torch.distributed once).  peer: bbr_push_shard -- every rank copies its block into every "
+                         "rank's gather buffer (hipMemcpyPeerAsync through IPC handles), a host barrier orders the landing. "
+                         "native and peer have not been run on more than one GPU (DESIGN.md section 6)")
     ap.add_argument("--force-dist", action="store_true", help="exercise the all-gather path with WORLD_SIZE = 1")
     ap.add_argument("--render-pass", default="forward", choices=["forward", "deferred"],
                     help="forward_brdf.* (the path BASELINE measures) or the reference's deferred path, gbuffer.* + brdf.*")
@@ -208,6 +215,30 @@ def main():
         gathered_t = [torch.empty((world * shard_rows, W, 4), dtype=torch.float32, device="cuda") for _ in range(2)]  # [rank][shard row]
         frame_t = [torch.empty((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
         packed = args.gather == "packed" and not args.present
+        from bibim_renderer_amd import partition as P
+        form = P.SHARD_RGBA8 if args.present else (P.SHARD_PACKED if packed else P.SHARD_RGBA32F)
+        if args.exchange == "native":
+            # the 128-byte id: made by rank 0's library, handed round by the harness, one ncclCommInitRank per rank
+            box = [r.comm_unique_id() if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(box, src=0)
+            r.comm_init(rank, world, box[0])
+        if args.exchange == "peer":
+            import ctypes
+            hip = ctypes.CDLL("libamdhip64.so")
+            block = r.exchange_block_bytes(form)
+            mine = []
+            for _ in range(2):   # plain hipMalloc allocations: their IPC handles open in the peers as they are
+                ptr = ctypes.c_void_p()
+                if hip.hipMalloc(ctypes.byref(ptr), ctypes.c_size_t(block * world)) != 0:
+                    raise SystemExit("hipMalloc of a gather buffer failed")
+                mine.append(ptr.value)
+            handles = [None] * world
+            dist.all_gather_object(handles, (local_rank, [r.ipc_export(p) for p in mine]))
+            peer_devs = [h[0] for h in handles]
+            peer_ptrs = [[mine[b] if p == rank else r.ipc_open(handles[p][1][b]) for p in range(world)] for b in range(2)]
+            pushed = [torch.cuda.Event(), torch.cuda.Event()]
+            pending = []
         if packed:
             pb = r.packed_shard_bytes()
             packed_t = [torch.empty((pb,), dtype=torch.uint8, device="cuda") for _ in range(2)]
@@ -235,6 +266,25 @@ def main():
                 r.present()
             return
         b = n & 1
+        if args.exchange == "native":
+            # library-owned shard, gather buffer and whole frame per frame slot; the exchange is the frame's last step on
+            # the slot's own stream, so the next frame of the slot is ordered behind it and the other slots render meanwhile
+            S.draw_frame(r, scene, cam, settings, material)
+            if args.present:
+                r.present()
+            r.allgather_frame(form)
+            return
+        if args.exchange == "peer":
+            S.draw_frame(r, scene, cam, settings, material)
+            if args.present:
+                r.present()
+            if pending:
+                finish_peer(pending.pop())     # frame n - 1: everyone's blocks have landed -> un-interleave; the GPU renders n meanwhile
+            r.push_shard(form, peer_ptrs[b], peer_devs)
+            r.stream_wait_frame(ag_stream.cuda_stream)
+            pushed[b].record(ag_stream)
+            pending.append(n)
+            return
         if n >= 2:
             r.wait_event(consumed[b].cuda_event)             # shard[b] is free again once gather n-2 has read it
         r.set_output_device_ptr(shard_t[b].data_ptr(), shard_t[b].numel() * 4)
@@ -270,7 +320,19 @@ def main():
                 r.unpack_gathered(gathered_t[b].data_ptr(), frame_t[b].data_ptr(), up_stream.cuda_stream)
             unpacked[b].record(up_stream)
 
+    def finish_peer(m):
+        b = m & 1
+        pushed[b].synchronize()            # this rank's copies of frame m have landed in every peer
+        if m >= 1:
+            unpacked[b ^ 1].synchronize()  # ... and its un-interleave of frame m - 1 is done: after the barrier the peers
+        dist.barrier()                     #     overwrite that buffer with frame m + 1.  Barrier: so have everyone's
+        whole = frame8_t[b] if args.present else frame_t[b]
+        r.unpack_whole(form, peer_ptrs[b][rank], whole.data_ptr(), ag_stream.cuda_stream)
+        unpacked[b].record(ag_stream)
+
     def fence():
+        if dist_path and args.exchange == "peer" and pending:
+            finish_peer(pending.pop())
         r.synchronize()
         torch.cuda.synchronize()
         if dist is not None:   # (--force-dist runs the same collectives with one rank)
@@ -394,7 +456,10 @@ def main():
     if args.verify and dist_path:
         last = (step_no[0] - 1) & 1
         torch.cuda.synchronize()
-        got = (frame8_t[last] if args.present else frame_t[last]).cpu().numpy()
+        if args.exchange == "native":
+            got = r.read_whole_frame(form)
+        else:
+            got = (frame8_t[last] if args.present else frame_t[last]).cpu().numpy()
         r2 = Renderer(cfg.width, cfg.height, device=local_rank)
         r2.set_option("render_pass", 1 if args.render_pass == "deferred" else 0)
         m2 = r2.upload_material(maps)
@@ -457,7 +522,9 @@ def main():
                        "instances": cfg.n_instances, "lights": len(cfg.lights), "triangles": int(stats["n_prims"]),
                        "textures": f"{cfg.texture_size}x{cfg.texture_size} RGBA8 x5 (seed 0x5EED)",
                        "partition": "single GPU" if world == 1 else f"interleaved {args.band_rows or r.tile_height()}-row bands, "
-                                    f"{world} ranks, ncclAllGather of " + (
+                                    f"{world} ranks, " + {"torch": "ncclAllGather (torch.distributed) of ",
+                                                          "native": "bbr_allgather_frame (ncclAllGather on the frame's stream) of ",
+                                                          "peer": "bbr_push_shard (hipMemcpyPeerAsync into every rank's buffer) of "}[args.exchange] + (
                                         "RGBA8 shards" if args.present else
                                         "shards packed as rgb + alpha bit (lossless, 12.1 B/pixel)" if args.gather == "packed"
                                         else "RGBA32F shards") + " + un-interleave",

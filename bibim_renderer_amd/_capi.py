@@ -88,7 +88,21 @@ SIGNATURES = {
     "bbr_present_timing": (C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_float)]),
     "bbr_presented_device_ptr": (C.c_int, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
     "bbr_unpack_gathered_rgba8": (C.c_int, [_P, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bbr_comm_unique_id": (C.c_int, [_P, _P]),
+    "bbr_comm_init": (C.c_int, [_P, C.c_int32, C.c_int32, _P]),
+    "bbr_comm_destroy": (C.c_int, [_P]),
+    "bbr_exchange_block_bytes": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_uint64)]),
+    "bbr_allgather_frame": (C.c_int, [_P, C.c_int32, _P, _P, _P]),
+    "bbr_push_shard": (C.c_int, [_P, C.c_int32, C.POINTER(_P), C.POINTER(C.c_int32), _P]),
+    "bbr_unpack_whole": (C.c_int, [_P, C.c_int32, _P, _P, _P]),
+    "bbr_whole_frame_device_ptr": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64)]),
+    "bbr_read_whole_frame": (C.c_int, [_P, _P]),
+    "bbr_ipc_export": (C.c_int, [_P, _P, _P]),
+    "bbr_ipc_open": (C.c_int, [_P, _P, C.POINTER(_P)]),
+    "bbr_ipc_close": (C.c_int, [_P, _P]),
 }
+COMM_ID_BYTES, IPC_HANDLE_BYTES = 128, 64
+SHARD_RGBA32F, SHARD_PACKED, SHARD_RGBA8 = 0, 1, 2
 
 # every symbol include/bibim_scene.h declares (C surface of the C++ Scene/Camera/drawFrame shim)
 _F = C.c_float

@@ -5,6 +5,9 @@
 // (all draws) -> k_raster (per tile) -> k_shade (per visible pixel).  No host synchronisation inside a frame; capacities (bins, broad list, clip arena) are
 // checked lazily at the next synchronising call and the frame is re-rendered once after growing them.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // types and prototypes only: the library is opened at bbr_comm_init (see the exchange section)
+
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -25,6 +28,19 @@ using namespace bbr;
 namespace {
 
 std::string g_create_error;
+
+// RCCL, opened once per process at the first bbr_comm_unique_id / bbr_comm_init and never closed (it owns threads): the
+// single-GPU path loads and runs without it.
+struct Rccl {
+  void *lib = nullptr;
+  decltype(&ncclGetUniqueId) get_unique_id = nullptr;
+  decltype(&ncclCommInitRank) comm_init_rank = nullptr;
+  decltype(&ncclAllGather) all_gather = nullptr;
+  decltype(&ncclCommDestroy) comm_destroy = nullptr;
+  decltype(&ncclGetErrorString) error_string = nullptr;
+};
+Rccl g_rccl;
+std::mutex g_rccl_mutex;
 
 struct Mesh {
   Vertex *d_vertices = nullptr;
@@ -134,8 +150,10 @@ struct FrameSlot {
   void release_tile_buffers() {
     d_tile_count.release(); d_bins.release(); d_frags.release(); d_frag_count.release(); d_tile_order.release(); d_items.release(); d_item_groups.release();
   }
+  // native exchange (bbr_allgather_frame / bbr_push_shard) with library-owned buffers: every rank's block, the whole frame
+  DeviceBuffer<uint8_t> d_gathered, d_whole;
   void release_all() {
-    d_staging.release(); d_tris.release(); d_attrs.release(); d_clip.release();
+    d_staging.release(); d_tris.release(); d_attrs.release(); d_clip.release(); d_gathered.release(); d_whole.release();
     d_block_stats.release();
     release_tile_buffers(); d_broad.release(); d_frame.release(); d_present.release(); d_background.release(); d_depth.release();
     if (h_staging) (void)hipHostFree(h_staging);
@@ -242,6 +260,10 @@ struct bbr_context {
   // dependent kernels (copy -> geometry -> raster -> items -> shade) then only waits for itself.  (Round 1 timed the
   // layouts on the first ~500 frames of every workload and switched by itself; the measurement was fragile and made
   // the frame rate a function of history.)
+  ncclComm_t comm = nullptr;
+  int comm_rank = -1, comm_world = 0;
+  int exchange_slot = -1, exchange_form = -1;  // where the last exchange left the whole frame (library-owned buffers)
+  void *exchange_whole = nullptr;
   static constexpr int kLayouts = 3;
   int layout_mode = 2;  // the option
   int layout = 2;       // layout of the frame being submitted
@@ -977,6 +999,7 @@ const char *bbr_last_error(const bbr_context *ctx) { return ctx ? ctx->last_erro
 static void release_context(bbr_context *c) {
   (void)hipSetDevice(c->device);
   (void)drain(c);
+  if (c->comm) (void)g_rccl.comm_destroy(c->comm);
   for (Mesh &m : c->meshes) {
     if (m.d_vertices) (void)hipFree(m.d_vertices);
     if (m.d_indices) (void)hipFree(m.d_indices);
@@ -1839,6 +1862,273 @@ int bbr_unpack_gathered_packed(bbr_context *c, const void *gathered, void *frame
                      (float4 *)frame, c->width, c->height, c->world, c->eff_band_rows(), c->shard_rows(),
                      packed_block_bytes(c), packed_mask_offset(c));
   HIP_TRY(c, hipGetLastError());
+  return BBR_OK;
+}
+
+// ================================================================================================
+// native exchange (BASELINE config #4): the step in which every rank gets the whole frame
+//   collective form: RCCL all-gather of the ranks' blocks (ring over xGMI), one process per GPU
+//   peer form:       every rank copies its block into every rank's gather buffer (hipMemcpyPeerAsync); for one process
+//                    that drives several GPUs, or several processes that exchanged IPC handles
+// Both run on the stream of the frame's slot, right behind its k_shade: with stream layout 2 a frame's kernels share a
+// stream with nothing else, so the exchange is simply the frame's last step, the next frame of the same slot is ordered
+// behind it without an event, and the frames of the other slots render while the links are busy.
+// ================================================================================================
+namespace {
+
+size_t exchange_block_bytes(const bbr_context *c, int form) {
+  const size_t n = (size_t)c->width * c->shard_rows();
+  return form == BBR_SHARD_RGBA32F ? n * 16 : (form == BBR_SHARD_PACKED ? packed_block_bytes(c) : n * 4);
+}
+
+int open_rccl(bbr_context *c) {
+  std::lock_guard<std::mutex> lock(g_rccl_mutex);
+  if (g_rccl.lib) return BBR_OK;
+  void *lib = nullptr;
+  for (const char *name : {"librccl.so.1", "librccl.so"}) {
+    lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+    if (lib) break;
+  }
+  if (!lib) return fail(c, BBR_ERR_HIP, std::string("RCCL not found (librccl.so.1): ") + dlerror());
+  Rccl r;
+  r.get_unique_id = (decltype(r.get_unique_id))dlsym(lib, "ncclGetUniqueId");
+  r.comm_init_rank = (decltype(r.comm_init_rank))dlsym(lib, "ncclCommInitRank");
+  r.all_gather = (decltype(r.all_gather))dlsym(lib, "ncclAllGather");
+  r.comm_destroy = (decltype(r.comm_destroy))dlsym(lib, "ncclCommDestroy");
+  r.error_string = (decltype(r.error_string))dlsym(lib, "ncclGetErrorString");
+  if (!r.get_unique_id || !r.comm_init_rank || !r.all_gather || !r.comm_destroy || !r.error_string)
+    return fail(c, BBR_ERR_HIP, "librccl lacks an entry point");
+  r.lib = lib;
+  g_rccl = r;
+  return BBR_OK;
+}
+
+#define RCCL_TRY(ctx, expr)                                                                                    \
+  do {                                                                                                         \
+    ncclResult_t _r = (expr);                                                                                  \
+    if (_r != ncclSuccess) return fail(ctx, BBR_ERR_HIP, std::string(#expr) + ": " + g_rccl.error_string(_r)); \
+  } while (0)
+
+// Put this rank's block of the last frame where the exchange reads it: `dst` (the rank's slot of a gather buffer, or a
+// peer's).  rgba32f / rgba8 blocks that already live there (the frame was rendered into the slot) cost nothing.
+int stage_block(bbr_context *c, FrameSlot &s, int form, void *dst, hipStream_t st) {
+  const size_t n = (size_t)c->width * c->shard_rows();
+  if (form == BBR_SHARD_PACKED) {
+    hipLaunchKernelGGL(k_pack_shard, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float4 *)s.out_used, (float *)dst,
+                       (unsigned long long *)((uint8_t *)dst + packed_mask_offset(c)), n);
+    HIP_TRY(c, hipGetLastError());
+    return BBR_OK;
+  }
+  const void *src = form == BBR_SHARD_RGBA32F ? (const void *)s.out_used : (const void *)s.present.out;
+  if (src != dst) HIP_TRY(c, hipMemcpyAsync(dst, src, exchange_block_bytes(c, form), hipMemcpyDeviceToDevice, st));
+  return BBR_OK;
+}
+
+int check_exchange(bbr_context *c, int form, const char *who) {
+  if (form != BBR_SHARD_RGBA32F && form != BBR_SHARD_PACKED && form != BBR_SHARD_RGBA8)
+    return fail(c, BBR_ERR_INVALID_ARGUMENT, std::string(who) + ": form must be BBR_SHARD_RGBA32F, _PACKED or _RGBA8");
+  if (!c->have_frame || c->last_slot < 0) return fail(c, BBR_ERR_NOT_IN_FRAME, std::string(who) + ": nothing rendered");
+  const FrameSlot &s = c->slots[c->last_slot];
+  if (form == BBR_SHARD_RGBA8) {
+    if (!s.present.active || !s.present.out) return fail(c, BBR_ERR_NOT_IN_FRAME, std::string(who) + ": BBR_SHARD_RGBA8 needs bbr_present first");
+  } else if (s.fused) {
+    return fail(c, BBR_ERR_INVALID_ARGUMENT, std::string(who) + ": no fp32 frame with option present_fused (use BBR_SHARD_RGBA8)");
+  }
+  return BBR_OK;
+}
+
+int unpack_whole(bbr_context *c, int form, const void *gathered, void *whole, hipStream_t st) {
+  const size_t n = (size_t)c->width * c->height;
+  const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  if (form == BBR_SHARD_RGBA32F)
+    hipLaunchKernelGGL(k_unpack_gathered, grid, block, 0, st, (const float4 *)gathered, (float4 *)whole, c->width, c->height, c->world,
+                       c->eff_band_rows(), c->shard_rows());
+  else if (form == BBR_SHARD_PACKED)
+    hipLaunchKernelGGL(k_unpack_gathered_packed, grid, block, 0, st, (const uint8_t *)gathered, (float4 *)whole, c->width, c->height,
+                       c->world, c->eff_band_rows(), c->shard_rows(), packed_block_bytes(c), packed_mask_offset(c));
+  else
+    hipLaunchKernelGGL(k_unpack_gathered_rgba8, grid, block, 0, st, (const uint32_t *)gathered, (uint32_t *)whole, c->width, c->height,
+                       c->world, c->eff_band_rows(), c->shard_rows());
+  HIP_TRY(c, hipGetLastError());
+  return BBR_OK;
+}
+
+}  // namespace
+
+int bbr_comm_unique_id(bbr_context *c, uint8_t *out_id) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  BBR_ON_DEVICE(c);
+  if (!out_id) return fail(c, BBR_ERR_INVALID_ARGUMENT, "comm_unique_id: NULL");
+  int rc = open_rccl(c);
+  if (rc) return rc;
+  static_assert(BBR_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "BBR_COMM_ID_BYTES");
+  ncclUniqueId id;
+  RCCL_TRY(c, g_rccl.get_unique_id(&id));
+  memcpy(out_id, id.internal, BBR_COMM_ID_BYTES);
+  return BBR_OK;
+}
+
+int bbr_comm_init(bbr_context *c, int32_t rank, int32_t world, const uint8_t *unique_id) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  BBR_ON_DEVICE(c);
+  if (!unique_id || world < 1 || rank < 0 || rank >= world) return fail(c, BBR_ERR_INVALID_ARGUMENT, "comm_init: bad rank / world / id");
+  if (c->comm) return fail(c, BBR_ERR_INVALID_ARGUMENT, "comm_init: the context already has a communicator (bbr_comm_destroy first)");
+  int rc = open_rccl(c);
+  if (rc) return rc;
+  ncclUniqueId id;
+  memcpy(id.internal, unique_id, BBR_COMM_ID_BYTES);
+  RCCL_TRY(c, g_rccl.comm_init_rank(&c->comm, world, id, rank));  // collective: returns once every rank has called it
+  c->comm_rank = rank;
+  c->comm_world = world;
+  return BBR_OK;
+}
+
+int bbr_comm_destroy(bbr_context *c) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  BBR_ON_DEVICE(c);
+  if (!c->comm) return BBR_OK;
+  int rc = drain(c);
+  if (rc) return rc;
+  ncclComm_t comm = c->comm;
+  c->comm = nullptr;
+  c->comm_rank = -1;
+  c->comm_world = 0;
+  RCCL_TRY(c, g_rccl.comm_destroy(comm));
+  return BBR_OK;
+}
+
+int bbr_exchange_block_bytes(const bbr_context *c, int32_t form, uint64_t *out_bytes) {
+  if (!c || !out_bytes || form < 0 || form > BBR_SHARD_RGBA8) return BBR_ERR_INVALID_ARGUMENT;
+  *out_bytes = exchange_block_bytes(c, form);
+  return BBR_OK;
+}
+
+int bbr_allgather_frame(bbr_context *c, int32_t form, void *gathered, void *whole, void *stream) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  BBR_ON_DEVICE(c);
+  int rc = check_exchange(c, form, "allgather_frame");
+  if (rc) return rc;
+  if (!c->comm) return fail(c, BBR_ERR_NOT_IN_FRAME, "allgather_frame: no communicator (bbr_comm_init)");
+  if (c->comm_rank != c->rank || c->comm_world != c->world)
+    return fail(c, BBR_ERR_INVALID_ARGUMENT, "allgather_frame: the communicator's rank / world differ from the partition's (bbr_set_partition)");
+  FrameSlot &s = c->slots[c->last_slot];
+  const size_t block = exchange_block_bytes(c, form);
+  if (!gathered) {
+    HIP_TRY(c, s.d_gathered.ensure(block * (size_t)c->world));
+    gathered = s.d_gathered.ptr;
+  }
+  if (!whole) {
+    HIP_TRY(c, s.d_whole.ensure((size_t)c->width * c->height * (form == BBR_SHARD_RGBA8 ? 4 : 16)));
+    whole = s.d_whole.ptr;
+  }
+  hipStream_t st = stream ? (hipStream_t)stream : s.stream_used;
+  // (also on the slot's own stream: a separate presentation pass may have run on another one and moved the event there)
+  HIP_TRY(c, hipStreamWaitEvent(st, s.ev_shade_done, 0));
+  uint8_t *mine = (uint8_t *)gathered + block * (size_t)c->rank;
+  rc = stage_block(c, s, form, mine, st);
+  if (rc) return rc;
+  // in place: the send buffer is this rank's slot of the receive buffer
+  RCCL_TRY(c, g_rccl.all_gather(mine, gathered, block, ncclUint8, c->comm, st));
+  rc = unpack_whole(c, form, gathered, whole, st);
+  if (rc) return rc;
+  if (!stream) HIP_TRY(c, hipEventRecord(s.ev_shade_done, st));  // "the frame is done" now includes its exchange
+  c->exchange_slot = c->last_slot;
+  c->exchange_form = form;
+  c->exchange_whole = whole;
+  return BBR_OK;
+}
+
+int bbr_push_shard(bbr_context *c, int32_t form, void *const *peer_gathered, const int32_t *peer_devices, void *stream) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  BBR_ON_DEVICE(c);
+  int rc = check_exchange(c, form, "push_shard");
+  if (rc) return rc;
+  if (!peer_gathered || !peer_devices) return fail(c, BBR_ERR_INVALID_ARGUMENT, "push_shard: NULL");
+  FrameSlot &s = c->slots[c->last_slot];
+  const size_t block = exchange_block_bytes(c, form);
+  hipStream_t st = stream ? (hipStream_t)stream : s.stream_used;
+  // (also on the slot's own stream: a separate presentation pass may have run on another one and moved the event there)
+  HIP_TRY(c, hipStreamWaitEvent(st, s.ev_shade_done, 0));
+  for (int p = 0; p < c->world; ++p)
+    if (!peer_gathered[p]) return fail(c, BBR_ERR_INVALID_ARGUMENT, "push_shard: a peer's gather buffer is NULL");
+  // the block is made once, in this rank's own gather buffer, and copied from there to the peers, nearest first
+  // (rank + 1, rank + 2, ...: at any moment every link carries one copy, as in one step of a ring)
+  uint8_t *mine = (uint8_t *)peer_gathered[c->rank] + block * (size_t)c->rank;
+  rc = stage_block(c, s, form, mine, st);
+  if (rc) return rc;
+  for (int k = 1; k < c->world; ++k) {
+    const int p = (c->rank + k) % c->world;
+    HIP_TRY(c, hipMemcpyPeerAsync((uint8_t *)peer_gathered[p] + block * (size_t)c->rank, peer_devices[p], mine, c->device, block, st));
+  }
+  if (!stream) HIP_TRY(c, hipEventRecord(s.ev_shade_done, st));
+  return BBR_OK;
+}
+
+int bbr_unpack_whole(bbr_context *c, int32_t form, const void *gathered, void *whole, void *stream) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  BBR_ON_DEVICE(c);
+  if (form < 0 || form > BBR_SHARD_RGBA8 || !gathered) return fail(c, BBR_ERR_INVALID_ARGUMENT, "unpack_whole: bad form / NULL");
+  if (c->last_slot < 0) return fail(c, BBR_ERR_NOT_IN_FRAME, "unpack_whole: nothing rendered");
+  FrameSlot &s = c->slots[c->last_slot];
+  if (!whole) {
+    HIP_TRY(c, s.d_whole.ensure((size_t)c->width * c->height * (form == BBR_SHARD_RGBA8 ? 4 : 16)));
+    whole = s.d_whole.ptr;
+  }
+  int rc = unpack_whole(c, form, gathered, whole, stream ? (hipStream_t)stream : s.stream_used);
+  if (rc) return rc;
+  c->exchange_slot = c->last_slot;
+  c->exchange_form = form;
+  c->exchange_whole = whole;
+  return BBR_OK;
+}
+
+int bbr_whole_frame_device_ptr(bbr_context *c, void **out_ptr, uint64_t *out_bytes) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  if (!out_ptr) return fail(c, BBR_ERR_INVALID_ARGUMENT, "whole_frame_device_ptr: NULL");
+  if (c->exchange_slot < 0 || !c->exchange_whole) return fail(c, BBR_ERR_NOT_IN_FRAME, "whole_frame_device_ptr: no exchange yet");
+  *out_ptr = c->exchange_whole;
+  if (out_bytes) *out_bytes = (uint64_t)c->width * c->height * (c->exchange_form == BBR_SHARD_RGBA8 ? 4 : 16);
+  return BBR_OK;
+}
+
+int bbr_read_whole_frame(bbr_context *c, void *host) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  BBR_ON_DEVICE(c);
+  if (!host) return fail(c, BBR_ERR_INVALID_ARGUMENT, "read_whole_frame: NULL");
+  if (c->exchange_slot < 0 || !c->exchange_whole) return fail(c, BBR_ERR_NOT_IN_FRAME, "read_whole_frame: no exchange yet");
+  int rc = drain(c);  // (not sync_and_fix: a re-render on one rank alone would leave the collective unmatched)
+  if (rc) return rc;
+  HIP_TRY(c, hipMemcpy(host, c->exchange_whole, (size_t)c->width * c->height * (c->exchange_form == BBR_SHARD_RGBA8 ? 4 : 16),
+                       hipMemcpyDeviceToHost));
+  return BBR_OK;
+}
+
+int bbr_ipc_export(bbr_context *c, void *device_ptr, uint8_t *out_handle) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  BBR_ON_DEVICE(c);
+  if (!device_ptr || !out_handle) return fail(c, BBR_ERR_INVALID_ARGUMENT, "ipc_export: NULL");
+  static_assert(BBR_IPC_HANDLE_BYTES == sizeof(hipIpcMemHandle_t), "BBR_IPC_HANDLE_BYTES");
+  hipIpcMemHandle_t h;
+  HIP_TRY(c, hipIpcGetMemHandle(&h, device_ptr));
+  memcpy(out_handle, &h, sizeof h);
+  return BBR_OK;
+}
+
+int bbr_ipc_open(bbr_context *c, const uint8_t *handle, void **out_ptr) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  BBR_ON_DEVICE(c);
+  if (!handle || !out_ptr) return fail(c, BBR_ERR_INVALID_ARGUMENT, "ipc_open: NULL");
+  hipIpcMemHandle_t h;
+  memcpy(&h, handle, sizeof h);
+  HIP_TRY(c, hipIpcOpenMemHandle(out_ptr, h, hipIpcMemLazyEnablePeerAccess));
+  return BBR_OK;
+}
+
+int bbr_ipc_close(bbr_context *c, void *ptr) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  BBR_ON_DEVICE(c);
+  if (!ptr) return fail(c, BBR_ERR_INVALID_ARGUMENT, "ipc_close: NULL");
+  HIP_TRY(c, hipIpcCloseMemHandle(ptr));
   return BBR_OK;
 }
 

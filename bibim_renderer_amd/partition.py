@@ -87,3 +87,44 @@ def unpack_gathered_packed(gathered, height, width, world, band_rows):
         bits = np.unpackbits(g[r, mask_offset:mask_offset + ((n + 63) // 64) * 8], bitorder="little")[:n]
         shards[r, ..., 3] = bits.reshape(rows, width).astype(np.float32)
     return unpack_gathered(shards, height, band_rows)
+
+
+# ---- the native exchange (bbr_allgather_frame / bbr_push_shard, include/bibim_hip.h): block sizes and copy order ----
+
+SHARD_RGBA32F, SHARD_PACKED, SHARD_RGBA8 = 0, 1, 2
+
+
+def exchange_block_bytes(form, height, width, world, band_rows):
+    """bytes one rank contributes to the exchange (bbr_exchange_block_bytes)"""
+    rows = shard_rows(height, world, band_rows)
+    if form == SHARD_PACKED:
+        return packed_layout(rows, width)[0]
+    return rows * width * (16 if form == SHARD_RGBA32F else 4)
+
+
+def push_order(rank, world):
+    """peer form: the ranks this rank copies its block to, in order -- nearest first (rank + 1, rank + 2, ...), so that
+    step k of every rank together is a permutation: each rank receives exactly one block per step, as in a ring step"""
+    return [(rank + k) % world for k in range(1, world)]
+
+
+def push_offset(rank, block_bytes):
+    """byte offset of `rank`'s block inside every rank's gather buffer (the same layout ncclAllGather produces)"""
+    return rank * block_bytes
+
+
+def encode_block(shard, form):
+    """a rank's shard [rows, W, 4] as the bytes that travel (uint8): float32 RGBA, the packed form, or RGBA8"""
+    if form == SHARD_PACKED:
+        return pack_shard_bits(shard)
+    return np.ascontiguousarray(shard, np.float32 if form == SHARD_RGBA32F else np.uint8).view(np.uint8).reshape(-1)
+
+
+def decode_gathered(gathered, form, height, width, world, band_rows):
+    """world blocks back to back (uint8) -> the whole frame [H, W, 4] (what bbr_unpack_whole leaves in `whole`)"""
+    g = np.ascontiguousarray(gathered, np.uint8)
+    if form == SHARD_PACKED:
+        return unpack_gathered_packed(g, height, width, world, band_rows)
+    rows = shard_rows(height, world, band_rows)
+    dt = np.float32 if form == SHARD_RGBA32F else np.uint8
+    return unpack_gathered(g.view(dt).reshape(world, rows, width, 4), height, band_rows)

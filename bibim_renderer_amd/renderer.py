@@ -7,6 +7,7 @@ import weakref
 
 import numpy as np
 
+from . import _capi
 from ._capi import BbrImage, BbrStats, BibimError, lib
 
 MAP_NAMES = ("albedo", "metallic", "roughness", "ao", "normal", "height")
@@ -251,6 +252,64 @@ class Renderer:
     def unpack_gathered_packed(self, gathered_ptr, frame_ptr, stream_handle=None):
         self._check(self._L.bbr_unpack_gathered_packed(self._ctx, C.c_void_p(gathered_ptr), C.c_void_p(frame_ptr),
                                                        C.c_void_p(stream_handle) if stream_handle else None))
+
+    # -- native exchange (include/bibim_hip.h, "native exchange") --
+    def comm_unique_id(self) -> bytes:
+        buf = (C.c_uint8 * _capi.COMM_ID_BYTES)()
+        self._check(self._L.bbr_comm_unique_id(self._ctx, buf))
+        return bytes(buf)
+
+    def comm_init(self, rank, world, unique_id: bytes):
+        assert len(unique_id) == _capi.COMM_ID_BYTES
+        buf = (C.c_uint8 * _capi.COMM_ID_BYTES).from_buffer_copy(unique_id)
+        self._check(self._L.bbr_comm_init(self._ctx, rank, world, buf))
+
+    def comm_destroy(self):
+        self._check(self._L.bbr_comm_destroy(self._ctx))
+
+    def exchange_block_bytes(self, form):
+        n = C.c_uint64()
+        self._check(self._L.bbr_exchange_block_bytes(self._ctx, form, C.byref(n)))
+        return n.value
+
+    def allgather_frame(self, form, gathered_ptr=None, whole_ptr=None, stream_handle=None):
+        self._check(self._L.bbr_allgather_frame(self._ctx, form, C.c_void_p(gathered_ptr) if gathered_ptr else None,
+                                                C.c_void_p(whole_ptr) if whole_ptr else None,
+                                                C.c_void_p(stream_handle) if stream_handle else None))
+
+    def push_shard(self, form, peer_gathered_ptrs, peer_devices, stream_handle=None):
+        n = len(peer_gathered_ptrs)
+        ptrs = (C.c_void_p * n)(*[C.c_void_p(p) for p in peer_gathered_ptrs])
+        devs = (C.c_int32 * n)(*peer_devices)
+        self._check(self._L.bbr_push_shard(self._ctx, form, ptrs, devs, C.c_void_p(stream_handle) if stream_handle else None))
+
+    def unpack_whole(self, form, gathered_ptr, whole_ptr=None, stream_handle=None):
+        self._check(self._L.bbr_unpack_whole(self._ctx, form, C.c_void_p(gathered_ptr), C.c_void_p(whole_ptr) if whole_ptr else None,
+                                             C.c_void_p(stream_handle) if stream_handle else None))
+
+    def whole_frame_device_ptr(self):
+        p, n = C.c_void_p(), C.c_uint64()
+        self._check(self._L.bbr_whole_frame_device_ptr(self._ctx, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def read_whole_frame(self, form=0):
+        out = np.empty((self.height, self.width, 4), np.uint8 if form == _capi.SHARD_RGBA8 else np.float32)
+        self._check(self._L.bbr_read_whole_frame(self._ctx, _ptr(out)))
+        return out
+
+    def ipc_export(self, device_ptr) -> bytes:
+        buf = (C.c_uint8 * _capi.IPC_HANDLE_BYTES)()
+        self._check(self._L.bbr_ipc_export(self._ctx, C.c_void_p(device_ptr), buf))
+        return bytes(buf)
+
+    def ipc_open(self, handle: bytes):
+        buf = (C.c_uint8 * _capi.IPC_HANDLE_BYTES).from_buffer_copy(handle)
+        p = C.c_void_p()
+        self._check(self._L.bbr_ipc_open(self._ctx, buf, C.byref(p)))
+        return p.value
+
+    def ipc_close(self, ptr):
+        self._check(self._L.bbr_ipc_close(self._ctx, C.c_void_p(ptr)))
 
     def wait_event(self, event_handle):
         self._check(self._L.bbr_wait_event(self._ctx, C.c_void_p(event_handle)))

@@ -255,6 +255,46 @@ int bbr_present_timing(bbr_context *ctx, uint32_t *out_launches, float *out_avg_
 /* hdr_tone_mapping.frag:9-18 alone on the fp32 frame, in place (no quantisation) */
 int bbr_tone_map(bbr_context *ctx, int32_t enable_tone_mapping, float exposure);
 
+/* ---- native exchange: every rank gets the whole frame (BASELINE config #4) ----
+ * The reference renders on one GPU; with a partition (bbr_set_partition) each rank holds a compact shard and the frame
+ * is completed by one exchange step.  Two native forms, both queued on the stream of the frame's slot right behind its
+ * shading (with stream layout 2 that stream carries nothing else: the next frame of the slot is ordered behind the
+ * exchange without an event, the other slots render meanwhile), or on `hip_stream` when one is given (made to wait for
+ * the frame first):
+ *   collective  bbr_comm_unique_id on rank 0 -> the 128 bytes reach every rank by the host's own means ->
+ *               bbr_comm_init on every rank (ncclCommInitRank; one process per GPU) -> per frame bbr_allgather_frame:
+ *               [pack into this rank's slot of `gathered`] -> ncclAllGather in place (ring over xGMI) -> un-interleave into
+ *               `whole`.  librccl is opened with dlopen at the first of these calls; a single-GPU host never loads it.
+ *   peer        bbr_push_shard: this rank's block copied into every rank's gather buffer with hipMemcpyPeerAsync, nearest
+ *               rank first -- for one process driving several GPUs (one context each) or processes that exchanged
+ *               bbr_ipc_export handles.  The host orders "all pushes have landed" (events or a barrier) before
+ *               bbr_unpack_whole.
+ * Block forms (what travels per rank; bbr_exchange_block_bytes): BBR_SHARD_RGBA32F the fp32 shard (16 B/pixel),
+ * BBR_SHARD_PACKED rgb + one alpha bit per pixel (12.1 B, lossless: alpha is 0 or 1; = bbr_pack_shard), BBR_SHARD_RGBA8
+ * the presented shard (4 B; needs bbr_present).  `gathered` / `whole` = NULL use buffers owned by the frame's slot
+ * (bbr_whole_frame_device_ptr, bbr_read_whole_frame).  An exchange never re-renders (one rank alone must not repeat a
+ * collective): let the capacities settle with one synchronised frame first, as after any scene change.
+ * Not yet run on more than one GPU: see DESIGN.md section 6. */
+#define BBR_COMM_ID_BYTES 128
+#define BBR_IPC_HANDLE_BYTES 64
+#define BBR_SHARD_RGBA32F 0
+#define BBR_SHARD_PACKED 1
+#define BBR_SHARD_RGBA8 2
+int bbr_comm_unique_id(bbr_context *ctx, uint8_t *out_id /* BBR_COMM_ID_BYTES */);
+int bbr_comm_init(bbr_context *ctx, int32_t rank, int32_t world, const uint8_t *unique_id /* BBR_COMM_ID_BYTES */);
+int bbr_comm_destroy(bbr_context *ctx);
+int bbr_exchange_block_bytes(const bbr_context *ctx, int32_t form, uint64_t *out_bytes);
+int bbr_allgather_frame(bbr_context *ctx, int32_t form, void *gathered_device /* world blocks, or NULL */,
+                        void *whole_device /* height*width pixels, or NULL */, void *hip_stream);
+int bbr_push_shard(bbr_context *ctx, int32_t form, void *const *peer_gathered /* [world] device pointers */,
+                   const int32_t *peer_devices /* [world] HIP device of each */, void *hip_stream);
+int bbr_unpack_whole(bbr_context *ctx, int32_t form, const void *gathered_device, void *whole_device, void *hip_stream);
+int bbr_whole_frame_device_ptr(bbr_context *ctx, void **out_ptr, uint64_t *out_bytes);
+int bbr_read_whole_frame(bbr_context *ctx, void *host /* height*width*16 bytes (RGBA8 form: *4); synchronises */);
+int bbr_ipc_export(bbr_context *ctx, void *device_ptr, uint8_t *out_handle /* BBR_IPC_HANDLE_BYTES */);
+int bbr_ipc_open(bbr_context *ctx, const uint8_t *handle, void **out_ptr);
+int bbr_ipc_close(bbr_context *ctx, void *ptr);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,45 @@
+"""bench.py's N > 1 code paths as far as one GPU lets them run: the native collective with a one-rank communicator, and
+the torch / peer exchanges as two real processes that share cuda:0 (BBR_BENCH_SINGLE_DEVICE=1; gloo stands in for RCCL,
+which refuses two ranks on one GPU).  Every run ends with --verify: the gathered frame equals the unpartitioned render,
+bit for bit.  These are rehearsals of the control flow, not measurements."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+COMMON = ["--workload", "c2", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--verify"]
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _line(proc):
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    lines = [l for l in proc.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, proc.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("extra", [[], ["--gather", "rgba32f"], ["--present"]])
+def test_native_collective_with_one_rank(extra):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    out = _line(subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--force-dist", "--exchange", "native"] + COMMON + extra,
+                               cwd=ROOT, capture_output=True, text=True, timeout=600, env=env))
+    assert out["verified_against_unpartitioned_render"] is True and out["n_gpus"] == 1
+
+
+@pytest.mark.parametrize("exchange,extra", [("peer", []), ("peer", ["--present"]), ("torch", [])])
+def test_two_ranks_on_one_gpu(exchange, extra):
+    env = dict(os.environ, BBR_BENCH_BACKEND="gloo", BBR_BENCH_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--exchange", exchange] + COMMON + extra
+    out = _line(subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env))
+    assert out["verified_against_unpartitioned_render"] is True and out["n_gpus"] == 2
+    assert out["scaling"] == "strong"
+    assert ("bbr_push_shard" if exchange == "peer" else "torch.distributed") in out["config"]["partition"]

@@ -152,12 +152,71 @@ def test_device_side_unpack_matches_host_unpack(maps64):
         r.close()
 
 
+@pytest.fixture(scope="module")
+def c4_whole_frame():
+    """C4 = C3's frame (3840x2160, 16 balls, 4 lights, 2048^2 maps) rendered unpartitioned; that frame is compared with
+    the oracle bit for bit in test_gpu_parity.py::test_c3_full_size_4k"""
+    cfg = configs.C4
+    maps = textures.make_material(cfg.texture_size)
+    sc = scenes.shaderball_scene(cfg, bbo.MaterialData(maps))
+    r = Renderer(cfg.width, cfg.height)
+    h = r.render_scene(sc)
+    want = r.read_framebuffer()
+    st = r.stats()
+    r.close()
+    assert st["n_shaded"] == json.load(open(os.path.join(GOLDEN, "n_shaded.json")))["c3"]["n_shaded"]
+    return cfg, sc, want
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_c4_full_size_4k_split_over_2_4_8_ranks(c4_whole_frame, world):
+    """BASELINE config #4 at full size: the 4K frame split into interleaved tile-high bands over `world` ranks, every
+    rank's shard rendered on this one GPU, gathered in both payload forms bench.py offers -- rgba32f shards rendered
+    straight into the gather slots, and packed shards (rgb + alpha bit) -- and unpacked on the device: the frame every rank
+    ends up with is the unpartitioned frame, bit for bit, and the ranks' coverage counts add up to the oracle's."""
+    import torch
+    cfg, sc, want = c4_whole_frame
+    rs = [Renderer(cfg.width, cfg.height) for _ in range(world)]
+    band = rs[0].tile_height()
+    shard_rows = P.shard_rows(cfg.height, world, band)
+    gathered = torch.zeros((world, shard_rows, cfg.width, 4), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    handles, n_shaded, pb = None, 0, None
+    for rank, r in enumerate(rs):
+        r.set_partition(rank, world, band)
+        assert r.shard_rows() == shard_rows
+        pb = r.packed_shard_bytes()
+        r.set_output_device_ptr(gathered[rank].data_ptr(), gathered[rank].numel() * 4)
+        r.render_scene(sc)
+        r.synchronize()
+        n_shaded += r.stats()["n_shaded"]
+    assert n_shaded == json.load(open(os.path.join(GOLDEN, "n_shaded.json")))["c3"]["n_shaded"]
+    packed = torch.full((world * pb,), 0xAB, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    for rank, r in enumerate(rs):
+        r.pack_shard(packed[rank * pb:].data_ptr())
+        r.synchronize()
+    for form in ("rgba32f", "packed"):
+        frame = torch.full((cfg.height, cfg.width, 4), 3.0, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        if form == "rgba32f":
+            rs[-1].unpack_gathered(gathered.data_ptr(), frame.data_ptr())
+        else:
+            rs[-1].unpack_gathered_packed(packed.data_ptr(), frame.data_ptr())
+        rs[-1].synchronize()
+        torch.cuda.synchronize()
+        got = frame.cpu().numpy()
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), form
+    for r in rs:
+        r.close()
+
+
 def test_c5_8k_properties():
-    """BASELINE config #5 at full size (7680x4320, 64 balls, 8 lights): coverage count against the oracle's
+    """BASELINE config #5 at full size (7680x4320, 64 balls, 8 lights, 2048^2 maps): coverage count against the oracle's
     committed N_shaded, determinism, and the whole frame against the oracle, bit for bit."""
     cfg = configs.C5
-    maps = textures.make_material(512)
-    cfgs = cfg.scaled(cfg.width, cfg.height, 512)
+    maps = textures.make_material(cfg.texture_size)   # 2048^2 maps, as BASELINE's configuration has them
+    cfgs = cfg
     r = Renderer(cfg.width, cfg.height)
     material = r.upload_material(maps)
     scene, cam, settings = S.config_scene(r, cfgs)

@@ -52,6 +52,44 @@ def test_packed_form_round_trip_and_layout():
         assert np.array_equal(back.view(np.uint32), frame.view(np.uint32))
 
 
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 8])
+def test_push_order_is_a_ring_step_at_every_step(world):
+    """peer form: at step k the destinations of all ranks are a permutation (every rank receives exactly one block, every
+    link direction carries one copy), and over the world - 1 steps every rank has sent to every other rank once"""
+    orders = [P.push_order(r, world) for r in range(world)]
+    for k in range(world - 1):
+        assert sorted(o[k] for o in orders) == list(range(world))
+    for r, o in enumerate(orders):
+        assert sorted(o) == [x for x in range(world) if x != r]
+
+
+@pytest.mark.parametrize("form", [P.SHARD_RGBA32F, P.SHARD_PACKED, P.SHARD_RGBA8])
+@pytest.mark.parametrize("H,W,world,band", [(270, 17, 4, 32), (130, 390, 3, 64), (2160, 64, 8, 32), (64, 64, 1, 32)])
+def test_peer_exchange_model_leaves_the_same_gather_buffer_on_every_rank(form, H, W, world, band):
+    """every rank's gather buffer after all pushes == what ncclAllGather leaves there (blocks in rank order), and it
+    decodes to the frame; block sizes are the ones bbr_exchange_block_bytes reports (16-byte multiples)"""
+    rng = np.random.Generator(np.random.PCG64(H + W + world))
+    if form == P.SHARD_RGBA8:
+        frame = rng.integers(0, 256, (H, W, 4), dtype=np.uint8)
+    else:
+        frame = rng.standard_normal((H, W, 4)).astype(np.float32)
+        frame[..., 3] = rng.integers(0, 2, (H, W)).astype(np.float32)
+    block = P.exchange_block_bytes(form, H, W, world, band)
+    assert block % 16 == 0 or form != P.SHARD_PACKED
+    blocks = [P.encode_block(P.pack_shard(frame, r, world, band), form) for r in range(world)]
+    assert all(b.size == block for b in blocks)
+    bufs = [np.full(world * block, 0xAB, np.uint8) for _ in range(world)]
+    for r in range(world):
+        bufs[r][P.push_offset(r, block):P.push_offset(r, block) + block] = blocks[r]   # staged in the rank's own buffer
+        for dst in P.push_order(r, world):
+            bufs[dst][P.push_offset(r, block):P.push_offset(r, block) + block] = blocks[r]
+    want = np.concatenate(blocks)
+    for b in bufs:
+        assert np.array_equal(b, want)
+    back = P.decode_gathered(bufs[-1], form, H, W, world, band)
+    assert back.dtype == frame.dtype and np.array_equal(back.view(np.uint8), frame.view(np.uint8))
+
+
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
@@ -82,6 +120,21 @@ def _rank_main(rank, world, port, band_rows, q):
     dist.all_gather_into_tensor(gathered_packed, packed)
     frame_packed = P.unpack_gathered_packed(gathered_packed.numpy(), H, W, world, band_rows)
     assert np.array_equal(frame_packed.view(np.uint32), frame.view(np.uint32))
+    # the peer form of the native exchange (bbr_push_shard): every rank sends its block to every rank's gather buffer in
+    # P.push_order -- here as point-to-point messages; step k of all ranks together is one ring step
+    for form in (P.SHARD_RGBA32F, P.SHARD_PACKED):
+        block = P.exchange_block_bytes(form, H, W, world, band_rows)
+        mine_block = torch.from_numpy(P.encode_block(shard.numpy(), form).copy())
+        assert mine_block.numel() == block
+        buf = torch.zeros(world * block, dtype=torch.uint8)
+        buf[P.push_offset(rank, block):P.push_offset(rank, block) + block] = mine_block
+        for k, dst in enumerate(P.push_order(rank, world), start=1):
+            src = (rank - k) % world                      # whose block lands here in the same step
+            req = dist.isend(mine_block, dst)
+            dist.recv(buf[P.push_offset(src, block):P.push_offset(src, block) + block], src)
+            req.wait()
+        pushed = P.decode_gathered(buf.numpy(), form, H, W, world, band_rows)
+        assert np.array_equal(pushed.view(np.uint32), frame.view(np.uint32))
     total = torch.tensor([n]); dist.all_reduce(total)
     if rank == 0:
         full, _, _, st = bbo.render(sc, want_prim=False, want_depth=False)
