@@ -30,22 +30,62 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 
 
-def profiled_traffic(workload, kernel="k_shade"):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/*_pmc_hbm.json, written by
-    tools/profile_summary.py: FETCH_SIZE and WRITE_SIZE collected in separate passes, FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for gfx950).  None when no profile of this workload is committed."""
+def _committed_summary(pattern, workload, kernel):
+    """newest profiles/<pattern> of this workload that holds `kernel` AND was measured on the kernels of this tree
+    (kernel_source_sha256, bibim_renderer_amd/build_id.py).  Returns (entry, path, None) or (None, path_or_None, why)."""
     import glob
-    best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.json"))):
+    from bibim_renderer_amd.build_id import kernel_source_sha256
+    mine, stale = kernel_source_sha256(), None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), reverse=True):
         try:
             d = json.load(open(f))
         except (OSError, ValueError):
             continue
-        if d.get("workload") == workload and kernel in d.get("kernels", {}):
-            best = (f, d["kernels"][kernel])
-    if best is None:
-        return None, None
-    return int(best[1]["hbm_bytes_per_launch"]), os.path.relpath(best[0], ROOT)
+        if d.get("workload") != workload or kernel not in d.get("kernels", {}):
+            continue
+        if d.get("kernel_source_sha256") == mine:
+            return d["kernels"][kernel], os.path.relpath(f, ROOT), None
+        stale = stale or os.path.relpath(f, ROOT)
+    return None, stale, ("measured on other kernel sources than this tree's" if stale else "no summary of this workload committed")
+
+
+def profiled_traffic(workload, kernel="k_shade"):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/*_pmc_hbm.json, written by
+    tools/profile_summary.py: FETCH_SIZE and WRITE_SIZE collected in separate passes, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  (None, "<file>: stale ...") when the summary belongs to another build."""
+    e, path, why = _committed_summary("*_pmc_hbm.json", workload, kernel)
+    if e is None:
+        return None, (f"{path}: {why}" if path else why)
+    return int(e["hbm_bytes_per_launch"]), path
+
+
+# vector-ALU issue: one wave64 instruction per SIMD every 2 cycles is what plain fp32 / integer instructions reach with two
+# or more waves on a SIMD (profiles/r02_issue_rate.txt: 2.05-2.4 cycles; 64 lanes x 2 flop / 2 cycles x 4 SIMDs x 256 CUs x
+# 2.4 GHz = the 157 TFLOP/s fp32 vector peak of the data sheet)
+VALU_ISSUE_CYCLES = 2.0
+SHADER_CLOCK_GHZ = 2.4
+
+
+def valu_roofline(workload, kernel, avg_kernel_ms, n_cus):
+    """Second roofline of the dominant kernel: executed vector-ALU wave-instructions per launch (SQ_INSTS_VALU and its
+    classes, profiles/*_pmc_sq.json) against the issue peak, at the kernel duration measured live in this run."""
+    e, path, why = _committed_summary("*_pmc_sq.json", workload, kernel)
+    peak = n_cus * 4 * SHADER_CLOCK_GHZ / VALU_ISSUE_CYCLES   # G wave-instructions / s
+    out = {"bound": "valu", "kernel": kernel, "peak": round(peak, 1), "unit": "G wave-instr/s",
+           "peak_is": f"{n_cus} CUs x 4 SIMDs x {SHADER_CLOCK_GHZ} GHz / {VALU_ISSUE_CYCLES} cycles per wave64 instruction",
+           "achieved": None, "frac": None, "source": path if e is not None else (f"{path}: {why}" if path else why)}
+    if e is None or "SQ_INSTS_VALU" not in e or avg_kernel_ms <= 0:
+        return out
+    n = float(e["SQ_INSTS_VALU"])
+    achieved = n / (avg_kernel_ms * 1e-3) / 1e9
+    classes = {k[len("SQ_INSTS_VALU_"):].lower(): int(v) for k, v in e.items() if k.startswith("SQ_INSTS_VALU_")}
+    classes["other (compare, select, min/max, move, lane ops)"] = int(n - sum(classes.values()))
+    out.update({"achieved": round(achieved, 1), "frac": round(achieved / peak, 4), "valu_instructions_per_launch": int(n),
+                "by_class": classes, "issue_floor_ms": round(n / (peak * 1e9) * 1e3, 5),
+                "other_instructions_per_launch": {k[len("SQ_INSTS_"):].lower(): int(v) for k, v in e.items()
+                                                  if k in ("SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS",
+                                                           "SQ_INSTS_BRANCH")}})
+    return out
 
 
 def algorithmic_bytes(cfg, n_shaded, n_ball_vertices):
@@ -367,11 +407,23 @@ def main():
         r.set_option("timing_stride", event_stride)
         r.timing_reset()
     fence()
+    frames_before = step_no[0] + r.stats()["bin_overflow"]   # frames submitted so far (incl. the re-renders after overflows)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    fence()
+    # the closing bracket of the timed region: every stream of the device drained (hipDeviceSynchronize) and all ranks
+    # there.  The library's own synchronising call additionally copies the frame's counter block to the host to look for
+    # a capacity overflow; that check is not part of the K steps and runs right after the clock stops.
+    if dist_path and args.exchange == "peer" and pending:
+        finish_peer(pending.pop())
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+        torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    fence()
+    if r.stats()["bin_overflow"] != stats["bin_overflow"]:
+        raise SystemExit("a capacity overflowed inside the timed region: the frames timed were incomplete")
     gc.enable()
 
     if dist is not None:
@@ -405,7 +457,7 @@ def main():
                     "traffic_source": traffic_src,
                     "algorithmic_bytes_per_launch": int(shade_bytes), "avg_kernel_ms": round(avg_shade_ms, 5),
                     "launches_timed": int(n_ev), "event_stride": event_stride,
-                    "frames_in_flight": args.frames_in_flight,
+                    "frames_in_flight": args.frames_in_flight, "frames_before_timed_region": int(frames_before),
                     "frame_algorithmic_bytes": int(balg["total"]),
                     "frame_achieved_gbs": round(balg["total"] / (ms_per_step * 1e-3) / 1e9, 2),
                     "frame_frac": round(balg["total"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -413,6 +465,8 @@ def main():
                     # what actually limits the kernel (profiles/*_pmc_sq.txt): vector-ALU issue, not HBM.  fp32 flops per
                     # shaded pixel from the committed counters (2*fma + mul + add wave-instructions x 64 lanes / N_shaded)
                     "limiter": "vector ALU issue (see DESIGN.md, k_shade)"}
+        if world == 1 and not args.force_dist:
+            roofline["valu"] = valu_roofline(args.workload, "k_shade", avg_shade_ms, 256)
 
     if roofline is not None and not dist_path and not args.present_fused:
         # Outside the timed region: the same kernels with one frame in flight, i.e. without the other frame's
@@ -433,6 +487,10 @@ def main():
             "avg_raster_ms": round(ra1, 5), "avg_device_frame_latency_ms": round(f1, 5),
             "achieved": round(shade_bytes / (s1 * 1e-3) / 1e9, 2) if s1 > 0 else 0.0,
             "frac": round(shade_bytes / (s1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if s1 > 0 else 0.0}
+        v = roofline.get("valu")
+        if v and v.get("valu_instructions_per_launch") and s1 > 0:
+            a1 = v["valu_instructions_per_launch"] / (s1 * 1e-3) / 1e9
+            v["one_frame_in_flight"] = {"avg_kernel_ms": round(s1, 5), "achieved": round(a1, 1), "frac": round(a1 / v["peak"], 4)}
         # the next row of SURVEY 8(f), measured beside the path: k_present alone, 16 B read + 4 B written per pixel
         import dataclasses
         settings_tm = dataclasses.replace(settings, enable_tone_mapping=1, exposure=1.0)

@@ -1443,7 +1443,6 @@ struct CookedLight {
 };
 struct ShadeShared {
   CookedLight lights[kMaxNumLights];
-  float view_pos[4];
 };
 
 BB_DEV CookedLight cook_light(const Light &l) {
@@ -1469,13 +1468,39 @@ BB_DEV CookedLight cook_light(const Light &l) {
 template <int THREADS>
 BB_DEV void stage_lights(const ShadeParams &sp, const Light *__restrict__ lights, ShadeShared &sh) {
   for (int li = (int)threadIdx.x; li < sp.num_lights; li += THREADS) sh.lights[li] = cook_light(lights[li]);
-  if (threadIdx.x < 3) sh.view_pos[threadIdx.x] = sp.view_pos[threadIdx.x];
 }
 
-BB_DEV float4 light_surface(const ShadeParams &sp, const ShadeShared &sh, f3 P, f3 normal, f3 albedo, float metallic,
+// Where the light loop finds its cooked lights.
+//  * LdsLights: a table staged by the workgroup itself (stage_lights + barrier): k_deferred_background.
+//  * ConstLights: the frame's table in global memory, cooked once per frame by k_shade_items and read through the SCALAR
+//    cache (constant address space -> s_load into scalar registers): k_shade.  No LDS, no staging code, and above all no
+//    workgroup barrier in front of the light loop -- the four waves of a workgroup never wait for each other, and a light's
+//    type is already a scalar (no v_readfirstlane, 9 issue cycles each).  The price: a VALU instruction that reads one of
+//    the light's fields takes it as its one scalar operand.
+struct LdsLights {
+  const ShadeShared &sh;
+  BB_DEV CookedLight get(int li) const { return sh.lights[li]; }
+  BB_DEV static int type_of(const CookedLight &c) { return __builtin_amdgcn_readfirstlane(c.type); }
+};
+typedef const CookedLight __attribute__((address_space(4))) *ConstCooked;
+struct ConstLights {
+  ConstCooked table;
+  BB_DEV CookedLight get(int li) const {
+    ConstCooked c = table + li;
+    CookedLight o;
+    o.px = c->px; o.py = c->py; o.pz = c->pz; o.type = c->type;
+    o.cr = c->cr; o.cg = c->cg; o.cb = c->cb; o.outer = c->outer;
+    o.dx = c->dx; o.dy = c->dy; o.dz = c->dz; o.inv_eps = c->inv_eps;
+    return o;
+  }
+  BB_DEV static int type_of(const CookedLight &c) { return c.type; }
+};
+
+template <typename Lights>
+BB_DEV float4 light_surface(const ShadeParams &sp, const Lights lights, f3 P, f3 normal, f3 albedo, float metallic,
                             float roughness, float ao) {
   // per-pixel invariants
-  const f3 V = normalize3(sub3(mk3(sh.view_pos[0], sh.view_pos[1], sh.view_pos[2]), P));
+  const f3 V = normalize3(sub3(mk3(sp.view_pos[0], sp.view_pos[1], sp.view_pos[2]), P));
   const f3 N = normalize3(normal);
   const float NdotV = sat01(dot3(V, N));
   const float rr = roughness + 1.0f;
@@ -1489,22 +1514,14 @@ BB_DEV float4 light_surface(const ShadeParams &sp, const ShadeShared &sh, f3 P, 
   const f3 kda = mk3((om * albedo.x) * kInvPi, (om * albedo.y) * kInvPi, (om * albedo.z) * kInvPi);
 
   f3 Lo = mk3(0.0f, 0.0f, 0.0f);
-  // The light's position, type and colour are fetched one iteration ahead (LDS broadcasts into registers), so the
-  // loop never waits for them.
-  float n_px = 0.f, n_py = 0.f, n_pz = 0.f, n_cr = 0.f, n_cg = 0.f, n_cb = 0.f;
-  int n_type = 0;
-  if (sp.num_lights > 0) {
-    const CookedLight &c0 = sh.lights[0];
-    n_px = c0.px; n_py = c0.py; n_pz = c0.pz; n_type = c0.type; n_cr = c0.cr; n_cg = c0.cg; n_cb = c0.cb;
-  }
+  // The next light is fetched one iteration ahead (LDS broadcasts / scalar loads), so the loop never waits for it.
+  CookedLight nxt = {};
+  if (sp.num_lights > 0) nxt = lights.get(0);
   for (int li = 0; li < sp.num_lights; ++li) {
-    const CookedLight &cl = sh.lights[li];
-    const float px = n_px, py = n_py, pz = n_pz, cr = n_cr, cg = n_cg, cb = n_cb;
-    const int type = __builtin_amdgcn_readfirstlane(n_type);
-    {
-      const CookedLight &cn = sh.lights[li + 1 < sp.num_lights ? li + 1 : li];
-      n_px = cn.px; n_py = cn.py; n_pz = cn.pz; n_type = cn.type; n_cr = cn.cr; n_cg = cn.cg; n_cb = cn.cb;
-    }
+    const CookedLight cl = nxt;
+    const float px = cl.px, py = cl.py, pz = cl.pz, cr = cl.cr, cg = cl.cg, cb = cl.cb;
+    const int type = Lights::type_of(cl);
+    nxt = lights.get(li + 1 < sp.num_lights ? li + 1 : li);
     f3 L;
     float att;
     if (type == 0 || type == 1) {
@@ -1557,7 +1574,7 @@ __global__ __launch_bounds__(kBackgroundThreads) void k_deferred_background(Shad
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     // (buffer_visualize.frag on a cleared texel: rgb 0, alpha 1)
     const float4 c = gbuffer_view >= 0 ? make_float4(0.f, 0.f, 0.f, 1.f)
-                                       : light_surface(sp, sh, mk3(0.f, 0.f, 0.f), mk3(0.f, 0.f, 0.f), mk3(0.f, 0.f, 0.f), 0.f, 0.f, 0.f);
+                                       : light_surface(sp, LdsLights{sh}, mk3(0.f, 0.f, 0.f), mk3(0.f, 0.f, 0.f), mk3(0.f, 0.f, 0.f), 0.f, 0.f, 0.f);
     out[0] = c;
     // out[1].x: the same colour as a presented pixel (fused presentation)
     if (tables) out[1] = make_float4(__uint_as_float(present_pixel(c.x, c.y, c.z, *tables, sp.tone_enable, sp.exposure, 1)), 0.f, 0.f, 0.f);
@@ -1589,9 +1606,15 @@ template <int TILE_W, int TILE_H>
 __global__ __launch_bounds__(kItemsThreads) void k_shade_items(FrameParams fp, const uint32_t *__restrict__ frag_count,
                                                                const uint32_t *__restrict__ item_groups,
                                                                uint32_t *__restrict__ items, int grid_x, int grid_y,
-                                                               uint32_t *__restrict__ host_count) {
+                                                               uint32_t *__restrict__ host_count,
+                                                               const Light *__restrict__ lights, int num_lights,
+                                                               CookedLight *__restrict__ cooked) {
   __shared__ uint32_t s_wave[2][kItemsThreads / 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // the frame's cooked light table (k_shade reads it through the scalar cache): once per frame, by the last workgroup
+  // (the one with the fewest slots to scan)
+  if (blockIdx.x == gridDim.x - 1)
+    for (int li = tid; li < num_lights; li += kItemsThreads) cooked[li] = cook_light(lights[li]);
   const uint32_t n_slots = (uint32_t)grid_x * (uint32_t)grid_y;
   const uint32_t first = blockIdx.x * (uint32_t)kItemsThreads;
   uint32_t before = 0u;  // (independent loads: one round trip)
@@ -1638,16 +1661,21 @@ __global__ __launch_bounds__(kItemsThreads) void k_shade_items(FrameParams fp, c
 // record -> clip slot -> texels, ~0.8 us each under load -- against ~0.9 us of issue time per 64 fragments: its
 // duration followed T = 66 us + 264 us / (waves per SIMD) at C3 (measured by padding LDS: 2, 3, 4, 7 waves -> 198,
 // 151, 132, 109 us), and a body that only loaded the fragment and stored a constant still took 52 us.  Hence:
-//  * PERSISTENT waves: a fixed grid of resident waves walks the work list of k_shade_items in a strided loop.  No wave
-//    is launched for an empty part of a tile, the cooked light table is built once per workgroup instead of once per
-//    256 fragments, and kernel arguments / list heads are read once per wave, not once per 64 fragments.
-//  * the chain is cut to two round trips per item: the fragment words of the NEXT item are prefetched during the light
-//    loop (k_raster pads every list to a multiple of 64, so they can be fetched before the count is known), and the
-//    fragment word carries the clip-arena slot of a clipped sub-triangle, so its planes are fetched together with the
-//    primitive record instead of after it.
-//  * many waves per SIMD rather than a deep software pipeline: a gfx950 wave issues at most one instruction of ANY
-//    kind every ~4 cycles (tools/microbench/issue_rate.hip), so the vector ALU (one instruction every 2 cycles) only
-//    fills up with four or more waves that are all busy issuing.
+//  * ONE WAVE = ONE ITEM of 64 fragments from the list of k_shade_items (item = grid row, tile column, chunk of the
+//    tile's fragment list): no wave is launched for an empty part of a tile, every launched wave is full (k_raster pads
+//    each list to a multiple of 64 with copies of its first fragment), and no count has to be read before the fragments.
+//    The main launch is sized on the host from the item count the same frame slot produced one frame earlier (pinned
+//    word written by k_shade_items) plus 3 % + 64; a second, 32-workgroup instantiation (TAIL) walks whatever lies beyond
+//    that estimate in a loop, so a frame that suddenly has more fragments is still complete.
+//  * the chain is cut to three round trips per item (item word -> fragment words -> record + texels): the fragment
+//    word carries the clip-arena slot of a clipped sub-triangle, so its planes are fetched together with the primitive
+//    record instead of after it; a wave whose 64 fragments share one primitive fetches the record through the scalar
+//    cache (constant address space); the cooked light table is staged into LDS while the first loads are in flight.
+//  * many waves per SIMD (68 VGPRs -> 7) rather than a persistent, software-pipelined loop: a gfx950 wave issues at
+//    most one instruction of ANY kind every ~4 cycles (profiles/r02_issue_rate.txt), so the vector ALU (one instruction
+//    every 2 cycles) only fills up with several waves that are all busy issuing.  The persistent forms were built and
+//    measured in round 2 ("dead ends"): loop-carried state costs 36 VGPRs, and every forced
+//    occupancy spilled.
 // ------------------------------------------------------------------------------------------------
 #ifndef BB_SHADE_THREADS
 #define BB_SHADE_THREADS 256
@@ -1678,21 +1706,19 @@ struct ItemFrag {
 // grid from the item count of the frame this slot rendered before (frames are coherent), so nearly every wave launched
 // has an item.  TAIL = true: a small fixed grid loops over whatever lies behind the part the main launch covered (a
 // scene that suddenly grew); normally nothing.  Two instantiations because the loop form costs registers: the compiler
-// keeps 104 live around a loop where the straight-line body needs 68 -- four waves per SIMD instead of seven.
+// keeps ~100 live around a loop where the straight-line body fits 64 -- four waves per SIMD instead of eight.  The main
+// instantiation asks for eight waves per SIMD (amdgpu_waves_per_eu): the allocator then gets from 67 registers to 64
+// without a spill, and the eighth wave is worth 3.4 us of the kernel's 76 at C3 (latency hiding is what this kernel runs on).
 template <int TILE_W, int TILE_H, bool DEFERRED, bool PRESENT = false, bool TAIL = false>
-__global__ __launch_bounds__(kShadeThreads) void k_shade(
-    FrameParams fp, ShadeParams sp, const Light *__restrict__ lights, const ShadeRec *__restrict__ recs,
+__global__ __launch_bounds__(kShadeThreads) __attribute__((amdgpu_waves_per_eu(TAIL ? 1 : (DEFERRED ? 7 : 8)))) void k_shade(
+    FrameParams fp, ShadeParams sp, const CookedLight *__restrict__ cooked, const ShadeRec *__restrict__ recs,
     const ClipSlot *__restrict__ clip_arena, const unsigned long long *__restrict__ frags,
     const uint32_t *__restrict__ frag_count, const uint32_t *__restrict__ items, uint32_t first_item,
     const MaterialDesc *__restrict__ materials, float4 *__restrict__ out,
     uint2 *__restrict__ gbuffer, const SrgbTables *__restrict__ tables, uint32_t *__restrict__ out8,
     Counters *__restrict__ ctr, Counters *__restrict__ ctr_done, uint32_t *__restrict__ item_groups) {
   constexpr int TILE_PIXELS = TILE_W * TILE_H;
-  __shared__ ShadeShared sh;
-#ifdef BB_EXP_LDS_PAD
-  __shared__ char exp_pad[BB_EXP_LDS_PAD];  // experiment: fewer workgroups per CU
-  if (fp.width < 0) exp_pad[threadIdx.x] = 1;
-#endif
+  const ConstLights lights_c{(ConstCooked)cooked};
   // The frame's counter block has done its job (k_geometry filled it, k_raster read it): keep a copy for the host's
   // statistics / overflow check and clear the block for the next frame of this slot.  Frames of different slots
   // share nothing, so their kernels may overlap freely.
@@ -1710,21 +1736,16 @@ __global__ __launch_bounds__(kShadeThreads) void k_shade(
 #define BB_KSTAMP(i) do { } while (0)
 #endif
   const int lane = (int)(threadIdx.x & 63u);
-  const uint32_t n_items = items[0];
-  if (first_item + blockIdx.x * (uint32_t)kShadeWaves >= n_items) return;  // the whole workgroup: nothing left for it
-  // this wave's (first) item: wave-uniform, everything derived from it lives in scalar registers
+  // this wave's (first) item: wave-uniform, everything derived from it lives in scalar registers.  The item word is read
+  // together with the item count, not after it (the list has room for every index a launch can produce): one dependent
+  // round trip less in front of the fragments.
   uint32_t j = first_item + (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (uint32_t)kShadeWaves + (threadIdx.x >> 6)));
-  // The cooked light table is written now and only needed by the light loop: the barrier sits right in front of the
-  // loop, so the light fetch overlaps the fragment's own memory round trips (fragment -> primitive record -> texels).
-  stage_lights<kShadeThreads>(sp, lights, sh);
+  uint32_t item = items[1u + (TAIL ? 0u : j)];
+  const uint32_t n_items = items[0];
   if (BB_ABLATE(2048u)) sp.num_lights = 0;
-  if (j >= n_items) {  // a wave without an item: its workgroup still needs it at the barrier
-    __syncthreads();
-    return;
-  }
-  bool first_pass = true;
+  if (j >= n_items) return;  // a wave without an item (the kernel has no barrier: waves come and go on their own)
   do {  // (a loop only in the TAIL instantiation)
-  const uint32_t item = items[1u + j];
+  if (TAIL) item = items[1u + j];
   const int chunk = (int)(item & 63u);
   const int tx = (int)((item >> 6) & 8191u);
   int ty, out_tile_row;
@@ -1798,7 +1819,7 @@ __global__ __launch_bounds__(kShadeThreads) void k_shade(
   {
     const uint32_t clip1 = (uint32_t)(frag >> (32 + kFragPixBits));
     const uint32_t ref_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)ref);
-    if (__ballot(ref != ref_u) == 0ull && !BB_ABLATE(4096u)) {
+    if ((__ballot(ref != ref_u) == 0ull && !BB_ABLATE(4096u)) || BB_ABLATE(8192u)) {
       // (the constant address space is what makes these scalar loads -- and keeps the compiler from merging the two
       //  forms back into one that gathers: both buffers were written by k_geometry and are read-only here)
       typedef const ShadeRec __attribute__((address_space(4))) *ConstRecs;
@@ -1810,6 +1831,7 @@ __global__ __launch_bounds__(kShadeThreads) void k_shade(
     }
   }
 
+  BB_KSTAMP(2);  // record (+ clip slot) arrived, varyings interpolated
   // texture fetches, forward_brdf.frag:16-22
   const float u = BB_ABLATE(8u) ? 0.5f : a[0], v = BB_ABLATE(8u) ? 0.5f : a[1];
   f3 albedo, normal;
@@ -1912,17 +1934,15 @@ __global__ __launch_bounds__(kShadeThreads) void k_shade(
       dst[0] = lo;
       dst[1] = hi;
     }
-    if (first_pass) __syncthreads();  // cooked lights visible (the only barrier of the kernel; every wave reaches exactly one)
     if (fp.gbuffer_view >= 0) {
       // buffer_visualize.frag:8-12 instead of brdf.frag (recordCommand, src/main.cpp:96-121): the rgb of one attachment
       const f3 shown = fp.gbuffer_view == 0 ? P : (fp.gbuffer_view == 1 ? normal : (fp.gbuffer_view == 2 ? albedo : mk3(metallic, roughness, ao)));
       color = make_float4(shown.x, shown.y, shown.z, 1.0f);
     } else {
-      color = light_surface(sp, sh, P, normal, albedo, metallic, roughness, ao);
+      color = light_surface(sp, lights_c, P, normal, albedo, metallic, roughness, ao);
     }
   } else {
-    if (first_pass) __syncthreads();  // cooked lights visible (the only barrier of the kernel; every wave reaches exactly one)
-    color = light_surface(sp, sh, mk3(a[2], a[3], a[4]), normal, albedo, metallic, roughness, ao);
+    color = light_surface(sp, lights_c, mk3(a[2], a[3], a[4]), normal, albedo, metallic, roughness, ao);
   }
   BB_KSTAMP(4);  // light loop done
   if (BB_ABLATE(2u)) color = make_float4(1.f, 1.f, 1.f, 1.f);
@@ -1934,14 +1954,13 @@ __global__ __launch_bounds__(kShadeThreads) void k_shade(
   {
     BB_KSTAMP(5);
     const uint32_t wv = blockIdx.x * (uint32_t)kShadeWaves + (threadIdx.x >> 6);
-    if (!TAIL && lane == 0 && wv < 4096u) {
-      unsigned long long *d = g_shade_stamps + (size_t)wv * 8;
+    if (!TAIL && lane == 0 && wv >= 30000u && wv < 34096u) {  // waves from the middle of the launch: steady state
+      unsigned long long *d = g_shade_stamps + (size_t)(wv - 30000u) * 8;
       for (int q = 0; q < 5; ++q) d[q] = st_t[q + 1] - st_t[q];
       d[5] = 1;
     }
   }
 #endif
-  first_pass = false;
   j += gridDim.x * (uint32_t)kShadeWaves;
   asm volatile("" ::: "memory");
   } while (TAIL && j < n_items);

@@ -123,6 +123,7 @@ struct FrameSlot {
   DeviceBuffer<uint32_t> d_frag_count;
   DeviceBuffer<uint32_t> d_tile_order;  // k_raster launch slots, heaviest tiles first
   DeviceBuffer<uint32_t> d_items;       // k_shade's work list: [0] = count, then slot << 6 | chunk of 64 fragments
+  DeviceBuffer<CookedLight> d_cooked;   // the frame's light table as the light loop consumes it (k_shade_items -> k_shade)
   DeviceBuffer<uint32_t> d_item_groups; // 64-fragment chunks per group of 256 launch slots (k_raster -> k_shade_items)
   DeviceBuffer<float4> d_frame;
   DeviceBuffer<float4> d_background;  // deferred path: colour of the pixels no geometry covers
@@ -148,7 +149,7 @@ struct FrameSlot {
   uint32_t n_prims = 0;
 
   void release_tile_buffers() {
-    d_tile_count.release(); d_bins.release(); d_frags.release(); d_frag_count.release(); d_tile_order.release(); d_items.release(); d_item_groups.release();
+    d_tile_count.release(); d_bins.release(); d_frags.release(); d_frag_count.release(); d_tile_order.release(); d_items.release(); d_item_groups.release(); d_cooked.release();
   }
   // native exchange (bbr_allgather_frame / bbr_push_shard) with library-owned buffers: every rank's block, the whole frame
   DeviceBuffer<uint8_t> d_gathered, d_whole;
@@ -384,10 +385,12 @@ int ensure_slot_buffers(bbr_context *c, FrameSlot &s) {
   HIP_TRY(c, s.d_frag_count.ensure(tiles, true));
 #endif
   HIP_TRY(c, s.d_tile_order.ensure(tiles * kOrderBuckets));
-  HIP_TRY(c, s.d_items.ensure(1 + tiles * (size_t)(c->tile_w() * c->tile_h() / 64), true));
+  // (+ kShadeWaves: the last workgroup of k_shade's main launch reads the item words of all its waves before it knows the count)
+  HIP_TRY(c, s.d_items.ensure(1 + tiles * (size_t)(c->tile_w() * c->tile_h() / 64) + kShadeWaves, true));
   if (tiles > (size_t)kItemGroupSlots * kItemGroups)  // 65536 launch slots: 8192 x 8192 pixels at 32 x 32 tiles
     return fail(c, BBR_ERR_INVALID_ARGUMENT, "frame too large for this tile size: set option tile_mode to 0 (64 x 64 tiles)");
   HIP_TRY(c, s.d_item_groups.ensure(kItemGroups, true));
+  HIP_TRY(c, s.d_cooked.ensure(kMaxNumLights));
   if (c->deferred) HIP_TRY(c, s.d_background.ensure(2));
   if (c->overlays && &s != &c->ov) HIP_TRY(c, s.d_depth.ensure((size_t)c->width * c->height));
   if (c->present_fused && &s != &c->ov) {
@@ -466,10 +469,10 @@ void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const Fra
                      fp.deferred ? s.d_background.ptr : nullptr, (c->overlays && c->world == 1) ? s.d_depth.ptr : nullptr,
                      s.h_flags, out8, s.d_item_groups.ptr);
   s.has_depth = c->overlays && c->world == 1;
-  // k_shade is persistent: a fixed grid of resident waves walks the frame's work list (64 fragments per item), which a
-  // single workgroup builds from the per-tile fragment counts as soon as k_raster is done
+  // k_shade's work list (64 fragments per item), built from the per-tile fragment counts as soon as k_raster is done; the
+  // same launch cooks the frame's light table
   hipLaunchKernelGGL((k_shade_items<TW, TH>), dim3((unsigned)((fp.tiles_x * grid_y + kItemsThreads - 1) / kItemsThreads)), dim3(kItemsThreads), 0, sr, fp, s.d_frag_count.ptr, s.d_item_groups.ptr, s.d_items.ptr,
-                     fp.tiles_x, grid_y, s.h_flags ? s.h_flags + 2 : nullptr);
+                     fp.tiles_x, grid_y, s.h_flags ? s.h_flags + 2 : nullptr, d_lights, sp.num_lights, s.d_cooked.ptr);
   if (ev && c->timing == 1) (void)hipEventRecord(ev[2], sr);
   if (ss != sr) {
     (void)hipEventRecord(s.ev_raster_done, sr);
@@ -491,12 +494,12 @@ void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const Fra
   auto shade = [&](auto deferred, auto present) {
     if (tail) {
       hipLaunchKernelGGL((k_shade<TW, TH, decltype(deferred)::value, decltype(present)::value, true>), dim3(32), dim3(kShadeThreads),
-                         0, sr, fp, sp, d_lights, s.d_attrs.ptr, s.d_clip.ptr, s.d_frags.ptr, s.d_frag_count.ptr, s.d_items.ptr,
+                         0, sr, fp, sp, s.d_cooked.ptr, s.d_attrs.ptr, s.d_clip.ptr, s.d_frags.ptr, s.d_frag_count.ptr, s.d_items.ptr,
                          main_wgs * (uint32_t)kShadeWaves, c->d_materials.ptr, out, gbuf, tables, out8, ctr, ctr_done, nullptr);
       if (ss != sr) (void)hipEventRecord(s.ev_tail_done, sr);
     }
     hipLaunchKernelGGL((k_shade<TW, TH, decltype(deferred)::value, decltype(present)::value, false>), dim3(main_wgs),
-                       dim3(kShadeThreads), 0, ss, fp, sp, d_lights, s.d_attrs.ptr, s.d_clip.ptr, s.d_frags.ptr,
+                       dim3(kShadeThreads), 0, ss, fp, sp, s.d_cooked.ptr, s.d_attrs.ptr, s.d_clip.ptr, s.d_frags.ptr,
                        s.d_frag_count.ptr, s.d_items.ptr, 0u, c->d_materials.ptr, out, gbuf, tables, out8, ctr, ctr_done, s.d_item_groups.ptr);
     if (tail && ss != sr) (void)hipStreamWaitEvent(ss, s.ev_tail_done, 0);
   };
@@ -1665,6 +1668,10 @@ int bbr_set_option(bbr_context *c, const char *name, int64_t value) {
   if (n == "timing") {
     if (value < 0 || value > 2) return fail(c, BBR_ERR_INVALID_ARGUMENT, "timing: 0, 1 or 2");
     c->timing = (int)value;
+    if (value && c->ring.empty()) {  // here, not in the first timed frame: 2560 hipEventCreate calls take half a millisecond
+      c->ring.resize(bbr_context::kRingEvents * bbr_context::kRingCap);
+      for (auto &e : c->ring) HIP_TRY(c, hipEventCreate(&e));
+    }
     c->ring_frames = 0;
     c->present_launches = 0;
     c->timing_tick = 0;

@@ -3,12 +3,12 @@ sys.path.insert(0, '.')
 import numpy as np
 from bibim_renderer_amd import configs, textures, Renderer, _capi
 from bibim_renderer_amd import scene as S
-_capi.LIB_PATH = 'tools/_tmp/lib_stamps.so'
+import os; _capi.LIB_PATH = os.path.abspath('tools/_keep/stamps.so')
 cfg = configs.CONFIGS[sys.argv[1]]
 r = Renderer(cfg.width, cfg.height)
 r.set_option('frames_in_flight', 1)
 if len(sys.argv) > 2: r.set_option('ablate', int(sys.argv[2]))
-material = r.upload_material(textures.make_material(256))
+material = r.upload_material(textures.make_material(cfg.texture_size))
 scene, cam, settings = S.config_scene(r, cfg)
 for _ in range(4): S.draw_frame(r, scene, cam, settings, material)
 r.synchronize()

@@ -22,7 +22,7 @@ L.bbr_debug_shade_stamps.argtypes = [C.c_void_p, C.c_void_p]
 assert L.bbr_debug_shade_stamps(r._ctx, buf.ctypes.data) == 0
 live = buf[buf[:, 5] > 0]
 n = live[:, 5].astype(np.float64)
-names = ["launch -> item, count, fragment arrived", "record (+ clip slot) arrived, barycentrics", "varyings, taps arrived, filter", "barrier + light loop", "store"]
+names = ["launch -> item, count, fragment arrived", "record (+ clip slot) arrived, varyings", "taps arrived, filter, normal", "light loop", "store"]
 print(f"{len(live)} waves sampled")
 for i, nm in enumerate(names):
     per = live[:, i] / n
