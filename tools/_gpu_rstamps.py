@@ -20,6 +20,7 @@ L.bbr_debug_raster_stamps.argtypes = [C.c_void_p, C.c_void_p]
 assert L.bbr_debug_raster_stamps(r._ctx, buf.ctypes.data) == 0
 t = buf[:, :6].astype(np.int64); info = buf[:, 6]
 n_entries = (info >> np.uint64(32)).astype(np.int64); n_cov = (info & np.uint64(0xFFFFFFFF)).astype(np.int64)
+cls = np.stack([(buf[:, 7] >> np.uint64(16 * k)) & np.uint64(0xFFFF) for k in range(4)], 1).astype(np.int64)
 t0 = t[:, 0].min()
 rel = (t - t0) * 10 / 1e3
 life = rel[:, 4] - rel[:, 0]
@@ -29,6 +30,7 @@ names = ['init+counts', 'stage', 'raster', 'compact']
 for lo, hi, tag in ((0, 0, 'empty'), (1, 8, '1-8 entries'), (9, 64, '9-64'), (65, 256, '65-256'), (257, 10**9, '>256')):
     m = (n_entries >= lo) & (n_entries <= hi)
     if m.sum() == 0: continue
+    print(f'   entries by class (tiny, small, large, every-tile): mean {cls[m].mean(0).round(1).tolist()} max {cls[m].max(0).tolist()}')
     print(f'{tag:12s} tiles {int(m.sum()):5d} life {life[m].mean():6.2f} us  phases ' + ' '.join(f'{n}={d[m, i].mean():.2f}' for i, n in enumerate(names)) + f'  cov {n_cov[m].mean():.0f}')
 # concurrency: average number of WGs alive
 ev = np.concatenate([np.stack([rel[:, 0], np.ones(nt)], 1), np.stack([rel[:, 4], -np.ones(nt)], 1)])
