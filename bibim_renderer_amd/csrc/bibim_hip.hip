@@ -151,9 +151,21 @@ struct FrameSlot {
   void release_tile_buffers() {
     d_tile_count.release(); d_bins.release(); d_frags.release(); d_frag_count.release(); d_tile_order.release(); d_items.release(); d_item_groups.release(); d_cooked.release();
   }
+  // option "frame_graph": the frame's copy + kernels as one hipGraph, replayed while the launch arguments repeat
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t graph_exec = nullptr;
+  std::vector<uint8_t> graph_key, last_key;  // arguments the instantiated graph was captured with / of the previous frame
+  void release_graph() {
+    if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+    if (graph) (void)hipGraphDestroy(graph);
+    graph_exec = nullptr;
+    graph = nullptr;
+    graph_key.clear();
+  }
   // native exchange (bbr_allgather_frame / bbr_push_shard) with library-owned buffers: every rank's block, the whole frame
   DeviceBuffer<uint8_t> d_gathered, d_whole;
   void release_all() {
+    release_graph();
     d_staging.release(); d_tris.release(); d_attrs.release(); d_clip.release(); d_gathered.release(); d_whole.release();
     d_block_stats.release();
     release_tile_buffers(); d_broad.release(); d_frame.release(); d_present.release(); d_background.release(); d_depth.release();
@@ -265,6 +277,8 @@ struct bbr_context {
   int comm_rank = -1, comm_world = 0;
   int exchange_slot = -1, exchange_form = -1;  // where the last exchange left the whole frame (library-owned buffers)
   void *exchange_whole = nullptr;
+  bool frame_graph = false;  // option "frame_graph"
+  uint32_t graph_launches = 0, graph_captures = 0;
   static constexpr int kLayouts = 3;
   int layout_mode = 2;  // the option
   int layout = 2;       // layout of the frame being submitted
@@ -430,7 +444,8 @@ int upload_material_table(bbr_context *c) {
 
 template <int TW, int TH>
 void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const FrameParams &fp, const Mat4 &pv,
-                  const Mat4 &view, const ShadeParams &sp, const Light *d_lights, const DrawDesc *d_draws, uint32_t n_draws, float4 *out) {
+                  const Mat4 &view, const ShadeParams &sp, const Light *d_lights, const DrawDesc *d_draws, uint32_t n_draws, float4 *out,
+                  bool capturing) {
   const int slot_index = (int)(&s - c->slots);
   hipStream_t sg = c->frame_geom_stream(slot_index), sr = c->raster_stream(slot_index), ss = c->frame_shade_stream(slot_index);
   Counters *ctr = c->d_counters.ptr + s.ctr_index, *ctr_done = c->d_counters_done.ptr + s.ctr_index;
@@ -510,7 +525,7 @@ void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const Fra
     if (out8) shade(std::false_type{}, std::true_type{});
     else shade(std::false_type{}, std::false_type{});
   }
-  (void)hipEventRecord(s.ev_shade_done, ss);
+  if (!capturing) (void)hipEventRecord(s.ev_shade_done, ss);  // (a captured frame: recorded behind the graph launch)
   s.stream_used = ss;
   if (ev) {
     (void)hipEventRecord(ev[4], ss);
@@ -617,8 +632,6 @@ int submit_frame_into(bbr_context *c, int slot_index) {
     if (c->timing == 1) HIP_TRY(c, hipEventRecord(c->ring[bbr_context::kRingEvents * (c->ring_frames % bbr_context::kRingCap)], sg));
   }
   s.ctr_index = slot_index;
-  HIP_TRY(c, hipMemcpyAsync(s.d_staging.ptr, s.h_staging, total, hipMemcpyHostToDevice, sg));
-
   const Light *d_lights = reinterpret_cast<const Light *>(s.d_staging.ptr);
   const DrawDesc *d_draws = reinterpret_cast<const DrawDesc *>(s.d_staging.ptr + lights_bytes);
   FrameParams fp = make_params(c);
@@ -634,8 +647,52 @@ int submit_frame_into(bbr_context *c, int slot_index) {
   float4 *out = c->ext_out ? reinterpret_cast<float4 *>(c->ext_out) : s.d_frame.ptr;
   const FrameSlot *prev = (c->last_slot >= 0 && c->last_slot != slot_index) ? &c->slots[c->last_slot] : nullptr;
 
-  if (c->tile_mode == 0) launch_frame<64, 64>(c, s, prev, fp, pv, view, sp, d_lights, d_draws, c->n_live_draws, out);
-  else launch_frame<32, 32>(c, s, prev, fp, pv, view, sp, d_lights, d_draws, c->n_live_draws, out);
+  // Option "frame_graph": with one stream per frame slot (layout 2) a frame is a straight line of nodes -- copy, geometry,
+  // raster, items, shade tail, shade -- whose launch arguments only change when the camera, the frame size or a buffer
+  // does.  Once they have repeated, the line is captured into a hipGraph and replayed with ONE launch call per frame
+  // (the staged block -- lights, draw descriptors, instances -- is copied by the graph's own node, so its CONTENT may
+  // change freely); any other frame is launched node by node as usual.
+  bool shares_out = false;
+  for (const FrameSlot &o : c->slots) shares_out |= &o != &s && o.in_flight && o.out_used == out;
+  const bool graphable = c->frame_graph && c->pipelined() && c->layout == 2 && !c->timing_this && !c->dump_vis && !c->dump_gbuffer &&
+                         !shares_out && c->n_prims != 0;
+  std::vector<uint8_t> key;
+  if (graphable) {
+    auto put = [&](const void *p, size_t n) { key.insert(key.end(), (const uint8_t *)p, (const uint8_t *)p + n); };
+    const void *ptrs[] = {s.d_staging.ptr, s.h_staging, s.d_tris.ptr, s.d_attrs.ptr, s.d_clip.ptr, s.d_tile_count.ptr, s.d_bins.ptr,
+                          s.d_broad.ptr, c->d_materials.ptr, s.d_block_stats.ptr, s.d_frags.ptr, s.d_frag_count.ptr, s.h_flags,
+                          s.d_item_groups.ptr, s.d_items.ptr, s.d_cooked.ptr, s.d_background.ptr, s.d_depth.ptr, s.d_tile_order.ptr,
+                          s.d_present.ptr, c->d_srgb_tables.ptr, c->d_counters.ptr, c->d_counters_done.ptr, out, (const void *)sg};
+    const uint32_t words[] = {(uint32_t)total, c->n_live_draws, c->n_prims, s.h_flags ? s.h_flags[2] : 0u, (uint32_t)c->tile_mode,
+                              (uint32_t)c->present_fused, (uint32_t)c->tile_order, (uint32_t)c->overlays, (uint32_t)c->world,
+                              (uint32_t)c->local_bands(), (uint32_t)s.ctr_index};
+    put(&fp, sizeof fp); put(&sp, sizeof sp); put(&pv, sizeof pv); put(&view, sizeof view); put(ptrs, sizeof ptrs); put(words, sizeof words);
+  }
+  auto enqueue = [&](bool capturing) {
+    (void)hipMemcpyAsync(s.d_staging.ptr, s.h_staging, total, hipMemcpyHostToDevice, sg);
+    if (c->tile_mode == 0) launch_frame<64, 64>(c, s, prev, fp, pv, view, sp, d_lights, d_draws, c->n_live_draws, out, capturing);
+    else launch_frame<32, 32>(c, s, prev, fp, pv, view, sp, d_lights, d_draws, c->n_live_draws, out, capturing);
+  };
+  if (graphable && s.graph_exec && key == s.graph_key) {
+    HIP_TRY(c, hipGraphLaunch(s.graph_exec, sg));
+    HIP_TRY(c, hipEventRecord(s.ev_shade_done, sg));
+    s.stream_used = sg;
+    s.has_depth = c->overlays && c->world == 1;
+    ++c->graph_launches;
+  } else if (graphable && key == s.last_key) {  // the arguments have repeated: worth a capture
+    s.release_graph();
+    HIP_TRY(c, hipStreamBeginCapture(sg, hipStreamCaptureModeThreadLocal));
+    enqueue(true);
+    HIP_TRY(c, hipStreamEndCapture(sg, &s.graph));
+    HIP_TRY(c, hipGraphInstantiate(&s.graph_exec, s.graph, nullptr, nullptr, 0));
+    s.graph_key = key;
+    HIP_TRY(c, hipGraphLaunch(s.graph_exec, sg));
+    HIP_TRY(c, hipEventRecord(s.ev_shade_done, sg));
+    ++c->graph_captures;
+  } else {
+    enqueue(false);
+  }
+  s.last_key = key;
   HIP_TRY(c, hipGetLastError());
   s.in_flight = true;
   s.fused = c->present_fused;
@@ -1477,6 +1534,13 @@ int bbr_stream_layout_state(const bbr_context *c, int32_t *out_layout, int32_t *
   return BBR_OK;
 }
 
+int bbr_frame_graph_state(const bbr_context *c, uint32_t *out_launches, uint32_t *out_captures) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  if (out_launches) *out_launches = c->graph_launches;
+  if (out_captures) *out_captures = c->graph_captures;
+  return BBR_OK;
+}
+
 int bbr_shard_rows(const bbr_context *c, int32_t *out_rows) {
   if (!c || !out_rows) return BBR_ERR_INVALID_ARGUMENT;
   *out_rows = c->shard_rows();
@@ -1710,6 +1774,9 @@ int bbr_set_option(bbr_context *c, const char *name, int64_t value) {
   } else if (n == "stream_layout") {
     if (value < 0 || value >= bbr_context::kLayouts) return fail(c, BBR_ERR_INVALID_ARGUMENT, "stream_layout: 0, 1 or 2");
     c->layout_mode = (int)value;
+  } else if (n == "frame_graph") {
+    c->frame_graph = value != 0;
+    for (FrameSlot &s : c->slots) s.release_graph();
   } else if (n == "broad_cap" || n == "clip_cap") {
     // starting capacity of the every-tile list / the clip arena (entries); both double when a frame overflows them
     if (value < 1 || value > (1 << 24)) return fail(c, BBR_ERR_INVALID_ARGUMENT, n + " out of range (1 .. 2^24)");

@@ -200,8 +200,15 @@ int bbr_timing_summary(bbr_context *ctx, uint32_t *out_frames, float *out_avg_fr
  *                            raster of frame N).  2 (default): every kernel of a frame on the stream of its frame slot
  *                            (frames share nothing, whole frames overlap).  Three frames in flight, us per frame for
  *                            0 / 1 / 2: 1080p, one ShaderBall 84.5 / 67.1 / 37.3; 4K, sixteen 191.5 / 153.6 / 148.6.
+ *   "frame_graph" 0|1        (default 0) with stream layout 2 and more than one frame in flight: once a frame slot has seen
+ *                            the same launch arguments twice (same camera, sizes and buffers; the CONTENT of lights,
+ *                            draw descriptors and instances may change), its copy + kernels are captured into a
+ *                            hipGraph and every further such frame is ONE hipGraphLaunch; other frames are launched
+ *                            node by node as usual.  Same pixels either way.  bbr_frame_graph_state counts both.
  *   "ablate" bits            diagnostic builds only (make EXTRA=-DBB_ABLATE): skip parts of the pipeline */
 int bbr_set_option(bbr_context *ctx, const char *name, int64_t value);
+/* option "frame_graph": frames launched as a graph / graphs captured since bbr_create */
+int bbr_frame_graph_state(const bbr_context *ctx, uint32_t *out_launches, uint32_t *out_captures);
 /* The stream layout in use (option "stream_layout"; 0 while only one frame is in flight).  *out_decided is always 1 and
  * out_ms[3] all zero: the layout is a plain option, nothing is timed at run time (round 1 did). */
 int bbr_stream_layout_state(const bbr_context *ctx, int32_t *out_layout, int32_t *out_decided, float *out_ms);

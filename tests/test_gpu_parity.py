@@ -3,6 +3,7 @@ oracle on the same seeded inputs.  Integer results (winning primitive, depth bit
 bit-exact; colour must satisfy BASELINE's tolerance |d| <= 1e-4 * max(1, |ref|) per channel (the contract is
 written so that it is in fact bit-exact; the tests report when it is)."""
 import json
+from dataclasses import replace
 import os
 
 import numpy as np
@@ -489,6 +490,46 @@ def test_diagnostic_reads_keep_the_presented_image(maps64):
         first = r.read_presented()
         assert np.array_equal(first, r.read_presented())
         r.close()
+
+
+def test_frames_replayed_as_a_graph_are_the_same_frames(maps64):
+    """option frame_graph: a frame slot whose launch arguments repeat replays its copy + kernels as one hipGraph; a frame
+    with other arguments (another camera) is launched node by node again, and lights may change under a captured graph
+    (the staged block is copied by the graph's own node)"""
+    cfg = configs.C3.scaled(480, 270, 64)
+    sc = scenes.shaderball_scene(cfg, bbo.MaterialData(maps64))
+    ref, _, _, _ = bbo.render(sc)
+    r = Renderer(sc.width, sc.height)
+    r.set_option("frames_in_flight", 3)
+    r.set_option("frame_graph", 1)
+    h = r.render_scene(sc)
+    r.synchronize()                         # capacities settle
+    for _ in range(12):
+        h = r.render_scene(sc, h)
+    launches, captures = r.frame_graph_state()
+    assert captures == 3 and launches >= 3, (launches, captures)   # one graph per frame slot
+    assert np.array_equal(r.read_framebuffer().view(np.uint32), ref.view(np.uint32))
+    # other lights, same arguments: still the captured graphs
+    sc2 = scenes.shaderball_scene(cfg, bbo.MaterialData(maps64))
+    sc2.draws = sc.draws
+    sc2.frame = scenes.frame_uniforms([scenes.light(0, pos=(1.0 + i, 3.0, 2.0 - i), color=(0.3, 0.9, 0.5), intensity=70.0)
+                                       for i in range(len(cfg.lights))])   # same light COUNT (a launch argument), other lights
+    ref2, _, _, _ = bbo.render(sc2)
+    for _ in range(4):
+        h = r.render_scene(sc2, h)
+    assert r.frame_graph_state()[1] == captures
+    assert np.array_equal(r.read_framebuffer().view(np.uint32), ref2.view(np.uint32))
+    # another camera: new arguments -> plain launches, then new captures once they repeat
+    sc3 = scenes.shaderball_scene(replace(cfg, cam_pos=(0.5, 2.5, -2.5)), bbo.MaterialData(maps64))
+    sc3.draws = sc.draws
+    ref3, _, _, _ = bbo.render(sc3)
+    h = r.render_scene(sc3, h)
+    assert np.array_equal(r.read_framebuffer().view(np.uint32), ref3.view(np.uint32))
+    for _ in range(8):
+        h = r.render_scene(sc3, h)
+    assert r.frame_graph_state()[1] > captures
+    assert np.array_equal(r.read_framebuffer().view(np.uint32), ref3.view(np.uint32))
+    r.close()
 
 
 def test_api_lifecycle_user_stream_frees_and_timing(maps64):
