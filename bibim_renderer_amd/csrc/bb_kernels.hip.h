@@ -744,6 +744,7 @@ struct BilinearTaps {
   float fx, fy;
 };
 
+template <bool BLOCKED = false>
 BB_DEV BilinearTaps bilinear_taps(float u, float v, int w, int h) {
   float x = fmaf(u, (float)w, -0.5f);
   float y = fmaf(v, (float)h, -0.5f);
@@ -761,6 +762,20 @@ BB_DEV BilinearTaps bilinear_taps(float u, float v, int w, int h) {
   } else {
     x0 = wrap_repeat(ix, w); x1 = wrap_repeat(ix + 1, w);
     y0 = wrap_repeat(iy, h); y1 = wrap_repeat(iy + 1, h);
+  }
+  if (BLOCKED) {
+    // the packed material is stored block-linear, 4 x 4 texels per 144-byte block (written by bbr_upload_material):
+    // texel (x, y) = record ((y >> 2) * ceil(w / 4) + (x >> 2)) * 16 + (y & 3) * 4 + (x & 3).  A minified tap set touches
+    // one or two 128-byte lines instead of always two rows 9 w bytes apart.
+    const int w4 = (w + 3) >> 2;
+    const uint32_t row0 = ((uint32_t)mul32(y0 >> 2, w4) << 4) + (((uint32_t)y0 & 3u) << 2);
+    const uint32_t row1 = ((uint32_t)mul32(y1 >> 2, w4) << 4) + (((uint32_t)y1 & 3u) << 2);
+    const uint32_t col0 = (((uint32_t)x0 >> 2) << 4) + ((uint32_t)x0 & 3u), col1 = (((uint32_t)x1 >> 2) << 4) + ((uint32_t)x1 & 3u);
+    t.o00 = row0 + col0;
+    t.o10 = row0 + col1;
+    t.o01 = row1 + col0;
+    t.o11 = row1 + col1;
+    return t;
   }
   const uint32_t row0 = (uint32_t)mul32(y0, w), row1 = (uint32_t)mul32(y1, w);
   t.o00 = row0 + (uint32_t)x0;
@@ -1775,6 +1790,10 @@ __global__ __launch_bounds__(kShadeThreads) __attribute__((amdgpu_waves_per_eu(T
   // this wave's (first) item: wave-uniform, everything derived from it lives in scalar registers.  The item word is read
   // together with the item count, not after it (the list has room for every index a launch can produce): one dependent
   // round trip less in front of the fragments.
+  // (Workgroup b runs on XCD b % 8 -- tools/microbench/xcd_map.hip -- so neighbouring items, which share records and
+  //  texels, land in eight different L2s.  Giving each XCD a contiguous eighth of the item list cut k_shade's fetch traffic
+  //  by 23 % and made it 12 % SLOWER (98 vs 88 us): a hot region then loads one L2 / one XCD's texture units instead of
+  //  eight; runs of 4 / 16 / 64 workgroups per XCD: 87 / 89 / 94 us, no traffic gain.  Plain round-robin stays.)
   uint32_t j = first_item + (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (uint32_t)kShadeWaves + (threadIdx.x >> 6)));
   uint32_t item = items[1u + (TAIL ? 0u : j)];
   const uint32_t n_items = items[0];
@@ -1874,7 +1893,7 @@ __global__ __launch_bounds__(kShadeThreads) __attribute__((amdgpu_waves_per_eu(T
   float metallic, roughness, ao;
   if (packed_dims != 0u) {
     // packed material: one set of taps, four 12-byte loads of 9-byte records
-    const BilinearTaps tp = bilinear_taps(u, v, (int)(packed_dims & 0xFFFFu), (int)(packed_dims >> 16));
+    const BilinearTaps tp = bilinear_taps<true>(u, v, (int)(packed_dims & 0xFFFFu), (int)(packed_dims >> 16));
     const uint8_t *tb = packed_texels;
     uint32_t t00[3], t10[3], t01[3], t11[3];
     __builtin_memcpy(t00, tb + texel_offset(tp.o00), 12);

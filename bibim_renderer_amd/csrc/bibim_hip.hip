@@ -1256,8 +1256,11 @@ int bbr_upload_material(bbr_context *c, const bbr_image maps[BBR_MAP_COUNT], int
       }
     }
     if (ok) {
+      // block-linear: 4 x 4 texel blocks of 144 bytes, blocks in row-major order (packed_texel_index in bb_kernels.hip.h):
+      // the 2 x 2 footprint of a bilinear tap set then falls into one block 9 times out of 16
       const size_t n_texels = (size_t)pw * ph;
-      std::vector<uint8_t> host(n_texels * kPackedTexelBytes + kPackedTexelPad, 0);
+      const size_t w4 = ((size_t)pw + 3) / 4, h4 = ((size_t)ph + 3) / 4;
+      std::vector<uint8_t> host(w4 * h4 * 16 * kPackedTexelBytes + kPackedTexelPad, 0);
       auto texel = [&](int k, size_t i) -> const uint8_t * {
         const bbr_image &im = maps[k];
         return (im.rgba && im.width > 0 && im.height > 0) ? im.rgba + 4 * i : k_default[k];
@@ -1265,7 +1268,8 @@ int bbr_upload_material(bbr_context *c, const bbr_image maps[BBR_MAP_COUNT], int
       for (size_t i = 0; i < n_texels; ++i) {
         const uint8_t *al = texel(kMapAlbedo, i), *me = texel(kMapMetallic, i), *ro = texel(kMapRoughness, i);
         const uint8_t *ao = texel(kMapAO, i), *no = texel(kMapNormal, i);
-        uint8_t *t = host.data() + i * kPackedTexelBytes;
+        const size_t x = i % (size_t)pw, y = i / (size_t)pw;
+        uint8_t *t = host.data() + (((y >> 2) * w4 + (x >> 2)) * 16 + (y & 3) * 4 + (x & 3)) * kPackedTexelBytes;
         t[0] = al[0]; t[1] = al[1]; t[2] = al[2]; t[3] = me[0];
         t[4] = no[0]; t[5] = no[1]; t[6] = no[2]; t[7] = ro[0];
         t[8] = ao[0];
