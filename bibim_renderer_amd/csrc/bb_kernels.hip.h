@@ -974,7 +974,11 @@ BB_DEV void raster_triangle_wave(const RasterTri &t, uint32_t ref, int tile_x0, 
 constexpr int kItemsThreads = 256;  // launch slots per workgroup of k_shade_items
 constexpr int kItemGroupSlots = 32, kItemGroups = 2048;  // k_raster's chunk totals: one counter per 32 launch slots (fewer
                                                           // addresses made the atomics cost k_raster 7 us at C3)
-constexpr int kItemChunkBits = 6, kItemTxBits = 13;  // item = grid row << 19 | tile column << 6 | chunk of 64 fragments
+constexpr int kItemChunkBits = 6, kItemTxBits = 12;  // item = full << 31 | grid row << 18 | tile column << 6 | chunk of 64 fragments
+// A tile that ONE triangle covers completely and nothing else touches has no fragment list: its count word carries this flag
+// and the tile's list holds a single word (pixel field 0); fragment p of the tile is that word with p in the pixel field.
+// k_shade_items hands the flag on in the item word, so that k_shade knows before it loads anything.
+constexpr uint32_t kFullTile = 0x80000000u;
 constexpr int kFragPixBits = 12;  // pixel-in-tile field of a fragment's high word (tiles of up to 64x64); the clip slot + 1 sits above it
 constexpr int kTileThreads = 256;
 constexpr int kTileWaves = kTileThreads / 64;
@@ -1394,9 +1398,9 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
   if (fast_full) {
     const unsigned long long ref = (unsigned long long)(s_full_ref - 1u);
     const unsigned long long hi = (unsigned long long)s_full_clip << kFragPixBits;
-    for (int p = tid; p < TILE_PIXELS; p += kTileThreads) my_frags[p] = ((hi | (unsigned long long)(uint32_t)p) << 32) | ref;
     if (tid == 0) {
-      frag_count[tile] = (uint32_t)TILE_PIXELS;
+      my_frags[0] = (hi << 32) | ref;  // the whole list: 8 bytes instead of 8 KB written here and read back by k_shade
+      frag_count[tile] = (uint32_t)TILE_PIXELS | kFullTile;
       if (item_groups) atomicAdd(&item_groups[slot / kItemGroupSlots], (uint32_t)(TILE_PIXELS / 64));
     }
     return;
@@ -1646,7 +1650,8 @@ BB_DEV uint32_t slot_chunks(const FrameParams &fp, const uint32_t *__restrict__ 
   const int gy = (int)(slot / (uint32_t)grid_x), tx = (int)(slot - (uint32_t)gy * (uint32_t)grid_x);
   int ty, out_tile_row;
   if (!tile_row(fp, gy, ty, out_tile_row)) return 0u;
-  return (frag_count[(uint32_t)ty * (uint32_t)fp.tiles_x + (uint32_t)tx] + 63u) >> 6;
+  const uint32_t n = frag_count[(uint32_t)ty * (uint32_t)fp.tiles_x + (uint32_t)tx];
+  return (((n & ~kFullTile) + 63u) >> 6) | (n & kFullTile);  // (chunks, with the full-tile flag kept on top)
 }
 
 // One workgroup per 256 launch slots, no communication between workgroups: the items in front of a workgroup's slots are
@@ -1674,7 +1679,8 @@ __global__ __launch_bounds__(kItemsThreads) void k_shade_items(FrameParams fp, c
     const uint32_t g = (uint32_t)q * kItemsThreads + (uint32_t)tid;
     before += g < first / kItemGroupSlots ? item_groups[g] : 0u;
   }
-  const uint32_t chunks = slot_chunks(fp, frag_count, first + (uint32_t)tid, n_slots, grid_x);
+  const uint32_t chunks_flag = slot_chunks(fp, frag_count, first + (uint32_t)tid, n_slots, grid_x);
+  const uint32_t chunks = chunks_flag & ~kFullTile;
   uint32_t incl = chunks;  // inclusive scan of this workgroup's slots, wave level
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
@@ -1694,7 +1700,7 @@ __global__ __launch_bounds__(kItemsThreads) void k_shade_items(FrameParams fp, c
   const uint32_t slot = first + (uint32_t)tid;
   if (chunks != 0u) {
     const uint32_t gy = slot / (uint32_t)grid_x, tx = slot - gy * (uint32_t)grid_x;
-    const uint32_t word = (gy << (kItemChunkBits + kItemTxBits)) | (tx << kItemChunkBits);
+    const uint32_t word = (chunks_flag & kFullTile) | (gy << (kItemChunkBits + kItemTxBits)) | (tx << kItemChunkBits);
     for (uint32_t c = 0; c < chunks; ++c) items[at + c] = word | c;
   }
   // the workgroup of the last slot knows the total
@@ -1802,13 +1808,23 @@ __global__ __launch_bounds__(kShadeThreads) __attribute__((amdgpu_waves_per_eu(T
   do {  // (a loop only in the TAIL instantiation)
   if (TAIL) item = items[1u + j];
   const int chunk = (int)(item & 63u);
-  const int tx = (int)((item >> 6) & 8191u);
+  const int tx = (int)((item >> kItemChunkBits) & ((1u << kItemTxBits) - 1u));
   int ty, out_tile_row;
-  tile_row(fp, (int)(item >> 19), ty, out_tile_row);
+  tile_row(fp, (int)((item & ~kFullTile) >> (kItemChunkBits + kItemTxBits)), ty, out_tile_row);
   const uint32_t tile = (uint32_t)ty * (uint32_t)fp.tiles_x + (uint32_t)tx;
-  const uint32_t n_frag = frag_count[tile];
-  const bool valid = (uint32_t)chunk * 64u + (uint32_t)lane < n_frag;
-  const unsigned long long frag = frags[(size_t)tile * TILE_PIXELS + (uint32_t)chunk * 64u + (uint32_t)lane];
+  bool valid;
+  unsigned long long frag;
+  if (item & kFullTile) {
+    // a tile one triangle covers completely: no list, no count -- one word through the scalar cache, the pixel is the
+    // lane's own (and the wave is uniform: its primitive record comes through the scalar cache too)
+    typedef const unsigned long long __attribute__((address_space(4))) *ConstFrags;
+    frag = ((ConstFrags)frags)[(size_t)tile * TILE_PIXELS] + ((unsigned long long)((uint32_t)chunk * 64u + (uint32_t)lane) << 32);
+    valid = true;
+  } else {
+    const uint32_t n_frag = frag_count[tile];
+    valid = (uint32_t)chunk * 64u + (uint32_t)lane < n_frag;
+    frag = frags[(size_t)tile * TILE_PIXELS + (uint32_t)chunk * 64u + (uint32_t)lane];
+  }
   BB_KSTAMP(1);  // item word, count and fragment arrived
   const uint32_t ref = (uint32_t)frag;
   uint32_t prim = BB_ABLATE(16u) ? 0u : (ref >> 3);

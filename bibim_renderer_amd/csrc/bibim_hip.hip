@@ -342,7 +342,7 @@ Mat4 proj_view(const ViewUniformBlock &v) {
 }
 
 FrameParams make_params(const bbr_context *c) {
-  FrameParams fp;
+  FrameParams fp = {};  // (the overlay fields stay 0 for the main pass: the block is also the key of option frame_graph)
   fp.width = c->width;
   fp.height = c->height;
   fp.half_w = 0.5f * (float)c->width;
@@ -638,7 +638,7 @@ int submit_frame_into(bbr_context *c, int slot_index) {
   // forward: gl_Position = (P*V) * posWorld; deferred: P * (V * posWorld) -- the kernel gets P and V separately
   Mat4 pv = c->deferred ? c->view_u.proj : proj_view(c->view_u);
   const Mat4 view = c->view_u.view;
-  ShadeParams sp;
+  ShadeParams sp = {};
   std::memcpy(sp.view_pos, c->view_u.view_pos, sizeof sp.view_pos);
   sp.enable_normal_map = c->view_u.enable_normal_map;
   sp.tone_enable = c->frame_u.enable_tone_mapping;
@@ -1592,7 +1592,7 @@ int bbr_get_stats(bbr_context *c, bbr_stats *out) {
     int band_tiles = c->eff_band_rows() / c->tile_h();
     for (int ty = 0; ty < c->tiles_y(); ++ty) {
       if (c->world > 1 && ((ty / band_tiles) % c->world) != c->rank) continue;
-      for (int tx = 0; tx < c->tiles_x(); ++tx) out->n_shaded += fc[(size_t)ty * c->tiles_x() + tx];
+      for (int tx = 0; tx < c->tiles_x(); ++tx) out->n_shaded += fc[(size_t)ty * c->tiles_x() + tx] & ~kFullTile;
     }
   }
   out->n_broad_tris = h.n_broad;
