@@ -158,8 +158,11 @@ def main():
                     help="HIP events around k_shade on every n-th step of the timed region; 0 = ten samples spread over it (events on every step cost "
                          "about 6 %% of the frame rate they are there to describe: each pair keeps consecutive k_shade launches "
                          "from overlapping head to tail)")
-    ap.add_argument("--frames-in-flight", type=int, default=3, choices=[1, 2, 3, 4],
-                    help="frames queued on the GPU at once (the reference keeps 2; 3 keeps the host off the critical path: +2 %%)")
+    ap.add_argument("--frames-in-flight", type=int, default=None, choices=[1, 2, 3, 4],
+                    help="frames queued on the GPU at once (the reference keeps 2).  Default 3, and 4 for c2: a 1080p frame is a "
+                         "chain of dependent kernels ~95 us long that fills a fraction of the GPU, so its rate is chain length / "
+                         "frames in flight (C2: 48 / 34 / 28 us per frame with 2 / 3 / 4); at 4K three frames fill the machine "
+                         "(C3: 147 / 134 / 135 us)")
     ap.add_argument("--stream-layout", type=int, default=2, choices=[0, 1, 2],
                     help="option stream_layout of the library (include/bibim_hip.h); 2 (one stream per frame slot) is its default")
     ap.add_argument("--frame-graph", type=int, default=0, choices=[0, 1],
@@ -187,6 +190,8 @@ def main():
                     help="every step also runs the presentation step (tone map + sRGB + RGBA8, SURVEY 8(f) rank 1); "
                          "for N > 1 the RGBA8 shards are gathered instead of the fp32 ones (a quarter of the payload)")
     args = ap.parse_args()
+    if args.frames_in_flight is None:
+        args.frames_in_flight = 4 if args.workload == "c2" else 3
 
     # The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints a version banner when its
     # communicator comes up): from here on file descriptor 1 is stderr, and the JSON line goes to the real stdout.
