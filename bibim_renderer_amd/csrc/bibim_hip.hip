@@ -1,8 +1,8 @@
 // bibim_hip.hip -- C-ABI (include/bibim_hip.h) over the HIP kernels in bb_kernels.hip.h.
 //
-// One context = one GPU, one HIP stream, all buffers resident in HBM for the context's lifetime.
-// A frame is: [H2D of lights + draw descriptors + instances, one async copy from pinned staging] -> k_geometry
-// (all draws) -> k_raster (per tile) -> k_shade (per visible pixel).  No host synchronisation inside a frame; capacities (bins, broad list, clip arena) are
+// One context = one GPU, up to four frames in flight (each on the stream of its slot), all buffers resident in HBM for the
+// context's lifetime.  A frame is: [H2D of lights + draw descriptors + instances, one async copy from pinned staging] ->
+// k_geometry (all draws) -> k_raster (per tile; also the frame's item list and light table) -> k_shade (per 64 visible pixels).  No host synchronisation inside a frame; capacities (bins, broad list, clip arena) are
 // checked lazily at the next synchronising call and the frame is re-rendered once after growing them.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>  // types and prototypes only: the library is opened at bbr_comm_init (see the exchange section)
@@ -123,7 +123,7 @@ struct FrameSlot {
   DeviceBuffer<uint32_t> d_frag_count;
   DeviceBuffer<uint32_t> d_tile_order;  // k_raster launch slots, heaviest tiles first
   DeviceBuffer<uint32_t> d_items;       // k_shade's work list: [0] = count, then slot << 6 | chunk of 64 fragments
-  DeviceBuffer<CookedLight> d_cooked;   // the frame's light table as the light loop consumes it (k_shade_items -> k_shade)
+  DeviceBuffer<CookedLight> d_cooked;   // the frame's light table as the light loop consumes it (k_raster -> k_shade)
   DeviceBuffer<uint32_t> d_item_regions; // items appended per region of the frame's item list (k_raster -> k_shade)
   DeviceBuffer<float4> d_frame;
   DeviceBuffer<float4> d_background;  // deferred path: colour of the pixels no geometry covers
@@ -502,7 +502,7 @@ void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const Fra
   if (ev) (void)hipEventRecord(ev[3], ss);  // completes when the shade stream has seen "raster done"
   uint2 *gbuf = (fp.deferred && c->dump_gbuffer) ? c->d_gbuffer.ptr : nullptr;
   // Main launch: one item (64 fragments) per wave, four per workgroup, sized from the item count of the frame this slot
-  // rendered last (k_shade_items leaves it in pinned host memory) plus 3 %; tail launch: a small persistent grid for
+  // rendered last (k_shade's first workgroup leaves the list's extent in pinned host memory) plus 3 %; tail launch: a small persistent grid for
   // whatever lies behind that (a scene that suddenly grew; normally nothing, and its workgroups exit at once).
   const uint32_t max_items = (uint32_t)item_list_capacity(c);  // (the list's extent: 32 x its fullest region)
   const uint32_t seen = s.h_flags ? s.h_flags[2] : 0u;
