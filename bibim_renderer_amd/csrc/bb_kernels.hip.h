@@ -62,9 +62,6 @@ BB_DEV float bb_rcp_slow(float x) { return 1.0f / x; }
 // exec-mask save / restore -- five scalar instructions and a branch around each of the shader's sixteen guards per
 // pixel, a tenth of a wave's issue slots.)
 BB_DEV float bb_rsqrt(float x) {
-#ifdef BB_EXPERIMENT_HW_TRANS
-  return __builtin_amdgcn_rsqf(x);
-#endif
   float y = __uint_as_float(0x5F375A86u - (__float_as_uint(x) >> 1));
   const float h = 0.5f * x;
   y = y * fmaf(-(h * y), y, 1.5f);
@@ -82,9 +79,6 @@ BB_DEV float bb_rsqrt(float x) {
 // tools/microbench/exact_rcp.hip) -- the result does not depend on which 1-ulp seed the hardware returns.  The same
 // idea does not work for 1/sqrt (13 % of the inputs end up off by an ulp), so bb_rsqrt keeps its integer seed.
 BB_DEV float bb_rcp(float x) {
-#ifdef BB_EXPERIMENT_HW_TRANS
-  return __builtin_amdgcn_rcpf(x);
-#endif
   const float y0 = __builtin_amdgcn_rcpf(x);
   float y = fmaf(y0, fmaf(-x, y0, 1.0f), y0);
   // a seed that is not a normal number (x zero, denormal, huge, infinite or NaN): the IEEE division.  One v_cmp_class
@@ -99,9 +93,6 @@ BB_DEV float bb_rcp(float x) {
 // branch are a twentieth of k_shade's instruction stream).  Each use states its proof; k_selftest_rcp checks the
 // whole range [2^-100, 2^100] against the IEEE division.
 BB_DEV float bb_rcp_normal(float x) {
-#ifdef BB_EXPERIMENT_HW_TRANS
-  return __builtin_amdgcn_rcpf(x);
-#endif
   const float y = __builtin_amdgcn_rcpf(x);
   return fmaf(y, fmaf(-x, y, 1.0f), y);
 }
@@ -517,6 +508,9 @@ BB_DEV void clip_primitive_wave(ClipWork &w, int owner, const float (*clip)[4], 
 // reads count[J % 32] beside its item word.  (Round 2 first built the list with a scan kernel between k_raster and
 // k_shade: 4.5 us and a kernel boundary on every frame's chain of dependent kernels.)
 constexpr int kItemRegions = 32;
+// each region's counter in a cache line of its own (128 bytes apart): atomics on one LINE serialise like atomics on one
+// address (all 32 counters in one line cost k_raster 36 us at C5's 32 640 tiles)
+constexpr int kItemRegionStride = 32;
 
 // One thread per primitive, all draw calls of the frame in one launch (API order = primitive index order).
 // OVERLAY = true is the overlay subpass (light markers, corner gizmo): other vertex programs and a
@@ -530,7 +524,7 @@ __global__ __launch_bounds__(256) void k_geometry(const DrawDesc *__restrict__ d
                                                   const MaterialDesc *__restrict__ materials,
                                                   BlockStats *__restrict__ block_stats, uint32_t *__restrict__ item_regions) {
   // the item counters of the slot's previous frame have done their job (its k_shade is complete: same stream)
-  if (item_regions && blockIdx.x == 0 && threadIdx.x < (unsigned)kItemRegions) item_regions[threadIdx.x] = 0u;
+  if (item_regions && blockIdx.x == 0 && threadIdx.x < (unsigned)kItemRegions) item_regions[threadIdx.x * kItemRegionStride] = 0u;
 #ifdef BB_STAMPS
 #define BB_STAMP(i) do { if (threadIdx.x == 0) reinterpret_cast<unsigned long long *>(clip_arena + fp.clip_cap)[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
 #else
@@ -1279,11 +1273,13 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
   __shared__ uint32_t s_clip_ref[kClipRefs], s_clip_slot[kClipRefs], s_n_clip_refs, s_full_clip;
   __shared__ unsigned long long s_pad_frag;
   __shared__ uint32_t s_item_base;
-  // this tile's items (one per 64 fragments) go to the frame's list: every thread of the workgroup calls it
+  // this tile's items (one per 64 fragments) go to the frame's list: every thread of the workgroup calls it.  (Reserving
+  // the room earlier -- a counting sweep over the keys, so that the compaction's stores cover the atomic's round trip --
+  // cost more than it hid: k_raster +6 us at C5.)
   auto append_items = [&](uint32_t chunks, uint32_t flag) {
     if (!items || chunks == 0u) return;  // (uniform)
     const uint32_t region = slot & (uint32_t)(kItemRegions - 1);
-    if (tid == 0) s_item_base = atomicAdd(&item_regions[region], chunks);
+    if (tid == 0) s_item_base = atomicAdd(&item_regions[region * kItemRegionStride], chunks);
     __syncthreads();
     if ((uint32_t)tid < chunks)
       items[1u + (size_t)(s_item_base + (uint32_t)tid) * kItemRegions + region] =
@@ -1733,7 +1729,7 @@ __global__ __launch_bounds__(kShadeThreads) __attribute__((amdgpu_waves_per_eu(T
   // the extent of the frame's item list (32 x the fullest region) goes to pinned host memory: it sizes the main launch of
   // this slot's next frame
   if (!TAIL && blockIdx.x == 0 && threadIdx.x < 64u && host_extent) {
-    uint32_t m = threadIdx.x < (unsigned)kItemRegions ? item_regions[threadIdx.x] : 0u;
+    uint32_t m = threadIdx.x < (unsigned)kItemRegions ? item_regions[threadIdx.x * kItemRegionStride] : 0u;
 #pragma unroll
     for (int d = 1; d < kItemRegions; d <<= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d));
     if (threadIdx.x == 0) *host_extent = m * (uint32_t)kItemRegions;
@@ -1761,18 +1757,18 @@ __global__ __launch_bounds__(kShadeThreads) __attribute__((amdgpu_waves_per_eu(T
   uint32_t item = TAIL ? 0u : ((ConstWords)items)[1u + j];
   uint32_t n_items;  // TAIL: the extent of the list; otherwise j + 1 if this wave's item exists
   if (TAIL) {
-    uint32_t m = (uint32_t)lane < (uint32_t)kItemRegions ? item_regions[lane] : 0u;
+    uint32_t m = (uint32_t)lane < (uint32_t)kItemRegions ? item_regions[lane * kItemRegionStride] : 0u;
 #pragma unroll
     for (int d = 1; d < kItemRegions; d <<= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d));
     n_items = (uint32_t)__builtin_amdgcn_readfirstlane((int)m) * (uint32_t)kItemRegions;
   } else {
-    n_items = (j >> 5) < ((ConstWords)item_regions)[j & (uint32_t)(kItemRegions - 1)] ? j + 1u : 0u;
+    n_items = (j >> 5) < ((ConstWords)item_regions)[(j & (uint32_t)(kItemRegions - 1)) * kItemRegionStride] ? j + 1u : 0u;
   }
   if (BB_ABLATE(2048u)) sp.num_lights = 0;
   if (j >= n_items) return;  // a wave without an item (the kernel has no barrier: waves come and go on their own)
   do {  // (a loop only in the TAIL instantiation)
   if (TAIL) {
-    if ((j >> 5) >= item_regions[j & (uint32_t)(kItemRegions - 1)]) {  // a hole: this region is shorter than the fullest
+    if ((j >> 5) >= item_regions[(j & (uint32_t)(kItemRegions - 1)) * kItemRegionStride]) {  // a hole: this region is shorter than the fullest
       j += gridDim.x * (uint32_t)kShadeWaves;
       continue;
     }

@@ -411,7 +411,7 @@ int ensure_slot_buffers(bbr_context *c, FrameSlot &s) {
   HIP_TRY(c, s.d_items.ensure(1 + item_list_capacity(c) + kShadeWaves, true));
   if (c->tiles_x() > (1 << kItemTxBits) || c->tiles_y() > (1 << (31 - kItemChunkBits - kItemTxBits)))
     return fail(c, BBR_ERR_INVALID_ARGUMENT, "frame too large for the item word");  // (32768 pixels are 1024 tiles)
-  HIP_TRY(c, s.d_item_regions.ensure(kItemRegions, true));
+  HIP_TRY(c, s.d_item_regions.ensure(kItemRegions * kItemRegionStride, true));
   HIP_TRY(c, s.d_cooked.ensure(kMaxNumLights));
   if (c->deferred) HIP_TRY(c, s.d_background.ensure(2));
   if (c->overlays && &s != &c->ov) HIP_TRY(c, s.d_depth.ensure((size_t)c->width * c->height));
@@ -463,7 +463,7 @@ void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const Fra
                        c->n_prims, pv, view, fp, s.d_tris.ptr, s.d_attrs.ptr, s.d_clip.ptr, ctr, s.d_tile_count.ptr,
                        s.d_bins.ptr, s.d_broad.ptr, c->d_materials.ptr, s.d_block_stats.ptr, s.d_item_regions.ptr);
   else  // (k_geometry's first workgroup clears the slot's item counters; no geometry, no k_geometry)
-    (void)hipMemsetAsync(s.d_item_regions.ptr, 0, kItemRegions * sizeof(uint32_t), sg);
+    (void)hipMemsetAsync(s.d_item_regions.ptr, 0, kItemRegions * kItemRegionStride * sizeof(uint32_t), sg);
   if (ev && c->timing == 1) (void)hipEventRecord(ev[1], sg);
   if (sr != sg) {
     (void)hipEventRecord(s.ev_geom_done, sg);
