@@ -501,17 +501,6 @@ BB_DEV void clip_primitive_wave(ClipWork &w, int owner, const float (*clip)[4], 
   }
 }
 
-// The frame's item list is written by k_raster itself: a tile's workgroup reserves room for its chunks with ONE returning
-// atomic and stores the item words.  A single counter would serialise 5 600 atomics per C3 frame on one address (a
-// device-scope counter takes ~90 per us); the list is therefore kItemRegions interleaved sub-lists -- tile slot s appends
-// to region s % 32, entry i of region r is item number 32 i + r -- which the slots fill evenly, and k_shade's wave J
-// reads count[J % 32] beside its item word.  (Round 2 first built the list with a scan kernel between k_raster and
-// k_shade: 4.5 us and a kernel boundary on every frame's chain of dependent kernels.)
-constexpr int kItemRegions = 32;
-// each region's counter in a cache line of its own (128 bytes apart): atomics on one LINE serialise like atomics on one
-// address (all 32 counters in one line cost k_raster 36 us at C5's 32 640 tiles)
-constexpr int kItemRegionStride = 32;
-
 // One thread per primitive, all draw calls of the frame in one launch (API order = primitive index order).
 // OVERLAY = true is the overlay subpass (light markers, corner gizmo): other vertex programs and a
 // per-primitive viewport, everything downstream of the vertex stage shared.
@@ -522,9 +511,7 @@ __global__ __launch_bounds__(256) void k_geometry(const DrawDesc *__restrict__ d
                                                   Counters *__restrict__ ctr, uint32_t *__restrict__ tile_count,
                                                   uint32_t *__restrict__ bins, BroadTri *__restrict__ broad_list,
                                                   const MaterialDesc *__restrict__ materials,
-                                                  BlockStats *__restrict__ block_stats, uint32_t *__restrict__ item_regions) {
-  // the item counters of the slot's previous frame have done their job (its k_shade is complete: same stream)
-  if (item_regions && blockIdx.x == 0 && threadIdx.x < (unsigned)kItemRegions) item_regions[threadIdx.x * kItemRegionStride] = 0u;
+                                                  BlockStats *__restrict__ block_stats) {
 #ifdef BB_STAMPS
 #define BB_STAMP(i) do { if (threadIdx.x == 0) reinterpret_cast<unsigned long long *>(clip_arena + fp.clip_cap)[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
 #else
@@ -975,10 +962,16 @@ BB_DEV void raster_triangle_wave(const RasterTri &t, uint32_t ref, int tile_x0, 
   }
 }
 
+constexpr int kItemsThreads = 256;  // launch slots per workgroup of k_shade_items
+// words between two of k_raster's chunk counters: a 128-byte cache line each.  Atomics on one LINE serialise like atomics on
+// one address (packed 32 to a line they cost k_raster 5 us at C5's 32 640 tiles)
+constexpr int kItemGroupStride = 32;
+constexpr int kItemGroupSlots = 32, kItemGroups = 2048;  // k_raster's chunk totals: one counter per 32 launch slots (fewer
+                                                          // addresses made the atomics cost k_raster 7 us at C3)
 constexpr int kItemChunkBits = 6, kItemTxBits = 12;  // item = full << 31 | grid row << 18 | tile column << 6 | chunk of 64 fragments
 // A tile that ONE triangle covers completely and nothing else touches has no fragment list: its count word carries this flag
 // and the tile's list holds a single word (pixel field 0); fragment p of the tile is that word with p in the pixel field.
-// k_raster sets the flag in the tile's item words too, so that k_shade knows before it loads anything.
+// k_shade_items hands the flag on in the item word, so that k_shade knows before it loads anything.
 constexpr uint32_t kFullTile = 0x80000000u;
 constexpr int kFragPixBits = 12;  // pixel-in-tile field of a fragment's high word (tiles of up to 64x64); the clip slot + 1 sits above it
 constexpr int kTileThreads = 256;
@@ -1171,39 +1164,6 @@ BB_DEV RasterTri staged_tri(const StagedTri &st, int j) {
 // OVERLAY = true (overlay subpass): the keys start from the scene's resolved depth (`depth_io`, read) instead of 0,
 // gizmo primitives are scissored to their rectangle and biased above everything else, pixels no overlay primitive
 // wins are left alone (no background fill).  OVERLAY = false with depth_io != nullptr stores the resolved depth.
-// One light as k_shade's light loop consumes it (48 bytes): cooked once per frame by k_raster's first workgroup and read
-// through the scalar cache; k_deferred_background stages its own copy in LDS.
-struct CookedLight {
-  float px, py, pz;
-  int32_t type;
-  float cr, cg, cb;  // color * intensity
-  float outer;
-  float dx, dy, dz;  // type 1: normalize(-dir); type 2: -normalize(dir)
-  float inv_eps;     // type 1: 1 / (inner - outer)
-};
-struct ShadeShared {
-  CookedLight lights[kMaxNumLights];
-};
-
-BB_DEV CookedLight cook_light(const Light &l) {
-  CookedLight c;
-  c.px = l.pos[0]; c.py = l.pos[1]; c.pz = l.pos[2];
-  c.type = l.type;
-  c.cr = l.color[0] * l.intensity; c.cg = l.color[1] * l.intensity; c.cb = l.color[2] * l.intensity;
-  c.outer = l.outer_cutoff;
-  c.dx = c.dy = c.dz = 0.0f;
-  c.inv_eps = 0.0f;
-  if (l.type == 1) {
-    const f3 d = normalize3(neg3(ld3(l.dir)));
-    c.dx = d.x; c.dy = d.y; c.dz = d.z;
-    c.inv_eps = bb_rcp(l.inner_cutoff - l.outer_cutoff);
-  } else if (l.type == 2) {
-    const f3 d = neg3(normalize3(ld3(l.dir)));
-    c.dx = d.x; c.dy = d.y; c.dz = d.z;
-  }
-  return c;
-}
-
 template <int TILE_W, int TILE_H, bool OVERLAY = false>
 __global__ __launch_bounds__(kTileThreads) void k_raster(
     FrameParams fp, const RasterTri *__restrict__ tris, const ClipSlot *__restrict__ clip_arena,
@@ -1212,8 +1172,7 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
     unsigned long long *__restrict__ frags, uint32_t *__restrict__ frag_count, float4 *__restrict__ out,
     uint32_t *__restrict__ vis_prim, float *__restrict__ vis_depth, const uint32_t *__restrict__ tile_order,
     const float4 *__restrict__ background, float *__restrict__ depth_io, uint32_t *__restrict__ host_flags,
-    uint32_t *__restrict__ out8, uint32_t *__restrict__ item_regions, uint32_t *__restrict__ items,
-    const Light *__restrict__ lights, int num_lights, CookedLight *__restrict__ cooked) {
+    uint32_t *__restrict__ out8, uint32_t *__restrict__ item_groups) {
   constexpr int TILE_PIXELS = TILE_W * TILE_H;
   __shared__ unsigned long long keys[TILE_PIXELS];
   __shared__ StagedTri st;
@@ -1222,10 +1181,7 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // {overflow bits, bin_need, -, every-tile entries asked for, clip slots asked for} of this frame straight into pinned host
   // memory (final since k_geometry ended): the host looks at them when it reuses the frame's slot -- a few stores instead
-  // of a copy kernel on the stream.  (Word 2 is the frame's shade item count, stored by k_shade.)
-  // the frame's cooked light table (k_shade reads it through the scalar cache): once per frame, by the first workgroup
-  if (cooked && blockIdx.x == 0 && blockIdx.y == 0)
-    for (int li = tid; li < num_lights; li += kTileThreads) cooked[li] = cook_light(lights[li]);
+  // of a copy kernel on the stream.  (Word 2 is the frame's shade item count, stored by k_shade_items.)
   if (host_flags && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
     host_flags[0] = ctr->overflow;
     host_flags[1] = ctr->bin_need;
@@ -1272,19 +1228,6 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
   constexpr uint32_t kClipRefs = 32;
   __shared__ uint32_t s_clip_ref[kClipRefs], s_clip_slot[kClipRefs], s_n_clip_refs, s_full_clip;
   __shared__ unsigned long long s_pad_frag;
-  __shared__ uint32_t s_item_base;
-  // this tile's items (one per 64 fragments) go to the frame's list: every thread of the workgroup calls it.  (Reserving
-  // the room earlier -- a counting sweep over the keys, so that the compaction's stores cover the atomic's round trip --
-  // cost more than it hid: k_raster +6 us at C5.)
-  auto append_items = [&](uint32_t chunks, uint32_t flag) {
-    if (!items || chunks == 0u) return;  // (uniform)
-    const uint32_t region = slot & (uint32_t)(kItemRegions - 1);
-    if (tid == 0) s_item_base = atomicAdd(&item_regions[region * kItemRegionStride], chunks);
-    __syncthreads();
-    if ((uint32_t)tid < chunks)
-      items[1u + (size_t)(s_item_base + (uint32_t)tid) * kItemRegions + region] =
-          flag | ((uint32_t)grid_row << (kItemChunkBits + kItemTxBits)) | ((uint32_t)tx << kItemChunkBits) | (uint32_t)tid;
-  };
   if (tid < (int)kBinClasses)
     s_n_cls[tid] = BB_ABLATE(1u | (256u << tid)) ? 0u : min(tile_count[tile * kBinClasses + tid], fp.bin_cap);
   // A frame whose every-tile list overflowed (bit 1 of ctr->overflow, final since k_geometry ended) is rendered again after
@@ -1452,8 +1395,8 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
     if (tid == 0) {
       my_frags[0] = (hi << 32) | ref;  // the whole list: 8 bytes instead of 8 KB written here and read back by k_shade
       frag_count[tile] = (uint32_t)TILE_PIXELS | kFullTile;
+      if (item_groups) atomicAdd(&item_groups[(slot / kItemGroupSlots) * kItemGroupStride], (uint32_t)(TILE_PIXELS / 64));
     }
-    append_items((uint32_t)(TILE_PIXELS / 64), kFullTile);
     return;
   }
   const uint32_t n_clip_refs = s_n_clip_refs <= kClipRefs ? s_n_clip_refs : 0u;  // too many: k_shade looks the slots up
@@ -1502,8 +1445,11 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
     const uint32_t n = s_count;
     if (n != 0u && (n & 63u) != 0u && tid < (int)(64u - (n & 63u))) my_frags[n + (uint32_t)tid] = s_pad_frag;
   }
-  if (tid == 0) frag_count[tile] = s_count;  // (N_shaded = sum of these, taken on the host on demand)
-  append_items((s_count + 63u) >> 6, 0u);
+  if (tid == 0) {
+    frag_count[tile] = s_count;  // (N_shaded = sum of these, taken on the host on demand)
+    // 64-fragment chunks per group of 256 launch slots: what k_shade_items needs to place this group's items
+    if (item_groups && s_count) atomicAdd(&item_groups[(slot / kItemGroupSlots) * kItemGroupStride], (s_count + 63u) >> 6);
+  }
   BB_RSTAMP(4);
   if (tid == 0) {
     BB_RSTAMP(5);
@@ -1530,9 +1476,42 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
 //                                                           rounding puts a cosine of unit vectors above 1 (<= 2 ulp)
 // Why the shape matters on gfx950 (tools/microbench/issue_rate.hip, profiles/r02_issue_rate.txt): v_fma/mul/add_f32 on
 // VGPR operands issue every 2 cycles per SIMD, but ANY scalar-register operand, v_max, v_cmp, every conversion and
-// v_pk_* cost more (iso_* rows).  Per-light constants are cooked once per frame and reach the loop through the scalar
-// cache (ConstLights below).
+// v_pk_* cost 4, v_rcp 8.  Light data therefore reaches the loop through LDS (ds_read broadcasts cost no vector-ALU
+// cycle) instead of scalar loads, per-light constants are cooked once per workgroup, and the loop body is 216 issue
+// cycles per light against 286 for the statement-by-statement form.
 // ------------------------------------------------------------------------------------------------
+
+// One light as the loop consumes it: 48 bytes in LDS, written once per workgroup by cook_light.
+struct CookedLight {
+  float px, py, pz;
+  int32_t type;
+  float cr, cg, cb;  // color * intensity
+  float outer;
+  float dx, dy, dz;  // type 1: normalize(-dir); type 2: -normalize(dir)
+  float inv_eps;     // type 1: 1 / (inner - outer)
+};
+struct ShadeShared {
+  CookedLight lights[kMaxNumLights];
+};
+
+BB_DEV CookedLight cook_light(const Light &l) {
+  CookedLight c;
+  c.px = l.pos[0]; c.py = l.pos[1]; c.pz = l.pos[2];
+  c.type = l.type;
+  c.cr = l.color[0] * l.intensity; c.cg = l.color[1] * l.intensity; c.cb = l.color[2] * l.intensity;
+  c.outer = l.outer_cutoff;
+  c.dx = c.dy = c.dz = 0.0f;
+  c.inv_eps = 0.0f;
+  if (l.type == 1) {
+    const f3 d = normalize3(neg3(ld3(l.dir)));
+    c.dx = d.x; c.dy = d.y; c.dz = d.z;
+    c.inv_eps = bb_rcp(l.inner_cutoff - l.outer_cutoff);
+  } else if (l.type == 2) {
+    const f3 d = neg3(normalize3(ld3(l.dir)));
+    c.dx = d.x; c.dy = d.y; c.dz = d.z;
+  }
+  return c;
+}
 
 // every thread of the workgroup; the caller synchronises
 template <int THREADS>
@@ -1542,7 +1521,7 @@ BB_DEV void stage_lights(const ShadeParams &sp, const Light *__restrict__ lights
 
 // Where the light loop finds its cooked lights.
 //  * LdsLights: a table staged by the workgroup itself (stage_lights + barrier): k_deferred_background.
-//  * ConstLights: the frame's table in global memory, cooked once per frame by k_raster and read through the SCALAR
+//  * ConstLights: the frame's table in global memory, cooked once per frame by k_shade_items and read through the SCALAR
 //    cache (constant address space -> s_load into scalar registers): k_shade.  No LDS, no staging code, and above all no
 //    workgroup barrier in front of the light loop -- the four waves of a workgroup never wait for each other, and a light's
 //    type is already a scalar (no v_readfirstlane, 9 issue cycles each).  The price: a VALU instruction that reads one of
@@ -1652,6 +1631,80 @@ __global__ __launch_bounds__(kBackgroundThreads) void k_deferred_background(Shad
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_shade_items: the work list of k_shade.  One item = 64 consecutive fragments of one tile's list; the list of all
+// items of the frame lets a fixed number of resident waves walk the frame's fragments in a strided loop, prefetching
+// the next items' data while they shade the current one.  A single workgroup scans the per-tile fragment counts
+// (launch slots in k_raster's grid order): items[0] = number of items, items[1 + j] = slot << 4 | chunk64 ...
+// (a tile of 64x64 pixels has 64 chunks: the chunk field is 6 bits).
+// ------------------------------------------------------------------------------------------------
+
+// chunks of 64 fragments in the list of launch slot `slot` (0 past the frame)
+BB_DEV uint32_t slot_chunks(const FrameParams &fp, const uint32_t *__restrict__ frag_count, uint32_t slot, uint32_t n_slots, int grid_x) {
+  if (slot >= n_slots) return 0u;
+  const int gy = (int)(slot / (uint32_t)grid_x), tx = (int)(slot - (uint32_t)gy * (uint32_t)grid_x);
+  int ty, out_tile_row;
+  if (!tile_row(fp, gy, ty, out_tile_row)) return 0u;
+  const uint32_t n = frag_count[(uint32_t)ty * (uint32_t)fp.tiles_x + (uint32_t)tx];
+  return (((n & ~kFullTile) + 63u) >> 6) | (n & kFullTile);  // (chunks, with the full-tile flag kept on top)
+}
+
+// One workgroup per 256 launch slots, no communication between workgroups: the items in front of a workgroup's slots are
+// the sum of k_raster's per-group totals (eight independent loads per thread), its own 256 slots get a scan, then their items are
+// written.  (A single workgroup doing all of it took 25 us at C3 -- 70 000 scattered 4-byte stores through ONE compute
+// unit's address unit; every workgroup summing the raw counts in front of it took 13 us of dependent loads.)
+template <int TILE_W, int TILE_H>
+__global__ __launch_bounds__(kItemsThreads) void k_shade_items(FrameParams fp, const uint32_t *__restrict__ frag_count,
+                                                               const uint32_t *__restrict__ item_groups,
+                                                               uint32_t *__restrict__ items, int grid_x, int grid_y,
+                                                               uint32_t *__restrict__ host_count,
+                                                               const Light *__restrict__ lights, int num_lights,
+                                                               CookedLight *__restrict__ cooked) {
+  __shared__ uint32_t s_wave[2][kItemsThreads / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // the frame's cooked light table (k_shade reads it through the scalar cache): once per frame, by the last workgroup
+  // (the one with the fewest slots to scan)
+  if (blockIdx.x == gridDim.x - 1)
+    for (int li = tid; li < num_lights; li += kItemsThreads) cooked[li] = cook_light(lights[li]);
+  const uint32_t n_slots = (uint32_t)grid_x * (uint32_t)grid_y;
+  const uint32_t first = blockIdx.x * (uint32_t)kItemsThreads;
+  uint32_t before = 0u;  // (independent loads: one round trip)
+#pragma unroll
+  for (int q = 0; q < kItemGroups / kItemsThreads; ++q) {
+    const uint32_t g = (uint32_t)q * kItemsThreads + (uint32_t)tid;
+    before += g < first / kItemGroupSlots ? item_groups[g * kItemGroupStride] : 0u;
+  }
+  const uint32_t chunks_flag = slot_chunks(fp, frag_count, first + (uint32_t)tid, n_slots, grid_x);
+  const uint32_t chunks = chunks_flag & ~kFullTile;
+  uint32_t incl = chunks;  // inclusive scan of this workgroup's slots, wave level
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
+    if (lane >= d) incl += up;
+    before += (uint32_t)__shfl_xor((int)before, d);  // (butterfly sum: every lane ends with the wave's total)
+  }
+  if (lane == 63) s_wave[0][wave] = incl;
+  if (lane == 0) s_wave[1][wave] = before;
+  __syncthreads();
+  uint32_t at = 1u + incl - chunks;
+#pragma unroll
+  for (int w = 0; w < kItemsThreads / 64; ++w) {
+    at += s_wave[1][w];
+    if (w < wave) at += s_wave[0][w];
+  }
+  const uint32_t slot = first + (uint32_t)tid;
+  if (chunks != 0u) {
+    const uint32_t gy = slot / (uint32_t)grid_x, tx = slot - gy * (uint32_t)grid_x;
+    const uint32_t word = (chunks_flag & kFullTile) | (gy << (kItemChunkBits + kItemTxBits)) | (tx << kItemChunkBits);
+    for (uint32_t c = 0; c < chunks; ++c) items[at + c] = word | c;
+  }
+  // the workgroup of the last slot knows the total
+  if (first + (uint32_t)kItemsThreads >= n_slots && tid == kItemsThreads - 1) {
+    items[0] = at + chunks - 1u;
+    if (host_count) *host_count = at + chunks - 1u;  // pinned host memory: sizes the launch of this slot's next frame
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_shade: forward_brdf.frag + brdf.glsl once per visible pixel.
 //
 // What bounded the first version of this kernel (one workgroup per 256 fragments of a tile) was not arithmetic but the
@@ -1659,13 +1712,12 @@ __global__ __launch_bounds__(kBackgroundThreads) void k_deferred_background(Shad
 // record -> clip slot -> texels, ~0.8 us each under load -- against ~0.9 us of issue time per 64 fragments: its
 // duration followed T = 66 us + 264 us / (waves per SIMD) at C3 (measured by padding LDS: 2, 3, 4, 7 waves -> 198,
 // 151, 132, 109 us), and a body that only loaded the fragment and stored a constant still took 52 us.  Hence:
-//  * ONE WAVE = ONE ITEM of 64 fragments (item = grid row, tile column, chunk of the tile's fragment list), taken from the
-//    list k_raster's workgroups append to (kItemRegions interleaved sub-lists): no wave is launched for an empty part of a
-//    tile, every launched wave is full (k_raster pads each list to a multiple of 64 with copies of its first fragment),
-//    and no per-tile count has to be read before the fragments.  The main launch is sized on the host from the extent the
-//    same frame slot's list had one frame earlier (a pinned word written by k_shade's first workgroup) plus 3 % + 64; a
-//    second, 32-workgroup instantiation (TAIL) walks whatever lies beyond that estimate in a loop, so a frame that
-//    suddenly has more fragments is still complete.
+//  * ONE WAVE = ONE ITEM of 64 fragments from the list of k_shade_items (item = grid row, tile column, chunk of the
+//    tile's fragment list): no wave is launched for an empty part of a tile, every launched wave is full (k_raster pads
+//    each list to a multiple of 64 with copies of its first fragment), and no count has to be read before the fragments.
+//    The main launch is sized on the host from the item count the same frame slot produced one frame earlier (pinned
+//    word written by k_shade_items) plus 3 % + 64; a second, 32-workgroup instantiation (TAIL) walks whatever lies beyond
+//    that estimate in a loop, so a frame that suddenly has more fragments is still complete.
 //  * the chain is cut to three round trips per item (item word -> fragment words -> record + texels): the fragment
 //    word carries the clip-arena slot of a clipped sub-triangle, so its planes are fetched together with the primitive
 //    record instead of after it; a wave whose 64 fragments share one primitive fetches the record through the scalar
@@ -1715,8 +1767,7 @@ __global__ __launch_bounds__(kShadeThreads) __attribute__((amdgpu_waves_per_eu(T
     const uint32_t *__restrict__ frag_count, const uint32_t *__restrict__ items, uint32_t first_item,
     const MaterialDesc *__restrict__ materials, float4 *__restrict__ out,
     uint2 *__restrict__ gbuffer, const SrgbTables *__restrict__ tables, uint32_t *__restrict__ out8,
-    Counters *__restrict__ ctr, Counters *__restrict__ ctr_done, const uint32_t *__restrict__ item_regions,
-    uint32_t *__restrict__ host_extent) {
+    Counters *__restrict__ ctr, Counters *__restrict__ ctr_done, uint32_t *__restrict__ item_groups) {
   constexpr int TILE_PIXELS = TILE_W * TILE_H;
   const ConstLights lights_c{(ConstCooked)cooked};
   // The frame's counter block has done its job (k_geometry filled it, k_raster read it): keep a copy for the host's
@@ -1726,14 +1777,8 @@ __global__ __launch_bounds__(kShadeThreads) __attribute__((amdgpu_waves_per_eu(T
     reinterpret_cast<uint32_t *>(ctr_done)[threadIdx.x] = reinterpret_cast<uint32_t *>(ctr)[threadIdx.x];
     reinterpret_cast<uint32_t *>(ctr)[threadIdx.x] = 0u;
   }
-  // the extent of the frame's item list (32 x the fullest region) goes to pinned host memory: it sizes the main launch of
-  // this slot's next frame
-  if (!TAIL && blockIdx.x == 0 && threadIdx.x < 64u && host_extent) {
-    uint32_t m = threadIdx.x < (unsigned)kItemRegions ? item_regions[threadIdx.x * kItemRegionStride] : 0u;
-#pragma unroll
-    for (int d = 1; d < kItemRegions; d <<= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d));
-    if (threadIdx.x == 0) *host_extent = m * (uint32_t)kItemRegions;
-  }
+  if (!TAIL && blockIdx.x == 0 && item_groups)  // (k_shade_items is done with them)
+    for (uint32_t g = threadIdx.x; g < (uint32_t)kItemGroups; g += kShadeThreads) item_groups[g * kItemGroupStride] = 0u;
 #ifdef BB_STAMPS
   unsigned long long st_t[8];
   st_t[0] = __builtin_amdgcn_s_memtime();
@@ -1750,30 +1795,12 @@ __global__ __launch_bounds__(kShadeThreads) __attribute__((amdgpu_waves_per_eu(T
   //  by 23 % and made it 12 % SLOWER (98 vs 88 us): a hot region then loads one L2 / one XCD's texture units instead of
   //  eight; runs of 4 / 16 / 64 workgroups per XCD: 87 / 89 / 94 us, no traffic gain.  Plain round-robin stays.)
   uint32_t j = first_item + (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (uint32_t)kShadeWaves + (threadIdx.x >> 6)));
-  // item number J = entry J / 32 of region J % 32; it exists if the region holds that many.  The item word is read
-  // together with the region's count, not after it (the list has room for every index a launch can produce): one
-  // dependent round trip less in front of the fragments.
-  typedef const uint32_t __attribute__((address_space(4))) *ConstWords;
-  uint32_t item = TAIL ? 0u : ((ConstWords)items)[1u + j];
-  uint32_t n_items;  // TAIL: the extent of the list; otherwise j + 1 if this wave's item exists
-  if (TAIL) {
-    uint32_t m = (uint32_t)lane < (uint32_t)kItemRegions ? item_regions[lane * kItemRegionStride] : 0u;
-#pragma unroll
-    for (int d = 1; d < kItemRegions; d <<= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d));
-    n_items = (uint32_t)__builtin_amdgcn_readfirstlane((int)m) * (uint32_t)kItemRegions;
-  } else {
-    n_items = (j >> 5) < ((ConstWords)item_regions)[(j & (uint32_t)(kItemRegions - 1)) * kItemRegionStride] ? j + 1u : 0u;
-  }
+  uint32_t item = items[1u + (TAIL ? 0u : j)];
+  const uint32_t n_items = items[0];
   if (BB_ABLATE(2048u)) sp.num_lights = 0;
   if (j >= n_items) return;  // a wave without an item (the kernel has no barrier: waves come and go on their own)
   do {  // (a loop only in the TAIL instantiation)
-  if (TAIL) {
-    if ((j >> 5) >= item_regions[(j & (uint32_t)(kItemRegions - 1)) * kItemRegionStride]) {  // a hole: this region is shorter than the fullest
-      j += gridDim.x * (uint32_t)kShadeWaves;
-      continue;
-    }
-    item = items[1u + j];
-  }
+  if (TAIL) item = items[1u + j];
   const int chunk = (int)(item & 63u);
   const int tx = (int)((item >> kItemChunkBits) & ((1u << kItemTxBits) - 1u));
   int ty, out_tile_row;

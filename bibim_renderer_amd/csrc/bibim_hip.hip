@@ -1,8 +1,8 @@
 // bibim_hip.hip -- C-ABI (include/bibim_hip.h) over the HIP kernels in bb_kernels.hip.h.
 //
-// One context = one GPU, up to four frames in flight (each on the stream of its slot), all buffers resident in HBM for the
-// context's lifetime.  A frame is: [H2D of lights + draw descriptors + instances, one async copy from pinned staging] ->
-// k_geometry (all draws) -> k_raster (per tile; also the frame's item list and light table) -> k_shade (per 64 visible pixels).  No host synchronisation inside a frame; capacities (bins, broad list, clip arena) are
+// One context = one GPU, one HIP stream, all buffers resident in HBM for the context's lifetime.
+// A frame is: [H2D of lights + draw descriptors + instances, one async copy from pinned staging] -> k_geometry
+// (all draws) -> k_raster (per tile) -> k_shade (per visible pixel).  No host synchronisation inside a frame; capacities (bins, broad list, clip arena) are
 // checked lazily at the next synchronising call and the frame is re-rendered once after growing them.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>  // types and prototypes only: the library is opened at bbr_comm_init (see the exchange section)
@@ -123,8 +123,8 @@ struct FrameSlot {
   DeviceBuffer<uint32_t> d_frag_count;
   DeviceBuffer<uint32_t> d_tile_order;  // k_raster launch slots, heaviest tiles first
   DeviceBuffer<uint32_t> d_items;       // k_shade's work list: [0] = count, then slot << 6 | chunk of 64 fragments
-  DeviceBuffer<CookedLight> d_cooked;   // the frame's light table as the light loop consumes it (k_raster -> k_shade)
-  DeviceBuffer<uint32_t> d_item_regions; // items appended per region of the frame's item list (k_raster -> k_shade)
+  DeviceBuffer<CookedLight> d_cooked;   // the frame's light table as the light loop consumes it (k_shade_items -> k_shade)
+  DeviceBuffer<uint32_t> d_item_groups; // 64-fragment chunks per group of 256 launch slots (k_raster -> k_shade_items)
   DeviceBuffer<float4> d_frame;
   DeviceBuffer<float4> d_background;  // deferred path: colour of the pixels no geometry covers
   DeviceBuffer<float> d_depth;        // option "overlays": the frame's resolved depth, for bbr_draw_overlays
@@ -149,7 +149,7 @@ struct FrameSlot {
   uint32_t n_prims = 0;
 
   void release_tile_buffers() {
-    d_tile_count.release(); d_bins.release(); d_frags.release(); d_frag_count.release(); d_tile_order.release(); d_items.release(); d_item_regions.release(); d_cooked.release();
+    d_tile_count.release(); d_bins.release(); d_frags.release(); d_frag_count.release(); d_tile_order.release(); d_items.release(); d_item_groups.release(); d_cooked.release();
   }
   // option "frame_graph": the frame's copy + kernels as one hipGraph, replayed while the launch arguments repeat
   hipGraph_t graph = nullptr;
@@ -376,12 +376,6 @@ int drain(bbr_context *c) {
 
 int ensure_srgb_tables(bbr_context *c);
 
-// item numbers a frame can produce: 32 x (the most chunks one region can receive)
-size_t item_list_capacity(const bbr_context *c) {
-  const size_t tiles = (size_t)c->tiles_x() * c->tiles_y();
-  return (size_t)kItemRegions * ((tiles + kItemRegions - 1) / kItemRegions) * (size_t)(c->tile_w() * c->tile_h() / 64);
-}
-
 int ensure_slot_buffers(bbr_context *c, FrameSlot &s) {
   size_t tiles = (size_t)c->tiles_x() * c->tiles_y();
   size_t out_rows = (size_t)std::max(c->height, c->shard_rows());
@@ -405,13 +399,11 @@ int ensure_slot_buffers(bbr_context *c, FrameSlot &s) {
   HIP_TRY(c, s.d_frag_count.ensure(tiles, true));
 #endif
   HIP_TRY(c, s.d_tile_order.ensure(tiles * kOrderBuckets));
-  // the item list: kItemRegions interleaved sub-lists, each with room for every chunk of the tiles that append to it
-  // (+ kShadeWaves: the last workgroup of k_shade's main launch reads the item words of all its waves before it knows
-  // whether they exist)
-  HIP_TRY(c, s.d_items.ensure(1 + item_list_capacity(c) + kShadeWaves, true));
-  if (c->tiles_x() > (1 << kItemTxBits) || c->tiles_y() > (1 << (31 - kItemChunkBits - kItemTxBits)))
-    return fail(c, BBR_ERR_INVALID_ARGUMENT, "frame too large for the item word");  // (32768 pixels are 1024 tiles)
-  HIP_TRY(c, s.d_item_regions.ensure(kItemRegions * kItemRegionStride, true));
+  // (+ kShadeWaves: the last workgroup of k_shade's main launch reads the item words of all its waves before it knows the count)
+  HIP_TRY(c, s.d_items.ensure(1 + tiles * (size_t)(c->tile_w() * c->tile_h() / 64) + kShadeWaves, true));
+  if (tiles > (size_t)kItemGroupSlots * kItemGroups)  // 65536 launch slots: 8192 x 8192 pixels at 32 x 32 tiles
+    return fail(c, BBR_ERR_INVALID_ARGUMENT, "frame too large for this tile size: set option tile_mode to 0 (64 x 64 tiles)");
+  HIP_TRY(c, s.d_item_groups.ensure((size_t)kItemGroups * kItemGroupStride, true));
   HIP_TRY(c, s.d_cooked.ensure(kMaxNumLights));
   if (c->deferred) HIP_TRY(c, s.d_background.ensure(2));
   if (c->overlays && &s != &c->ov) HIP_TRY(c, s.d_depth.ensure((size_t)c->width * c->height));
@@ -461,9 +453,7 @@ void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const Fra
   if (c->n_prims)
     hipLaunchKernelGGL((k_geometry<TW, TH>), dim3((c->n_prims + 255) / 256), dim3(256), 0, sg, d_draws, n_draws,
                        c->n_prims, pv, view, fp, s.d_tris.ptr, s.d_attrs.ptr, s.d_clip.ptr, ctr, s.d_tile_count.ptr,
-                       s.d_bins.ptr, s.d_broad.ptr, c->d_materials.ptr, s.d_block_stats.ptr, s.d_item_regions.ptr);
-  else  // (k_geometry's first workgroup clears the slot's item counters; no geometry, no k_geometry)
-    (void)hipMemsetAsync(s.d_item_regions.ptr, 0, kItemRegions * kItemRegionStride * sizeof(uint32_t), sg);
+                       s.d_bins.ptr, s.d_broad.ptr, c->d_materials.ptr, s.d_block_stats.ptr);
   if (ev && c->timing == 1) (void)hipEventRecord(ev[1], sg);
   if (sr != sg) {
     (void)hipEventRecord(s.ev_geom_done, sg);
@@ -492,8 +482,12 @@ void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const Fra
                      s.d_frag_count.ptr, out, c->dump_vis ? c->d_vis_prim.ptr : nullptr,
                      c->dump_vis ? c->d_vis_depth.ptr : nullptr, ordered ? s.d_tile_order.ptr : nullptr,
                      fp.deferred ? s.d_background.ptr : nullptr, (c->overlays && c->world == 1) ? s.d_depth.ptr : nullptr,
-                     s.h_flags, out8, s.d_item_regions.ptr, s.d_items.ptr, d_lights, sp.num_lights, s.d_cooked.ptr);
+                     s.h_flags, out8, s.d_item_groups.ptr);
   s.has_depth = c->overlays && c->world == 1;
+  // k_shade's work list (64 fragments per item), built from the per-tile fragment counts as soon as k_raster is done; the
+  // same launch cooks the frame's light table
+  hipLaunchKernelGGL((k_shade_items<TW, TH>), dim3((unsigned)((fp.tiles_x * grid_y + kItemsThreads - 1) / kItemsThreads)), dim3(kItemsThreads), 0, sr, fp, s.d_frag_count.ptr, s.d_item_groups.ptr, s.d_items.ptr,
+                     fp.tiles_x, grid_y, s.h_flags ? s.h_flags + 2 : nullptr, d_lights, sp.num_lights, s.d_cooked.ptr);
   if (ev && c->timing == 1) (void)hipEventRecord(ev[2], sr);
   if (ss != sr) {
     (void)hipEventRecord(s.ev_raster_done, sr);
@@ -502,9 +496,9 @@ void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const Fra
   if (ev) (void)hipEventRecord(ev[3], ss);  // completes when the shade stream has seen "raster done"
   uint2 *gbuf = (fp.deferred && c->dump_gbuffer) ? c->d_gbuffer.ptr : nullptr;
   // Main launch: one item (64 fragments) per wave, four per workgroup, sized from the item count of the frame this slot
-  // rendered last (k_shade's first workgroup leaves the list's extent in pinned host memory) plus 3 %; tail launch: a small persistent grid for
+  // rendered last (k_shade_items leaves it in pinned host memory) plus 3 %; tail launch: a small persistent grid for
   // whatever lies behind that (a scene that suddenly grew; normally nothing, and its workgroups exit at once).
-  const uint32_t max_items = (uint32_t)item_list_capacity(c);  // (the list's extent: 32 x its fullest region)
+  const uint32_t max_items = (uint32_t)(fp.tiles_x * grid_y) * (uint32_t)(TW * TH / 64);
   const uint32_t seen = s.h_flags ? s.h_flags[2] : 0u;
   uint32_t est = seen ? seen + seen / 32u + 64u : max_items;
   if (est > max_items) est = max_items;
@@ -516,14 +510,12 @@ void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const Fra
     if (tail) {
       hipLaunchKernelGGL((k_shade<TW, TH, decltype(deferred)::value, decltype(present)::value, true>), dim3(32), dim3(kShadeThreads),
                          0, sr, fp, sp, s.d_cooked.ptr, s.d_attrs.ptr, s.d_clip.ptr, s.d_frags.ptr, s.d_frag_count.ptr, s.d_items.ptr,
-                         main_wgs * (uint32_t)kShadeWaves, c->d_materials.ptr, out, gbuf, tables, out8, ctr, ctr_done, s.d_item_regions.ptr,
-                         (uint32_t *)nullptr);
+                         main_wgs * (uint32_t)kShadeWaves, c->d_materials.ptr, out, gbuf, tables, out8, ctr, ctr_done, nullptr);
       if (ss != sr) (void)hipEventRecord(s.ev_tail_done, sr);
     }
     hipLaunchKernelGGL((k_shade<TW, TH, decltype(deferred)::value, decltype(present)::value, false>), dim3(main_wgs),
                        dim3(kShadeThreads), 0, ss, fp, sp, s.d_cooked.ptr, s.d_attrs.ptr, s.d_clip.ptr, s.d_frags.ptr,
-                       s.d_frag_count.ptr, s.d_items.ptr, 0u, c->d_materials.ptr, out, gbuf, tables, out8, ctr, ctr_done, s.d_item_regions.ptr,
-                       s.h_flags ? s.h_flags + 2 : (uint32_t *)nullptr);
+                       s.d_frag_count.ptr, s.d_items.ptr, 0u, c->d_materials.ptr, out, gbuf, tables, out8, ctr, ctr_done, s.d_item_groups.ptr);
     if (tail && ss != sr) (void)hipStreamWaitEvent(ss, s.ev_tail_done, 0);
   };
   if (fp.deferred) {
@@ -669,7 +661,7 @@ int submit_frame_into(bbr_context *c, int slot_index) {
     auto put = [&](const void *p, size_t n) { key.insert(key.end(), (const uint8_t *)p, (const uint8_t *)p + n); };
     const void *ptrs[] = {s.d_staging.ptr, s.h_staging, s.d_tris.ptr, s.d_attrs.ptr, s.d_clip.ptr, s.d_tile_count.ptr, s.d_bins.ptr,
                           s.d_broad.ptr, c->d_materials.ptr, s.d_block_stats.ptr, s.d_frags.ptr, s.d_frag_count.ptr, s.h_flags,
-                          s.d_item_regions.ptr, s.d_items.ptr, s.d_cooked.ptr, s.d_background.ptr, s.d_depth.ptr, s.d_tile_order.ptr,
+                          s.d_item_groups.ptr, s.d_items.ptr, s.d_cooked.ptr, s.d_background.ptr, s.d_depth.ptr, s.d_tile_order.ptr,
                           s.d_present.ptr, c->d_srgb_tables.ptr, c->d_counters.ptr, c->d_counters_done.ptr, out, (const void *)sg};
     const uint32_t words[] = {(uint32_t)total, c->n_live_draws, c->n_prims, s.h_flags ? s.h_flags[2] : 0u, (uint32_t)c->tile_mode,
                               (uint32_t)c->present_fused, (uint32_t)c->tile_order, (uint32_t)c->overlays, (uint32_t)c->world,
@@ -1023,12 +1015,11 @@ extern "C" int bbr_draw_overlays(bbr_context *c, int32_t gizmo_extent) {
       constexpr int TW = decltype(tw)::value, TH = decltype(th)::value;
       hipLaunchKernelGGL((k_geometry<TW, TH, true>), dim3((n_prims + 255) / 256), dim3(256), 0, st, d_draws, (uint32_t)draws.size(),
                          n_prims, ident, ident, fp, s.d_tris.ptr, s.d_attrs.ptr, s.d_clip.ptr, ctr, s.d_tile_count.ptr,
-                         s.d_bins.ptr, s.d_broad.ptr, c->d_materials.ptr, s.d_block_stats.ptr, (uint32_t *)nullptr);
+                         s.d_bins.ptr, s.d_broad.ptr, c->d_materials.ptr, s.d_block_stats.ptr);
       hipLaunchKernelGGL((k_raster<TW, TH, true>), dim3(fp.tiles_x, fp.tiles_y), dim3(kTileThreads), 0, st, fp, s.d_tris.ptr,
                          s.d_clip.ptr, ctr, s.d_tile_count.ptr, s.d_bins.ptr, s.d_broad.ptr, s.d_frags.ptr, s.d_frag_count.ptr,
                          (float4 *)nullptr, (uint32_t *)nullptr, (float *)nullptr, (const uint32_t *)nullptr,
-                         (const float4 *)nullptr, fs.d_depth.ptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
-                         (uint32_t *)nullptr, (const Light *)nullptr, 0, (CookedLight *)nullptr);
+                         (const float4 *)nullptr, fs.d_depth.ptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
       constexpr int kChunks = TW * TH / kShadeThreads;
       hipLaunchKernelGGL((k_shade_overlay<TW, TH>), dim3(fp.tiles_x * kChunks, fp.tiles_y), dim3(kShadeThreads), 0, st, fp,
                          s.d_attrs.ptr, s.d_clip.ptr, s.d_frags.ptr, s.d_frag_count.ptr, c->d_srgb_tables.ptr, fs.present.out);

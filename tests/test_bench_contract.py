@@ -37,7 +37,7 @@ def test_committed_bench_line_follows_the_contract():
     # kernel trace is what the HIP events bracket, minus what the events also see (they are recorded on the frame's
     # stream in front of the tail instantiation and behind the main one, while two other frames share the GPU)
     names = [l.split(",")[0] for l in open(os.path.join(ROOT, "profiles", "r02_bench_kernel_stats.csv")).read().splitlines()[1:]]
-    assert r["kernel"] == "k_shade" and {"k_shade", "k_shade_tail", "k_raster", "k_geometry"} <= set(names)
+    assert r["kernel"] == "k_shade" and {"k_shade", "k_shade_tail", "k_shade_items", "k_raster", "k_geometry"} <= set(names)
     phases = open(os.path.join(ROOT, "profiles", "r02_bench_kernel_phases.txt")).read()
     line = [l for l in phases.splitlines() if l.startswith("k_shade ")][0]
     timed = float(line.split("mean=")[1].split("us")[0])
