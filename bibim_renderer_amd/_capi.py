@@ -98,6 +98,9 @@ SIGNATURES = {
     "bbr_unpack_whole": (C.c_int, [_P, C.c_int32, _P, _P, _P]),
     "bbr_whole_frame_device_ptr": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64)]),
     "bbr_read_whole_frame": (C.c_int, [_P, _P]),
+    "bbr_device_alloc": (C.c_int, [_P, C.c_uint64, C.POINTER(_P)]),
+    "bbr_device_free": (C.c_int, [_P, _P]),
+    "bbr_copy_to_host": (C.c_int, [_P, _P, _P, C.c_uint64]),
     "bbr_ipc_export": (C.c_int, [_P, _P, _P]),
     "bbr_ipc_open": (C.c_int, [_P, _P, C.POINTER(_P)]),
     "bbr_ipc_close": (C.c_int, [_P, _P]),

@@ -2181,6 +2181,36 @@ int bbr_read_whole_frame(bbr_context *c, void *host) {
   return BBR_OK;
 }
 
+int bbr_device_alloc(bbr_context *c, uint64_t bytes, void **out_ptr) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  BBR_ON_DEVICE(c);
+  if (!out_ptr || !bytes) return fail(c, BBR_ERR_INVALID_ARGUMENT, "device_alloc: NULL / zero bytes");
+  *out_ptr = nullptr;
+  HIP_TRY(c, hipMalloc(out_ptr, bytes));
+  HIP_TRY(c, zero_fill_sync(*out_ptr, bytes));
+  return BBR_OK;
+}
+
+int bbr_device_free(bbr_context *c, void *ptr) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  BBR_ON_DEVICE(c);
+  if (!ptr) return BBR_OK;
+  int rc = drain(c);
+  if (rc) return rc;
+  HIP_TRY(c, hipFree(ptr));
+  return BBR_OK;
+}
+
+int bbr_copy_to_host(bbr_context *c, void *host, const void *device_ptr, uint64_t bytes) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  BBR_ON_DEVICE(c);
+  if (!host || !device_ptr) return fail(c, BBR_ERR_INVALID_ARGUMENT, "copy_to_host: NULL");
+  int rc = drain(c);
+  if (rc) return rc;
+  HIP_TRY(c, hipMemcpy(host, device_ptr, bytes, hipMemcpyDeviceToHost));
+  return BBR_OK;
+}
+
 int bbr_ipc_export(bbr_context *c, void *device_ptr, uint8_t *out_handle) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
   BBR_ON_DEVICE(c);

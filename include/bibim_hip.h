@@ -298,6 +298,10 @@ int bbr_push_shard(bbr_context *ctx, int32_t form, void *const *peer_gathered /*
 int bbr_unpack_whole(bbr_context *ctx, int32_t form, const void *gathered_device, void *whole_device, void *hip_stream);
 int bbr_whole_frame_device_ptr(bbr_context *ctx, void **out_ptr, uint64_t *out_bytes);
 int bbr_read_whole_frame(bbr_context *ctx, void *host /* height*width*16 bytes (RGBA8 form: *4); synchronises */);
+/* plain device memory on the context's GPU (zero-filled), for hosts that do not link HIP themselves: gather buffers */
+int bbr_device_alloc(bbr_context *ctx, uint64_t bytes, void **out_ptr);
+int bbr_device_free(bbr_context *ctx, void *ptr);
+int bbr_copy_to_host(bbr_context *ctx, void *host, const void *device_ptr, uint64_t bytes); /* drains the context first */
 int bbr_ipc_export(bbr_context *ctx, void *device_ptr, uint8_t *out_handle /* BBR_IPC_HANDLE_BYTES */);
 int bbr_ipc_open(bbr_context *ctx, const uint8_t *handle, void **out_ptr);
 int bbr_ipc_close(bbr_context *ctx, void *ptr);

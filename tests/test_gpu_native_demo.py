@@ -58,3 +58,33 @@ def test_native_demo_writes_the_oracles_image(tmp_path, deferred):
     # the OBJ round trip expands to one vertex per corner, which draws the same triangles
     want, _ = bbo.overlay(osc.frame, osc.view, depth, bbo.present(hdr, 1, 1.5), gv, gix, 100)
     assert np.array_equal(got, want[..., :3])
+
+
+@pytest.mark.parametrize("ranks,form", [(3, "packed"), (8, "rgba8"), (2, "rgba32f")])
+def test_multi_gpu_demo_completes_the_frame_with_peer_pushes(tmp_path, ranks, form):
+    """examples/multi_gpu_demo.cpp: one C++ process, `ranks` contexts (all on this box's one GPU), every rank renders its
+    bands and pushes its block into every rank's gather buffer (bbr_push_shard), bbr_unpack_whole: the last rank's whole
+    frame, presented, must be the oracle's presented image of the unpartitioned frame"""
+    exe = tmp_path / "mgdemo"
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "multi_gpu_demo.cpp"), "-L" + os.path.join(ROOT, "bibim_renderer_amd"),
+                           "-lbibim_hip", "-Wl,-rpath," + os.path.join(ROOT, "bibim_renderer_amd"), "-o", str(exe)])
+    ball = S.load_shaderball_vertices()
+    (tmp_path / "ball.bin").write_bytes(np.ascontiguousarray(ball).tobytes())
+    W, H = 640, 360
+    cmd = [str(exe), "--vertices-bin", str(tmp_path / "ball.bin"), "--size", str(W), str(H), "--grid", "4", "--frames", "4",
+           "--ranks", str(ranks), "--form", form, "--tone-map", "1.2", "--out", str(tmp_path / "f.ppm")]
+    out = subprocess.run(cmd, check=True, capture_output=True, text=True).stdout
+    assert f"over {ranks} ranks" in out and "Mpixels/s" in out
+    raw = (tmp_path / "f.ppm").read_bytes()
+    header = f"P6\n{W} {H}\n255\n".encode()
+    assert raw.startswith(header)
+    got = np.frombuffer(raw[len(header):], np.uint8).reshape(H, W, 3)
+    # the same scene for the oracle: the C3 layout (16 balls, camera of the demo) with the scene class's default lights and
+    # the default material, normal map on, tone map on with exposure 1.2
+    osc = scenes.shaderball_scene(configs.C3.scaled(W, H, 64), bbo.MaterialData())
+    osc.frame = scenes.frame_uniforms(scenes.reference_default_lights(), 1, 1.2)
+    osc.view["enable_normal_map"] = 1
+    hdr, _, _, _ = bbo.render(osc)
+    want = bbo.present(hdr, 1, 1.2)
+    assert np.array_equal(got, want[..., :3])
