@@ -63,6 +63,7 @@ def profiled_traffic(workload, kernel="k_shade"):
 # or more waves on a SIMD (profiles/r02_issue_rate.txt: 2.05-2.4 cycles; 64 lanes x 2 flop / 2 cycles x 4 SIMDs x 256 CUs x
 # 2.4 GHz = the 157 TFLOP/s fp32 vector peak of the data sheet)
 VALU_ISSUE_CYCLES = 2.0
+FP32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector (non-matrix) peak
 SHADER_CLOCK_GHZ = 2.4
 
 
@@ -80,6 +81,12 @@ def valu_roofline(workload, kernel, avg_kernel_ms, n_cus):
     achieved = n / (avg_kernel_ms * 1e-3) / 1e9
     classes = {k[len("SQ_INSTS_VALU_"):].lower(): int(v) for k, v in e.items() if k.startswith("SQ_INSTS_VALU_")}
     classes["other (compare, select, min/max, move, lane ops)"] = int(n - sum(classes.values()))
+    # the same launch as FP32 flop/s against the data sheet's vector peak (fma = 2 flop, mul / add = 1, 64 lanes)
+    flop = 64.0 * (2.0 * float(e.get("SQ_INSTS_VALU_FMA_F32", 0)) + float(e.get("SQ_INSTS_VALU_MUL_F32", 0)) +
+                   float(e.get("SQ_INSTS_VALU_ADD_F32", 0)))
+    tflops = flop / (avg_kernel_ms * 1e-3) / 1e12
+    out.update({"fp32_tflops": round(tflops, 2), "fp32_peak_tflops": FP32_VECTOR_PEAK_TFLOPS,
+                "fp32_frac": round(tflops / FP32_VECTOR_PEAK_TFLOPS, 4), "fp32_flop_per_launch": int(flop)})
     out.update({"achieved": round(achieved, 1), "frac": round(achieved / peak, 4), "valu_instructions_per_launch": int(n),
                 "by_class": classes, "issue_floor_ms": round(n / (peak * 1e9) * 1e3, 5),
                 "other_instructions_per_launch": {k[len("SQ_INSTS_"):].lower(): int(v) for k, v in e.items()
@@ -498,7 +505,9 @@ def main():
         v = roofline.get("valu")
         if v and v.get("valu_instructions_per_launch") and s1 > 0:
             a1 = v["valu_instructions_per_launch"] / (s1 * 1e-3) / 1e9
-            v["one_frame_in_flight"] = {"avg_kernel_ms": round(s1, 5), "achieved": round(a1, 1), "frac": round(a1 / v["peak"], 4)}
+            v["one_frame_in_flight"] = {"avg_kernel_ms": round(s1, 5), "achieved": round(a1, 1), "frac": round(a1 / v["peak"], 4),
+                                        "fp32_tflops": round(v["fp32_flop_per_launch"] / (s1 * 1e-3) / 1e12, 2),
+                                        "fp32_frac": round(v["fp32_flop_per_launch"] / (s1 * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS, 4)}
         # the next row of SURVEY 8(f), measured beside the path: k_present alone, 16 B read + 4 B written per pixel
         import dataclasses
         settings_tm = dataclasses.replace(settings, enable_tone_mapping=1, exposure=1.0)

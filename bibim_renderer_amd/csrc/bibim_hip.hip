@@ -278,6 +278,7 @@ struct bbr_context {
   int exchange_slot = -1, exchange_form = -1;  // where the last exchange left the whole frame (library-owned buffers)
   void *exchange_whole = nullptr;
   bool frame_graph = false;  // option "frame_graph"
+  int64_t no_tail_items = 40000;  // option "no_tail_items": frames with at most this many item slots get no tail launch
   uint32_t graph_launches = 0, graph_captures = 0;
   static constexpr int kLayouts = 3;
   int layout_mode = 2;  // the option
@@ -502,6 +503,10 @@ void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const Fra
   const uint32_t seen = s.h_flags ? s.h_flags[2] : 0u;
   uint32_t est = seen ? seen + seen / 32u + 64u : max_items;
   if (est > max_items) est = max_items;
+  // A small frame is launched at full coverage instead: workgroups without an item leave after one scalar load, and a few
+  // thousand of them cost less than the tail launch's kernel boundary on the frame's chain of dependent kernels (at
+  // 1080p the chain's length over the frames in flight IS the frame rate).
+  if (max_items <= (uint32_t)c->no_tail_items) est = max_items;
   const uint32_t main_wgs = std::max(1u, (est + kShadeWaves - 1) / kShadeWaves);
   // The tail runs on the raster stream, beside the main launch (their items are disjoint): in front of or behind it on
   // one stream an empty tail would still cost the frame a kernel boundary (~4 us).
@@ -1481,6 +1486,8 @@ int bbr_set_partition(bbr_context *c, int32_t rank, int32_t world, int32_t band_
   c->rank = rank;
   c->world = world;
   c->band_rows = band_rows;
+  c->exchange_slot = -1;  // (block sizes change with the partition)
+  c->exchange_whole = nullptr;
   if (c->ext_out) {
     uint64_t need = (uint64_t)c->width * (world > 1 ? c->shard_rows() : c->height) * 16;
     if (c->ext_out_bytes < need) {
@@ -1521,6 +1528,8 @@ int bbr_resize(bbr_context *c, int32_t width, int32_t height) {
   c->d_vis_prim.release();
   c->d_vis_depth.release();
   c->d_gbuffer.release();
+  c->exchange_slot = -1;  // (the whole frame of the last exchange had the old extent)
+  c->exchange_whole = nullptr;
   c->have_frame = false;
   c->last_slot = -1;
   // a caller-owned output buffer was sized for the old extent: the caller sets it again (bbr_set_output_device_ptr)
@@ -1778,6 +1787,9 @@ int bbr_set_option(bbr_context *c, const char *name, int64_t value) {
   } else if (n == "stream_layout") {
     if (value < 0 || value >= bbr_context::kLayouts) return fail(c, BBR_ERR_INVALID_ARGUMENT, "stream_layout: 0, 1 or 2");
     c->layout_mode = (int)value;
+  } else if (n == "no_tail_items") {
+    if (value < 0) return fail(c, BBR_ERR_INVALID_ARGUMENT, "no_tail_items must be >= 0");
+    c->no_tail_items = value;
   } else if (n == "frame_graph") {
     c->frame_graph = value != 0;
     for (FrameSlot &s : c->slots) s.release_graph();

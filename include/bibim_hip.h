@@ -200,6 +200,11 @@ int bbr_timing_summary(bbr_context *ctx, uint32_t *out_frames, float *out_avg_fr
  *                            raster of frame N).  2 (default): every kernel of a frame on the stream of its frame slot
  *                            (frames share nothing, whole frames overlap).  Three frames in flight, us per frame for
  *                            0 / 1 / 2: 1080p, one ShaderBall 84.5 / 67.1 / 37.3; 4K, sixteen 191.5 / 153.6 / 148.6.
+ *   "no_tail_items" n        (default 40000) k_shade's main launch is sized from the item count the frame slot produced
+ *                            one frame earlier and a small tail launch covers what that estimate misses; a frame with at
+ *                            most n item slots (tiles x 64-fragment chunks per tile: 1080p has 32 640) is launched at
+ *                            full coverage instead, without the tail launch's kernel boundary (C2: 34.5 -> 32.5 us per
+ *                            frame with three frames in flight, 27.6 -> 26.4 with four)
  *   "frame_graph" 0|1        (default 0) with stream layout 2 and more than one frame in flight: once a frame slot has seen
  *                            the same launch arguments twice (same camera, sizes and buffers; the CONTENT of lights,
  *                            draw descriptors and instances may change), its copy + kernels are captured into a

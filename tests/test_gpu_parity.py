@@ -757,6 +757,7 @@ def test_a_frame_with_many_more_fragments_than_the_one_before(maps64, layout):
     r = Renderer(960, 540)
     r.set_option("frames_in_flight", 3)
     r.set_option("stream_layout", layout)
+    r.set_option("no_tail_items", 0)             # (a frame this small would otherwise be launched at full coverage, without a tail)
     hb = hs = None
     for rep in range(3):
         for _ in range(4):                       # every slot has seen the small frame
