@@ -156,3 +156,37 @@ def test_world2_gloo_allgather_reassembles_the_frame(band_rows):
         assert p.exitcode == 0
     same, count_ok = q.get(timeout=10)
     assert same and count_ok
+
+
+def test_exchange_model_on_random_shapes():
+    """hypothesis: for any frame shape, world size and band height the blocks pushed in P.push_order leave the all-gather
+    layout on every rank and decode to the frame, in all three block forms"""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=60, deadline=None)
+    @given(st.integers(1, 200), st.integers(1, 90), st.integers(1, 9), st.sampled_from([32, 64, 96]), st.sampled_from([0, 1, 2]),
+           st.integers(0, 2 ** 31 - 1))
+    def run(H, W, world, band, form, seed):
+        rng = np.random.Generator(np.random.PCG64(seed))
+        if form == P.SHARD_RGBA8:
+            frame = rng.integers(0, 256, (H, W, 4), dtype=np.uint8)
+        else:
+            frame = rng.standard_normal((H, W, 4)).astype(np.float32)
+            frame[..., 3] = rng.integers(0, 2, (H, W)).astype(np.float32)
+        block = P.exchange_block_bytes(form, H, W, world, band)
+        blocks = [P.encode_block(P.pack_shard(frame, r, world, band), form) for r in range(world)]
+        assert all(b.size == block for b in blocks)
+        bufs = [np.zeros(world * block, np.uint8) for _ in range(world)]
+        for r in range(world):
+            for dst in [r] + P.push_order(r, world):
+                bufs[dst][P.push_offset(r, block):P.push_offset(r, block) + block] = blocks[r]
+        for b in bufs[1:]:
+            assert np.array_equal(b, bufs[0])
+        back = P.decode_gathered(bufs[0], form, H, W, world, band)
+        assert np.array_equal(back.view(np.uint8), frame.view(np.uint8))
+        # every framebuffer row belongs to exactly one rank, at most shard_rows of them per rank
+        rk, sr = P.shard_row_of(H, world, band)
+        assert rk.max() < world and sr.max() < P.shard_rows(H, world, band)
+        assert len({(int(a), int(b)) for a, b in zip(rk, sr)}) == H
+
+    run()
