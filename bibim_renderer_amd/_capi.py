@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libbibim_hip.so")
+LIB_PATH = os.environ.get("BBR_LIB") or os.path.join(HERE, "libbibim_hip.so")  # (BBR_LIB: another build of the library, for A/B timing)
 
 BBR_OK = 0
 STATUS = {0: "BBR_OK", -1: "BBR_ERR_INVALID_ARGUMENT", -2: "BBR_ERR_NO_DEVICE", -3: "BBR_ERR_HIP",
