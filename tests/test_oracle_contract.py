@@ -239,8 +239,8 @@ def np_bilinear(img, u, v):
     (the reference's sampler: src/render.cpp createSampler, SMP_LINEAR).  Vulkan 1.3 spec 16.5-16.8: (s, t) * size - 0.5,
     i0 = floor, weights = frac, wrap = mod size; UNORM: texel / 255.  binary64."""
     h, w = img.shape[:2]
-    x = np.float64(u) * w - 0.5
-    y = np.float64(v) * h - 0.5
+    x = np.asarray(u, np.float64) * w - 0.5
+    y = np.asarray(v, np.float64) * h - 0.5
     i0, j0 = np.floor(x), np.floor(y)
     a, b = x - i0, y - j0
     i0, j0 = i0.astype(np.int64), j0.astype(np.int64)
@@ -276,3 +276,80 @@ def test_missing_maps_sample_the_default_material():
     for m, rgb in want.items():
         got = bbo.sample(None, m, 0.3, 0.7)
         assert np.allclose(got[:3], rgb, atol=1e-7), (m, got)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# vertex stage and the head of the fragment stage
+# ---------------------------------------------------------------------------------------------------------------------
+def glsl_f64_vertex_stage(view, inst, vertex):
+    """forward_brdf.vert:24-37 in binary64.  Matrices arrive as the reference stores them (Mat4::M[column][row], the
+    bytes GLSL reads as column-major): numpy's [i][j] is column i, row j, so `M * v` is v @ M."""
+    f = lambda a: np.asarray(a, np.float64)
+    model, inv_model = f(inst["model"]), f(inst["inv_model"])
+    pos = np.append(f(vertex["pos"]), 1.0)
+    pos_world = pos @ model                                   # aModel * vec4(aPosition, 1.0)
+    clip = (pos_world @ f(view["view"])) @ f(view["proj"])    # uProjMat * uViewMat * posWorld
+    normal_mat = inv_model[:3, :3].T                          # transpose(mat3(aInvModel)), still [column][row]
+    N = _normalize(f(vertex["normal"]) @ normal_mat)
+    T = _normalize(f(vertex["tangent"]) @ normal_mat)
+    B = np.cross(N, T)
+    return clip, np.concatenate([f(vertex["uv"]), pos_world[:3], N, T, B])
+
+
+def test_vertex_stage_against_the_glsl_in_binary64():
+    rng = np.random.Generator(np.random.PCG64(77))
+    view = scenes.view_uniforms((0.3, 2.0, -2.5), 20.0, -15.0, 1920, 1080, 1)
+    worst = 0.0
+    for _ in range(2000):
+        # a rotation * non-uniform scale * translation, as the scene's instances are built (src/scene.cpp:180-187)
+        m = bbo.mat_mul(bbo.mat_translate(*rng.uniform(-5, 5, 3)),
+                        bbo.mat_mul(bbo.mat_rotate_y(rng.uniform(-180, 180)),
+                                    bbo.mat_mul(bbo.mat_rotate_x(rng.uniform(-180, 180)), bbo.mat_scale(*rng.uniform(0.01, 2, 3)))))
+        inst = np.zeros((), bbo.INSTANCE_DTYPE)
+        inst["model"], inst["inv_model"] = m, bbo.mat_inverse(m)
+        vtx = np.zeros((), bbo.VERTEX_DTYPE)
+        vtx["pos"], vtx["uv"] = rng.uniform(-50, 50, 3), rng.uniform(0, 1, 2)
+        n = rng.normal(size=3)
+        t = np.cross(n, rng.normal(size=3))
+        vtx["normal"], vtx["tangent"] = n / np.linalg.norm(n), t / np.linalg.norm(t)
+        clip, vary = bbo.vertex_stage(view, inst, vtx)
+        want_clip, want_vary = glsl_f64_vertex_stage(view, inst, vtx)
+        worst = max(worst, np.abs(clip - want_clip).max() / np.abs(want_clip).max(),
+                    np.abs(vary[:5] - want_vary[:5]).max() / max(1.0, np.abs(want_vary[:5]).max()),
+                    np.abs(vary[5:] - want_vary[5:]).max())        # unit vectors: absolute
+    assert worst <= 1e-5, worst
+
+
+def test_fragment_head_normal_mapping_against_the_glsl_in_binary64():
+    """forward_brdf.frag:16-25: the five texture reads and `normal = vTBN * (texture(normal).xyz * 2 - 1)`, then one light:
+    the whole fragment stage through bbo.shade_fragment against sampling (np_bilinear) + the binary64 light loop"""
+    from bibim_renderer_amd import textures
+    rng = np.random.Generator(np.random.PCG64(91))
+    maps = textures.make_material(32)
+    mat = bbo.MaterialData(maps)
+    lights = [scenes.light(0, pos=(1.0, 4.0, 2.0), color=(1.0, 0.8, 0.8), intensity=50.0)]
+    frame = scenes.frame_uniforms(lights)
+    view = scenes.view_uniforms((0.0, 3.0, 5.0), 0.0, 0.0, 64, 64, 1)
+    l64 = [dict(type=0, pos=np.array([1.0, 4.0, 2.0]), dir=np.zeros(3), color=np.float64(np.float32([1.0, 0.8, 0.8])),
+                intensity=50.0, inner=0.0, outer=0.0)]
+    worst = 0.0
+    n_checked = 0
+    for _ in range(3000):
+        uv = rng.uniform(-1, 2, 2).astype(np.float32)
+        P = rng.uniform(-2, 2, 3).astype(np.float32)
+        N = _normalize(rng.normal(size=3)); T = _normalize(np.cross(N, rng.normal(size=3))); B = np.cross(N, T)
+        vary = np.concatenate([uv, P, N, T, B]).astype(np.float32)
+        got = bbo.shade_fragment(frame, view, mat, vary, literal=True)[:3].astype(np.float64)
+        s = lambda name: np_bilinear(maps[name], np.asarray(uv[:1], np.float64), np.asarray(uv[1:], np.float64))[0]
+        albedo, metallic, roughness, ao = s("albedo")[:3], s("metallic")[0], s("roughness")[0], s("ao")[0]
+        v64 = np.float64(vary)
+        tbn = np.stack([v64[8:11], v64[11:14], v64[5:8]], axis=1)          # mat3(T, B, N): columns
+        normal = tbn @ (s("normal")[:3] * 2 - 1)
+        args = (l64, np.float64(np.float32([0.0, 3.0, 5.0])), v64[None, 2:5], normal[None], albedo[None],
+                np.array([metallic]), np.array([roughness]), np.array([ao]))
+        if conditioning(args[0], args[1], args[2], args[3], args[6])[0] < WELL:
+            continue
+        want = glsl_f64_light_loop(*args)[0]
+        worst = max(worst, np.abs(got - want).max() / max(np.abs(want).max(), 1e-30))
+        n_checked += 1
+    assert n_checked >= 1500 and worst <= 2e-5, (n_checked, worst)   # (two binary32 stages in a row: sampling, then the loop)
