@@ -172,6 +172,8 @@ def main():
                          "(C3: 147 / 134 / 135 us)")
     ap.add_argument("--stream-layout", type=int, default=2, choices=[0, 1, 2],
                     help="option stream_layout of the library (include/bibim_hip.h); 2 (one stream per frame slot) is its default")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="any other option of the library (bbr_set_option), e.g. --opt no_tail_items=0; recorded in config.options")
     ap.add_argument("--frame-graph", type=int, default=0, choices=[0, 1],
                     help="option frame_graph of the library: repeated frames are launched as one hipGraph per frame slot")
     ap.add_argument("--gather", default="packed", choices=["packed", "rgba32f"],
@@ -248,6 +250,8 @@ def main():
     r.set_option("frames_in_flight", args.frames_in_flight)
     r.set_option("stream_layout", args.stream_layout)
     r.set_option("frame_graph", args.frame_graph)
+    for o in args.opt:
+        r.set_option(o.split("=")[0], int(o.split("=")[1]))
     r.set_option("render_pass", 1 if args.render_pass == "deferred" else 0)
     if args.present_fused:
         if not args.present:
@@ -607,7 +611,7 @@ def main():
                        "output": ("presented RGBA8 (fused)" if args.present_fused else "RGBA32F frame + presented RGBA8")
                                  if args.present else "RGBA32F frame",
                        "render_pass": args.render_pass,
-                       "stream_layout": layout},
+                       "stream_layout": layout, **({"options": args.opt} if args.opt else {})},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         if verified is not None:
