@@ -483,7 +483,7 @@ def main():
                     "n_shaded": int(n_shaded_total),
                     # what actually limits the kernel (profiles/*_pmc_sq.txt): vector-ALU issue, not HBM.  fp32 flops per
                     # shaded pixel from the committed counters (2*fma + mul + add wave-instructions x 64 lanes / N_shaded)
-                    "limiter": "vector ALU issue (see DESIGN.md, k_shade)"}
+                    "limiter": "wave-slot time: four dependent load phases per wave at the maximum of eight waves per SIMD; vector-ALU issue is 0.69 of the kernel alone (DESIGN.md section 3, k_shade)"}
         if world == 1 and not args.force_dist:
             roofline["valu"] = valu_roofline(args.workload, "k_shade", avg_shade_ms, 256)
 
