@@ -49,6 +49,24 @@ def _committed_summary(pattern, workload, kernel):
     return None, stale, ("measured on other kernel sources than this tree's" if stale else "no summary of this workload committed")
 
 
+def committed_trace_ms(workload, kernel="k_shade"):
+    """mean duration of `kernel`'s timed launches by the kernel trace of the same command under rocprofv3
+    (profiles/*bench_kernel_phases.txt, newest round first): what `roofline.frac` can be reproduced from.  Returns
+    (timed_region_ms, alone_ms, file) or (None, None, None)."""
+    import glob
+    import re
+    pat = "*_bench_kernel_phases.txt" if workload == "c3" else f"*_{workload}_bench_kernel_phases.txt"
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", pat)), reverse=True):
+        if workload == "c3" and re.search(r"_c\d_bench_kernel_phases", f):
+            continue
+        for line in open(f):
+            if line.split() and line.split()[0] == kernel:
+                m = re.findall(r"mean=\s*([0-9.]+) us", line)
+                if len(m) >= 2:
+                    return float(m[0]) * 1e-3, float(m[1]) * 1e-3, os.path.relpath(f, ROOT)
+    return None, None, None
+
+
 def profiled_traffic(workload, kernel="k_shade"):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/*_pmc_hbm.json, written by
     tools/profile_summary.py: FETCH_SIZE and WRITE_SIZE collected in separate passes, FETCH_SIZE doubled as
@@ -125,8 +143,8 @@ def cpu_baseline(cfg, maps, budget_s=20.0):
         assert rc == 0
         return st.n_shaded
 
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = max(1, min(cores, 16))  # a one-GPU box's CPU share
+    cores_available = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(cores_available, 16))  # threads used: at most a one-GPU box's CPU share
     bands = [(y, min(y + 32, H)) for y in range(0, H, 32)]
     # single thread, whole frame in one call (the scalar port as written)
     t0 = time.perf_counter()
@@ -144,10 +162,28 @@ def cpu_baseline(cfg, maps, budget_s=20.0):
             if reps >= 20 or t_single + t_multi + t_multi / reps > budget_s:
                 break
     mpix = W * H / 1e6
-    return {"value": round(mpix * reps / t_multi, 3), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+    return {"value": round(mpix * reps / t_multi, 3), "unit": "Mpixels/s", "cores": cores, "cores_available": cores_available,
+            "host_logical_cpus": os.cpu_count(), "kind": "port",
             "sample": f"{reps} full {cfg.name} frame(s) ({W}x{H}), oracle/bb_oracle.c, {cores} threads over 32-row bands; "
                       f"single-thread whole-frame run: {mpix / t_single:.3f} Mpixels/s",
             "single_thread_value": round(mpix / t_single, 3), "n_shaded": int(n1)}, rgba
+
+
+def self_launch(n_ranks):
+    """Run this very command line as n_ranks ranks under torch.distributed.run (one process per GPU, RCCL over xGMI; rendezvous on
+    127.0.0.1 at a free port).  Returns the launcher's exit code.  Nothing here imports torch or touches a GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what this pool's driver supports (RCCL, peer pushes)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -202,6 +238,13 @@ def main():
     if args.frames_in_flight is None:
         args.frames_in_flight = 4 if args.workload == "c2" else 3
 
+    # `python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves, as CHILD processes of
+    # torch.distributed.run, before this process has imported torch or made any HIP call (a process that has touched the
+    # GPU must never be replaced or re-executed on this pool).  Rank 0's JSON line reaches the caller through the
+    # inherited stdout; the exit code is the launcher's (non-zero if any rank failed).
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
+
     # The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints a version banner when its
     # communicator comes up): from here on file descriptor 1 is stderr, and the JSON line goes to the real stdout.
     sys.stdout.flush()
@@ -214,9 +257,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback exists)")
@@ -227,6 +267,7 @@ def main():
     if os.environ.get("BBR_BENCH_SINGLE_DEVICE") == "1":
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    n_cus = int(torch.cuda.get_device_properties(local_rank).multi_processor_count)
     dist = None
     if world > 1 or args.force_dist:
         import torch.distributed as dist
@@ -426,7 +467,8 @@ def main():
         r.set_option("timing_stride", event_stride)
         r.timing_reset()
     fence()
-    frames_before = step_no[0] + r.stats()["bin_overflow"]   # frames submitted so far (incl. the re-renders after overflows)
+    overflow_before = r.stats()["bin_overflow"]
+    frames_before = step_no[0] + overflow_before   # frames submitted so far (incl. the re-renders after overflows)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -441,7 +483,7 @@ def main():
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     fence()
-    if r.stats()["bin_overflow"] != stats["bin_overflow"]:
+    if r.stats()["bin_overflow"] != overflow_before:   # (overflows healed during the warm-up frames do not count)
         raise SystemExit("a capacity overflowed inside the timed region: the frames timed were incomplete")
     gc.enable()
 
@@ -481,11 +523,25 @@ def main():
                     "frame_achieved_gbs": round(balg["total"] / (ms_per_step * 1e-3) / 1e9, 2),
                     "frame_frac": round(balg["total"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                     "n_shaded": int(n_shaded_total),
-                    # what actually limits the kernel (profiles/*_pmc_sq.txt): vector-ALU issue, not HBM.  fp32 flops per
-                    # shaded pixel from the committed counters (2*fma + mul + add wave-instructions x 64 lanes / N_shaded)
-                    "limiter": "wave-slot time: four dependent load phases per wave at the maximum of eight waves per SIMD; vector-ALU issue is 0.69 of the kernel alone (DESIGN.md section 3, k_shade)"}
+                    "limiter": None}   # filled in below from this run's own figures
+        t_ms, t_alone_ms, t_src = committed_trace_ms(args.workload)
+        roofline["avg_kernel_ms_is"] = (f"HIP events around k_shade on its own stream with {args.frames_in_flight} frames in flight: an "
+                                        "OVERLAPPED latency (the kernel shares the GPU with the other frames' kernels and the events also "
+                                        "bracket the dispatch gaps), so it can exceed ms_per_step; `frac` uses it and is the conservative figure")
+        if t_ms:
+            roofline.update({"trace_kernel_ms": round(t_ms, 5), "trace_kernel_alone_ms": round(t_alone_ms, 5), "trace_source": t_src,
+                             "trace_frac": round(shade_bytes / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                             "trace_alone_frac": round(shade_bytes / (t_alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
         if world == 1 and not args.force_dist:
-            roofline["valu"] = valu_roofline(args.workload, "k_shade", avg_shade_ms, 256)
+            roofline["valu"] = valu_roofline(args.workload, "k_shade", avg_shade_ms, n_cus)
+        if dist is not None:
+            # every rank's own k_shade figures (its bands of the frame), gathered to rank 0's line
+            mine = {"rank": rank, "device": local_rank, "n_shaded": int(stats["n_shaded"]), "avg_kernel_ms": round(avg_shade_ms, 5),
+                    "algorithmic_bytes_per_launch": int(shade_bytes), "achieved": round(achieved, 2),
+                    "frac": round(achieved / HBM_PEAK_GBS, 4)}
+            per_rank = [None] * world
+            dist.all_gather_object(per_rank, mine)
+            roofline["per_rank"] = per_rank
 
     if roofline is not None and not dist_path and not args.present_fused:
         # Outside the timed region: the same kernels with one frame in flight, i.e. without the other frame's
@@ -512,6 +568,32 @@ def main():
             v["one_frame_in_flight"] = {"avg_kernel_ms": round(s1, 5), "achieved": round(a1, 1), "frac": round(a1 / v["peak"], 4),
                                         "fp32_tflops": round(v["fp32_flop_per_launch"] / (s1 * 1e-3) / 1e12, 2),
                                         "fp32_frac": round(v["fp32_flop_per_launch"] / (s1 * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS, 4)}
+        # what limits the kernel, from THIS run: its vector-ALU issue floor (committed instruction counts of this workload and
+        # these kernel sources / 2-cycle issue) against its duration alone on the GPU; no figure when no such summary exists
+        if v and v.get("issue_floor_ms") and s1 > 0:
+            roofline["limiter"] = (f"k_shade alone {s1 * 1e3:.1f} us against a vector-ALU issue floor of {v['issue_floor_ms'] * 1e3:.1f} us "
+                                   f"({v['issue_floor_ms'] / s1:.2f}); the rest is dependent-load latency at the hardware's eight waves per "
+                                   "SIMD (DESIGN.md section 3, k_shade); HBM is not the limiter")
+        else:
+            roofline["limiter"] = "no instruction-count summary of this workload on these kernel sources (profiles/*_pmc_sq.json)"
+        # the reference's own setting, two frames in flight (src/main.cpp:38), and one frame's device latency
+        r.set_option("timing", 0)
+        r.set_option("frames_in_flight", 2)
+        for _ in range(6):
+            step()
+        fence()
+        n2 = max(10, min(args.steps, 100))
+        t2 = time.perf_counter()
+        for _ in range(n2):
+            step()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter() - t2
+        fence()
+        roofline["frames_in_flight_2"] = {"ms_per_step": round(t2 / n2 * 1e3, 5), "steps": n2,
+                                          "value": round(W * H * n2 / t2 / 1e6, 2), "unit": "Mpixels/s",
+                                          "what": "the same step with the reference's two frames in flight (numFrames, src/main.cpp:38)"}
+        roofline["single_frame_device_latency_ms"] = round(f1, 5)
+        r.set_option("timing", 1)
         # the next row of SURVEY 8(f), measured beside the path: k_present alone, 16 B read + 4 B written per pixel
         import dataclasses
         settings_tm = dataclasses.replace(settings, enable_tone_mapping=1, exposure=1.0)
@@ -574,7 +656,7 @@ def main():
             raise SystemExit(f"rank {rank}: gathered frame differs from the unpartitioned render in {rows.size} rows "
                              f"(first {rows[:8].tolist()}, last {rows[-3:].tolist()}){extra}")
 
-    cpu, parity = None, None
+    cpu, parity, parity_literal = None, None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu, oracle_frame = cpu_baseline(cfg, maps, args.cpu_budget)
         if cpu["n_shaded"] != n_shaded_total:
@@ -590,6 +672,20 @@ def main():
                       "pixels": int(W * H)}
             if not parity["within_1e-4_times_max_1_ref"]:
                 raise SystemExit(f"GPU frame outside the 1e-4 tolerance of the oracle: {parity}")
+            parity["oracle_form"] = ("contract: the kernel's own evaluation order of the light loop (oracle/bb_oracle.c "
+                                     "light_surface_contract); bit_exact here is NOT parity with the GLSL -- see parity_vs_literal")
+            # ... and against the LITERAL form: forward_brdf.frag:29-70 / brdf.glsl statement by statement
+            from oracle import bbo, scenes
+            lit, _ = bbo.render_bands(scenes.shaderball_scene(cfg, bbo.MaterialData(maps)), flags=bbo.FLAG_LITERAL)
+            dl = np.abs(gpu_frame.astype(np.float64) - lit.astype(np.float64))
+            parity_literal = {"oracle_form": "literal: the GLSL statement by statement (BBO_FLAG_LITERAL)",
+                              "tolerance": "absolute 1e-4 per channel (BASELINE.json); also 1e-4 * max(1, |ref|) (BASELINE.md)",
+                              "within_abs_1e-4": bool((dl <= 1e-4).all()),
+                              "within_1e-4_times_max_1_ref": bool((dl <= 1e-4 * np.maximum(1.0, np.abs(lit))).all()),
+                              "max_abs_diff": float(np.nanmax(dl)), "max_abs_ref": float(np.nanmax(np.abs(lit))),
+                              "bit_exact": bool(np.array_equal(gpu_frame.view(np.uint32), lit.view(np.uint32))), "pixels": int(W * H)}
+            if not parity_literal["within_1e-4_times_max_1_ref"]:
+                raise SystemExit(f"GPU frame outside the 1e-4 tolerance of the literal GLSL form: {parity_literal}")
 
     if rank == 0:
         out = {
@@ -613,11 +709,24 @@ def main():
                        "render_pass": args.render_pass,
                        "stream_layout": layout, **({"options": args.opt} if args.opt else {})},
             "roofline": roofline, "cpu_baseline": cpu,
+            # `value` is W*H / t: every pixel of the frame is produced, but only N_shaded of them run the PBR
+            # shader (the rest get the clear colour from k_raster); the shaded-only rate:
+            "shaded_mpixels_per_s": round(n_shaded_total * args.steps / elapsed / 1e6, 2),
+            "shaded_fraction_of_frame": round(n_shaded_total / float(W * H), 4),
         }
+        if dist_path:
+            out["exchange"] = {"who": args.exchange, "form": {P.SHARD_RGBA8: "rgba8", P.SHARD_PACKED: "packed rgb + alpha bit",
+                                                              P.SHARD_RGBA32F: "rgba32f"}[form],
+                               "bytes_per_rank_block": int(r.exchange_block_bytes(form)),
+                               "bytes_received_per_rank_per_frame": int(r.exchange_block_bytes(form)) * (world - 1),
+                               "ranks_in_communicator": int(dist.get_world_size()), "backend": backend,
+                               "band_rows": int(args.band_rows or r.tile_height()), "shard_rows": int(r.shard_rows())}
         if verified is not None:
             out["verified_against_unpartitioned_render"] = verified
         if parity is not None:
             out["parity_vs_oracle"] = parity
+        if parity_literal is not None:
+            out["parity_vs_literal"] = parity_literal
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
 

@@ -4,8 +4,11 @@
 //                (reference: src/shaders/forward_brdf.vert:24-37; state src/render.cpp:1069-1125)
 //   k_raster     per screen tile: LDS-resident 64-bit visibility keys (depth | primitive) filled with
 //                ds_max_u64, ballot/popcount compaction of the covered pixels into the tile's fragment list
+//   k_shade_items  the frame's shading work list: one item per 64 fragments of a tile's list (scan of the per-tile counts);
+//                also cooks the frame's light table
 //   k_shade      forward_brdf.frag + brdf.glsl once per visible pixel (src/shaders/forward_brdf.frag:15-76,
-//                brdf.glsl:2-36)
+//                brdf.glsl:2-36): one wave per item; a TAIL instantiation loops over what the main launch's estimate missed
+//   k_present, k_tone_map, k_deferred_background, k_shade_overlay, k_pack_shard / k_unpack_*: the rows either side of the path
 //
 // Arithmetic contract: every floating-point expression below has the same operand order and the same
 // explicit fmaf() placement as the CPU oracle; the file is compiled with -ffp-contract=off, IEEE
@@ -1474,14 +1477,15 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
 //   radiance NdotL                 = (color intensity) (att NdotL)                color * intensity once per light
 //   max(N.V, 0), max(N.L, 0), max(H.V, 0) = saturate(...)   the three cosines that do not feed q: differs only where
 //                                                           rounding puts a cosine of unit vectors above 1 (<= 2 ulp)
-// Why the shape matters on gfx950 (tools/microbench/issue_rate.hip, profiles/r02_issue_rate.txt): v_fma/mul/add_f32 on
-// VGPR operands issue every 2 cycles per SIMD, but ANY scalar-register operand, v_max, v_cmp, every conversion and
-// v_pk_* cost 4, v_rcp 8.  Light data therefore reaches the loop through LDS (ds_read broadcasts cost no vector-ALU
-// cycle) instead of scalar loads, per-light constants are cooked once per workgroup, and the loop body is 216 issue
-// cycles per light against 286 for the statement-by-statement form.
+// Why the shape matters on gfx950 (tools/microbench/issue_rate.hip, profiles/r02_issue_rate.txt): with two or more waves on
+// a SIMD, v_fma/mul/add_f32 issue every 2.05-2.4 cycles -- also with one scalar-register operand (row iso_fma_sgpr_operand:
+// 2.7) -- while v_max / v_cmp / conversions cost ~4, a transcendental 13 and a packed, DPP or 24-bit-multiply instruction in
+// a stream of plain ones 9-10.  Per-light constants are cooked once per FRAME (k_shade_items) and reach k_shade's loop through
+// the scalar cache (ConstLights below: s_load into scalar registers, the light's type already a scalar); only
+// k_deferred_background still stages them in LDS (LdsLights).
 // ------------------------------------------------------------------------------------------------
 
-// One light as the loop consumes it: 48 bytes in LDS, written once per workgroup by cook_light.
+// One light as the loop consumes it: 48 bytes, written once per frame by cook_light.
 struct CookedLight {
   float px, py, pz;
   int32_t type;
@@ -1631,11 +1635,10 @@ __global__ __launch_bounds__(kBackgroundThreads) void k_deferred_background(Shad
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_shade_items: the work list of k_shade.  One item = 64 consecutive fragments of one tile's list; the list of all
-// items of the frame lets a fixed number of resident waves walk the frame's fragments in a strided loop, prefetching
-// the next items' data while they shade the current one.  A single workgroup scans the per-tile fragment counts
-// (launch slots in k_raster's grid order): items[0] = number of items, items[1 + j] = slot << 4 | chunk64 ...
-// (a tile of 64x64 pixels has 64 chunks: the chunk field is 6 bits).
+// k_shade_items: the work list of k_shade.  One item = 64 consecutive fragments of one tile's list; k_shade runs one
+// wave per item (no wave for an empty part of a tile, none half empty).  items[0] = number of items, items[1 + j] =
+// full-tile flag << 31 | grid row << 18 | tile column << 6 | chunk of 64 fragments (a tile of 64x64 pixels has 64 chunks: the
+// chunk field is 6 bits), in launch-slot (= screen) order: neighbouring waves shade neighbouring pixels.
 // ------------------------------------------------------------------------------------------------
 
 // chunks of 64 fragments in the list of launch slot `slot` (0 past the frame)
@@ -1721,8 +1724,8 @@ __global__ __launch_bounds__(kItemsThreads) void k_shade_items(FrameParams fp, c
 //  * the chain is cut to three round trips per item (item word -> fragment words -> record + texels): the fragment
 //    word carries the clip-arena slot of a clipped sub-triangle, so its planes are fetched together with the primitive
 //    record instead of after it; a wave whose 64 fragments share one primitive fetches the record through the scalar
-//    cache (constant address space); the cooked light table is staged into LDS while the first loads are in flight.
-//  * many waves per SIMD (68 VGPRs -> 7) rather than a persistent, software-pipelined loop: a gfx950 wave issues at
+//    cache (constant address space), and so does every wave the frame's cooked light table: no LDS, no barrier.
+//  * many waves per SIMD (64 VGPRs -> the hardware's eight) rather than a persistent, software-pipelined loop: a gfx950 wave issues at
 //    most one instruction of ANY kind every ~4 cycles (profiles/r02_issue_rate.txt), so the vector ALU (one instruction
 //    every 2 cycles) only fills up with several waves that are all busy issuing.  The persistent forms were built and
 //    measured in round 2 ("dead ends"): loop-carried state costs 36 VGPRs, and every forced

@@ -1417,6 +1417,8 @@ void bbo_camera_view(const float *pos, float yaw, float pitch, bbo_mat4 *out) { 
   bbo_mat4_look_at(pos, target, up, out);
 }
 
+uint32_t bbo_contract_revision(void) { return BBO_CONTRACT_REVISION; }
+
 uint32_t bbo_sizeof(int what) {
   switch (what) {
   case 0: return (uint32_t)sizeof(bbo_vertex);

@@ -112,6 +112,16 @@ typedef struct {
                                     light_surface_contract in bb_oracle.c).  The GPU is bit-identical to the
                                     default and within BASELINE's 1e-4 of the literal form. */
 
+/* Revision of the arithmetic contract (the default, shipped evaluation order).  The frozen frames under tests/golden/
+ * record the revision that minted them (tests/golden/CONTRACT.json): a change of the contract form is a new number here,
+ * a line in the history of that file and re-minted fixtures, never a silent re-freeze.  The LITERAL form has no
+ * revision: it is the GLSL statement by statement.
+ *   1  round 1: three divisions in the specular term, integer-seed rcp / rsqrt sequences
+ *   2  round 2: one correctly rounded reciprocal behind the GGX denominator, hoisted kD*albedo/PI and color*intensity,
+ *      saturate for N.V, N.L, H.V (light_surface_contract) */
+#define BBO_CONTRACT_REVISION 2
+uint32_t bbo_contract_revision(void);
+
 typedef struct {
   uint64_t n_prims;         /* triangles submitted */
   uint64_t n_raster_tris;   /* sub-triangles that survived clip + cull */

@@ -136,7 +136,14 @@ def lib():
         L.bbo_camera_view.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_void_p]
         L.bbo_sizeof.restype = C.c_uint32
         L.bbo_sizeof.argtypes = [C.c_int]
+        L.bbo_contract_revision.restype = C.c_uint32
+        L.bbo_contract_revision.argtypes = []
     return _lib
+
+
+def contract_revision() -> int:
+    """BBO_CONTRACT_REVISION of the built oracle: which evaluation order the default (shipped) form is (bb_oracle.h)."""
+    return int(lib().bbo_contract_revision())
 
 
 def _p(a):
@@ -275,6 +282,30 @@ def render(scene: Scene, y0=0, y1=None, flags=0, want_prim=True, want_depth=True
     if rc != 0:
         raise RuntimeError(f"bbo_render failed: {rc}")
     return rgba, prim, depth, st.as_dict()
+
+
+def render_bands(scene: Scene, flags=0, rows=32, threads=None):
+    """The whole frame, bands of `rows` rows over the host's cores (the C call drops the GIL; bands share nothing, so the
+    bits are those of one whole-frame call).  For BASELINE's full sizes: 4K in ~1 s, 8K in a few.  Returns (rgba, n_shaded)."""
+    from concurrent.futures import ThreadPoolExecutor
+    W, H = scene.width, scene.height
+    rgba = np.zeros((H, W, 4), np.float32)
+    arr = (Draw * max(1, len(scene.draws)))(*[d.c_struct() for d in scene.draws])
+    L = lib()
+
+    def band(y0):
+        st = Stats()
+        rc = L.bbo_render(_p(scene.frame), _p(scene.view), arr, len(scene.draws), W, H, y0, min(y0 + rows, H), flags, _p(rgba),
+                          None, None, C.byref(st))
+        if rc != 0:
+            raise RuntimeError(f"bbo_render failed: {rc}")
+        return st.n_shaded
+
+    if threads is None:
+        threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    with ThreadPoolExecutor(max(1, min(threads, 16))) as ex:
+        n = sum(ex.map(band, range(0, H, rows)))
+    return rgba, int(n)
 
 
 def render_deferred(scene: Scene, y0=0, y1=None, want_gbuffer=True, flags=0):

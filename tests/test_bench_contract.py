@@ -72,3 +72,35 @@ def test_traffic_and_valu_come_from_summaries_of_the_same_kernel_sources():
         assert bench.valu_roofline("c3", "k_shade", 0.1, 256)["achieved"] is None
     finally:
         build_id.kernel_source_sha256 = real
+
+
+def test_bench_with_gpus_n_and_no_launcher_starts_its_own_ranks_before_touching_torch():
+    """`python bench.py --gpus 8 ...` (the driver's N = 1 command form with another N): the ranks are started as children of
+    torch.distributed.run before this process has imported torch or made a HIP call, with the same arguments, rendezvous
+    on 127.0.0.1, and the launcher's exit code is handed on."""
+    import subprocess
+    import sys
+    code = r'''
+import os, subprocess, sys
+os.environ.pop("WORLD_SIZE", None)
+seen = {}
+def fake_call(cmd, env=None):
+    seen["cmd"], seen["env"] = cmd, env
+    return 7
+subprocess.call = fake_call
+sys.argv = ["bench.py", "--gpus", "8", "--steps", "20", "--warmup", "5"]
+import bench
+try:
+    bench.main()
+    raise AssertionError("main() returned")
+except SystemExit as e:
+    assert e.code == 7, e.code
+assert "torch" not in sys.modules, "torch was imported before the ranks were started"
+c = seen["cmd"]
+assert c[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in c and c[c.index("--nproc-per-node") + 1] == "8"
+assert c[c.index("--master-addr") + 1] == "127.0.0.1" and c[-6:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+assert c[-7].endswith("bench.py") and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+print("ok")
+'''
+    p = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and p.stdout.strip() == "ok", p.stderr[-2000:]

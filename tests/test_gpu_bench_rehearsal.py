@@ -43,3 +43,17 @@ def test_two_ranks_on_one_gpu(exchange, extra):
     assert out["verified_against_unpartitioned_render"] is True and out["n_gpus"] == 2
     assert out["scaling"] == "strong"
     assert ("bbr_push_shard" if exchange == "peer" else "torch.distributed") in out["config"]["partition"]
+
+
+def test_bare_bench_command_with_two_gpus_launches_its_own_ranks():
+    """`python3 bench.py --gpus 2 --steps 20 --warmup 5` with no launcher around it (what a driver that reuses its N = 1
+    command form would run): bench.py starts the two ranks itself and relays rank 0's line.  Rehearsed on the one GPU."""
+    env = dict(os.environ, BBR_BENCH_BACKEND="gloo", BBR_BENCH_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = _line(subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "20", "--warmup", "5", "--workload", "c2",
+                                "--verify"], cwd=ROOT, capture_output=True, text=True, timeout=900, env=env))
+    assert out["n_gpus"] == 2 and out["verified_against_unpartitioned_render"] is True
+    assert out["exchange"]["ranks_in_communicator"] == 2 and out["exchange"]["bytes_per_rank_block"] > 0
+    assert [p["rank"] for p in out["roofline"]["per_rank"]] == [0, 1]
+    assert sum(p["n_shaded"] for p in out["roofline"]["per_rank"]) == out["roofline"]["n_shaded"]

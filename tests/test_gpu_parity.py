@@ -86,6 +86,27 @@ def test_c3_full_size_4k():
     assert st["n_shaded"] == json.load(open(os.path.join(GOLDEN, "n_shaded.json")))["c3"]["n_shaded"]
 
 
+@pytest.mark.parametrize("name", ["c2", "c3"])
+def test_full_size_frame_against_the_literal_glsl_form(name):
+    """The HIP frame against the oracle's LITERAL form -- forward_brdf.frag:29-70 / brdf.glsl statement by statement, no
+    re-association -- at BASELINE's full sizes with 2048^2 maps.  `check` above is bit-exact against the CONTRACT form, which
+    is the kernel's own evaluation order; THIS is the comparison that says the shipped order still renders the GLSL.
+    Tolerance, stated: absolute 1e-4 per channel (BASELINE.json), hence also 1e-4 * max(1, |ref|)."""
+    cfg = configs.CONFIGS[name]
+    sc = scenes.shaderball_scene(cfg, bbo.MaterialData(textures.make_material(cfg.texture_size)))
+    literal, n_shaded = bbo.render_bands(sc, flags=bbo.FLAG_LITERAL)
+    r = Renderer(sc.width, sc.height)
+    r.render_scene(sc)
+    img = r.read_framebuffer()
+    st = r.stats()
+    r.close()
+    assert st["n_shaded"] == n_shaded and np.isfinite(literal).all() and np.isfinite(img).all()
+    d = np.abs(img.astype(np.float64) - literal.astype(np.float64))
+    assert d.max() <= 1e-4, float(d.max())
+    assert_frame_close(img, literal)
+    assert np.array_equal(img[..., 3], literal[..., 3])
+
+
 def test_normal_map_off_and_reference_default_lights(maps64):
     """reference defaults: EnableNormalMap = 0, three lights incl. a directional one and the radians-as-cosine quirk"""
     cfg = configs.C2.scaled(256, 144, 64)

@@ -92,3 +92,17 @@ def test_texture_generator_is_deterministic():
     h = hashlib.sha256(b"".join(m[k].tobytes() for k in ("albedo", "metallic", "roughness", "ao", "normal"))).hexdigest()
     assert h == open(os.path.join(GOLDEN, "textures64.sha256")).read().strip()
     assert m["roughness"][..., 0].min() >= 39  # never 0: brdf.glsl's 0/0 hazard stays out of the benchmark
+
+
+def test_frozen_frames_carry_the_contract_revision_that_minted_them():
+    """tests/golden/CONTRACT.json (tools/make_fixtures.py contract_manifest): the frozen frames are the ones that file
+    lists, minted by the contract revision the oracle is built with -- a re-mint without a new BBO_CONTRACT_REVISION, or a
+    new revision without re-minted frames, fails here instead of passing silently."""
+    import hashlib
+    m = json.load(open(os.path.join(GOLDEN, "CONTRACT.json")))
+    assert m["contract_revision"] == bbo.contract_revision()
+    assert m["history"][-1]["contract_revision"] == m["contract_revision"] and m["history"][-1]["files"] == m["files"]
+    revs = [h["contract_revision"] for h in m["history"]]
+    assert revs == sorted(revs)
+    for name, digest in m["files"].items():
+        assert hashlib.sha256(open(os.path.join(GOLDEN, name), "rb").read()).hexdigest() == digest, name

@@ -294,8 +294,31 @@ def deferred():
     print("deferred", info)
 
 
+def contract_manifest():
+    """tests/golden/CONTRACT.json: which revision of the arithmetic contract (oracle/bb_oracle.h, BBO_CONTRACT_REVISION)
+    minted the frozen frames, and their hashes -- a re-mint shows up as a diff of this file next to a new revision."""
+    from oracle import bbo
+    frozen = ["oracle_frames.npz", "deferred.npz", "presented.npz", "overlays.npz"]
+    path = os.path.join(GOLD, "CONTRACT.json")
+    old = json.load(open(path)) if os.path.exists(path) else {"history": []}
+    rev = bbo.contract_revision()
+    files = {f: hashlib.sha256(open(os.path.join(GOLD, f), "rb").read()).hexdigest() for f in frozen}
+    if old.get("contract_revision") != rev or old.get("files") != files:
+        old["history"] = old.get("history", []) + [{"contract_revision": rev, "files": files}]
+    old.update({"contract_revision": rev, "files": files,
+                "note": "frames frozen from the oracle's CONTRACT (default) form; keys *_literal_rgba_bits inside them are the "
+                        "statement-by-statement form, which has no revision.  tests/test_oracle_golden_frames.py refuses a "
+                        "fixture whose hash or revision differs from this file."})
+    json.dump(old, open(path, "w"), indent=1)
+    print("contract manifest", rev)
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     which = sys.argv[1:] or ["shaderball", "math_golden", "default_texels", "gizmo", "golden_frames", "n_shaded", "present", "deferred", "reference_pngs", "uv_sphere", "overlays"]
+    if sys.argv[1:] == ["contract_manifest"]:
+        contract_manifest()
+        sys.exit(0)
     for w in which:
         globals()[w]()
+    contract_manifest()
