@@ -210,8 +210,6 @@ def main():
                     help="option stream_layout of the library (include/bibim_hip.h); 2 (one stream per frame slot) is its default")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="any other option of the library (bbr_set_option), e.g. --opt no_tail_items=0; recorded in config.options")
-    ap.add_argument("--frame-graph", type=int, default=0, choices=[0, 1],
-                    help="option frame_graph of the library: repeated frames are launched as one hipGraph per frame slot")
     ap.add_argument("--gather", default="packed", choices=["packed", "rgba32f"],
                     help="N > 1: what the all-gather moves -- the shard as rgb + one alpha bit per pixel (lossless, 12.1 B per "
                          "pixel; default) or as plain RGBA32F (16 B); the reassembled frame is the same, bit for bit")
@@ -290,7 +288,6 @@ def main():
         r.set_option("tile_mode", args.tile_mode)
     r.set_option("frames_in_flight", args.frames_in_flight)
     r.set_option("stream_layout", args.stream_layout)
-    r.set_option("frame_graph", args.frame_graph)
     for o in args.opt:
         r.set_option(o.split("=")[0], int(o.split("=")[1]))
     r.set_option("render_pass", 1 if args.render_pass == "deferred" else 0)

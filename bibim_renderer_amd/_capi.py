@@ -88,7 +88,6 @@ SIGNATURES = {
     "bbr_present_timing": (C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_float)]),
     "bbr_presented_device_ptr": (C.c_int, [_P, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
     "bbr_unpack_gathered_rgba8": (C.c_int, [_P, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "bbr_frame_graph_state": (C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "bbr_comm_unique_id": (C.c_int, [_P, _P]),
     "bbr_comm_init": (C.c_int, [_P, C.c_int32, C.c_int32, _P]),
     "bbr_comm_destroy": (C.c_int, [_P]),

@@ -969,7 +969,7 @@ constexpr int kItemsThreads = 256;  // launch slots per workgroup of k_shade_ite
 // words between two of k_raster's chunk counters: a 128-byte cache line each.  Atomics on one LINE serialise like atomics on
 // one address (packed 32 to a line they cost k_raster 5 us at C5's 32 640 tiles)
 constexpr int kItemGroupStride = 32;
-constexpr int kItemGroupSlots = 32, kItemGroups = 2048;  // k_raster's chunk totals: one counter per 32 launch slots (fewer
+constexpr int kItemGroupSlots = 32, kItemGroups = 4096;  // k_raster's chunk totals: one counter per 32 launch slots (fewer
                                                           // addresses made the atomics cost k_raster 7 us at C3)
 constexpr int kItemChunkBits = 6, kItemTxBits = 12;  // item = full << 31 | grid row << 18 | tile column << 6 | chunk of 64 fragments
 // A tile that ONE triangle covers completely and nothing else touches has no fragment list: its count word carries this flag
@@ -977,8 +977,10 @@ constexpr int kItemChunkBits = 6, kItemTxBits = 12;  // item = full << 31 | grid
 // k_shade_items hands the flag on in the item word, so that k_shade knows before it loads anything.
 constexpr uint32_t kFullTile = 0x80000000u;
 constexpr int kFragPixBits = 12;  // pixel-in-tile field of a fragment's high word (tiles of up to 64x64); the clip slot + 1 sits above it
-constexpr int kTileThreads = 256;
-constexpr int kTileWaves = kTileThreads / 64;
+// threads of k_raster's workgroup for a tile size: 256 for the large tiles, ONE wave for 16 x 16 -- the workgroup then
+// needs no barrier at all and a tile nothing is binned to costs the machine one wave, not four
+template <int TILE_W, int TILE_H>
+constexpr int tile_threads() { return TILE_W * TILE_H <= 256 ? 64 : 256; }
 
 // One lane rasterises one small triangle into the tile's LDS keys.  Bounding box <= 16 px in each direction
 // => every edge-function term fits 32 bits and steps are plain adds.
@@ -1086,57 +1088,6 @@ BB_DEV bool tile_row(const FrameParams &fp, int grid_y, int &ty, int &out_tile_r
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_tile_order: heaviest-first launch order for k_raster.  Tile costs span two orders of magnitude (a sky tile
-// lives ~5 us, a tile of a distant ShaderBall up to ~45 us); in plain row order the heavy tiles of the middle rows
-// start late and the kernel ends in a ~25 us tail with a few dozen workgroups alive (BB_STAMPS build).
-// One thread per launch slot: bucket = log2 of an estimate of the raster rounds the tile's bins need; every wave
-// reserves room in each bucket with one atomic (lanes 0..15 own one bucket each, so a wave pays a single round
-// trip) and writes its slots into order[bucket][...].  k_raster turns its launch index into (bucket, offset) with
-// the sixteen totals.  The order inside a bucket is arbitrary, which cannot change the image: tiles are independent.
-// A single-workgroup counting sort was tried first and cost 25-35 us -- more than the tail it removes.
-// ------------------------------------------------------------------------------------------------
-constexpr int kOrderBuckets = 16;
-constexpr int kOrderThreads = 256;
-
-BB_DEV uint32_t tile_cost_bucket(const uint32_t *__restrict__ tile_count, uint32_t tile, uint32_t bin_cap) {
-  const uint32_t c0 = min(tile_count[tile * kBinClasses + 0], bin_cap), c1 = min(tile_count[tile * kBinClasses + 1], bin_cap),
-                 c2 = min(tile_count[tile * kBinClasses + 2], bin_cap);
-  // class 0 runs 256 triangles at a time, class 1 sixteen, class 2 four
-  const uint32_t cost = c0 + 8u * c1 + 32u * c2 + 1u;
-  const uint32_t lg = 31u - (uint32_t)__clz((int)cost);
-  return (uint32_t)(kOrderBuckets - 1) - min(lg, (uint32_t)(kOrderBuckets - 1));  // heaviest first
-}
-
-__global__ __launch_bounds__(kOrderThreads) void k_tile_order(FrameParams fp, const uint32_t *__restrict__ tile_count,
-                                                               Counters *__restrict__ ctr, uint32_t *__restrict__ order,
-                                                               int grid_x, int grid_y) {
-  const int lane = threadIdx.x & 63;
-  const uint32_t n = (uint32_t)grid_x * (uint32_t)grid_y;
-  const uint32_t lin = blockIdx.x * kOrderThreads + threadIdx.x;
-  const bool live = lin < n;
-  uint32_t bkt = 0xFFu;
-  if (live) {
-    const int gy = (int)(lin / (uint32_t)grid_x), tx = (int)(lin - (uint32_t)gy * (uint32_t)grid_x);
-    int ty, out_tile_row;
-    bkt = tile_row(fp, gy, ty, out_tile_row)
-              ? tile_cost_bucket(tile_count, (uint32_t)ty * (uint32_t)fp.tiles_x + (uint32_t)tx, fp.bin_cap)
-              : (uint32_t)(kOrderBuckets - 1);  // slots past the frame: last, they exit at once
-  }
-  uint32_t my_count = 0u;            // lane b < 16: this wave's slots in bucket b
-  unsigned long long my_peers = 0;  // lanes of my bucket
-#pragma unroll
-  for (uint32_t b = 0; b < (uint32_t)kOrderBuckets; ++b) {
-    const unsigned long long same = __ballot(bkt == b);
-    if ((uint32_t)lane == b) my_count = (uint32_t)__popcll(same);
-    if (bkt == b) my_peers = same;
-  }
-  uint32_t at = 0u;
-  if (my_count) at = atomicAdd(&ctr->order_hist[lane], my_count);
-  const uint32_t base = (uint32_t)__shfl((int)at, (int)(bkt & 15u));
-  if (live) order[(size_t)bkt * n + base + (uint32_t)__popcll(my_peers & ((1ull << lane) - 1ull))] = lin;
-}
-
-// ------------------------------------------------------------------------------------------------
 // k_raster: one workgroup per screen tile.  LDS-resident 64-bit keys (depth bits << 32 | primitive) filled with
 // ds_max_u64 -- depth op GREATER_OR_EQUAL with "later primitive wins ties" falls out of the key order -- then
 // ballot/popcount compaction of the covered pixels into the tile's fragment list.  Background pixels get the
@@ -1147,8 +1098,7 @@ __global__ __launch_bounds__(kOrderThreads) void k_tile_order(FrameParams fp, co
 // split over the raster classes, instead of two per loop iteration.  The every-tile list rides along as extra
 // "large" entries after a per-tile accept/reject test.
 // ------------------------------------------------------------------------------------------------
-constexpr int kStage = kTileThreads;  // staged entries per chunk (one per thread)
-
+template <int kStage>  // staged entries per chunk (one per thread)
 struct StagedTri {  // struct-of-arrays in LDS: thread j owns column j when filling
   int X0[kStage], Y0[kStage], X1[kStage], Y1[kStage], X2[kStage], Y2[kStage];
   float z0[kStage], dzdx[kStage], dzdy[kStage];
@@ -1156,7 +1106,8 @@ struct StagedTri {  // struct-of-arrays in LDS: thread j owns column j when fill
   uint32_t box[kStage];  // px0 | px1 << 8 | py0 << 16 | py1 << 24 relative to the tile; 0xFFFFFFFF = skip
 };
 
-BB_DEV RasterTri staged_tri(const StagedTri &st, int j) {
+template <int kStage>
+BB_DEV RasterTri staged_tri(const StagedTri<kStage> &st, int j) {
   RasterTri t;
   t.X0 = st.X0[j]; t.Y0 = st.Y0[j]; t.X1 = st.X1[j]; t.Y1 = st.Y1[j]; t.X2 = st.X2[j]; t.Y2 = st.Y2[j];
   t.z0 = st.z0[j]; t.dzdx = st.dzdx[j]; t.dzdy = st.dzdy[j];
@@ -1168,17 +1119,18 @@ BB_DEV RasterTri staged_tri(const StagedTri &st, int j) {
 // gizmo primitives are scissored to their rectangle and biased above everything else, pixels no overlay primitive
 // wins are left alone (no background fill).  OVERLAY = false with depth_io != nullptr stores the resolved depth.
 template <int TILE_W, int TILE_H, bool OVERLAY = false>
-__global__ __launch_bounds__(kTileThreads) void k_raster(
+__global__ __launch_bounds__((tile_threads<TILE_W, TILE_H>())) void k_raster(
     FrameParams fp, const RasterTri *__restrict__ tris, const ClipSlot *__restrict__ clip_arena,
     Counters *__restrict__ ctr, uint32_t *__restrict__ tile_count,
     const uint32_t *__restrict__ bins, const BroadTri *__restrict__ broad_list,
     unsigned long long *__restrict__ frags, uint32_t *__restrict__ frag_count, float4 *__restrict__ out,
-    uint32_t *__restrict__ vis_prim, float *__restrict__ vis_depth, const uint32_t *__restrict__ tile_order,
+    uint32_t *__restrict__ vis_prim, float *__restrict__ vis_depth,
     const float4 *__restrict__ background, float *__restrict__ depth_io, uint32_t *__restrict__ host_flags,
     uint32_t *__restrict__ out8, uint32_t *__restrict__ item_groups) {
   constexpr int TILE_PIXELS = TILE_W * TILE_H;
+  constexpr int kTileThreads = tile_threads<TILE_W, TILE_H>(), kTileWaves = kTileThreads / 64, kStage = kTileThreads;
   __shared__ unsigned long long keys[TILE_PIXELS];
-  __shared__ StagedTri st;
+  __shared__ StagedTri<kStage> st;
   __shared__ uint32_t s_count;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1191,19 +1143,10 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
     host_flags[3] = ctr->n_broad;
     host_flags[4] = ctr->n_clip_slots;
   }
-  // launch slot -> tile: plain row order, or heaviest tiles first (k_tile_order)
-  uint32_t slot = blockIdx.y * gridDim.x + blockIdx.x;
-  if (tile_order) {
-    uint32_t b = 0u, start = 0u;  // (bucket, offset) of this launch index from the bucket totals; uniform
-    for (; b + 1u < (uint32_t)kOrderBuckets; ++b) {
-      const uint32_t h = ctr->order_hist[b];
-      if (slot < start + h) break;
-      start += h;
-    }
-    slot = tile_order[(size_t)b * (gridDim.x * gridDim.y) + (slot - start)];
-  }
-  const int grid_row = (int)(slot / gridDim.x);
-  const int tx = (int)(slot - (uint32_t)grid_row * gridDim.x);
+  // launch slot -> tile: plain row order
+  const uint32_t slot = blockIdx.y * gridDim.x + blockIdx.x;
+  const int grid_row = (int)blockIdx.y;
+  const int tx = (int)blockIdx.x;
   int ty, out_tile_row;
   const bool live = tile_row(fp, grid_row, ty, out_tile_row);
   if (!live) return;
@@ -1218,25 +1161,89 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
   const int out_y0 = out_tile_row * TILE_H;
   const int rx1 = min(tile_x0 + TILE_W, fp.width) - 1, ry1 = min(tile_y0 + TILE_H, fp.height) - 1;
 
-  // The tile's bin counts are read ONCE per workgroup, published through LDS, and only cleared (for the slot's next
-  // frame) after the barrier.  When every thread read them from global memory and threads 0..2 cleared them right
-  // away, a wave that started late -- other processes sharing the GPU are enough -- could read the cleared value:
-  // its loop bounds then disagreed with the other waves' and a handful of triangles of the tile went missing (seen as
-  // ~100 wrong pixels in one tile of one frame in a few hundred, never on an otherwise idle GPU).
-  __shared__ uint32_t s_n_cls[kBinClasses];
-  __shared__ uint32_t s_n_valid, s_full_ref;  // staged entries that touch the tile; (reference + 1) of one that covers all of it
   // Clipped sub-triangles that touch this tile: (reference, clip-arena slot + 1).  The slot goes into the fragment word,
   // so that k_shade can fetch the sub-triangle's planes together with the primitive record instead of after it.
   // More than kClipRefs of them: the field stays 0 and k_shade finds the slot through the record (one more round trip).
   constexpr uint32_t kClipRefs = 32;
-  __shared__ uint32_t s_clip_ref[kClipRefs], s_clip_slot[kClipRefs], s_n_clip_refs, s_full_clip;
+  __shared__ uint32_t s_clip_ref[kClipRefs], s_clip_slot[kClipRefs], s_n_clip_refs;
   __shared__ unsigned long long s_pad_frag;
-  if (tid < (int)kBinClasses)
-    s_n_cls[tid] = BB_ABLATE(1u | (256u << tid)) ? 0u : min(tile_count[tile * kBinClasses + tid], fp.bin_cap);
+  // The tile's bin counts: every thread reads them itself (uniform address: one line), decides with them, and only AFTER
+  // the workgroup's first barrier are they cleared for the slot's next frame -- a wave arrives at that barrier with its
+  // loads returned, so no wave, however late it started, can see the cleared value.  (Cleared right after the read, a
+  // late wave disagreed with its workgroup about the loop bounds: ~100 wrong pixels in one frame of a few hundred
+  // whenever other processes shared the GPU.)
+  uint32_t n_cls[kBinClasses];
+#pragma unroll
+  for (uint32_t c = 0; c < kBinClasses; ++c)
+    n_cls[c] = BB_ABLATE(1u | (256u << c)) ? 0u : min(tile_count[tile * kBinClasses + c], fp.bin_cap);
   // A frame whose every-tile list overflowed (bit 1 of ctr->overflow, final since k_geometry ended) is rendered again after
   // the host has grown the list: the clip path reserves a run of entries and writes none of them when the run does not
   // fit, so a prefix of the list may hold entries never written this frame -- the overflowed frame takes none of it.
   const uint32_t n_broad = (BB_ABLATE(5u) || (ctr->overflow & 2u)) ? 0u : min(ctr->n_broad, fp.broad_cap);
+
+  // the pixel's colour when no geometry covers it.  forward: the clear colour (src/main.cpp:84); deferred: brdf.frag on the
+  // cleared G-buffer texel (k_deferred_background); fused presentation: the same colours as presented pixels (the clear
+  // colour presents as (0, 0, 0, 255))
+  auto store_background = [&](int x, int y) {
+    const size_t o = (size_t)(out_y0 + y) * (size_t)fp.width + (size_t)(tile_x0 + x);
+    if (out8) out8[o] = background ? __float_as_uint(background[1].x) : 0xFF000000u;
+    else out[o] = background ? background[0] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  };
+
+  // ---- light tiles: no LDS, no barrier ----
+  // Most tiles of a frame hold no binned triangle at all: sky, or ground that ONE huge (every-tile-list) triangle covers
+  // completely -- 6595 of C3's 8160.  Each of the four waves settles that by itself from the same uniform data (the bin
+  // counts above and a classification of the <= 64 list entries, one per lane), so the workgroup agrees without talking:
+  //   nothing touches the tile       -> its pixels get the background colour, its fragment count is 0
+  //   one triangle covers all of it  -> every pixel's winner is known without a depth atomic: the fragment list is ONE
+  //                                     word and the count carries kFullTile (k_shade makes the 64 fragment words of an
+  //                                     item from the lane index)
+  // and the workgroup is gone after two memory round trips.  Through the general path below these tiles lived 4.8 us each
+  // (8 KB of keys cleared, a barrier, one staged entry, another barrier: in-kernel stamps) and held 28 % of the frame's
+  // wave-slot time between them.  Anything else falls through.
+  if (!OVERLAY && !vis_prim && !depth_io && (n_cls[0] | n_cls[1] | n_cls[2]) == 0u && n_broad <= 64u) {
+    bool ok = false, full = false;
+    uint32_t ref = 0u, clip_slot1 = 0u;
+    if ((uint32_t)lane < n_broad) {
+      const BroadTri &b = broad_list[lane];
+      const RasterTri t = b.tri;
+      ref = b.ref;
+      clip_slot1 = b.pad[0];
+      const int32_t minX = min(t.X0, min(t.X1, t.X2)), maxX = max(t.X0, max(t.X1, t.X2));
+      const int32_t minY = min(t.Y0, min(t.Y1, t.Y2)), maxY = max(t.Y0, max(t.Y1, t.Y2));
+      const int px0 = max((minX - 128 + 255) >> 8, tile_x0), px1 = min((maxX - 128) >> 8, rx1);
+      const int py0 = max((minY - 128 + 255) >> 8, tile_y0), py1 = min((maxY - 128) >> 8, ry1);
+      if (px0 <= px1 && py0 <= py1) {
+        const int cls_rect = classify_rect(edge_setup(t), px0, px1, py0, py1);
+        ok = cls_rect != 0;
+        full = cls_rect == 2 && px1 - px0 + 1 == TILE_W && py1 - py0 + 1 == TILE_H;
+      }
+    }
+    const unsigned long long m_ok = __ballot(ok);
+    if (m_ok == 0ull) {
+      for (int p = tid; p < TILE_PIXELS; p += kTileThreads) {
+        int x, y;
+        tile_pixel<TILE_W>(p, x, y);
+        if (tile_x0 + x < fp.width && tile_y0 + y < fp.height) store_background(x, y);
+      }
+      if (tid == 0) frag_count[tile] = 0u;
+      BB_RSTAMP(5);
+      return;
+    }
+    if (__popcll(m_ok) == 1 && __ballot(full) == m_ok) {
+      if (tid == 0) {
+        const int src = __ffsll((long long)m_ok) - 1;
+        const unsigned long long fref = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)ref, src);
+        const unsigned long long fhi = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)clip_slot1, src) << kFragPixBits;
+        frags[(size_t)tile * TILE_PIXELS] = (fhi << 32) | fref;  // the whole list: 8 bytes instead of 8 KB
+        frag_count[tile] = (uint32_t)TILE_PIXELS | kFullTile;
+        if (item_groups) atomicAdd(&item_groups[(slot / kItemGroupSlots) * kItemGroupStride], (uint32_t)(TILE_PIXELS / 64));
+      }
+      BB_RSTAMP(5);
+      return;
+    }
+  }
+
   for (int p = tid; p < TILE_PIXELS; p += kTileThreads) {
     unsigned long long k0 = 0ull;
     if (OVERLAY) {  // depth test against what the scene left behind; low word 0 = "no overlay primitive here"
@@ -1250,16 +1257,11 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
   }
   if (tid == 0) {
     s_count = 0;
-    s_n_valid = 0;
-    s_full_ref = 0;
     s_n_clip_refs = 0;
-    s_full_clip = 0;
   }
-  __syncthreads();  // counts published, keys cleared
-  uint32_t n_cls[kBinClasses];
-#pragma unroll
-  for (uint32_t c = 0; c < kBinClasses; ++c) n_cls[c] = s_n_cls[c];
-  if (tid < (int)kBinClasses && n_cls[tid]) tile_count[tile * kBinClasses + tid] = 0;  // ready for the slot's next frame
+  __syncthreads();  // keys cleared; every wave has its copy of the counts
+  if (tid < (int)kBinClasses && (tid == 0 ? n_cls[0] : (tid == 1 ? n_cls[1] : n_cls[2])))
+    tile_count[tile * kBinClasses + tid] = 0;  // ready for the slot's next frame
 
   // entry order: class 0 | class 1 | class 2 | every-tile list
   const uint32_t e1 = n_cls[0], e2 = e1 + n_cls[1], e3 = e2 + n_cls[2], e_end = e3 + n_broad;
@@ -1270,7 +1272,6 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
     return (OVERLAY && (ref >> 3) >= fp.ov_first_gizmo_prim) ? 0x40000000u : 0u;
   };
   BB_RSTAMP(1);
-  bool fast_full = false;  // uniform over the workgroup
   for (uint32_t base = 0; base < e_end; base += kStage) {
     if (base) __syncthreads();  // previous chunk consumed
     // ---- stage: every thread fetches one entry (reference -> triangle record), all loads in flight together ----
@@ -1300,17 +1301,8 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
           py0 = max(py0, fp.ov_y0); py1 = min(py1, fp.ov_y1 - 1);
         }
         bool ok = px0 <= px1 && py0 <= py1;
-        int cls_rect = 1;
-        if (ok && e >= e3) {  // every-tile list: accept / reject
-          cls_rect = classify_rect(edge_setup(t), px0, px1, py0, py1);
-          ok = cls_rect != 0;
-        }
+        if (ok && e >= e3) ok = classify_rect(edge_setup(t), px0, px1, py0, py1) != 0;  // every-tile list: accept / reject
         if (ok) {
-          atomicAdd(&s_n_valid, 1u);
-          if (cls_rect == 2 && px1 - px0 + 1 == TILE_W && py1 - py0 + 1 == TILE_H) {  // covers every pixel of the tile
-            s_full_ref = ref + 1u;
-            s_full_clip = clip_slot1;
-          }
           if (clip_slot1) {
             const uint32_t k = atomicAdd(&s_n_clip_refs, 1u);
             if (k < kClipRefs) {
@@ -1329,13 +1321,6 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
     }
     __syncthreads();
     if (base == 0) BB_RSTAMP(2);
-    // One triangle covers the whole tile and nothing else touches it (most ground-plane tiles): every pixel's winner is
-    // known without a single depth atomic -- the fragment list is the pixel list.  (Same set of fragments as the general
-    // path; their order inside a tile's list is arbitrary there too.)
-    if (!OVERLAY && e_end <= (uint32_t)kStage && s_n_valid == 1u && s_full_ref != 0u && !vis_prim && !depth_io) {
-      fast_full = true;
-      break;
-    }
     const uint32_t hi = min(base + (uint32_t)kStage, e_end);
     // ---- class 0: one tiny triangle per lane ----
     // (with few of them in the chunk, two or four lanes share a triangle row by row: raster_triangle_rows)
@@ -1392,16 +1377,6 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
   // ---- compaction: covered pixels -> fragment list (ballot + popcount prefix); background written here ----
   // fragment = ((clip slot + 1) << kFragPixBits | pixel in tile) << 32 | reference
   unsigned long long *my_frags = frags + (size_t)tile * TILE_PIXELS;
-  if (fast_full) {
-    const unsigned long long ref = (unsigned long long)(s_full_ref - 1u);
-    const unsigned long long hi = (unsigned long long)s_full_clip << kFragPixBits;
-    if (tid == 0) {
-      my_frags[0] = (hi << 32) | ref;  // the whole list: 8 bytes instead of 8 KB written here and read back by k_shade
-      frag_count[tile] = (uint32_t)TILE_PIXELS | kFullTile;
-      if (item_groups) atomicAdd(&item_groups[(slot / kItemGroupSlots) * kItemGroupStride], (uint32_t)(TILE_PIXELS / 64));
-    }
-    return;
-  }
   const uint32_t n_clip_refs = s_n_clip_refs <= kClipRefs ? s_n_clip_refs : 0u;  // too many: k_shade looks the slots up
   for (int base = 0; base < TILE_PIXELS; base += kTileThreads) {
     int p = base + tid;
@@ -1427,11 +1402,7 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
       my_frags[wave_base + rank_in_wave] = fw;
       if (wave_base + rank_in_wave == 0u) s_pad_frag = fw;  // the list's first fragment doubles as its padding (below)
     } else if (in_frame && !OVERLAY) {
-      size_t o = (size_t)(out_y0 + y) * (size_t)fp.width + (size_t)gx;
-      // forward: the clear colour (src/main.cpp:84); deferred: brdf.frag on the cleared G-buffer texel (k_deferred_background)
-      // fused presentation: the same colours as presented pixels (the clear colour presents as (0, 0, 0, 255))
-      if (out8) out8[o] = background ? __float_as_uint(background[1].x) : 0xFF000000u;
-      else out[o] = background ? background[0] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      store_background(x, y);
     }
     if (vis_prim && in_frame) {
       size_t o = (size_t)gy * (size_t)fp.width + (size_t)gx;

@@ -168,8 +168,7 @@ struct Counters {
   uint32_t n_clip_slots;
   uint32_t overflow;  // bit0 bins, bit1 broad list, bit2 clip arena
   uint32_t bin_need;  // largest per-tile reference count seen when a bin overflowed
-  uint32_t pad[12];
-  uint32_t order_hist[16];  // k_tile_order: launch slots per cost bucket (heaviest bucket first)
+  uint32_t pad[28];
 };
 static_assert(sizeof(Counters) == 128, "Counters");
 

@@ -121,7 +121,6 @@ struct FrameSlot {
   DeviceBuffer<BroadTri> d_broad;
   DeviceBuffer<unsigned long long> d_frags;  // per tile: compacted (pixel << 32 | primitive ref) of covered pixels
   DeviceBuffer<uint32_t> d_frag_count;
-  DeviceBuffer<uint32_t> d_tile_order;  // k_raster launch slots, heaviest tiles first
   DeviceBuffer<uint32_t> d_items;       // k_shade's work list: [0] = count, then slot << 6 | chunk of 64 fragments
   DeviceBuffer<CookedLight> d_cooked;   // the frame's light table as the light loop consumes it (k_shade_items -> k_shade)
   DeviceBuffer<uint32_t> d_item_groups; // 64-fragment chunks per group of 256 launch slots (k_raster -> k_shade_items)
@@ -149,23 +148,11 @@ struct FrameSlot {
   uint32_t n_prims = 0;
 
   void release_tile_buffers() {
-    d_tile_count.release(); d_bins.release(); d_frags.release(); d_frag_count.release(); d_tile_order.release(); d_items.release(); d_item_groups.release(); d_cooked.release();
-  }
-  // option "frame_graph": the frame's copy + kernels as one hipGraph, replayed while the launch arguments repeat
-  hipGraph_t graph = nullptr;
-  hipGraphExec_t graph_exec = nullptr;
-  std::vector<uint8_t> graph_key, last_key;  // arguments the instantiated graph was captured with / of the previous frame
-  void release_graph() {
-    if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
-    if (graph) (void)hipGraphDestroy(graph);
-    graph_exec = nullptr;
-    graph = nullptr;
-    graph_key.clear();
+    d_tile_count.release(); d_bins.release(); d_frags.release(); d_frag_count.release(); d_items.release(); d_item_groups.release(); d_cooked.release();
   }
   // native exchange (bbr_allgather_frame / bbr_push_shard) with library-owned buffers: every rank's block, the whole frame
   DeviceBuffer<uint8_t> d_gathered, d_whole;
   void release_all() {
-    release_graph();
     d_staging.release(); d_tris.release(); d_attrs.release(); d_clip.release(); d_gathered.release(); d_whole.release();
     d_block_stats.release();
     release_tile_buffers(); d_broad.release(); d_frame.release(); d_present.release(); d_background.release(); d_depth.release();
@@ -226,15 +213,10 @@ struct bbr_context {
   void *ext_out = nullptr;
   uint64_t ext_out_bytes = 0;
 
-  int tile_mode = 1;  // 0: 64x64, 1: 32x32 (default: finer tiles balance better; measured on C3)
+  int tile_mode = 1;  // 0: 64x64, 1: 32x32, 2: 16x16 with one-wave raster workgroups
   uint32_t bin_cap = 512, broad_cap = 4096, clip_cap = 4096, broad_threshold = 16;
   int32_t rank = 0, world = 1, band_rows = 0;
   bool dump_vis = false;
-  // k_raster launch order: heaviest tiles first.  Shortens ONE frame (C3: raster 67 -> 54 us, frame 221 -> 209 us)
-  // by removing the kernel's tail, but with two frames in flight the tail is already filled by the other frame's
-  // k_shade and the extra kernel plus the co-scheduled heavy tiles cost throughput (C3 184 -> 190 us, C5 +2 %):
-  // off by default, option "tile_order".
-  bool tile_order = false;
   bool present_fused = false;  // option "present_fused": frames are written as presented RGBA8, no fp32 frame
   bool overlays = false;  // option "overlays": frames keep their depth so that bbr_draw_overlays can test against it
   Mesh marker_mesh, gizmo_mesh;  // generateUVSphereMesh(0.1, 16, 16) and the caller's gizmo, both as Vertex meshes
@@ -277,9 +259,7 @@ struct bbr_context {
   int comm_rank = -1, comm_world = 0;
   int exchange_slot = -1, exchange_form = -1;  // where the last exchange left the whole frame (library-owned buffers)
   void *exchange_whole = nullptr;
-  bool frame_graph = false;  // option "frame_graph"
   int64_t no_tail_items = 40000;  // option "no_tail_items": frames with at most this many item slots get no tail launch
-  uint32_t graph_launches = 0, graph_captures = 0;
   static constexpr int kLayouts = 3;
   int layout_mode = 2;  // the option
   int layout = 2;       // layout of the frame being submitted
@@ -296,8 +276,8 @@ struct bbr_context {
   // shading of frame N+1 instead of delaying it
   hipStream_t present_stream() const { return (user_stream || frames_in_flight == 1) ? shade_stream() : s_present; }
   int n_slots() const { return user_stream ? 1 : frames_in_flight; }
-  int tile_w() const { return tile_mode == 0 ? 64 : 32; }
-  int tile_h() const { return tile_mode == 0 ? 64 : 32; }
+  int tile_w() const { return tile_mode == 0 ? 64 : (tile_mode == 1 ? 32 : 16); }
+  int tile_h() const { return tile_w(); }
   int tiles_x() const { return (width + tile_w() - 1) / tile_w(); }
   int tiles_y() const { return (height + tile_h() - 1) / tile_h(); }
   int eff_band_rows() const { return band_rows > 0 ? band_rows : tile_h(); }
@@ -343,7 +323,7 @@ Mat4 proj_view(const ViewUniformBlock &v) {
 }
 
 FrameParams make_params(const bbr_context *c) {
-  FrameParams fp = {};  // (the overlay fields stay 0 for the main pass: the block is also the key of option frame_graph)
+  FrameParams fp = {};  // (the overlay fields stay 0 for the main pass)
   fp.width = c->width;
   fp.height = c->height;
   fp.half_w = 0.5f * (float)c->width;
@@ -353,7 +333,9 @@ FrameParams make_params(const bbr_context *c) {
   fp.bin_cap = c->bin_cap;
   fp.broad_cap = c->broad_cap;
   fp.clip_cap = c->clip_cap;
-  fp.broad_threshold = c->broad_threshold;
+  // (in tiles; the 16 x 16 mode keeps the threshold where it is in PIXELS: a triangle reaches the every-tile list, which
+  //  every tile of the frame looks at, when its box spans more than about 128 x 128 pixels)
+  fp.broad_threshold = c->tile_mode == 2 ? c->broad_threshold * 4u : c->broad_threshold;
   fp.rank = c->rank;
   fp.world = c->world;
   fp.band_tiles = c->eff_band_rows() / c->tile_h();
@@ -399,7 +381,6 @@ int ensure_slot_buffers(bbr_context *c, FrameSlot &s) {
 #else
   HIP_TRY(c, s.d_frag_count.ensure(tiles, true));
 #endif
-  HIP_TRY(c, s.d_tile_order.ensure(tiles * kOrderBuckets));
   // (+ kShadeWaves: the last workgroup of k_shade's main launch reads the item words of all its waves before it knows the count)
   HIP_TRY(c, s.d_items.ensure(1 + tiles * (size_t)(c->tile_w() * c->tile_h() / 64) + kShadeWaves, true));
   if (tiles > (size_t)kItemGroupSlots * kItemGroups)  // 65536 launch slots: 8192 x 8192 pixels at 32 x 32 tiles
@@ -445,8 +426,7 @@ int upload_material_table(bbr_context *c) {
 
 template <int TW, int TH>
 void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const FrameParams &fp, const Mat4 &pv,
-                  const Mat4 &view, const ShadeParams &sp, const Light *d_lights, const DrawDesc *d_draws, uint32_t n_draws, float4 *out,
-                  bool capturing) {
+                  const Mat4 &view, const ShadeParams &sp, const Light *d_lights, const DrawDesc *d_draws, uint32_t n_draws, float4 *out) {
   const int slot_index = (int)(&s - c->slots);
   hipStream_t sg = c->frame_geom_stream(slot_index), sr = c->raster_stream(slot_index), ss = c->frame_shade_stream(slot_index);
   Counters *ctr = c->d_counters.ptr + s.ctr_index, *ctr_done = c->d_counters_done.ptr + s.ctr_index;
@@ -474,14 +454,10 @@ void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const Fra
   const SrgbTables *tables = c->present_fused ? c->d_srgb_tables.ptr : nullptr;
   if (fp.deferred)
     hipLaunchKernelGGL(k_deferred_background, dim3(1), dim3(kBackgroundThreads), 0, sr, sp, d_lights, s.d_background.ptr, tables, fp.gbuffer_view);
-  const bool ordered = c->tile_order && c->n_prims;
-  if (ordered)
-    hipLaunchKernelGGL(k_tile_order, dim3((fp.tiles_x * grid_y + kOrderThreads - 1) / kOrderThreads), dim3(kOrderThreads),
-                       0, sr, fp, s.d_tile_count.ptr, ctr, s.d_tile_order.ptr, fp.tiles_x, grid_y);
-  hipLaunchKernelGGL((k_raster<TW, TH>), dim3(fp.tiles_x, grid_y), dim3(kTileThreads), 0, sr, fp, s.d_tris.ptr,
+  hipLaunchKernelGGL((k_raster<TW, TH>), dim3(fp.tiles_x, grid_y), dim3(tile_threads<TW, TH>()), 0, sr, fp, s.d_tris.ptr,
                      s.d_clip.ptr, ctr, s.d_tile_count.ptr, s.d_bins.ptr, s.d_broad.ptr, s.d_frags.ptr,
                      s.d_frag_count.ptr, out, c->dump_vis ? c->d_vis_prim.ptr : nullptr,
-                     c->dump_vis ? c->d_vis_depth.ptr : nullptr, ordered ? s.d_tile_order.ptr : nullptr,
+                     c->dump_vis ? c->d_vis_depth.ptr : nullptr,
                      fp.deferred ? s.d_background.ptr : nullptr, (c->overlays && c->world == 1) ? s.d_depth.ptr : nullptr,
                      s.h_flags, out8, s.d_item_groups.ptr);
   s.has_depth = c->overlays && c->world == 1;
@@ -530,7 +506,7 @@ void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const Fra
     if (out8) shade(std::false_type{}, std::true_type{});
     else shade(std::false_type{}, std::false_type{});
   }
-  if (!capturing) (void)hipEventRecord(s.ev_shade_done, ss);  // (a captured frame: recorded behind the graph launch)
+  (void)hipEventRecord(s.ev_shade_done, ss);
   s.stream_used = ss;
   if (ev) {
     (void)hipEventRecord(ev[4], ss);
@@ -652,52 +628,10 @@ int submit_frame_into(bbr_context *c, int slot_index) {
   float4 *out = c->ext_out ? reinterpret_cast<float4 *>(c->ext_out) : s.d_frame.ptr;
   const FrameSlot *prev = (c->last_slot >= 0 && c->last_slot != slot_index) ? &c->slots[c->last_slot] : nullptr;
 
-  // Option "frame_graph": with one stream per frame slot (layout 2) a frame is a straight line of nodes -- copy, geometry,
-  // raster, items, shade tail, shade -- whose launch arguments only change when the camera, the frame size or a buffer
-  // does.  Once they have repeated, the line is captured into a hipGraph and replayed with ONE launch call per frame
-  // (the staged block -- lights, draw descriptors, instances -- is copied by the graph's own node, so its CONTENT may
-  // change freely); any other frame is launched node by node as usual.
-  bool shares_out = false;
-  for (const FrameSlot &o : c->slots) shares_out |= &o != &s && o.in_flight && o.out_used == out;
-  const bool graphable = c->frame_graph && c->pipelined() && c->layout == 2 && !c->timing_this && !c->dump_vis && !c->dump_gbuffer &&
-                         !shares_out && c->n_prims != 0;
-  std::vector<uint8_t> key;
-  if (graphable) {
-    auto put = [&](const void *p, size_t n) { key.insert(key.end(), (const uint8_t *)p, (const uint8_t *)p + n); };
-    const void *ptrs[] = {s.d_staging.ptr, s.h_staging, s.d_tris.ptr, s.d_attrs.ptr, s.d_clip.ptr, s.d_tile_count.ptr, s.d_bins.ptr,
-                          s.d_broad.ptr, c->d_materials.ptr, s.d_block_stats.ptr, s.d_frags.ptr, s.d_frag_count.ptr, s.h_flags,
-                          s.d_item_groups.ptr, s.d_items.ptr, s.d_cooked.ptr, s.d_background.ptr, s.d_depth.ptr, s.d_tile_order.ptr,
-                          s.d_present.ptr, c->d_srgb_tables.ptr, c->d_counters.ptr, c->d_counters_done.ptr, out, (const void *)sg};
-    const uint32_t words[] = {(uint32_t)total, c->n_live_draws, c->n_prims, s.h_flags ? s.h_flags[2] : 0u, (uint32_t)c->tile_mode,
-                              (uint32_t)c->present_fused, (uint32_t)c->tile_order, (uint32_t)c->overlays, (uint32_t)c->world,
-                              (uint32_t)c->local_bands(), (uint32_t)s.ctr_index};
-    put(&fp, sizeof fp); put(&sp, sizeof sp); put(&pv, sizeof pv); put(&view, sizeof view); put(ptrs, sizeof ptrs); put(words, sizeof words);
-  }
-  auto enqueue = [&](bool capturing) {
-    (void)hipMemcpyAsync(s.d_staging.ptr, s.h_staging, total, hipMemcpyHostToDevice, sg);
-    if (c->tile_mode == 0) launch_frame<64, 64>(c, s, prev, fp, pv, view, sp, d_lights, d_draws, c->n_live_draws, out, capturing);
-    else launch_frame<32, 32>(c, s, prev, fp, pv, view, sp, d_lights, d_draws, c->n_live_draws, out, capturing);
-  };
-  if (graphable && s.graph_exec && key == s.graph_key) {
-    HIP_TRY(c, hipGraphLaunch(s.graph_exec, sg));
-    HIP_TRY(c, hipEventRecord(s.ev_shade_done, sg));
-    s.stream_used = sg;
-    s.has_depth = c->overlays && c->world == 1;
-    ++c->graph_launches;
-  } else if (graphable && key == s.last_key) {  // the arguments have repeated: worth a capture
-    s.release_graph();
-    HIP_TRY(c, hipStreamBeginCapture(sg, hipStreamCaptureModeThreadLocal));
-    enqueue(true);
-    HIP_TRY(c, hipStreamEndCapture(sg, &s.graph));
-    HIP_TRY(c, hipGraphInstantiate(&s.graph_exec, s.graph, nullptr, nullptr, 0));
-    s.graph_key = key;
-    HIP_TRY(c, hipGraphLaunch(s.graph_exec, sg));
-    HIP_TRY(c, hipEventRecord(s.ev_shade_done, sg));
-    ++c->graph_captures;
-  } else {
-    enqueue(false);
-  }
-  s.last_key = key;
+  (void)hipMemcpyAsync(s.d_staging.ptr, s.h_staging, total, hipMemcpyHostToDevice, sg);
+  if (c->tile_mode == 0) launch_frame<64, 64>(c, s, prev, fp, pv, view, sp, d_lights, d_draws, c->n_live_draws, out);
+  else if (c->tile_mode == 1) launch_frame<32, 32>(c, s, prev, fp, pv, view, sp, d_lights, d_draws, c->n_live_draws, out);
+  else launch_frame<16, 16>(c, s, prev, fp, pv, view, sp, d_lights, d_draws, c->n_live_draws, out);
   HIP_TRY(c, hipGetLastError());
   s.in_flight = true;
   s.fused = c->present_fused;
@@ -1021,16 +955,17 @@ extern "C" int bbr_draw_overlays(bbr_context *c, int32_t gizmo_extent) {
       hipLaunchKernelGGL((k_geometry<TW, TH, true>), dim3((n_prims + 255) / 256), dim3(256), 0, st, d_draws, (uint32_t)draws.size(),
                          n_prims, ident, ident, fp, s.d_tris.ptr, s.d_attrs.ptr, s.d_clip.ptr, ctr, s.d_tile_count.ptr,
                          s.d_bins.ptr, s.d_broad.ptr, c->d_materials.ptr, s.d_block_stats.ptr);
-      hipLaunchKernelGGL((k_raster<TW, TH, true>), dim3(fp.tiles_x, fp.tiles_y), dim3(kTileThreads), 0, st, fp, s.d_tris.ptr,
+      hipLaunchKernelGGL((k_raster<TW, TH, true>), dim3(fp.tiles_x, fp.tiles_y), dim3(tile_threads<TW, TH>()), 0, st, fp, s.d_tris.ptr,
                          s.d_clip.ptr, ctr, s.d_tile_count.ptr, s.d_bins.ptr, s.d_broad.ptr, s.d_frags.ptr, s.d_frag_count.ptr,
-                         (float4 *)nullptr, (uint32_t *)nullptr, (float *)nullptr, (const uint32_t *)nullptr,
+                         (float4 *)nullptr, (uint32_t *)nullptr, (float *)nullptr,
                          (const float4 *)nullptr, fs.d_depth.ptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
       constexpr int kChunks = TW * TH / kShadeThreads;
       hipLaunchKernelGGL((k_shade_overlay<TW, TH>), dim3(fp.tiles_x * kChunks, fp.tiles_y), dim3(kShadeThreads), 0, st, fp,
                          s.d_attrs.ptr, s.d_clip.ptr, s.d_frags.ptr, s.d_frag_count.ptr, c->d_srgb_tables.ptr, fs.present.out);
     };
     if (c->tile_mode == 0) launch(std::integral_constant<int, 64>{}, std::integral_constant<int, 64>{});
-    else launch(std::integral_constant<int, 32>{}, std::integral_constant<int, 32>{});
+    else if (c->tile_mode == 1) launch(std::integral_constant<int, 32>{}, std::integral_constant<int, 32>{});
+    else launch(std::integral_constant<int, 16>{}, std::integral_constant<int, 16>{});
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(st));
     Counters h = {};
@@ -1547,13 +1482,6 @@ int bbr_stream_layout_state(const bbr_context *c, int32_t *out_layout, int32_t *
   return BBR_OK;
 }
 
-int bbr_frame_graph_state(const bbr_context *c, uint32_t *out_launches, uint32_t *out_captures) {
-  if (!c) return BBR_ERR_INVALID_ARGUMENT;
-  if (out_launches) *out_launches = c->graph_launches;
-  if (out_captures) *out_captures = c->graph_captures;
-  return BBR_OK;
-}
-
 int bbr_shard_rows(const bbr_context *c, int32_t *out_rows) {
   if (!c || !out_rows) return BBR_ERR_INVALID_ARGUMENT;
   *out_rows = c->shard_rows();
@@ -1762,12 +1690,13 @@ int bbr_set_option(bbr_context *c, const char *name, int64_t value) {
     c->frames_in_flight = (int)value;
     c->frame_counter = 0;
   } else if (n == "tile_mode") {
-    if (value != 0 && value != 1) return fail(c, BBR_ERR_INVALID_ARGUMENT, "tile_mode: 0 (64x64) or 1 (32x32)");
-    if (c->world > 1 && c->band_rows % (value == 0 ? 64 : 32))
+    if (value < 0 || value > 2) return fail(c, BBR_ERR_INVALID_ARGUMENT, "tile_mode: 0 (64x64), 1 (32x32) or 2 (16x16)");
+    if (c->world > 1 && c->band_rows % (value == 0 ? 64 : (value == 1 ? 32 : 16)))
       return fail(c, BBR_ERR_INVALID_ARGUMENT, "tile_mode: band_rows not a multiple of the new tile height");
     c->tile_mode = (int)value;
     // bins and fragment lists are laid out per tile: drop them so that ensure() re-zeroes the counters
     for (FrameSlot &s : c->slots) s.release_tile_buffers();
+    c->ov.release_tile_buffers();
   } else if (n == "bin_cap") {
     if (value < 1 || value > (1 << 20)) return fail(c, BBR_ERR_INVALID_ARGUMENT, "bin_cap out of range");
     c->bin_cap = (uint32_t)value;
@@ -1782,17 +1711,12 @@ int bbr_set_option(bbr_context *c, const char *name, int64_t value) {
     c->present_fused = value != 0;
   } else if (n == "overlays") {
     c->overlays = value != 0;
-  } else if (n == "tile_order") {
-    c->tile_order = value != 0;
   } else if (n == "stream_layout") {
     if (value < 0 || value >= bbr_context::kLayouts) return fail(c, BBR_ERR_INVALID_ARGUMENT, "stream_layout: 0, 1 or 2");
     c->layout_mode = (int)value;
   } else if (n == "no_tail_items") {
     if (value < 0) return fail(c, BBR_ERR_INVALID_ARGUMENT, "no_tail_items must be >= 0");
     c->no_tail_items = value;
-  } else if (n == "frame_graph") {
-    c->frame_graph = value != 0;
-    for (FrameSlot &s : c->slots) s.release_graph();
   } else if (n == "broad_cap" || n == "clip_cap") {
     // starting capacity of the every-tile list / the clip arena (entries); both double when a frame overflows them
     if (value < 1 || value > (1 << 24)) return fail(c, BBR_ERR_INVALID_ARGUMENT, n + " out of range (1 .. 2^24)");

@@ -206,12 +206,6 @@ class Renderer:
         self._check(self._L.bbr_stream_layout_state(self._ctx, C.byref(lay), C.byref(dec), ms))
         return lay.value, bool(dec.value), [float(x) for x in ms]
 
-    def frame_graph_state(self):
-        """(frames launched as a hipGraph, graphs captured) since the context was created (option "frame_graph")"""
-        a, b = C.c_uint32(), C.c_uint32()
-        self._check(self._L.bbr_frame_graph_state(self._ctx, C.byref(a), C.byref(b)))
-        return a.value, b.value
-
     # -- multi-GPU partition --
     def set_partition(self, rank, world, band_rows=0):
         self._check(self._L.bbr_set_partition(self._ctx, rank, world, band_rows))

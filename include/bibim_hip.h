@@ -178,9 +178,11 @@ int bbr_timing_summary(bbr_context *ctx, uint32_t *out_frames, float *out_avg_fr
  *   "timing_stride" n        with "timing" on, only every n-th frame carries events (default 1): the events themselves
  *                            perturb a pipelined frame stream (two per frame: ~4 % of the C3 frame rate)
  *   "frames_in_flight" 1..4  default 2
- *   "tile_mode" 0|1          0: 64x64 tiles, 1: 32x32 tiles (default)
+ *   "tile_mode" 0|1|2        screen tile of the rasteriser: 0: 64x64, 1: 32x32 (256-thread raster workgroups), 2: 16x16
+ *                            (one wave per tile, no workgroup barrier).  Same pixels in every mode
  *   "bin_cap" n              initial references per (tile, raster class); grows by itself on overflow
- *   "broad_threshold" n      triangles touching more than n x n tiles go to the every-tile list
+ *   "broad_threshold" n      triangles touching more than n tiles go to the every-tile list (n in 32x32-tile units: the
+ *                            16x16 mode multiplies it by four, so the switch stays at the same size in pixels)
  *   "broad_cap" n            initial entries of the every-tile list (default 4096); doubles when a frame overflows it
  *   "clip_cap" n             initial sub-triangle slots of the clip arena (default 4096); doubles likewise
  *   "gbuffer_view" -1..3      deferred path only: instead of brdf.frag, buffer_visualize.frag shows the rgb of one G-buffer
@@ -192,8 +194,6 @@ int bbr_timing_summary(bbr_context *ctx, uint32_t *out_frames, float *out_avg_fr
  *                            encode fused into the raster / shade kernels): no fp32 frame, no k_present pass; bbr_present
  *                            then only marks (or copies to a caller buffer), bbr_read_framebuffer / bbr_read_shard fail
  *   "overlays" 0|1           keep every frame's resolved depth for bbr_draw_overlays (default 0)
- *   "tile_order" 0|1         launch the heaviest raster tiles first (shorter single frame, lower pipelined
- *                            throughput; default 0)
  *   "stream_layout" 0|1|2    how the kernels of the frames in flight are spread over HIP streams.  Same pixels in every
  *                            layout.  0: geometry + raster on one stream, shade on a second, present on a third.
  *                            1: as 0 with k_raster on a stream of its own (the geometry of frame N+1 overlaps the
@@ -205,15 +205,8 @@ int bbr_timing_summary(bbr_context *ctx, uint32_t *out_frames, float *out_avg_fr
  *                            most n item slots (tiles x 64-fragment chunks per tile: 1080p has 32 640) is launched at
  *                            full coverage instead, without the tail launch's kernel boundary (C2: 34.5 -> 32.5 us per
  *                            frame with three frames in flight, 27.6 -> 26.4 with four)
- *   "frame_graph" 0|1        (default 0) with stream layout 2 and more than one frame in flight: once a frame slot has seen
- *                            the same launch arguments twice (same camera, sizes and buffers; the CONTENT of lights,
- *                            draw descriptors and instances may change), its copy + kernels are captured into a
- *                            hipGraph and every further such frame is ONE hipGraphLaunch; other frames are launched
- *                            node by node as usual.  Same pixels either way.  bbr_frame_graph_state counts both.
  *   "ablate" bits            diagnostic builds only (make EXTRA=-DBB_ABLATE): skip parts of the pipeline */
 int bbr_set_option(bbr_context *ctx, const char *name, int64_t value);
-/* option "frame_graph": frames launched as a graph / graphs captured since bbr_create */
-int bbr_frame_graph_state(const bbr_context *ctx, uint32_t *out_launches, uint32_t *out_captures);
 /* The stream layout in use (option "stream_layout"; 0 while only one frame is in flight).  *out_decided is always 1 and
  * out_ms[3] all zero: the layout is a plain option, nothing is timed at run time (round 1 did). */
 int bbr_stream_layout_state(const bbr_context *ctx, int32_t *out_layout, int32_t *out_decided, float *out_ms);

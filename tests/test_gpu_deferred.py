@@ -41,7 +41,7 @@ def check(sc, tile_mode=None, **opts):
     return img, ref
 
 
-@pytest.mark.parametrize("tile_mode", [0, 1])
+@pytest.mark.parametrize("tile_mode", [0, 1, 2])
 def test_c2_and_c3_small(maps64, tile_mode):
     check(scenes.shaderball_scene(configs.C2.scaled(320, 180, 64), bbo.MaterialData(maps64)), tile_mode)
     check(scenes.shaderball_scene(configs.C3.scaled(640, 360, 64), bbo.MaterialData(maps64)), tile_mode)
@@ -79,7 +79,7 @@ def test_mixed_map_sizes_with_a_height_map():
 def test_heavy_clipping_overflow_replay_and_frames_in_flight(maps64):
     cfg = configs.C3.scaled(384, 216, 64)
     sc = scenes.shaderball_scene(cfg, bbo.MaterialData(maps64))
-    check(sc, bin_cap=8, frames_in_flight=3, tile_order=1)
+    check(sc, bin_cap=8, frames_in_flight=3)
     sc.view = scenes.view_uniforms((-1.0, -0.55, 1.6), 35.0, -5.0, cfg.width, cfg.height, 1, near=0.05)  # camera between the balls
     check(sc)
 

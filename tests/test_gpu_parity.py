@@ -43,12 +43,12 @@ def check(scene, tile_mode=None, expect_exact=True, **opts):
     return img, ref, st
 
 
-@pytest.mark.parametrize("tile_mode", [0, 1])
+@pytest.mark.parametrize("tile_mode", [0, 1, 2])
 def test_c2_small(maps64, tile_mode):
     check(scenes.shaderball_scene(configs.C2.scaled(320, 180, 64), bbo.MaterialData(maps64)), tile_mode)
 
 
-@pytest.mark.parametrize("tile_mode", [0, 1])
+@pytest.mark.parametrize("tile_mode", [0, 1, 2])
 def test_c3_small(maps256, tile_mode):
     check(scenes.shaderball_scene(configs.C3.scaled(960, 540, 256), bbo.MaterialData(maps256)), tile_mode)
 
@@ -282,14 +282,6 @@ def test_every_tile_list_and_clip_arena_overflow_through_a_clipped_primitive(map
     assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
 
 
-@pytest.mark.parametrize("tile_mode", [0, 1])
-def test_heaviest_first_tile_order_changes_nothing(maps64, tile_mode):
-    """option tile_order: k_raster takes its tiles from the bucketed order of k_tile_order; same image, same bits"""
-    check(scenes.shaderball_scene(configs.C3.scaled(800, 450, 64), bbo.MaterialData(maps64)), tile_mode, tile_order=1)
-    check(scenes.shaderball_scene(configs.C5.scaled(1024, 576, 64), bbo.MaterialData(maps64)), tile_mode, tile_order=1,
-          bin_cap=16)  # with the overflow-and-retry path in between
-
-
 @pytest.mark.parametrize("frames_in_flight", [1, 2, 3])
 def test_frames_in_flight_streams_of_different_frames(maps64, frames_in_flight):
     """two frames in flight on two streams: alternating scenes back to back, no synchronisation in between,
@@ -511,46 +503,6 @@ def test_diagnostic_reads_keep_the_presented_image(maps64):
         first = r.read_presented()
         assert np.array_equal(first, r.read_presented())
         r.close()
-
-
-def test_frames_replayed_as_a_graph_are_the_same_frames(maps64):
-    """option frame_graph: a frame slot whose launch arguments repeat replays its copy + kernels as one hipGraph; a frame
-    with other arguments (another camera) is launched node by node again, and lights may change under a captured graph
-    (the staged block is copied by the graph's own node)"""
-    cfg = configs.C3.scaled(480, 270, 64)
-    sc = scenes.shaderball_scene(cfg, bbo.MaterialData(maps64))
-    ref, _, _, _ = bbo.render(sc)
-    r = Renderer(sc.width, sc.height)
-    r.set_option("frames_in_flight", 3)
-    r.set_option("frame_graph", 1)
-    h = r.render_scene(sc)
-    r.synchronize()                         # capacities settle
-    for _ in range(12):
-        h = r.render_scene(sc, h)
-    launches, captures = r.frame_graph_state()
-    assert captures == 3 and launches >= 3, (launches, captures)   # one graph per frame slot
-    assert np.array_equal(r.read_framebuffer().view(np.uint32), ref.view(np.uint32))
-    # other lights, same arguments: still the captured graphs
-    import copy
-    sc2 = copy.copy(sc)   # same draws, same material objects (a new material would move the material table: new arguments)
-    sc2.frame = scenes.frame_uniforms([scenes.light(0, pos=(1.0 + i, 3.0, 2.0 - i), color=(0.3, 0.9, 0.5), intensity=70.0)
-                                       for i in range(len(cfg.lights))])   # same light COUNT (a launch argument), other lights
-    ref2, _, _, _ = bbo.render(sc2)
-    for _ in range(4):
-        h = r.render_scene(sc2, h)
-    assert r.frame_graph_state()[1] == captures
-    assert np.array_equal(r.read_framebuffer().view(np.uint32), ref2.view(np.uint32))
-    # another camera: new arguments -> plain launches, then new captures once they repeat
-    sc3 = copy.copy(sc)
-    sc3.view = scenes.shaderball_scene(replace(cfg, cam_pos=(0.5, 2.5, -2.5)), sc.draws[0].material).view
-    ref3, _, _, _ = bbo.render(sc3)
-    h = r.render_scene(sc3, h)
-    assert np.array_equal(r.read_framebuffer().view(np.uint32), ref3.view(np.uint32))
-    for _ in range(8):
-        h = r.render_scene(sc3, h)
-    assert r.frame_graph_state()[1] > captures
-    assert np.array_equal(r.read_framebuffer().view(np.uint32), ref3.view(np.uint32))
-    r.close()
 
 
 def test_api_lifecycle_user_stream_frees_and_timing(maps64):
