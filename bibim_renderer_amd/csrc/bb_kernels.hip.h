@@ -528,7 +528,6 @@ __global__ __launch_bounds__(256) void k_geometry(const DrawDesc *__restrict__ d
   const uint32_t prim = blockIdx.x * blockDim.x + threadIdx.x;
   bool needs_clip = false;
   float clip[3][4];
-  ShadeRec pa;
   bool binned = false;  // this lane holds an unclipped, set-up triangle that goes to tile bins
   uint32_t cls = 0;     // raster class of the triangle: bin segment (kBinClasses per tile)
   TileRange tr = {0, -1, 0, -1};
@@ -558,65 +557,28 @@ __global__ __launch_bounds__(256) void k_geometry(const DrawDesc *__restrict__ d
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     BB_STAMP(6);
 #endif
-    if (OVERLAY) {
-      // The host folds the matrices: ib.model = (P*V)*modelMat of the light (light.vert:11-14) or the gizmo's own
-      // projMat*viewMat (gizmo.vert:13-24); ib.inv_model row 0 = the light's colour, or the gizmo's viewMat whose
-      // upper 3x3 turns the normals (gizmo.vert:27).  draw.material is the program: 1 marker, 2 gizmo.
+    // ---- positions first: gl_Position of the three vertices decides whether the primitive can touch a pixel at all.  Half
+    // of a closed mesh faces away from the camera and is culled below; only the survivors pay for the rest of the vertex
+    // stage (normal matrix, two normalisations and a cross product per vertex) and for their 224-byte record ----
+    float pw[3][3];  // posWorld (main passes)
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const Vertex &v = vtx[k];
-        f4 c = mat4_mul(ib.model, f4{v.pos[0], v.pos[1], v.pos[2], 1.0f});
-        clip[k][0] = c.x; clip[k][1] = c.y; clip[k][2] = c.z; clip[k][3] = c.w;
-        float *o = pa.vary[k];
-#pragma unroll
-        for (int j = 0; j < kNumVary; ++j) o[j] = 0.0f;
-        if (draw.material == 1u) {
-          o[0] = ib.inv_model.M[0][0]; o[1] = ib.inv_model.M[0][1]; o[2] = ib.inv_model.M[0][2];
-        } else {
-          const Mat4 &gv = ib.inv_model;
-          f3 n = ld3(v.normal);
-          o[0] = v.tangent[0]; o[1] = v.tangent[1]; o[2] = v.tangent[2];  // the gizmo mesh keeps its colour there
-          o[3] = fmaf(gv.M[2][0], n.z, fmaf(gv.M[1][0], n.y, gv.M[0][0] * n.x));
-          o[4] = fmaf(gv.M[2][1], n.z, fmaf(gv.M[1][1], n.y, gv.M[0][1] * n.x));
-          o[5] = fmaf(gv.M[2][2], n.z, fmaf(gv.M[1][2], n.y, gv.M[0][2] * n.x));
-        }
-      }
-    } else {
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const Vertex &v = vtx[k];
+    for (int k = 0; k < 3; ++k) {
+      const Vertex &v = vtx[k];
+      f4 c;
+      if (OVERLAY) {
+        // The host folds the matrices: ib.model = (P*V)*modelMat of the light (light.vert:11-14) or the gizmo's own
+        // projMat*viewMat (gizmo.vert:13-24)
+        c = mat4_mul(ib.model, f4{v.pos[0], v.pos[1], v.pos[2], 1.0f});
+        pw[k][0] = pw[k][1] = pw[k][2] = 0.0f;
+      } else {
         // forward_brdf.vert:25,27
-        f4 pw = mat4_mul(ib.model, f4{v.pos[0], v.pos[1], v.pos[2], 1.0f});
+        const f4 w = mat4_mul(ib.model, f4{v.pos[0], v.pos[1], v.pos[2], 1.0f});
         // forward_brdf.vert:27 multiplies (P*V) * posWorld (pv = P*V); gbuffer.vert:19-22 P * (V * posWorld) (pv = P)
-        f4 c = fp.deferred ? mat4_mul(pv, mat4_mul(view, pw)) : mat4_mul(pv, pw);
-        clip[k][0] = c.x; clip[k][1] = c.y; clip[k][2] = c.z; clip[k][3] = c.w;
-        // :31-36  normalMat = transpose(mat3(aInvModel))
-        f3 n = ld3(v.normal), t = ld3(v.tangent);
-        const Mat4 &im = ib.inv_model;
-        f3 N = normalize3(mk3(dot3(ld3(im.M[0]), n), dot3(ld3(im.M[1]), n), dot3(ld3(im.M[2]), n)));
-        f3 T = normalize3(mk3(dot3(ld3(im.M[0]), t), dot3(ld3(im.M[1]), t), dot3(ld3(im.M[2]), t)));
-        f3 B = cross3(N, T);
-        float *o = pa.vary[k];
-        o[0] = v.uv[0]; o[1] = v.uv[1];
-        o[2] = pw.x; o[3] = pw.y; o[4] = pw.z;
-        o[5] = N.x; o[6] = N.y; o[7] = N.z;
-        o[8] = T.x; o[9] = T.y; o[10] = T.z;
-        o[11] = B.x; o[12] = B.y; o[13] = B.z;
+        c = fp.deferred ? mat4_mul(pv, mat4_mul(view, w)) : mat4_mul(pv, w);
+        pw[k][0] = w.x; pw[k][1] = w.y; pw[k][2] = w.z;
       }
+      clip[k][0] = c.x; clip[k][1] = c.y; clip[k][2] = c.z; clip[k][3] = c.w;
     }
-    if (OVERLAY) {  // draw.material is the overlay program here, not an index into the material table
-      pa.material = draw.material;
-      pa.packed = nullptr;
-      pa.packed_dims = 0u;
-      pa.clip_base = kNotClipped;
-    } else {
-      const MaterialDesc &md = materials[draw.material];
-      pa.material = draw.material;
-      pa.packed = md.packed;
-      pa.packed_dims = md.packed ? ((uint32_t)md.pw | ((uint32_t)md.ph << 16)) : 0u;
-      pa.clip_base = kNotClipped;
-    }
-
     if (OVERLAY && prim >= fp.ov_first_gizmo_prim) vp = Viewport{fp.ov_half, fp.ov_half, fp.ov_cx, fp.ov_cy};
     // trivial reject against the true frustum (cannot change any pixel)
     bool o_l = true, o_r = true, o_t = true, o_b = true, o_n = true, o_f = true, all_in = true;
@@ -629,31 +591,94 @@ __global__ __launch_bounds__(256) void k_geometry(const DrawDesc *__restrict__ d
 #pragma unroll
       for (int p = 0; p < 6; ++p) all_in &= (plane_dist(c, p) >= 0.0f);
     }
+    RasterTri t = {};
+    bool survives = false;  // unclipped, front-facing, holds a pixel centre (of this rank's bands)
     if (!(o_l | o_r | o_t | o_b | o_n | o_f)) {
       if (all_in) {
-        RasterTri t;
         float z0, z1, z2;
         if (project_vertex(clip[0], vp, t.X0, t.Y0, t.rw0, z0) && project_vertex(clip[1], vp, t.X1, t.Y1, t.rw1, z1) &&
             project_vertex(clip[2], vp, t.X2, t.Y2, t.rw2, z2) && setup_tri(t, z0, z1, z2) &&
             tile_range<TILE_W, TILE_H>(t, fp, tr)) {
-#ifdef BB_STAMPS
-          BB_STAMP(7);
-#endif
-          if (!BB_ABLATE(64u)) {
-            tris[prim] = t;
-            pa.X0 = t.X0; pa.Y0 = t.Y0;
-            pa.l1dx = t.l1dx; pa.l1dy = t.l1dy; pa.l2dx = t.l2dx; pa.l2dy = t.l2dy;
-            pa.rw0 = t.rw0; pa.rw1 = t.rw1; pa.rw2 = t.rw2;
-            recs[prim] = pa;
+          survives = true;
+          if (fp.world > 1) {
+            // screen-band partition: a primitive whose tile rows hold none of this rank's bands (band b belongs to rank
+            // b mod world) is somebody else's: no record, no bin entry.  (Every rank still runs the vertex positions of
+            // every primitive -- that is what tells it whose they are.)
+            const int b0 = tr.ty0 / fp.band_tiles, b1 = tr.ty1 / fp.band_tiles;
+            const int first = b0 + ((fp.rank - b0 % fp.world) + fp.world) % fp.world;
+            survives = first <= b1;
           }
-          n_raster = 1;
-          uint32_t ntiles = (uint32_t)(tr.tx1 - tr.tx0 + 1) * (uint32_t)(tr.ty1 - tr.ty0 + 1);
-          if (ntiles > fp.broad_threshold) broad_insert(t, prim << 3, fp, ctr, broad_list);
-          else binned = true;
-          cls = raster_class(t, fp);
         }
       } else if (!BB_ABLATE(128u)) {
         needs_clip = true;
+      }
+    }
+#ifdef BB_STAMPS
+    BB_STAMP(7);
+#endif
+    if (survives || needs_clip) {
+      // ---- the rest of the vertex stage and the primitive's record ----
+      ShadeRec pa;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const Vertex &v = vtx[k];
+        float *o = pa.vary[k];
+        if (OVERLAY) {
+          // ib.inv_model row 0 = the light's colour, or the gizmo's viewMat whose upper 3x3 turns the normals
+          // (gizmo.vert:27).  draw.material is the program: 1 marker, 2 gizmo.
+#pragma unroll
+          for (int j = 0; j < kNumVary; ++j) o[j] = 0.0f;
+          if (draw.material == 1u) {
+            o[0] = ib.inv_model.M[0][0]; o[1] = ib.inv_model.M[0][1]; o[2] = ib.inv_model.M[0][2];
+          } else {
+            const Mat4 &gv = ib.inv_model;
+            f3 n = ld3(v.normal);
+            o[0] = v.tangent[0]; o[1] = v.tangent[1]; o[2] = v.tangent[2];  // the gizmo mesh keeps its colour there
+            o[3] = fmaf(gv.M[2][0], n.z, fmaf(gv.M[1][0], n.y, gv.M[0][0] * n.x));
+            o[4] = fmaf(gv.M[2][1], n.z, fmaf(gv.M[1][1], n.y, gv.M[0][1] * n.x));
+            o[5] = fmaf(gv.M[2][2], n.z, fmaf(gv.M[1][2], n.y, gv.M[0][2] * n.x));
+          }
+        } else {
+          // :31-36  normalMat = transpose(mat3(aInvModel))
+          f3 n = ld3(v.normal), tg = ld3(v.tangent);
+          const Mat4 &im = ib.inv_model;
+          f3 N = normalize3(mk3(dot3(ld3(im.M[0]), n), dot3(ld3(im.M[1]), n), dot3(ld3(im.M[2]), n)));
+          f3 T = normalize3(mk3(dot3(ld3(im.M[0]), tg), dot3(ld3(im.M[1]), tg), dot3(ld3(im.M[2]), tg)));
+          f3 B = cross3(N, T);
+          o[0] = v.uv[0]; o[1] = v.uv[1];
+          o[2] = pw[k][0]; o[3] = pw[k][1]; o[4] = pw[k][2];
+          o[5] = N.x; o[6] = N.y; o[7] = N.z;
+          o[8] = T.x; o[9] = T.y; o[10] = T.z;
+          o[11] = B.x; o[12] = B.y; o[13] = B.z;
+        }
+      }
+      pa.material = draw.material;  // (overlay pass: the overlay program, not an index into the material table)
+      pa.packed = nullptr;
+      pa.packed_dims = 0u;
+      if (!OVERLAY) {
+        const MaterialDesc &md = materials[draw.material];
+        pa.packed = md.packed;
+        pa.packed_dims = md.packed ? ((uint32_t)md.pw | ((uint32_t)md.ph << 16)) : 0u;
+      }
+      pa.clip_base = kNotClipped;  // (a clipped primitive's is patched in once the clipper has its arena slots, below)
+      // planes of the unclipped triangle; zero for a primitive that goes through the clipper (its sub-triangles have their own)
+      pa.X0 = t.X0; pa.Y0 = t.Y0;
+      pa.l1dx = t.l1dx; pa.l1dy = t.l1dy; pa.l2dx = t.l2dx; pa.l2dy = t.l2dy;
+      pa.rw0 = t.rw0; pa.rw1 = t.rw1; pa.rw2 = t.rw2;
+      if (needs_clip) {
+        pa.X0 = pa.Y0 = 0;
+        pa.l1dx = pa.l1dy = pa.l2dx = pa.l2dy = pa.rw0 = pa.rw1 = pa.rw2 = 0.0f;
+      }
+      if (!BB_ABLATE(64u)) {
+        recs[prim] = pa;
+        if (survives) tris[prim] = t;
+      }
+      if (survives) {
+        n_raster = 1;
+        uint32_t ntiles = (uint32_t)(tr.tx1 - tr.tx0 + 1) * (uint32_t)(tr.ty1 - tr.ty0 + 1);
+        if (ntiles > fp.broad_threshold) broad_insert(t, prim << 3, fp, ctr, broad_list);
+        else binned = true;
+        cls = raster_class(t, fp);
       }
     }
   }
@@ -704,12 +729,7 @@ __global__ __launch_bounds__(256) void k_geometry(const DrawDesc *__restrict__ d
     if ((int)(threadIdx.x & 63) == owner) {
       n_clipped = 1;
       n_raster = (uint32_t)w.n_valid;
-      if (w.n_valid) {
-        pa.X0 = pa.Y0 = 0;
-        pa.l1dx = pa.l1dy = pa.l2dx = pa.l2dy = pa.rw0 = pa.rw1 = pa.rw2 = 0.0f;
-        pa.clip_base = w.base;
-        recs[prim] = pa;
-      }
+      if (w.n_valid) recs[prim].clip_base = w.base;  // (the record itself was written above, with zero planes)
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -2132,6 +2152,25 @@ __global__ void k_unpack_gathered_rgba8(const uint32_t *__restrict__ gathered, u
   int band = y / band_rows, r = y - band * band_rows;
   int rank = band % world, lb = band / world;
   frame[i] = gathered[((size_t)rank * shard_rows + (size_t)lb * band_rows + r) * (size_t)width + x];
+}
+
+// The peer form of the exchange as ONE kernel (bbr_push_shard, option "push_mode" 1): a workgroup loads a piece of this
+// rank's block once and stores it into the same place of EVERY peer's gather buffer -- world - 1 stores per load, each going
+// out over its own xGMI link, so all links of the full mesh carry a block at the same time (the direct pattern of SURVEY
+// section 5 / 8(e): shard / link bandwidth, where copies queued one behind the other take world - 1 times that).  The
+// peers' buffers are peer-accessible device memory (hipDeviceEnablePeerAccess or an opened IPC handle).
+constexpr int kMaxPushPeers = 15;
+struct PushTargets {
+  void *dst[kMaxPushPeers];
+};
+constexpr int kPushThreads = 256;
+template <typename V>
+__global__ __launch_bounds__(kPushThreads) void k_push_block(const V *__restrict__ src, PushTargets t, int n_targets, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * kPushThreads + threadIdx.x; i < n; i += (size_t)gridDim.x * kPushThreads) {
+    const V v = src[i];
+#pragma unroll 1
+    for (int k = 0; k < n_targets; ++k) reinterpret_cast<V *>(t.dst[k])[i] = v;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -259,6 +259,9 @@ struct bbr_context {
   int comm_rank = -1, comm_world = 0;
   int exchange_slot = -1, exchange_form = -1;  // where the last exchange left the whole frame (library-owned buffers)
   void *exchange_whole = nullptr;
+  int push_mode = 1;  // option "push_mode": 1 one kernel storing to every peer (all links at once), 0 copies one after the other
+  std::unordered_set<int> peer_mapped;  // devices whose memory this context's device can store to (peer access enabled)
+  bool last_push_direct = false;
   int64_t no_tail_items = 40000;  // option "no_tail_items": frames with at most this many item slots get no tail launch
   static constexpr int kLayouts = 3;
   int layout_mode = 2;  // the option
@@ -1714,6 +1717,9 @@ int bbr_set_option(bbr_context *c, const char *name, int64_t value) {
   } else if (n == "stream_layout") {
     if (value < 0 || value >= bbr_context::kLayouts) return fail(c, BBR_ERR_INVALID_ARGUMENT, "stream_layout: 0, 1 or 2");
     c->layout_mode = (int)value;
+  } else if (n == "push_mode") {
+    if (value != 0 && value != 1) return fail(c, BBR_ERR_INVALID_ARGUMENT, "push_mode: 0 (copies) or 1 (one kernel, all peers)");
+    c->push_mode = (int)value;
   } else if (n == "no_tail_items") {
     if (value < 0) return fail(c, BBR_ERR_INVALID_ARGUMENT, "no_tail_items must be >= 0");
     c->no_tail_items = value;
@@ -2065,16 +2071,54 @@ int bbr_push_shard(bbr_context *c, int32_t form, void *const *peer_gathered, con
   HIP_TRY(c, hipStreamWaitEvent(st, s.ev_shade_done, 0));
   for (int p = 0; p < c->world; ++p)
     if (!peer_gathered[p]) return fail(c, BBR_ERR_INVALID_ARGUMENT, "push_shard: a peer's gather buffer is NULL");
-  // the block is made once, in this rank's own gather buffer, and copied from there to the peers, nearest first
-  // (rank + 1, rank + 2, ...: at any moment every link carries one copy, as in one step of a ring)
+  // the block is made once, in this rank's own gather buffer, and goes from there to the peers
   uint8_t *mine = (uint8_t *)peer_gathered[c->rank] + block * (size_t)c->rank;
   rc = stage_block(c, s, form, mine, st);
   if (rc) return rc;
-  for (int k = 1; k < c->world; ++k) {
-    const int p = (c->rank + k) % c->world;
-    HIP_TRY(c, hipMemcpyPeerAsync((uint8_t *)peer_gathered[p] + block * (size_t)c->rank, peer_devices[p], mine, c->device, block, st));
+  // push_mode 1 (default): ONE kernel stores the block into every peer's buffer, all links busy at once.  It needs the
+  // peers' memory mapped into this device's address space: the same device, an opened IPC handle, or peer access, which
+  // is switched on here the first time a device shows up.  A peer that cannot be mapped: the copies below instead.
+  bool direct = c->push_mode == 1 && c->world > 1;
+  for (int p = 0; direct && p < c->world; ++p) {
+    const int dev = peer_devices[p];
+    if (dev == c->device || c->peer_mapped.count(dev)) continue;
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, c->device, dev) != hipSuccess || !can) { direct = false; break; }
+    const hipError_t e = hipDeviceEnablePeerAccess(dev, 0);
+    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { direct = false; break; }
+    (void)hipGetLastError();
+    c->peer_mapped.insert(dev);
   }
+  if (direct) {
+    const bool wide = block % 16 == 0 && ((uintptr_t)mine % 16) == 0;
+    const size_t n = wide ? block / 16 : block / 4;   // (every block form is a whole number of 4-byte words)
+    // a grid of one workgroup per CU: the copy is bound by the links (world - 1 x ~60 GB/s), not by the CUs it occupies
+    const unsigned grid = (unsigned)std::max<size_t>(1, std::min<size_t>((size_t)c->n_cus, (n + kPushThreads - 1) / kPushThreads));
+    for (int k0 = 1; k0 < c->world; k0 += kMaxPushPeers) {
+      PushTargets t = {};
+      int nt = 0;
+      for (int k = k0; k < c->world && nt < kMaxPushPeers; ++k)
+        t.dst[nt++] = (uint8_t *)peer_gathered[(c->rank + k) % c->world] + block * (size_t)c->rank;
+      if (wide) hipLaunchKernelGGL(k_push_block<uint4>, dim3(grid), dim3(kPushThreads), 0, st, (const uint4 *)mine, t, nt, n);
+      else hipLaunchKernelGGL(k_push_block<uint32_t>, dim3(grid), dim3(kPushThreads), 0, st, (const uint32_t *)mine, t, nt, n);
+    }
+    HIP_TRY(c, hipGetLastError());
+  } else {
+    // push_mode 0: copies queued one behind the other on the one stream, nearest rank first (rank + 1, rank + 2, ...): at any
+    // moment this rank drives ONE of its links -- ring timing on a full mesh
+    for (int k = 1; k < c->world; ++k) {
+      const int p = (c->rank + k) % c->world;
+      HIP_TRY(c, hipMemcpyPeerAsync((uint8_t *)peer_gathered[p] + block * (size_t)c->rank, peer_devices[p], mine, c->device, block, st));
+    }
+  }
+  c->last_push_direct = direct;
   if (!stream) HIP_TRY(c, hipEventRecord(s.ev_shade_done, st));
+  return BBR_OK;
+}
+
+int bbr_push_state(const bbr_context *c, int32_t *out_direct) {
+  if (!c || !out_direct) return BBR_ERR_INVALID_ARGUMENT;
+  *out_direct = c->last_push_direct ? 1 : 0;
   return BBR_OK;
 }
 

@@ -108,6 +108,23 @@ def push_order(rank, world):
     return [(rank + k) % world for k in range(1, world)]
 
 
+def push_steps(rank, world, direct=True):
+    """what bbr_push_shard queues, as steps that run one after the other, each a list of destinations served at the same
+    time.  direct (option push_mode 1): ONE kernel stores the block to every peer -- a single step with world - 1
+    destinations, one xGMI link each.  Otherwise world - 1 copies in push_order, one link at a time."""
+    order = push_order(rank, world)
+    return [order] if (direct and order) else [[d] for d in order]
+
+
+def push_links_busy(world, direct=True):
+    """per step: the set of (source, destination) link directions in use over all ranks (a rank drives one link per
+    destination of its step).  direct: one step with all world * (world - 1) directions of the full mesh; copies: world - 1
+    steps of `world` directions each, every rank sending and receiving on exactly one link."""
+    steps = [push_steps(r, world, direct) for r in range(world)]
+    n = max((len(s) for s in steps), default=0)
+    return [{(r, d) for r in range(world) if k < len(steps[r]) for d in steps[r][k]} for k in range(n)]
+
+
 def push_offset(rank, block_bytes):
     """byte offset of `rank`'s block inside every rank's gather buffer (the same layout ncclAllGather produces)"""
     return rank * block_bytes

@@ -283,6 +283,12 @@ class Renderer:
         devs = (C.c_int32 * n)(*peer_devices)
         self._check(self._L.bbr_push_shard(self._ctx, form, ptrs, devs, C.c_void_p(stream_handle) if stream_handle else None))
 
+    def push_was_direct(self):
+        """True if the last push_shard stored through the one-kernel direct form (option push_mode 1 and every peer mapped)"""
+        d = C.c_int32()
+        self._check(self._L.bbr_push_state(self._ctx, C.byref(d)))
+        return bool(d.value)
+
     def unpack_whole(self, form, gathered_ptr, whole_ptr=None, stream_handle=None):
         self._check(self._L.bbr_unpack_whole(self._ctx, form, C.c_void_p(gathered_ptr), C.c_void_p(whole_ptr) if whole_ptr else None,
                                              C.c_void_p(stream_handle) if stream_handle else None))

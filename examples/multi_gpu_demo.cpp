@@ -1,14 +1,15 @@
 // multi_gpu_demo.cpp -- BASELINE's configuration #4 natively in C++: ONE host process drives N ranks (a bbr_context
 // each, on GPU rank % bbr_device_count()), every rank renders its interleaved screen bands of the same frame, and the
-// frame is completed by the library's peer exchange: bbr_push_shard (hipMemcpyPeerAsync of the rank's block into every
-// rank's gather buffer) + bbr_unpack_whole.  No torch, no MPI, no HIP headers: g++ and libbibim_hip.so.
+// frame is completed by the library's peer exchange: bbr_push_shard (the rank's block into every rank's gather buffer, one
+// kernel storing to all peers at once) + bbr_unpack_whole.  No torch, no MPI, no HIP headers: g++ and libbibim_hip.so.
 //
 //   g++ -std=c++17 -O2 -Iinclude examples/multi_gpu_demo.cpp -Lbibim_renderer_amd -lbibim_hip -Wl,-rpath,$PWD/bibim_renderer_amd -o mgdemo
 //   ./mgdemo --vertices-bin ball.bin --ranks 8 [--size 3840 2160] [--grid 4] [--frames 50] [--form packed|rgba32f|rgba8]
 //            [--tone-map 1.0] [--out frame.ppm]
 // With fewer GPUs than ranks several ranks share a device (that is how the test runs it on one GPU).  The loop is the
 // simple one: all ranks render and push, the host waits for every rank ("all pushes have landed"), all ranks
-// un-interleave.  A production loop would double-buffer the gather buffers and keep two frames in flight, as bench.py does.
+// un-interleave -- and every rank owns TWO gather buffers used in turn: the un-interleave of frame n is only queued when
+// frame() returns, and the pushes of frame n + 1 must not overwrite the buffer it is still reading.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -62,10 +63,10 @@ int main(int argc, char **argv) {
     bbr_context *ctx = nullptr;
     int32_t device = 0, material = -1;
     bb::ShaderBallScene *scene = nullptr;
-    void *gathered = nullptr;
+    void *gathered[2] = {nullptr, nullptr};
   };
   std::vector<Rank> rk(ranks);
-  std::vector<void *> peer_gathered(ranks);
+  std::vector<void *> peer_gathered[2] = {std::vector<void *>(ranks), std::vector<void *>(ranks)};
   std::vector<int32_t> peer_devices(ranks);
   uint64_t block = 0;
   for (int r = 0; r < ranks; ++r) {
@@ -77,8 +78,10 @@ int main(int argc, char **argv) {
     if (bbr_upload_material(k.ctx, none, &k.material) != BBR_OK) return die("bbr_upload_material", k.ctx);
     k.scene = new bb::ShaderBallScene(k.ctx, ball.data(), (uint32_t)ball.size(), grid);
     if (bbr_exchange_block_bytes(k.ctx, form, &block) != BBR_OK) return die("bbr_exchange_block_bytes", k.ctx);
-    if (bbr_device_alloc(k.ctx, block * (uint64_t)ranks, &k.gathered) != BBR_OK) return die("bbr_device_alloc", k.ctx);
-    peer_gathered[r] = k.gathered;
+    for (int b = 0; b < 2; ++b) {
+      if (bbr_device_alloc(k.ctx, block * (uint64_t)ranks, &k.gathered[b]) != BBR_OK) return die("bbr_device_alloc", k.ctx);
+      peer_gathered[b][r] = k.gathered[b];
+    }
     peer_devices[r] = k.device;
   }
   bb::FreeLookCamera cam;
@@ -88,16 +91,18 @@ int main(int argc, char **argv) {
   settings.EnableToneMapping = tone;
   settings.Exposure = exposure;
 
+  int frame_no = 0;
   auto frame = [&]() -> int {
+    const int b = frame_no++ & 1;  // this frame's gather buffers; the other set may still be read by the previous frame's unpack
     for (Rank &k : rk) {  // every rank: its bands of the frame, then its block into every rank's gather buffer
       if (bb::drawFrame(k.ctx, *k.scene, cam, settings, k.material, width, height, 0.f) != BBR_OK) return die("drawFrame", k.ctx);
       if (form == BBR_SHARD_RGBA8 && bbr_present(k.ctx, nullptr, 1) != BBR_OK) return die("bbr_present", k.ctx);
-      if (bbr_push_shard(k.ctx, form, peer_gathered.data(), peer_devices.data(), nullptr) != BBR_OK) return die("bbr_push_shard", k.ctx);
+      if (bbr_push_shard(k.ctx, form, peer_gathered[b].data(), peer_devices.data(), nullptr) != BBR_OK) return die("bbr_push_shard", k.ctx);
     }
-    for (Rank &k : rk)  // all pushes have landed
+    for (Rank &k : rk)  // all pushes have landed (and the unpack of frame n - 1, which read the other buffers, is done)
       if (bbr_synchronize(k.ctx) != BBR_OK) return die("bbr_synchronize", k.ctx);
     for (Rank &k : rk)  // every rank un-interleaves its copy of the gathered blocks into the whole frame
-      if (bbr_unpack_whole(k.ctx, form, k.gathered, nullptr, nullptr) != BBR_OK) return die("bbr_unpack_whole", k.ctx);
+      if (bbr_unpack_whole(k.ctx, form, k.gathered[b], nullptr, nullptr) != BBR_OK) return die("bbr_unpack_whole", k.ctx);
     return 0;
   };
   // the first frames size the capacities (a synchronising call re-renders an overflowed frame, the exchange does not)
@@ -139,7 +144,8 @@ int main(int argc, char **argv) {
   std::printf("wrote %s\n", out.c_str());
   for (Rank &k : rk) {
     delete k.scene;
-    bbr_device_free(k.ctx, k.gathered);
+    bbr_device_free(k.ctx, k.gathered[0]);
+    bbr_device_free(k.ctx, k.gathered[1]);
     bbr_destroy(k.ctx);
   }
   return 0;

@@ -200,6 +200,8 @@ int bbr_timing_summary(bbr_context *ctx, uint32_t *out_frames, float *out_avg_fr
  *                            raster of frame N).  2 (default): every kernel of a frame on the stream of its frame slot
  *                            (frames share nothing, whole frames overlap).  Three frames in flight, us per frame for
  *                            0 / 1 / 2: 1080p, one ShaderBall 84.5 / 67.1 / 37.3; 4K, sixteen 191.5 / 153.6 / 148.6.
+ *   "push_mode" 0|1          bbr_push_shard: 1 (default) one kernel storing to every peer at once, 0 peer copies one after
+ *                            the other (see "native exchange" below)
  *   "no_tail_items" n        (default 40000) k_shade's main launch is sized from the item count the frame slot produced
  *                            one frame earlier and a small tail launch covers what that estimate misses; a frame with at
  *                            most n item slots (tiles x 64-fragment chunks per tile: 1080p has 32 640) is launched at
@@ -270,10 +272,15 @@ int bbr_tone_map(bbr_context *ctx, int32_t enable_tone_mapping, float exposure);
  *               bbr_comm_init on every rank (ncclCommInitRank; one process per GPU) -> per frame bbr_allgather_frame:
  *               [pack into this rank's slot of `gathered`] -> ncclAllGather in place (ring over xGMI) -> un-interleave into
  *               `whole`.  librccl is opened with dlopen at the first of these calls; a single-GPU host never loads it.
- *   peer        bbr_push_shard: this rank's block copied into every rank's gather buffer with hipMemcpyPeerAsync, nearest
- *               rank first -- for one process driving several GPUs (one context each) or processes that exchanged
- *               bbr_ipc_export handles.  The host orders "all pushes have landed" (events or a barrier) before
- *               bbr_unpack_whole.
+ *   peer        bbr_push_shard: this rank's block goes into every rank's gather buffer -- for one process driving several
+ *               GPUs (one context each) or processes that exchanged bbr_ipc_export handles.  Option "push_mode" 1
+ *               (default): ONE kernel loads the block once and stores it to all world - 1 peers, every xGMI link of the
+ *               full mesh busy at the same time (the direct pattern: block / link bandwidth); peer access to the other
+ *               devices is enabled on first use, and a peer that cannot be mapped falls back to mode 0.  "push_mode" 0:
+ *               hipMemcpyPeerAsync copies queued one behind the other, nearest rank first -- one link at a time, i.e.
+ *               ring timing.  bbr_push_state says which form the last push took.  The host orders "all pushes have
+ *               landed" (events or a barrier) before bbr_unpack_whole, and must not let a rank push frame n + 1 into a
+ *               buffer a peer is still un-interleaving frame n from: two gather buffers per rank, used in turn.
  * Block forms (what travels per rank; bbr_exchange_block_bytes): BBR_SHARD_RGBA32F the fp32 shard (16 B/pixel),
  * BBR_SHARD_PACKED rgb + one alpha bit per pixel (12.1 B, lossless: alpha is 0 or 1; = bbr_pack_shard), BBR_SHARD_RGBA8
  * the presented shard (4 B; needs bbr_present).  `gathered` / `whole` = NULL use buffers owned by the frame's slot
@@ -293,6 +300,8 @@ int bbr_allgather_frame(bbr_context *ctx, int32_t form, void *gathered_device /*
                         void *whole_device /* height*width pixels, or NULL */, void *hip_stream);
 int bbr_push_shard(bbr_context *ctx, int32_t form, void *const *peer_gathered /* [world] device pointers */,
                    const int32_t *peer_devices /* [world] HIP device of each */, void *hip_stream);
+/* 1 if the last bbr_push_shard stored through the one-kernel direct form, 0 if it queued copies */
+int bbr_push_state(const bbr_context *ctx, int32_t *out_direct);
 int bbr_unpack_whole(bbr_context *ctx, int32_t form, const void *gathered_device, void *whole_device, void *hip_stream);
 int bbr_whole_frame_device_ptr(bbr_context *ctx, void **out_ptr, uint64_t *out_bytes);
 int bbr_read_whole_frame(bbr_context *ctx, void *host /* height*width*16 bytes (RGBA8 form: *4); synchronises */);

@@ -70,15 +70,18 @@ def test_collective_form_with_a_one_rank_communicator(scene_and_frames):
     r.close()
 
 
-@pytest.mark.parametrize("world,form", [(2, P.SHARD_PACKED), (3, P.SHARD_RGBA32F), (4, P.SHARD_RGBA8), (8, P.SHARD_PACKED)])
-def test_peer_form_among_contexts_on_one_device(scene_and_frames, world, form):
-    """every rank pushes its block into every rank's gather buffer; afterwards all buffers hold the same bytes (the layout
+@pytest.mark.parametrize("world,form,push_mode", [(2, P.SHARD_PACKED, 1), (3, P.SHARD_RGBA32F, 1), (4, P.SHARD_RGBA8, 1),
+                                                   (8, P.SHARD_PACKED, 1), (8, P.SHARD_RGBA32F, 0), (3, P.SHARD_RGBA8, 0)])
+def test_peer_form_among_contexts_on_one_device(scene_and_frames, world, form, push_mode):
+    """every rank pushes its block into every rank's gather buffer -- with ONE kernel storing to all peers (push_mode 1, the
+    default) or with copies queued one behind the other (0); afterwards all buffers hold the same bytes (the layout
     ncclAllGather leaves), the host model of partition.py predicts them, and every rank unpacks the whole frame"""
     import torch
     cfg, sc, ref, ref8 = scene_and_frames
     band = 32
     rs = [Renderer(cfg.width, cfg.height) for _ in range(world)]
     for rank, r in enumerate(rs):
+        r.set_option("push_mode", push_mode)
         r.set_partition(rank, world, band)
     block = rs[0].exchange_block_bytes(form)
     assert block == P.exchange_block_bytes(form, cfg.height, cfg.width, world, band)
@@ -92,6 +95,7 @@ def test_peer_form_among_contexts_on_one_device(scene_and_frames, world, form):
         if form == P.SHARD_RGBA8:
             r.present()
         r.push_shard(form, ptrs, devs)
+        assert r.push_was_direct() == bool(push_mode)
     for r in rs:
         r.synchronize()          # "all pushes have landed": the host's part of the peer form
     host = [b.cpu().numpy() for b in bufs]

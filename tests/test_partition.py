@@ -63,6 +63,23 @@ def test_push_order_is_a_ring_step_at_every_step(world):
         assert sorted(o) == [x for x in range(world) if x != r]
 
 
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 8])
+def test_direct_push_drives_every_link_of_the_mesh_at_once(world):
+    """push_mode 1 (one kernel storing to all peers): a single step in which all world * (world - 1) link directions of the
+    full mesh carry a block, each exactly once -- SURVEY 8(e)'s direct pattern; push_mode 0 needs world - 1 steps of
+    `world` busy directions each, every rank sending and receiving on one link (ring timing)"""
+    direct = P.push_links_busy(world, direct=True)
+    every = {(a, b) for a in range(world) for b in range(world) if a != b}
+    assert direct == ([every] if world > 1 else [])
+    serial = P.push_links_busy(world, direct=False)
+    assert len(serial) == max(world - 1, 0) and set().union(*serial) == every if world > 1 else serial == []
+    for step in serial:
+        assert len(step) == world and sorted(a for a, _ in step) == sorted(b for _, b in step) == list(range(world))
+    # the same bytes land either way: destinations per rank are the same set
+    for r in range(world):
+        assert sorted(d for st in P.push_steps(r, world, True) for d in st) == sorted(d for st in P.push_steps(r, world, False) for d in st)
+
+
 @pytest.mark.parametrize("form", [P.SHARD_RGBA32F, P.SHARD_PACKED, P.SHARD_RGBA8])
 @pytest.mark.parametrize("H,W,world,band", [(270, 17, 4, 32), (130, 390, 3, 64), (2160, 64, 8, 32), (64, 64, 1, 32)])
 def test_peer_exchange_model_leaves_the_same_gather_buffer_on_every_rank(form, H, W, world, band):
