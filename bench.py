@@ -213,13 +213,13 @@ def main():
     ap.add_argument("--gather", default="packed", choices=["packed", "rgba32f"],
                     help="N > 1: what the all-gather moves -- the shard as rgb + one alpha bit per pixel (lossless, 12.1 B per "
                          "pixel; default) or as plain RGBA32F (16 B); the reassembled frame is the same, bit for bit")
-    ap.add_argument("--exchange", default="torch", choices=["torch", "native", "peer"],
-                    help="N > 1: who runs the exchange.  torch (default): torch.distributed all_gather_into_tensor (RCCL) on "
-                         "a stream of the harness + the library's un-interleave kernel.  native: bbr_allgather_frame -- the "
-                         "library packs, calls ncclAllGather on the frame's own stream and un-interleaves (the id travels "
-                         "through torch.distributed once).  peer: bbr_push_shard -- every rank copies its block into every "
-                         "rank's gather buffer (hipMemcpyPeerAsync through IPC handles), a host barrier orders the landing. "
-                         "native and peer have not been run on more than one GPU (DESIGN.md section 6)")
+    ap.add_argument("--exchange", default=None, choices=["torch", "native", "peer"],
+                    help="N > 1: who runs the exchange.  native (default): bbr_allgather_frame -- the library packs, calls "
+                         "ncclAllGather (RCCL over xGMI) on the frame's own stream and un-interleaves (the id travels through "
+                         "torch.distributed once).  torch: torch.distributed all_gather_into_tensor (RCCL) on a stream of the "
+                         "harness + the library's un-interleave kernel.  peer: bbr_push_shard -- one kernel stores this rank's "
+                         "block into every rank's gather buffer (IPC handles; all xGMI links at once), a host barrier orders "
+                         "the landing.  None of the three has run on more than one GPU (DESIGN.md section 5)")
     ap.add_argument("--force-dist", action="store_true", help="exercise the all-gather path with WORLD_SIZE = 1")
     ap.add_argument("--render-pass", default="forward", choices=["forward", "deferred"],
                     help="forward_brdf.* (the path BASELINE measures) or the reference's deferred path, gbuffer.* + brdf.*")
@@ -262,6 +262,8 @@ def main():
     # BBR_BENCH_SINGLE_DEVICE=1 puts every rank on cuda:0, so that the N > 1 code path (partition, shard buffers,
     # events, un-interleave) can be run as real separate processes on a one-GPU box, where RCCL refuses two ranks per GPU.
     backend = os.environ.get("BBR_BENCH_BACKEND", "nccl")
+    if args.exchange is None:   # (the gloo rehearsal on one GPU cannot open an RCCL communicator with two ranks per device)
+        args.exchange = "native" if backend == "nccl" else "torch"
     if os.environ.get("BBR_BENCH_SINGLE_DEVICE") == "1":
         local_rank = 0
     torch.cuda.set_device(local_rank)

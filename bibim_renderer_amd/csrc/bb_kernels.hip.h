@@ -182,6 +182,20 @@ BB_DEV int mul32(int a, int b) {
   return a * b;
 }
 
+// A pixel of the frame is written once and never read again by these kernels: a NON-TEMPORAL store (global_store ... nt).
+// 133 MB of pixels per 4K frame otherwise stream through the L2s as ordinary dirty lines and push out what the shading
+// does re-read -- texels and primitive records: with nt the pipelined C3 frame went 122.2 -> 110.6 us, C2 26.5 -> 24.9
+// (plain / nt / sc1: 122.2 / 110.6 / 120.0 us; sc1 drops the line from the L2 once written back, nt marks it
+// first-to-go from the start).
+typedef float v4f __attribute__((ext_vector_type(4)));
+BB_DEV void store_pixel(float4 *p, float4 v) {
+  const v4f q = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(q, reinterpret_cast<v4f *>(p));  // one global_store_dwordx4 ... nt
+}
+BB_DEV void store_pixel(uint32_t *p, uint32_t v) { __builtin_nontemporal_store(v, p); }
+// (The intermediates that are written once and read once -- fragment words, RasterTri records -- stay ordinary accesses:
+//  non-temporal they made the frame 2 % slower, 112.1 -> 114.8 / 113.8 us: their one reader does find them in the L2.)
+
 BB_DEV f4 mat4_mul(const Mat4 &m, f4 v) {
   f4 r;
   r.x = fmaf(m.M[3][0], v.w, fmaf(m.M[2][0], v.z, fmaf(m.M[1][0], v.y, m.M[0][0] * v.x)));
@@ -989,7 +1003,7 @@ constexpr int kItemsThreads = 256;  // launch slots per workgroup of k_shade_ite
 // words between two of k_raster's chunk counters: a 128-byte cache line each.  Atomics on one LINE serialise like atomics on
 // one address (packed 32 to a line they cost k_raster 5 us at C5's 32 640 tiles)
 constexpr int kItemGroupStride = 32;
-constexpr int kItemGroupSlots = 32, kItemGroups = 4096;  // k_raster's chunk totals: one counter per 32 launch slots (fewer
+constexpr int kItemGroupSlots = 32, kItemGroups = 2048;  // k_raster's chunk totals: one counter per 32 launch slots (fewer
                                                           // addresses made the atomics cost k_raster 7 us at C3)
 constexpr int kItemChunkBits = 6, kItemTxBits = 12;  // item = full << 31 | grid row << 18 | tile column << 6 | chunk of 64 fragments
 // A tile that ONE triangle covers completely and nothing else touches has no fragment list: its count word carries this flag
@@ -997,10 +1011,8 @@ constexpr int kItemChunkBits = 6, kItemTxBits = 12;  // item = full << 31 | grid
 // k_shade_items hands the flag on in the item word, so that k_shade knows before it loads anything.
 constexpr uint32_t kFullTile = 0x80000000u;
 constexpr int kFragPixBits = 12;  // pixel-in-tile field of a fragment's high word (tiles of up to 64x64); the clip slot + 1 sits above it
-// threads of k_raster's workgroup for a tile size: 256 for the large tiles, ONE wave for 16 x 16 -- the workgroup then
-// needs no barrier at all and a tile nothing is binned to costs the machine one wave, not four
-template <int TILE_W, int TILE_H>
-constexpr int tile_threads() { return TILE_W * TILE_H <= 256 ? 64 : 256; }
+constexpr int kTileThreads = 256;
+constexpr int kTileWaves = kTileThreads / 64;
 
 // One lane rasterises one small triangle into the tile's LDS keys.  Bounding box <= 16 px in each direction
 // => every edge-function term fits 32 bits and steps are plain adds.
@@ -1118,7 +1130,8 @@ BB_DEV bool tile_row(const FrameParams &fp, int grid_y, int &ty, int &out_tile_r
 // split over the raster classes, instead of two per loop iteration.  The every-tile list rides along as extra
 // "large" entries after a per-tile accept/reject test.
 // ------------------------------------------------------------------------------------------------
-template <int kStage>  // staged entries per chunk (one per thread)
+constexpr int kStage = kTileThreads;  // staged entries per chunk (one per thread)
+
 struct StagedTri {  // struct-of-arrays in LDS: thread j owns column j when filling
   int X0[kStage], Y0[kStage], X1[kStage], Y1[kStage], X2[kStage], Y2[kStage];
   float z0[kStage], dzdx[kStage], dzdy[kStage];
@@ -1126,8 +1139,7 @@ struct StagedTri {  // struct-of-arrays in LDS: thread j owns column j when fill
   uint32_t box[kStage];  // px0 | px1 << 8 | py0 << 16 | py1 << 24 relative to the tile; 0xFFFFFFFF = skip
 };
 
-template <int kStage>
-BB_DEV RasterTri staged_tri(const StagedTri<kStage> &st, int j) {
+BB_DEV RasterTri staged_tri(const StagedTri &st, int j) {
   RasterTri t;
   t.X0 = st.X0[j]; t.Y0 = st.Y0[j]; t.X1 = st.X1[j]; t.Y1 = st.Y1[j]; t.X2 = st.X2[j]; t.Y2 = st.Y2[j];
   t.z0 = st.z0[j]; t.dzdx = st.dzdx[j]; t.dzdy = st.dzdy[j];
@@ -1139,7 +1151,7 @@ BB_DEV RasterTri staged_tri(const StagedTri<kStage> &st, int j) {
 // gizmo primitives are scissored to their rectangle and biased above everything else, pixels no overlay primitive
 // wins are left alone (no background fill).  OVERLAY = false with depth_io != nullptr stores the resolved depth.
 template <int TILE_W, int TILE_H, bool OVERLAY = false>
-__global__ __launch_bounds__((tile_threads<TILE_W, TILE_H>())) void k_raster(
+__global__ __launch_bounds__(kTileThreads) void k_raster(
     FrameParams fp, const RasterTri *__restrict__ tris, const ClipSlot *__restrict__ clip_arena,
     Counters *__restrict__ ctr, uint32_t *__restrict__ tile_count,
     const uint32_t *__restrict__ bins, const BroadTri *__restrict__ broad_list,
@@ -1148,9 +1160,8 @@ __global__ __launch_bounds__((tile_threads<TILE_W, TILE_H>())) void k_raster(
     const float4 *__restrict__ background, float *__restrict__ depth_io, uint32_t *__restrict__ host_flags,
     uint32_t *__restrict__ out8, uint32_t *__restrict__ item_groups) {
   constexpr int TILE_PIXELS = TILE_W * TILE_H;
-  constexpr int kTileThreads = tile_threads<TILE_W, TILE_H>(), kTileWaves = kTileThreads / 64, kStage = kTileThreads;
   __shared__ unsigned long long keys[TILE_PIXELS];
-  __shared__ StagedTri<kStage> st;
+  __shared__ StagedTri st;
   __shared__ uint32_t s_count;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1206,8 +1217,8 @@ __global__ __launch_bounds__((tile_threads<TILE_W, TILE_H>())) void k_raster(
   // colour presents as (0, 0, 0, 255))
   auto store_background = [&](int x, int y) {
     const size_t o = (size_t)(out_y0 + y) * (size_t)fp.width + (size_t)(tile_x0 + x);
-    if (out8) out8[o] = background ? __float_as_uint(background[1].x) : 0xFF000000u;
-    else out[o] = background ? background[0] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (out8) store_pixel(&out8[o], background ? __float_as_uint(background[1].x) : 0xFF000000u);
+    else store_pixel(&out[o], background ? background[0] : make_float4(0.0f, 0.0f, 0.0f, 0.0f));
   };
 
   // ---- light tiles: no LDS, no barrier ----
@@ -2006,8 +2017,8 @@ __global__ __launch_bounds__(kShadeThreads) __attribute__((amdgpu_waves_per_eu(T
   BB_KSTAMP(4);  // light loop done
   if (BB_ABLATE(2u)) color = make_float4(1.f, 1.f, 1.f, 1.f);
   if (valid) {
-    if (PRESENT) out8[o] = present_pixel(color.x, color.y, color.z, *tables, sp.tone_enable, sp.exposure, 1);
-    else out[o] = color;
+    if (PRESENT) store_pixel(&out8[o], present_pixel(color.x, color.y, color.z, *tables, sp.tone_enable, sp.exposure, 1));
+    else store_pixel(&out[o], color);
   }
 #ifdef BB_STAMPS
   {
@@ -2101,9 +2112,10 @@ __global__ __launch_bounds__(kPresentThreads) void k_present(const float4 *__res
   for (int j = 0; j < kPresentPerThread; ++j) {
     const size_t i = base + (size_t)j * kPresentThreads;
     if (i >= n) break;
-    const float4 c = frame[i];
+    // (the fp32 frame is read once, the presented image written once: both non-temporal)
+    const v4f c = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(frame) + i);
     const uint32_t px = present_pixel(c.x, c.y, c.z, t, enable, exposure, hdr16);
-    out_rgba8[i] = px;
+    store_pixel(&out_rgba8[i], px);
   }
 }
 

@@ -213,7 +213,7 @@ struct bbr_context {
   void *ext_out = nullptr;
   uint64_t ext_out_bytes = 0;
 
-  int tile_mode = 1;  // 0: 64x64, 1: 32x32, 2: 16x16 with one-wave raster workgroups
+  int tile_mode = 1;  // 0: 64x64, 1: 32x32 (default: finer tiles balance better; 16x16 with one-wave workgroups measured slower)
   uint32_t bin_cap = 512, broad_cap = 4096, clip_cap = 4096, broad_threshold = 16;
   int32_t rank = 0, world = 1, band_rows = 0;
   bool dump_vis = false;
@@ -279,8 +279,8 @@ struct bbr_context {
   // shading of frame N+1 instead of delaying it
   hipStream_t present_stream() const { return (user_stream || frames_in_flight == 1) ? shade_stream() : s_present; }
   int n_slots() const { return user_stream ? 1 : frames_in_flight; }
-  int tile_w() const { return tile_mode == 0 ? 64 : (tile_mode == 1 ? 32 : 16); }
-  int tile_h() const { return tile_w(); }
+  int tile_w() const { return tile_mode == 0 ? 64 : 32; }
+  int tile_h() const { return tile_mode == 0 ? 64 : 32; }
   int tiles_x() const { return (width + tile_w() - 1) / tile_w(); }
   int tiles_y() const { return (height + tile_h() - 1) / tile_h(); }
   int eff_band_rows() const { return band_rows > 0 ? band_rows : tile_h(); }
@@ -336,9 +336,7 @@ FrameParams make_params(const bbr_context *c) {
   fp.bin_cap = c->bin_cap;
   fp.broad_cap = c->broad_cap;
   fp.clip_cap = c->clip_cap;
-  // (in tiles; the 16 x 16 mode keeps the threshold where it is in PIXELS: a triangle reaches the every-tile list, which
-  //  every tile of the frame looks at, when its box spans more than about 128 x 128 pixels)
-  fp.broad_threshold = c->tile_mode == 2 ? c->broad_threshold * 4u : c->broad_threshold;
+  fp.broad_threshold = c->broad_threshold;
   fp.rank = c->rank;
   fp.world = c->world;
   fp.band_tiles = c->eff_band_rows() / c->tile_h();
@@ -457,7 +455,7 @@ void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const Fra
   const SrgbTables *tables = c->present_fused ? c->d_srgb_tables.ptr : nullptr;
   if (fp.deferred)
     hipLaunchKernelGGL(k_deferred_background, dim3(1), dim3(kBackgroundThreads), 0, sr, sp, d_lights, s.d_background.ptr, tables, fp.gbuffer_view);
-  hipLaunchKernelGGL((k_raster<TW, TH>), dim3(fp.tiles_x, grid_y), dim3(tile_threads<TW, TH>()), 0, sr, fp, s.d_tris.ptr,
+  hipLaunchKernelGGL((k_raster<TW, TH>), dim3(fp.tiles_x, grid_y), dim3(kTileThreads), 0, sr, fp, s.d_tris.ptr,
                      s.d_clip.ptr, ctr, s.d_tile_count.ptr, s.d_bins.ptr, s.d_broad.ptr, s.d_frags.ptr,
                      s.d_frag_count.ptr, out, c->dump_vis ? c->d_vis_prim.ptr : nullptr,
                      c->dump_vis ? c->d_vis_depth.ptr : nullptr,
@@ -633,8 +631,7 @@ int submit_frame_into(bbr_context *c, int slot_index) {
 
   (void)hipMemcpyAsync(s.d_staging.ptr, s.h_staging, total, hipMemcpyHostToDevice, sg);
   if (c->tile_mode == 0) launch_frame<64, 64>(c, s, prev, fp, pv, view, sp, d_lights, d_draws, c->n_live_draws, out);
-  else if (c->tile_mode == 1) launch_frame<32, 32>(c, s, prev, fp, pv, view, sp, d_lights, d_draws, c->n_live_draws, out);
-  else launch_frame<16, 16>(c, s, prev, fp, pv, view, sp, d_lights, d_draws, c->n_live_draws, out);
+  else launch_frame<32, 32>(c, s, prev, fp, pv, view, sp, d_lights, d_draws, c->n_live_draws, out);
   HIP_TRY(c, hipGetLastError());
   s.in_flight = true;
   s.fused = c->present_fused;
@@ -958,7 +955,7 @@ extern "C" int bbr_draw_overlays(bbr_context *c, int32_t gizmo_extent) {
       hipLaunchKernelGGL((k_geometry<TW, TH, true>), dim3((n_prims + 255) / 256), dim3(256), 0, st, d_draws, (uint32_t)draws.size(),
                          n_prims, ident, ident, fp, s.d_tris.ptr, s.d_attrs.ptr, s.d_clip.ptr, ctr, s.d_tile_count.ptr,
                          s.d_bins.ptr, s.d_broad.ptr, c->d_materials.ptr, s.d_block_stats.ptr);
-      hipLaunchKernelGGL((k_raster<TW, TH, true>), dim3(fp.tiles_x, fp.tiles_y), dim3(tile_threads<TW, TH>()), 0, st, fp, s.d_tris.ptr,
+      hipLaunchKernelGGL((k_raster<TW, TH, true>), dim3(fp.tiles_x, fp.tiles_y), dim3(kTileThreads), 0, st, fp, s.d_tris.ptr,
                          s.d_clip.ptr, ctr, s.d_tile_count.ptr, s.d_bins.ptr, s.d_broad.ptr, s.d_frags.ptr, s.d_frag_count.ptr,
                          (float4 *)nullptr, (uint32_t *)nullptr, (float *)nullptr,
                          (const float4 *)nullptr, fs.d_depth.ptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
@@ -967,8 +964,7 @@ extern "C" int bbr_draw_overlays(bbr_context *c, int32_t gizmo_extent) {
                          s.d_attrs.ptr, s.d_clip.ptr, s.d_frags.ptr, s.d_frag_count.ptr, c->d_srgb_tables.ptr, fs.present.out);
     };
     if (c->tile_mode == 0) launch(std::integral_constant<int, 64>{}, std::integral_constant<int, 64>{});
-    else if (c->tile_mode == 1) launch(std::integral_constant<int, 32>{}, std::integral_constant<int, 32>{});
-    else launch(std::integral_constant<int, 16>{}, std::integral_constant<int, 16>{});
+    else launch(std::integral_constant<int, 32>{}, std::integral_constant<int, 32>{});
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(st));
     Counters h = {};
@@ -1693,8 +1689,8 @@ int bbr_set_option(bbr_context *c, const char *name, int64_t value) {
     c->frames_in_flight = (int)value;
     c->frame_counter = 0;
   } else if (n == "tile_mode") {
-    if (value < 0 || value > 2) return fail(c, BBR_ERR_INVALID_ARGUMENT, "tile_mode: 0 (64x64), 1 (32x32) or 2 (16x16)");
-    if (c->world > 1 && c->band_rows % (value == 0 ? 64 : (value == 1 ? 32 : 16)))
+    if (value != 0 && value != 1) return fail(c, BBR_ERR_INVALID_ARGUMENT, "tile_mode: 0 (64x64) or 1 (32x32)");
+    if (c->world > 1 && c->band_rows % (value == 0 ? 64 : 32))
       return fail(c, BBR_ERR_INVALID_ARGUMENT, "tile_mode: band_rows not a multiple of the new tile height");
     c->tile_mode = (int)value;
     // bins and fragment lists are laid out per tile: drop them so that ensure() re-zeroes the counters

@@ -178,11 +178,9 @@ int bbr_timing_summary(bbr_context *ctx, uint32_t *out_frames, float *out_avg_fr
  *   "timing_stride" n        with "timing" on, only every n-th frame carries events (default 1): the events themselves
  *                            perturb a pipelined frame stream (two per frame: ~4 % of the C3 frame rate)
  *   "frames_in_flight" 1..4  default 2
- *   "tile_mode" 0|1|2        screen tile of the rasteriser: 0: 64x64, 1: 32x32 (256-thread raster workgroups), 2: 16x16
- *                            (one wave per tile, no workgroup barrier).  Same pixels in every mode
+ *   "tile_mode" 0|1          0: 64x64 tiles, 1: 32x32 tiles (default)
  *   "bin_cap" n              initial references per (tile, raster class); grows by itself on overflow
- *   "broad_threshold" n      triangles touching more than n tiles go to the every-tile list (n in 32x32-tile units: the
- *                            16x16 mode multiplies it by four, so the switch stays at the same size in pixels)
+ *   "broad_threshold" n      triangles touching more than n tiles go to the every-tile list
  *   "broad_cap" n            initial entries of the every-tile list (default 4096); doubles when a frame overflows it
  *   "clip_cap" n             initial sub-triangle slots of the clip arena (default 4096); doubles likewise
  *   "gbuffer_view" -1..3      deferred path only: instead of brdf.frag, buffer_visualize.frag shows the rgb of one G-buffer

@@ -868,6 +868,7 @@ typedef struct {
   float *gbuffer; /* program 2, optional: width*height*16 floats */
   int32_t width;
   int literal;    /* BBO_FLAG_LITERAL: statement-by-statement light loop instead of the shipped evaluation order */
+  int output_uv;  /* BBO_FLAG_OUTPUT_UV: the interpolated vUV instead of the colour (measurement aid, forward program only) */
 } pipeline;
 
 static void shade_pixel(const pipeline *pl, const raster_tri *t, const float vary[3][NVARY], const void *mat,
@@ -876,6 +877,7 @@ static void shade_pixel(const pipeline *pl, const raster_tri *t, const float var
   tri_bary(t, px * SUBPIXEL_ONE + SUBPIXEL_ONE / 2, py * SUBPIXEL_ONE + SUBPIXEL_ONE / 2, beta);
   if (pl->program == 0) {
     interpolate(beta, vary, NVARY, attr);
+    if (pl->output_uv) { out[0] = attr[0]; out[1] = attr[1]; out[2] = 0.0f; out[3] = 1.0f; return; }
     shade_fragment(pl->literal, pl->fu, pl->vu, (const bbo_material *)mat, attr, out);
   } else if (pl->program == 2) {
     float g[16];
@@ -1023,7 +1025,7 @@ static int render_pbr(const bbo_frame_uniforms *frame, const bbo_view_uniforms *
   ctx.deferred = (flags & BBO_FLAG_DEFERRED) != 0;
   bbo_proj_view(view, &ctx.pv);
   pipeline pl = {ctx.deferred ? 2 : 0, &ctx, pbr_fetch, frame, view, ctx.deferred ? out_gbuffer : NULL, width,
-                 (flags & BBO_FLAG_LITERAL) != 0};
+                 (flags & BBO_FLAG_LITERAL) != 0, (flags & BBO_FLAG_OUTPUT_UV) != 0};
   int rc = render_core(&pl, (uint32_t)total, width, height, y0, y1, flags, out_rgba, out_prim, out_depth, stats);
   free(di);
   return rc;
@@ -1271,7 +1273,7 @@ int bbo_render_gizmo(const bbo_view_uniforms *view, const bbo_gizmo_vertex *vert
   gv.proj.M[0][0] = d;
   gv.proj.M[1][1] = -d;
   bbo_proj_view(&gv, &ctx.pv);
-  pipeline pl = {1, &ctx, gizmo_fetch, NULL, view, NULL, width, 0};
+  pipeline pl = {1, &ctx, gizmo_fetch, NULL, view, NULL, width, 0, 0};
   return render_core(&pl, n / 3, width, height, 0, height, 0, out_rgba, out_prim, out_depth, stats);
 }
 

@@ -122,6 +122,9 @@ typedef struct {
 #define BBO_CONTRACT_REVISION 2
 uint32_t bbo_contract_revision(void);
 
+#define BBO_FLAG_OUTPUT_UV 8     /* measurement aid (tools/texel_lines.py): out_rgba = (vUV.x, vUV.y, 0, 1) of the winning
+                                    fragment instead of its colour: which texels the frame's fetches touch */
+
 typedef struct {
   uint64_t n_prims;         /* triangles submitted */
   uint64_t n_raster_tris;   /* sub-triangles that survived clip + cull */

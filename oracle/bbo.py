@@ -85,6 +85,7 @@ class Stats(C.Structure):
 NO_PRIM = 0xFFFFFFFF
 FLAG_FORWARD_SHADE = 1
 FLAG_LITERAL = 4  # light loop statement by statement as the GLSL is written, instead of the shipped evaluation order
+FLAG_OUTPUT_UV = 8  # measurement aid: the winning fragment's interpolated vUV instead of its colour
 
 _lib = None
 

@@ -28,7 +28,7 @@ def reference_image(sc, deferred, gv, gi, extent, enable=0, exposure=1.0):
     return base, bbo.overlay(sc.frame, sc.view, depth, base, gv, gi, extent)
 
 
-@pytest.mark.parametrize("tile_mode", [0, 1, 2])
+@pytest.mark.parametrize("tile_mode", [0, 1])
 @pytest.mark.parametrize("deferred", [False, True])
 def test_markers_and_gizmo_match_the_oracle(maps64, tile_mode, deferred):
     raw, gi, gv = gizmo()
