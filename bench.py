@@ -316,12 +316,32 @@ def main():
         packed = args.gather == "packed" and not args.present
         from bibim_renderer_amd import partition as P
         form = P.SHARD_RGBA8 if args.present else (P.SHARD_PACKED if packed else P.SHARD_RGBA32F)
+        exchange_note = None
         if args.exchange == "native":
-            # the 128-byte id: made by rank 0's library, handed round by the harness, one ncclCommInitRank per rank
-            box = [r.comm_unique_id() if rank == 0 else None]
+            # the 128-byte id: made by rank 0's library, handed round by the harness, one ncclCommInitRank per rank.  If any
+            # rank cannot open its communicator (no librccl for dlopen, ...) ALL ranks fall back to the torch exchange -- a
+            # collective must be entered by everybody or by nobody.
+            ok, why = 1, ""
+            try:
+                box = [r.comm_unique_id() if rank == 0 else None]
+            except Exception as e:   # noqa: BLE001  (reported below)
+                box, ok, why = [None], 0, f"bbr_comm_unique_id: {e}"
             if world > 1:
                 dist.broadcast_object_list(box, src=0)
-            r.comm_init(rank, world, box[0])
+            if ok and box[0] is not None:
+                try:
+                    r.comm_init(rank, world, box[0])
+                except Exception as e:   # noqa: BLE001
+                    ok, why = 0, f"bbr_comm_init: {e}"
+            else:
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            if world > 1:
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                exchange_note = f"native exchange unavailable on some rank ({why or 'another rank'}): torch.distributed all-gather instead"
+                print(f"[bench rank {rank}] {exchange_note}", file=sys.stderr, flush=True)
+                args.exchange = "torch"
         if args.exchange == "peer":
             import ctypes
             hip = ctypes.CDLL("libamdhip64.so")
@@ -719,7 +739,8 @@ def main():
                                "bytes_per_rank_block": int(r.exchange_block_bytes(form)),
                                "bytes_received_per_rank_per_frame": int(r.exchange_block_bytes(form)) * (world - 1),
                                "ranks_in_communicator": int(dist.get_world_size()), "backend": backend,
-                               "band_rows": int(args.band_rows or r.tile_height()), "shard_rows": int(r.shard_rows())}
+                               "band_rows": int(args.band_rows or r.tile_height()), "shard_rows": int(r.shard_rows()),
+                               **({"note": exchange_note} if exchange_note else {})}
         if verified is not None:
             out["verified_against_unpartitioned_render"] = verified
         if parity is not None:

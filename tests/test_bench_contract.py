@@ -1,5 +1,5 @@
-"""The bench lines committed with the round's profiles (profiles/r02_bench.json: what `python3 bench.py` printed on an
-MI355X; r02_bench_under_rocprof.json: the same command under rocprofv3) carry every field of the measurement contract,
+"""The bench lines committed with the round's profiles (profiles/r03_bench.json: what `python3 bench.py` printed on an
+MI355X; r03_bench_under_rocprof.json: the same command under rocprofv3) carry every field of the measurement contract,
 and their numbers hang together with the committed kernel table and counter summaries."""
 import json
 import os
@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_follows_the_contract():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_under_rocprof.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_under_rocprof.json")))
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -36,9 +36,9 @@ def test_committed_bench_line_follows_the_contract():
     # the per-kernel table of the same run is committed beside it; the mean duration of k_shade's timed launches by the
     # kernel trace is what the HIP events bracket, minus what the events also see (they are recorded on the frame's
     # stream in front of the tail instantiation and behind the main one, while two other frames share the GPU)
-    names = [l.split(",")[0] for l in open(os.path.join(ROOT, "profiles", "r02_bench_kernel_stats.csv")).read().splitlines()[1:]]
+    names = [l.split(",")[0] for l in open(os.path.join(ROOT, "profiles", "r03_bench_kernel_stats.csv")).read().splitlines()[1:]]
     assert r["kernel"] == "k_shade" and {"k_shade", "k_shade_tail", "k_shade_items", "k_raster", "k_geometry"} <= set(names)
-    phases = open(os.path.join(ROOT, "profiles", "r02_bench_kernel_phases.txt")).read()
+    phases = open(os.path.join(ROOT, "profiles", "r03_bench_kernel_phases.txt")).read()
     line = [l for l in phases.splitlines() if l.startswith("k_shade ")][0]
     timed = float(line.split("mean=")[1].split("us")[0])
     alone = float(line.split("mean=")[2].split("us")[0])
@@ -49,15 +49,15 @@ def test_committed_bench_line_follows_the_contract():
 def test_traffic_and_valu_come_from_summaries_of_the_same_kernel_sources():
     """roofline.traffic / roofline.valu of the line bench.py printed without the profiler are the committed counter
     summaries' figures, and those summaries say which kernel sources they were measured on"""
-    d = json.load(open(os.path.join(ROOT, "profiles", "r02_bench.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r03_bench.json")))
     r = d["roofline"]
-    hbm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_hbm.json")))
-    sq = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_sq.json")))
+    hbm = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_hbm.json")))
+    sq = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_sq.json")))
     assert len(hbm["kernel_source_sha256"]) == 64 and hbm["kernel_source_sha256"] == sq["kernel_source_sha256"]
-    assert r["traffic_source"] == "profiles/r02_pmc_hbm.json" and r["traffic"] == hbm["kernels"]["k_shade"]["hbm_bytes_per_launch"]
+    assert r["traffic_source"] == "profiles/r03_pmc_hbm.json" and r["traffic"] == hbm["kernels"]["k_shade"]["hbm_bytes_per_launch"]
     assert r["traffic"] <= 1.8 * r["algorithmic_bytes_per_launch"]          # VERDICT round 1, item 2
     v = r["valu"]
-    assert v["bound"] == "valu" and v["source"] == "profiles/r02_pmc_sq.json"
+    assert v["bound"] == "valu" and v["source"] == "profiles/r03_pmc_sq.json"
     assert v["valu_instructions_per_launch"] == int(sq["kernels"]["k_shade"]["SQ_INSTS_VALU"])
     assert abs(v["frac"] - v["achieved"] / v["peak"]) < 1e-3 and sum(v["by_class"].values()) == v["valu_instructions_per_launch"]
     assert abs(v["achieved"] - v["valu_instructions_per_launch"] / (r["avg_kernel_ms"] * 1e-3) / 1e9) / v["achieved"] < 1e-3
