@@ -463,15 +463,10 @@ BB_DEV void clip_primitive_wave(ClipWork &w, int owner, const float (*clip)[4], 
   }
   if (__ballot(bad) != 0ull) return;
   const int n_slots = min(n - 2, kMaxSubTris);
-  uint32_t base = 0;
-  if (lane == 0) base = atomicAdd(&ctr->n_clip_slots, (uint32_t)n_slots);
-  base = (uint32_t)__shfl((int)base, 0);
-  if (base + (uint32_t)n_slots > fp.clip_cap) {
-    if (lane == 0) atomicOr(&ctr->overflow, 4u);
-    return;
-  }
   __builtin_amdgcn_wave_barrier();
-  // fan triangle i = (v0, v_i, v_i+1): lane i - 1
+  // fan triangle i = (v0, v_i, v_i+1): lane i - 1.  The setup needs no reservation, so it runs first and BOTH reservations
+  // -- arena slots (lane 0) and every-tile entries (lane 1) -- go out together afterwards: one memory round trip per clipped
+  // primitive instead of two (the ground plane's two primitives are k_geometry's critical path at 1080p: in-kernel stamps).
   bool ok = false;
   ClipSlot s;
   if (lane < n_slots) {
@@ -491,31 +486,35 @@ BB_DEV void clip_primitive_wave(ClipWork &w, int owner, const float (*clip)[4], 
     TileRange tr;
     ok = ok && tile_range<TILE_W, TILE_H>(s.tri, fp, tr);
     s.valid = ok ? 1u : 0u;
-    clip_arena[base + (uint32_t)lane] = s;
   }
   const unsigned long long m = __ballot(ok);
   const int n_valid = (int)__popcll(m);
-  if (lane == owner) {
+  uint32_t got = 0;
+  if (lane == 0) got = atomicAdd(&ctr->n_clip_slots, (uint32_t)n_slots);
+  if (lane == 1 && n_valid) got = atomicAdd(&ctr->n_broad, (uint32_t)n_valid);
+  const uint32_t base = (uint32_t)__shfl((int)got, 0), slot = (uint32_t)__shfl((int)got, 1);
+  const bool arena_fits = base + (uint32_t)n_slots <= fp.clip_cap;
+  const bool list_fits = slot + (uint32_t)n_valid <= fp.broad_cap;
+  if (!arena_fits && lane == 0) atomicOr(&ctr->overflow, 4u);
+  if (n_valid && !list_fits && lane == 0) atomicOr(&ctr->overflow, 2u);
+  if (arena_fits && lane < n_slots) clip_arena[base + (uint32_t)lane] = s;
+  if (lane == owner && arena_fits) {
     w.base = base;
     w.n_slots = n_slots;
   }
-  if (n_valid == 0) return;
-  uint32_t slot = 0;
-  if (lane == 0) slot = atomicAdd(&ctr->n_broad, (uint32_t)n_valid);
-  slot = (uint32_t)__shfl((int)slot, 0);
-  if (slot + (uint32_t)n_valid <= fp.broad_cap) {
-    if (ok) {
-      BroadTri b;
+  if (n_valid == 0 || !list_fits) return;  // (an overflowed list: the frame takes none of its entries, k_raster)
+  if (ok) {
+    // the run of entries is reserved and fits, so every one of them is written: a real entry, or -- when the arena had
+    // no room for the sub-triangles, and the frame is rendered again anyway -- an entry no tile can touch (all zero)
+    BroadTri b = {};
+    if (arena_fits) {
       b.tri = s.tri;
       b.ref = (w.prim << 3) | (uint32_t)lane;  // the OWNER's primitive (prim is per lane)
       b.pad[0] = base + (uint32_t)lane + 1u;     // its clip-arena slot + 1: travels into the fragment word (k_raster)
-      b.pad[1] = b.pad[2] = 0;
-      broad_list[slot + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = b;
     }
-    if (lane == owner) w.n_valid = n_valid;
-  } else if (lane == 0) {
-    atomicOr(&ctr->overflow, 2u);
+    broad_list[slot + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = b;
   }
+  if (lane == owner && arena_fits) w.n_valid = n_valid;
 }
 
 // One thread per primitive, all draw calls of the frame in one launch (API order = primitive index order).
@@ -535,17 +534,17 @@ __global__ __launch_bounds__(256) void k_geometry(const DrawDesc *__restrict__ d
 #define BB_STAMP(i) do { } while (0)
 #endif
   BB_STAMP(0);
-  __shared__ BlockStats bs;
   __shared__ ClipWork s_clip[4];  // one per wave
-  if (threadIdx.x == 0) bs = BlockStats{0u, 0u, 0u};
-  __syncthreads();
+  // (No workgroup barrier anywhere in this kernel: the four waves of a workgroup share nothing -- each has its own clip
+  //  workspace and leaves its own statistics record -- so a wave retires when ITS primitives are done.)
   const uint32_t prim = blockIdx.x * blockDim.x + threadIdx.x;
   bool needs_clip = false;
   float clip[3][4];
+  bool survives_out = false;  // this lane's primitive is rasterised unclipped (statistics)
   bool binned = false;  // this lane holds an unclipped, set-up triangle that goes to tile bins
   uint32_t cls = 0;     // raster class of the triangle: bin segment (kBinClasses per tile)
   TileRange tr = {0, -1, 0, -1};
-  uint32_t n_raster = 0, n_clipped = 0;
+  uint32_t clipped_raster = 0;  // wave-uniform: sub-triangles of this wave's clipped primitives that reached the every-tile list
   Viewport vp = {fp.half_w, fp.half_h, fp.half_w, fp.half_h};
   if (prim < n_prims) {
     uint32_t d = 0;
@@ -687,8 +686,8 @@ __global__ __launch_bounds__(256) void k_geometry(const DrawDesc *__restrict__ d
         recs[prim] = pa;
         if (survives) tris[prim] = t;
       }
+      survives_out = survives;
       if (survives) {
-        n_raster = 1;
         uint32_t ntiles = (uint32_t)(tr.tx1 - tr.tx0 + 1) * (uint32_t)(tr.ty1 - tr.ty0 + 1);
         if (ntiles > fp.broad_threshold) broad_insert(t, prim << 3, fp, ctr, broad_list);
         else binned = true;
@@ -740,21 +739,19 @@ __global__ __launch_bounds__(256) void k_geometry(const DrawDesc *__restrict__ d
     }
     clip_primitive_wave<TILE_W, TILE_H>(w, owner, cv, prim, fp, ovp, clip_arena, ctr, broad_list);
     __builtin_amdgcn_wave_barrier();
-    if ((int)(threadIdx.x & 63) == owner) {
-      n_clipped = 1;
-      n_raster = (uint32_t)w.n_valid;
-      if (w.n_valid) recs[prim].clip_base = w.base;  // (the record itself was written above, with zero planes)
-    }
+    clipped_raster += (uint32_t)w.n_valid;
+    if ((int)(threadIdx.x & 63) == owner && w.n_valid) recs[prim].clip_base = w.base;  // (the record itself was written above, with zero planes)
     __builtin_amdgcn_wave_barrier();
   }
   BB_STAMP(4);
-  if ((threadIdx.x & 63) == 0 && refs) atomicAdd(&bs.bin_refs, refs);
-  if (n_raster) atomicAdd(&bs.raster_tris, n_raster);
-  if (n_clipped) atomicAdd(&bs.clipped_prims, n_clipped);
-  __syncthreads();
-  // statistics leave the kernel as one record per workgroup (summed on the host on demand): a few thousand
-  // atomics on ONE counter word would serialise at ~90 per microsecond and dominate this kernel
-  if (threadIdx.x == 0) block_stats[blockIdx.x] = bs;
+  // statistics leave the kernel as one record per WAVE (summed on the host on demand): a few thousand atomics on ONE
+  // counter word would serialise at ~90 per microsecond and dominate this kernel
+  {
+    const uint32_t n_survivors = (uint32_t)__popcll(__ballot(survives_out));
+    const uint32_t n_clipped = (uint32_t)__popcll(__ballot(needs_clip));
+    if ((threadIdx.x & 63) == 0)
+      block_stats[blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6)] = BlockStats{n_survivors + clipped_raster, n_clipped, refs};
+  }
   BB_STAMP(5);
 }
 

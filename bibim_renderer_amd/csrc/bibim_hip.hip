@@ -115,7 +115,7 @@ struct FrameSlot {
   DeviceBuffer<ShadeRec> d_attrs;
   DeviceBuffer<ClipSlot> d_clip;
   int ctr_index = 0;                        // the slot's counter block (slot index; the overlay slot has the last one)
-  DeviceBuffer<BlockStats> d_block_stats;  // one record per k_geometry workgroup
+  DeviceBuffer<BlockStats> d_block_stats;  // one record per k_geometry wave
   DeviceBuffer<uint32_t> d_tile_count;
   DeviceBuffer<uint32_t> d_bins;
   DeviceBuffer<BroadTri> d_broad;
@@ -372,7 +372,7 @@ int ensure_slot_buffers(bbr_context *c, FrameSlot &s) {
 #endif
   HIP_TRY(c, c->d_counters.ensure(bbr_context::kCounterBlocks, true));
   HIP_TRY(c, c->d_counters_done.ensure(bbr_context::kCounterBlocks, true));
-  HIP_TRY(c, s.d_block_stats.ensure(std::max<size_t>((c->n_prims + 255) / 256, 1), true));
+  HIP_TRY(c, s.d_block_stats.ensure(std::max<size_t>((c->n_prims + 255) / 256, 1) * 4, true));
   HIP_TRY(c, s.d_tile_count.ensure(tiles * kBinClasses, true));
   HIP_TRY(c, s.d_bins.ensure(tiles * kBinClasses * c->bin_cap));
   HIP_TRY(c, s.d_broad.ensure(c->broad_cap, true));
@@ -931,7 +931,7 @@ extern "C" int bbr_draw_overlays(bbr_context *c, int32_t gizmo_extent) {
     HIP_TRY(c, s.d_attrs.ensure(n_prims));
     HIP_TRY(c, s.d_clip.ensure(c->clip_cap));
     HIP_TRY(c, c->d_counters.ensure(bbr_context::kCounterBlocks, true));
-    HIP_TRY(c, s.d_block_stats.ensure((n_prims + 255) / 256, true));
+    HIP_TRY(c, s.d_block_stats.ensure(((n_prims + 255) / 256) * 4, true));
     HIP_TRY(c, s.d_tile_count.ensure(tiles * kBinClasses, true));
     HIP_TRY(c, s.d_bins.ensure(tiles * kBinClasses * c->bin_cap));
     HIP_TRY(c, s.d_broad.ensure(c->broad_cap, true));
@@ -1511,7 +1511,7 @@ int bbr_get_stats(bbr_context *c, bbr_stats *out) {
   std::memset(out, 0, sizeof *out);
   out->n_prims = c->n_prims;
   {
-    size_t nb = (c->n_prims + 255) / 256;
+    size_t nb = ((c->n_prims + 255) / 256) * 4;  // (one record per wave of k_geometry)
     std::vector<BlockStats> bs(nb);
     if (nb) HIP_TRY(c, hipMemcpy(bs.data(), s.d_block_stats.ptr, nb * sizeof(BlockStats), hipMemcpyDeviceToHost));
     for (const BlockStats &b : bs) {
