@@ -474,19 +474,32 @@ def main():
         step()
     fence()
     layout, layout_decided, layout_ms = r.stream_layout_state()
-    for _ in range(args.warmup):
-        step()
     use_events = not args.no_timing_events
-    event_stride = max(1, min(args.event_stride, args.steps)) if args.event_stride > 0 else max(1, args.steps // 10)
+    # HIP events around k_shade on sampled steps of the timed region: ten samples of a long run, but never closer than every
+    # fourth step (a pair on every step costs ~6 % of the rate it describes; the driver's 20-step run gets five samples)
+    event_stride = max(1, min(args.event_stride, args.steps)) if args.event_stride > 0 else max(min(4, max(1, args.steps // 2)), args.steps // 10)
+    # Everything that synchronises or idles the GPU happens BEFORE the warm-up steps: switching the timing events on (their
+    # creation takes half a millisecond), the statistics read-back.  Between the last warm-up step and the clock there is
+    # only what the contract asks for -- barrier + synchronize -- so the timed steps start on a GPU that was busy a moment
+    # ago, as the frames of a running application do, not on one that has idled through a millisecond of bookkeeping.
     fence()
     if use_events:
         # timed region: only the two events that bracket the dominant kernel (the full five-event breakdown costs
         # 2-3 % of the frame rate; it is taken in the one-frame-in-flight pass after the timed region)
         r.set_option("timing", 2)
         r.set_option("timing_stride", event_stride)
-        r.timing_reset()
     fence()
-    overflow_before = r.stats()["bin_overflow"]
+    for _ in range(args.warmup):
+        step()
+    if dist_path and args.exchange == "peer" and pending:
+        finish_peer(pending.pop())
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+        torch.cuda.synchronize()
+    if use_events:
+        r.timing_reset()   # (host-side after the synchronize: the samples of the warm-up steps are dropped)
+    overflow_before = r.capacity_growths()   # host-side counter
     frames_before = step_no[0] + overflow_before   # frames submitted so far (incl. the re-renders after overflows)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -502,7 +515,7 @@ def main():
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     fence()
-    if r.stats()["bin_overflow"] != overflow_before:   # (overflows healed during the warm-up frames do not count)
+    if r.capacity_growths() != overflow_before:   # (overflows healed during the warm-up frames do not count)
         raise SystemExit("a capacity overflowed inside the timed region: the frames timed were incomplete")
     gc.enable()
 

@@ -1596,6 +1596,12 @@ int bbr_last_frame_time_ms(bbr_context *c, float *out_frame_ms, float *out_shade
   return BBR_OK;
 }
 
+int bbr_capacity_growths(const bbr_context *c, uint32_t *out_count) {
+  if (!c || !out_count) return BBR_ERR_INVALID_ARGUMENT;
+  *out_count = (uint32_t)c->retries;
+  return BBR_OK;
+}
+
 int bbr_timing_reset(bbr_context *c) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
   BBR_ON_DEVICE(c);

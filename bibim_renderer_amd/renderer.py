@@ -283,6 +283,12 @@ class Renderer:
         devs = (C.c_int32 * n)(*peer_devices)
         self._check(self._L.bbr_push_shard(self._ctx, form, ptrs, devs, C.c_void_p(stream_handle) if stream_handle else None))
 
+    def capacity_growths(self):
+        """capacity growths since the context was created (host-side counter: no synchronisation)"""
+        n = C.c_uint32()
+        self._check(self._L.bbr_capacity_growths(self._ctx, C.byref(n)))
+        return int(n.value)
+
     def push_was_direct(self):
         """True if the last push_shard stored through the one-kernel direct form (option push_mode 1 and every peer mapped)"""
         d = C.c_int32()
