@@ -3,7 +3,9 @@
 
 A step = one frame of the workload through the C++ Scene/Camera/drawFrame shim and the C ABI:
 updateScene + uniform fill + bbr_begin_frame/draw/end_frame -> k_geometry + k_raster + k_shade on the GPU, plus, for
-N > 1, the RCCL all-gather of the per-rank framebuffer shards over xGMI and the un-interleave kernel.
+N > 1, the RCCL all-gather of the per-rank framebuffer shards over xGMI and the un-interleave kernel (by default inside the
+library, bbr_allgather_frame, on the frame's own stream).  `python bench.py --gpus N` without a launcher starts its own N
+ranks (torch.distributed.run as a child process, before this process touches torch or the GPU).
 Inputs (mesh, textures) are resident in HBM before the timed region; per-frame instance matrices and
 uniform blocks (8 KB) are the only host->device traffic, as in the reference's render loop.
 

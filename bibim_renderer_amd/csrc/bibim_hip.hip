@@ -2092,7 +2092,8 @@ int bbr_push_shard(bbr_context *c, int32_t form, void *const *peer_gathered, con
     c->peer_mapped.insert(dev);
   }
   if (direct) {
-    const bool wide = block % 16 == 0 && ((uintptr_t)mine % 16) == 0;
+    bool wide = block % 16 == 0;   // 16-byte accesses when every address involved allows them, 4-byte ones otherwise
+    for (int p = 0; p < c->world; ++p) wide = wide && ((uintptr_t)peer_gathered[p] % 16) == 0;
     const size_t n = wide ? block / 16 : block / 4;   // (every block form is a whole number of 4-byte words)
     // a grid of one workgroup per CU: the copy is bound by the links (world - 1 x ~60 GB/s), not by the CUs it occupies
     const unsigned grid = (unsigned)std::max<size_t>(1, std::min<size_t>((size_t)c->n_cus, (n + kPushThreads - 1) / kPushThreads));

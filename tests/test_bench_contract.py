@@ -104,3 +104,23 @@ print("ok")
 '''
     p = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=120)
     assert p.returncode == 0 and p.stdout.strip() == "ok", p.stderr[-2000:]
+
+
+def test_trace_durations_quoted_in_the_bench_line_come_from_the_committed_phases_file():
+    """roofline.trace_kernel_ms / trace_frac: the kernel-trace durations of the same command under rocprofv3, so that `frac` can
+    be reproduced from profiles/ -- the parser picks the newest round's C3 file, not a c2 / c5 one"""
+    import bench
+    t, alone, src = bench.committed_trace_ms("c3")
+    assert src == "profiles/r03_bench_kernel_phases.txt" and 0.05 < alone < t < 0.2
+    t2, alone2, src2 = bench.committed_trace_ms("c2")
+    assert src2 == "profiles/r03_c2_bench_kernel_phases.txt" and alone2 < alone
+    d = json.load(open(os.path.join(ROOT, "profiles", "r03_bench.json")))
+    r = d["roofline"]
+    assert r["trace_source"] == src and abs(r["trace_kernel_ms"] - t) < 1e-6
+    assert abs(r["trace_frac"] - r["algorithmic_bytes_per_launch"] / (t * 1e-3) / 1e9 / r["peak"]) < 1e-3
+    # the round-3 honesty fields
+    assert d["shaded_mpixels_per_s"] < d["value"] and abs(d["shaded_fraction_of_frame"] - r["n_shaded"] / (3840 * 2160)) < 1e-3
+    assert d["cpu_baseline"]["cores"] <= d["cpu_baseline"]["cores_available"]
+    assert r["frames_in_flight_2"]["ms_per_step"] > 0 and r["single_frame_device_latency_ms"] > r["one_frame_in_flight"]["avg_kernel_ms"]
+    assert d["parity_vs_literal"]["within_abs_1e-4"] is True and d["parity_vs_literal"]["bit_exact"] is False
+    assert d["parity_vs_oracle"]["bit_exact"] is True

@@ -260,3 +260,31 @@ def test_tone_map_formula():
     np.testing.assert_allclose(on[0, :3], 1 - np.exp(-x[0, :3] * 1.5), rtol=1e-6)
     off = bbo.tone_map(x, 0, 1.5)
     assert np.array_equal(off[0, :3], x[0, :3]) and on[0, 3] == 1 and off[0, 3] == 1
+
+
+def test_band_parallel_render_is_the_whole_frame_render():
+    """bbo.render_bands (bands of rows over the host's cores, what the full-size tests and bench.py use) writes the same bits
+    as ONE bbo_render call, for band heights that do and do not divide the frame, in both forms of the light loop"""
+    from bibim_renderer_amd import configs, textures
+    sc = scenes.shaderball_scene(configs.C3.scaled(200, 117, 64), bbo.MaterialData(textures.make_material(64)))
+    for flags in (0, bbo.FLAG_LITERAL):
+        whole, _, _, st = bbo.render(sc, flags=flags)
+        for rows in (32, 7, 117, 500):
+            banded, n = bbo.render_bands(sc, flags=flags, rows=rows, threads=3)
+            assert n == st["n_shaded"] and np.array_equal(banded.view(np.uint32), whole.view(np.uint32)), (flags, rows)
+
+
+def test_output_uv_flag_gives_the_winning_fragments_vuv():
+    """BBO_FLAG_OUTPUT_UV (measurement aid of tools/texel_lines.py): same coverage as the colour render, alpha 1 on
+    geometry, and the interpolated vUV of the winner -- on the TriangleScene a point inside the triangle gets the
+    barycentric blend of the three vertex UVs, which stays inside their bounding box"""
+    sc = scenes.triangle_scene(64, 64)
+    colour, prim, _, _ = bbo.render(sc)
+    uv, _, _, _ = bbo.render(sc, flags=bbo.FLAG_OUTPUT_UV)
+    cov = prim != bbo.NO_PRIM
+    assert np.array_equal(uv[..., 3] == 1.0, cov) and (uv[~cov] == 0).all() and cov.any()
+    v = sc.draws[0].vertices["uv"]
+    lo, hi = v.min(axis=0) - 1e-6, v.max(axis=0) + 1e-6
+    assert (uv[cov][:, 0] >= lo[0]).all() and (uv[cov][:, 0] <= hi[0]).all()
+    assert (uv[cov][:, 1] >= lo[1]).all() and (uv[cov][:, 1] <= hi[1]).all() and (uv[cov][:, 2] == 0).all()
+    assert len(np.unique(uv[cov][:, :2], axis=0)) > cov.sum() // 2     # (it varies over the triangle)
