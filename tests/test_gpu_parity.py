@@ -107,6 +107,41 @@ def test_full_size_frame_against_the_literal_glsl_form(name):
     assert np.array_equal(img[..., 3], literal[..., 3])
 
 
+def _wall_scene(width, height, n_walls, maps, shrink=0.0, tilt=0.0):
+    """n_walls screen-filling quads (two huge triangles each: every-tile-list entries) at different depths in front of the
+    camera -- the case k_raster's light-tile path exists for, from one triangle per tile up to more entries than a wave
+    has lanes.  shrink > 0 pulls the walls' edges into the frame, so that tiles see partial coverage too."""
+    sc = scenes.triangle_scene(width, height, bbo.MaterialData(maps))
+    v = np.zeros(4, bbo.VERTEX_DTYPE)
+    e = 40.0 * (1.0 - shrink)
+    v["pos"] = [(-e, -e, 0), (-e, e, 0), (e, e, 0), (e, -e, 0)]
+    v["uv"] = [(0, 0), (0, 3), (3, 3), (3, 0)]
+    v["normal"] = (0, 0, -1)
+    v["tangent"] = (1, 0, 0)
+    idx = np.array([0, 1, 2, 2, 3, 0], np.uint32)     # clockwise seen from the camera: front-facing
+    inst = np.zeros(n_walls, bbo.INSTANCE_DTYPE)
+    for i in range(n_walls):
+        m = bbo.mat_mul(bbo.mat_translate(0.3 * i, -0.2 * i, 30.0 - 0.5 * i), bbo.mat_rotate_y(tilt * (i % 3 - 1)))
+        inst[i] = scenes.instance(m)
+    sc.draws = [bbo.DrawData(v, idx, inst, bbo.MaterialData(maps))]
+    sc.frame = scenes.frame_uniforms([scenes.light(0, pos=(2, 3, 10), color=(1, 0.9, 0.8), intensity=400.0),
+                                       scenes.light(2, dir=(0.2, -0.5, 1), color=(0.3, 0.4, 0.9), intensity=1.5)])
+    return sc
+
+
+@pytest.mark.parametrize("n_walls,shrink,tilt", [(1, 0.0, 0.0), (1, 0.7, 0.0), (2, 0.0, 12.0), (8, 0.75, 20.0), (33, 0.0, 0.0),
+                                                 (40, 0.8, 7.0)])
+def test_tiles_of_huge_triangles_through_the_light_tile_path(maps64, n_walls, shrink, tilt):
+    """k_raster decides per wave, without LDS or a barrier, whether a tile with nothing binned is empty, covered by ONE
+    every-tile-list triangle, or neither (then the general path): one wall (every interior tile full, the diagonal
+    tiles see two triangles), walls that end inside the frame (empty tiles, partial tiles), several walls (never
+    "one triangle"), and 66 / 80 list entries -- more than the 64 a wave classifies, so every tile takes the general path.
+    Frame sizes off the tile grid on purpose."""
+    for w, h in ((416, 240), (333, 207)):
+        _, _, st = check(_wall_scene(w, h, n_walls, maps64, shrink, tilt))
+        assert st["n_prims"] == 2 * n_walls
+
+
 def test_normal_map_off_and_reference_default_lights(maps64):
     """reference defaults: EnableNormalMap = 0, three lights incl. a directional one and the radians-as-cosine quirk"""
     cfg = configs.C2.scaled(256, 144, 64)
