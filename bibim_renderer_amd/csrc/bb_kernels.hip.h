@@ -1144,6 +1144,38 @@ BB_DEV RasterTri staged_tri(const StagedTri &st, int j) {
   return t;
 }
 
+// One light as the loop consumes it: 48 bytes, written once per frame by cook_light.
+struct CookedLight {
+  float px, py, pz;
+  int32_t type;
+  float cr, cg, cb;  // color * intensity
+  float outer;
+  float dx, dy, dz;  // type 1: normalize(-dir); type 2: -normalize(dir)
+  float inv_eps;     // type 1: 1 / (inner - outer)
+};
+struct ShadeShared {
+  CookedLight lights[kMaxNumLights];
+};
+
+BB_DEV CookedLight cook_light(const Light &l) {
+  CookedLight c;
+  c.px = l.pos[0]; c.py = l.pos[1]; c.pz = l.pos[2];
+  c.type = l.type;
+  c.cr = l.color[0] * l.intensity; c.cg = l.color[1] * l.intensity; c.cb = l.color[2] * l.intensity;
+  c.outer = l.outer_cutoff;
+  c.dx = c.dy = c.dz = 0.0f;
+  c.inv_eps = 0.0f;
+  if (l.type == 1) {
+    const f3 d = normalize3(neg3(ld3(l.dir)));
+    c.dx = d.x; c.dy = d.y; c.dz = d.z;
+    c.inv_eps = bb_rcp(l.inner_cutoff - l.outer_cutoff);
+  } else if (l.type == 2) {
+    const f3 d = neg3(normalize3(ld3(l.dir)));
+    c.dx = d.x; c.dy = d.y; c.dz = d.z;
+  }
+  return c;
+}
+
 // OVERLAY = true (overlay subpass): the keys start from the scene's resolved depth (`depth_io`, read) instead of 0,
 // gizmo primitives are scissored to their rectangle and biased above everything else, pixels no overlay primitive
 // wins are left alone (no background fill).  OVERLAY = false with depth_io != nullptr stores the resolved depth.
@@ -1155,7 +1187,8 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
     unsigned long long *__restrict__ frags, uint32_t *__restrict__ frag_count, float4 *__restrict__ out,
     uint32_t *__restrict__ vis_prim, float *__restrict__ vis_depth,
     const float4 *__restrict__ background, float *__restrict__ depth_io, uint32_t *__restrict__ host_flags,
-    uint32_t *__restrict__ out8, uint32_t *__restrict__ item_groups) {
+    uint32_t *__restrict__ out8, uint32_t *__restrict__ item_groups, uint32_t *__restrict__ item_head,
+    uint32_t *__restrict__ items, const Light *__restrict__ lights, int num_lights, CookedLight *__restrict__ cooked) {
   constexpr int TILE_PIXELS = TILE_W * TILE_H;
   __shared__ unsigned long long keys[TILE_PIXELS];
   __shared__ StagedTri st;
@@ -1171,6 +1204,23 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
     host_flags[3] = ctr->n_broad;
     host_flags[4] = ctr->n_clip_slots;
   }
+  // SHORT FRAMES (item_head != nullptr; the host decides by the frame's tile count): there is no k_shade_items launch.  The
+  // tiles append their items to the frame's list themselves -- one returning atomic per tile on the list's head word, which
+  // the frame's staging copy has zeroed -- and this kernel's first workgroup cooks the light table.  A 1080p frame is a
+  // chain of dependent kernels whose length over the frames in flight IS its rate; the scan kernel and its boundary were
+  // 9 of its 90 us.  The list is then in tile COMPLETION order, not screen order: at 4K that cost 13 % more texel traffic
+  // than it saved (round 2), which is why long frames keep k_shade_items.
+  if (item_head && cooked && blockIdx.x == 0 && blockIdx.y == 0)
+    for (int li = tid; li < num_lights; li += kTileThreads) cooked[li] = cook_light(lights[li]);
+  // (called by the first wave of the workgroup, all of its lanes)
+  auto append_items = [&](uint32_t chunks, uint32_t flag) {
+    uint32_t at = 0u;
+    if (lane == 0) at = atomicAdd(item_head, chunks);
+    at = (uint32_t)__shfl((int)at, 0);
+    if ((uint32_t)lane < chunks)
+      items[1u + at + (uint32_t)lane] = flag | ((uint32_t)blockIdx.y << (kItemChunkBits + kItemTxBits)) | ((uint32_t)blockIdx.x << kItemChunkBits) | (uint32_t)lane;
+  };
+  static_assert(TILE_PIXELS / 64 <= 64, "a tile's items are written by one wave");
   // launch slot -> tile: plain row order
   const uint32_t slot = blockIdx.y * gridDim.x + blockIdx.x;
   const int grid_row = (int)blockIdx.y;
@@ -1267,6 +1317,7 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
         frag_count[tile] = (uint32_t)TILE_PIXELS | kFullTile;
         if (item_groups) atomicAdd(&item_groups[(slot / kItemGroupSlots) * kItemGroupStride], (uint32_t)(TILE_PIXELS / 64));
       }
+      if (item_head && wave == 0) append_items((uint32_t)(TILE_PIXELS / 64), kFullTile);
       BB_RSTAMP(5);
       return;
     }
@@ -1452,6 +1503,7 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
     // 64-fragment chunks per group of 256 launch slots: what k_shade_items needs to place this group's items
     if (item_groups && s_count) atomicAdd(&item_groups[(slot / kItemGroupSlots) * kItemGroupStride], (s_count + 63u) >> 6);
   }
+  if (item_head && wave == 0 && s_count) append_items((s_count + 63u) >> 6, 0u);
   BB_RSTAMP(4);
   if (tid == 0) {
     BB_RSTAMP(5);
@@ -1483,38 +1535,6 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
 // the scalar cache (ConstLights below: s_load into scalar registers, the light's type already a scalar); only
 // k_deferred_background still stages them in LDS (LdsLights).
 // ------------------------------------------------------------------------------------------------
-
-// One light as the loop consumes it: 48 bytes, written once per frame by cook_light.
-struct CookedLight {
-  float px, py, pz;
-  int32_t type;
-  float cr, cg, cb;  // color * intensity
-  float outer;
-  float dx, dy, dz;  // type 1: normalize(-dir); type 2: -normalize(dir)
-  float inv_eps;     // type 1: 1 / (inner - outer)
-};
-struct ShadeShared {
-  CookedLight lights[kMaxNumLights];
-};
-
-BB_DEV CookedLight cook_light(const Light &l) {
-  CookedLight c;
-  c.px = l.pos[0]; c.py = l.pos[1]; c.pz = l.pos[2];
-  c.type = l.type;
-  c.cr = l.color[0] * l.intensity; c.cg = l.color[1] * l.intensity; c.cb = l.color[2] * l.intensity;
-  c.outer = l.outer_cutoff;
-  c.dx = c.dy = c.dz = 0.0f;
-  c.inv_eps = 0.0f;
-  if (l.type == 1) {
-    const f3 d = normalize3(neg3(ld3(l.dir)));
-    c.dx = d.x; c.dy = d.y; c.dz = d.z;
-    c.inv_eps = bb_rcp(l.inner_cutoff - l.outer_cutoff);
-  } else if (l.type == 2) {
-    const f3 d = neg3(normalize3(ld3(l.dir)));
-    c.dx = d.x; c.dy = d.y; c.dz = d.z;
-  }
-  return c;
-}
 
 // every thread of the workgroup; the caller synchronises
 template <int THREADS>
@@ -1769,7 +1789,8 @@ __global__ __launch_bounds__(kShadeThreads) __attribute__((amdgpu_waves_per_eu(T
     const uint32_t *__restrict__ frag_count, const uint32_t *__restrict__ items, uint32_t first_item,
     const MaterialDesc *__restrict__ materials, float4 *__restrict__ out,
     uint2 *__restrict__ gbuffer, const SrgbTables *__restrict__ tables, uint32_t *__restrict__ out8,
-    Counters *__restrict__ ctr, Counters *__restrict__ ctr_done, uint32_t *__restrict__ item_groups) {
+    Counters *__restrict__ ctr, Counters *__restrict__ ctr_done, uint32_t *__restrict__ item_groups,
+    const uint32_t *__restrict__ item_count) {
   constexpr int TILE_PIXELS = TILE_W * TILE_H;
   const ConstLights lights_c{(ConstCooked)cooked};
   // The frame's counter block has done its job (k_geometry filled it, k_raster read it): keep a copy for the host's
@@ -1798,7 +1819,7 @@ __global__ __launch_bounds__(kShadeThreads) __attribute__((amdgpu_waves_per_eu(T
   //  eight; runs of 4 / 16 / 64 workgroups per XCD: 87 / 89 / 94 us, no traffic gain.  Plain round-robin stays.)
   uint32_t j = first_item + (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (uint32_t)kShadeWaves + (threadIdx.x >> 6)));
   uint32_t item = items[1u + (TAIL ? 0u : j)];
-  const uint32_t n_items = items[0];
+  const uint32_t n_items = *item_count;  // (items[0], or the head word k_raster's tiles appended through: short frames)
   if (BB_ABLATE(2048u)) sp.num_lights = 0;
   if (j >= n_items) return;  // a wave without an item (the kernel has no barrier: waves come and go on their own)
   do {  // (a loop only in the TAIL instantiation)

@@ -427,7 +427,8 @@ int upload_material_table(bbr_context *c) {
 
 template <int TW, int TH>
 void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const FrameParams &fp, const Mat4 &pv,
-                  const Mat4 &view, const ShadeParams &sp, const Light *d_lights, const DrawDesc *d_draws, uint32_t n_draws, float4 *out) {
+                  const Mat4 &view, const ShadeParams &sp, const Light *d_lights, const DrawDesc *d_draws, uint32_t n_draws, float4 *out,
+                  uint32_t *d_item_head) {
   const int slot_index = (int)(&s - c->slots);
   hipStream_t sg = c->frame_geom_stream(slot_index), sr = c->raster_stream(slot_index), ss = c->frame_shade_stream(slot_index);
   Counters *ctr = c->d_counters.ptr + s.ctr_index, *ctr_done = c->d_counters_done.ptr + s.ctr_index;
@@ -455,17 +456,27 @@ void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const Fra
   const SrgbTables *tables = c->present_fused ? c->d_srgb_tables.ptr : nullptr;
   if (fp.deferred)
     hipLaunchKernelGGL(k_deferred_background, dim3(1), dim3(kBackgroundThreads), 0, sr, sp, d_lights, s.d_background.ptr, tables, fp.gbuffer_view);
+  // A SHORT frame (at most option "no_tail_items" item slots: 1080p has 32 640) has no k_shade_items launch: k_raster's tiles
+  // append their items themselves through the head word the staging copy has just zeroed, and its first workgroup cooks
+  // the lights.  One kernel and one kernel boundary less on the frame's chain of dependent kernels; such a frame is also
+  // shaded at full coverage, without the tail launch (below).
+  const uint32_t max_items = (uint32_t)(fp.tiles_x * grid_y) * (uint32_t)(TW * TH / 64);
+  const bool short_frame = max_items <= (uint32_t)c->no_tail_items;
+  uint32_t *item_head = short_frame ? d_item_head : nullptr;
   hipLaunchKernelGGL((k_raster<TW, TH>), dim3(fp.tiles_x, grid_y), dim3(kTileThreads), 0, sr, fp, s.d_tris.ptr,
                      s.d_clip.ptr, ctr, s.d_tile_count.ptr, s.d_bins.ptr, s.d_broad.ptr, s.d_frags.ptr,
                      s.d_frag_count.ptr, out, c->dump_vis ? c->d_vis_prim.ptr : nullptr,
                      c->dump_vis ? c->d_vis_depth.ptr : nullptr,
                      fp.deferred ? s.d_background.ptr : nullptr, (c->overlays && c->world == 1) ? s.d_depth.ptr : nullptr,
-                     s.h_flags, out8, s.d_item_groups.ptr);
+                     s.h_flags, out8, short_frame ? nullptr : s.d_item_groups.ptr, item_head, s.d_items.ptr, d_lights, sp.num_lights,
+                     s.d_cooked.ptr);
   s.has_depth = c->overlays && c->world == 1;
   // k_shade's work list (64 fragments per item), built from the per-tile fragment counts as soon as k_raster is done; the
   // same launch cooks the frame's light table
-  hipLaunchKernelGGL((k_shade_items<TW, TH>), dim3((unsigned)((fp.tiles_x * grid_y + kItemsThreads - 1) / kItemsThreads)), dim3(kItemsThreads), 0, sr, fp, s.d_frag_count.ptr, s.d_item_groups.ptr, s.d_items.ptr,
-                     fp.tiles_x, grid_y, s.h_flags ? s.h_flags + 2 : nullptr, d_lights, sp.num_lights, s.d_cooked.ptr);
+  if (!short_frame)
+    hipLaunchKernelGGL((k_shade_items<TW, TH>), dim3((unsigned)((fp.tiles_x * grid_y + kItemsThreads - 1) / kItemsThreads)), dim3(kItemsThreads), 0, sr, fp, s.d_frag_count.ptr, s.d_item_groups.ptr, s.d_items.ptr,
+                       fp.tiles_x, grid_y, s.h_flags ? s.h_flags + 2 : nullptr, d_lights, sp.num_lights, s.d_cooked.ptr);
+  const uint32_t *item_count = short_frame ? item_head : s.d_items.ptr;   // where k_shade finds the number of items
   if (ev && c->timing == 1) (void)hipEventRecord(ev[2], sr);
   if (ss != sr) {
     (void)hipEventRecord(s.ev_raster_done, sr);
@@ -476,14 +487,13 @@ void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const Fra
   // Main launch: one item (64 fragments) per wave, four per workgroup, sized from the item count of the frame this slot
   // rendered last (k_shade_items leaves it in pinned host memory) plus 3 %; tail launch: a small persistent grid for
   // whatever lies behind that (a scene that suddenly grew; normally nothing, and its workgroups exit at once).
-  const uint32_t max_items = (uint32_t)(fp.tiles_x * grid_y) * (uint32_t)(TW * TH / 64);
   const uint32_t seen = s.h_flags ? s.h_flags[2] : 0u;
   uint32_t est = seen ? seen + seen / 32u + 64u : max_items;
   if (est > max_items) est = max_items;
   // A small frame is launched at full coverage instead: workgroups without an item leave after one scalar load, and a few
   // thousand of them cost less than the tail launch's kernel boundary on the frame's chain of dependent kernels (at
   // 1080p the chain's length over the frames in flight IS the frame rate).
-  if (max_items <= (uint32_t)c->no_tail_items) est = max_items;
+  if (short_frame) est = max_items;
   const uint32_t main_wgs = std::max(1u, (est + kShadeWaves - 1) / kShadeWaves);
   // The tail runs on the raster stream, beside the main launch (their items are disjoint): in front of or behind it on
   // one stream an empty tail would still cost the frame a kernel boundary (~4 us).
@@ -492,12 +502,13 @@ void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const Fra
     if (tail) {
       hipLaunchKernelGGL((k_shade<TW, TH, decltype(deferred)::value, decltype(present)::value, true>), dim3(32), dim3(kShadeThreads),
                          0, sr, fp, sp, s.d_cooked.ptr, s.d_attrs.ptr, s.d_clip.ptr, s.d_frags.ptr, s.d_frag_count.ptr, s.d_items.ptr,
-                         main_wgs * (uint32_t)kShadeWaves, c->d_materials.ptr, out, gbuf, tables, out8, ctr, ctr_done, nullptr);
+                         main_wgs * (uint32_t)kShadeWaves, c->d_materials.ptr, out, gbuf, tables, out8, ctr, ctr_done, nullptr, item_count);
       if (ss != sr) (void)hipEventRecord(s.ev_tail_done, sr);
     }
     hipLaunchKernelGGL((k_shade<TW, TH, decltype(deferred)::value, decltype(present)::value, false>), dim3(main_wgs),
                        dim3(kShadeThreads), 0, ss, fp, sp, s.d_cooked.ptr, s.d_attrs.ptr, s.d_clip.ptr, s.d_frags.ptr,
-                       s.d_frag_count.ptr, s.d_items.ptr, 0u, c->d_materials.ptr, out, gbuf, tables, out8, ctr, ctr_done, s.d_item_groups.ptr);
+                       s.d_frag_count.ptr, s.d_items.ptr, 0u, c->d_materials.ptr, out, gbuf, tables, out8, ctr, ctr_done,
+                       short_frame ? nullptr : s.d_item_groups.ptr, item_count);
     if (tail && ss != sr) (void)hipStreamWaitEvent(ss, s.ev_tail_done, 0);
   };
   if (fp.deferred) {
@@ -568,7 +579,9 @@ int submit_frame_into(bbr_context *c, int slot_index) {
   size_t lights_bytes = sizeof(Light) * kMaxNumLights;
   size_t draws_bytes = (sizeof(DrawDesc) * c->draws.size() + 127) & ~(size_t)127;
   size_t inst_bytes = sizeof(InstanceBlock) * c->host_instances.size();
-  size_t total = lights_bytes + draws_bytes + inst_bytes;
+  // ... [item head: one zero word, 16-byte slot] -- k_raster's tiles count a short frame's items through it (launch_frame)
+  const size_t head_offset = (lights_bytes + draws_bytes + inst_bytes + 15) & ~(size_t)15;
+  size_t total = head_offset + 16;
   if (total > s.staging_cap) {
     if (s.h_staging) (void)hipHostFree(s.h_staging);
     s.h_staging = nullptr;
@@ -599,6 +612,8 @@ int submit_frame_into(bbr_context *c, int slot_index) {
     c->n_live_draws = k;
   }
   if (inst_bytes) std::memcpy((uint8_t *)s.h_staging + lights_bytes + draws_bytes, c->host_instances.data(), inst_bytes);
+  std::memset((uint8_t *)s.h_staging + head_offset, 0, 16);
+  uint32_t *d_item_head = reinterpret_cast<uint32_t *>(s.d_staging.ptr + head_offset);
 
   const int n_lights = std::min(std::max(c->frame_u.num_lights, 0), kMaxNumLights);
   c->layout = c->pipelined() ? c->layout_mode : 0;
@@ -630,8 +645,8 @@ int submit_frame_into(bbr_context *c, int slot_index) {
   const FrameSlot *prev = (c->last_slot >= 0 && c->last_slot != slot_index) ? &c->slots[c->last_slot] : nullptr;
 
   (void)hipMemcpyAsync(s.d_staging.ptr, s.h_staging, total, hipMemcpyHostToDevice, sg);
-  if (c->tile_mode == 0) launch_frame<64, 64>(c, s, prev, fp, pv, view, sp, d_lights, d_draws, c->n_live_draws, out);
-  else launch_frame<32, 32>(c, s, prev, fp, pv, view, sp, d_lights, d_draws, c->n_live_draws, out);
+  if (c->tile_mode == 0) launch_frame<64, 64>(c, s, prev, fp, pv, view, sp, d_lights, d_draws, c->n_live_draws, out, d_item_head);
+  else launch_frame<32, 32>(c, s, prev, fp, pv, view, sp, d_lights, d_draws, c->n_live_draws, out, d_item_head);
   HIP_TRY(c, hipGetLastError());
   s.in_flight = true;
   s.fused = c->present_fused;
@@ -958,7 +973,8 @@ extern "C" int bbr_draw_overlays(bbr_context *c, int32_t gizmo_extent) {
       hipLaunchKernelGGL((k_raster<TW, TH, true>), dim3(fp.tiles_x, fp.tiles_y), dim3(kTileThreads), 0, st, fp, s.d_tris.ptr,
                          s.d_clip.ptr, ctr, s.d_tile_count.ptr, s.d_bins.ptr, s.d_broad.ptr, s.d_frags.ptr, s.d_frag_count.ptr,
                          (float4 *)nullptr, (uint32_t *)nullptr, (float *)nullptr,
-                         (const float4 *)nullptr, fs.d_depth.ptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
+                         (const float4 *)nullptr, fs.d_depth.ptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
+                         (uint32_t *)nullptr, (uint32_t *)nullptr, (const Light *)nullptr, 0, (CookedLight *)nullptr);
       constexpr int kChunks = TW * TH / kShadeThreads;
       hipLaunchKernelGGL((k_shade_overlay<TW, TH>), dim3(fp.tiles_x * kChunks, fp.tiles_y), dim3(kShadeThreads), 0, st, fp,
                          s.d_attrs.ptr, s.d_clip.ptr, s.d_frags.ptr, s.d_frag_count.ptr, c->d_srgb_tables.ptr, fs.present.out);

@@ -203,11 +203,13 @@ int bbr_timing_summary(bbr_context *ctx, uint32_t *out_frames, float *out_avg_fr
  *                            0 / 1 / 2: 1080p, one ShaderBall 84.5 / 67.1 / 37.3; 4K, sixteen 191.5 / 153.6 / 148.6.
  *   "push_mode" 0|1          bbr_push_shard: 1 (default) one kernel storing to every peer at once, 0 peer copies one after
  *                            the other (see "native exchange" below)
- *   "no_tail_items" n        (default 40000) k_shade's main launch is sized from the item count the frame slot produced
- *                            one frame earlier and a small tail launch covers what that estimate misses; a frame with at
- *                            most n item slots (tiles x 64-fragment chunks per tile: 1080p has 32 640) is launched at
- *                            full coverage instead, without the tail launch's kernel boundary (C2: 34.5 -> 32.5 us per
- *                            frame with three frames in flight, 27.6 -> 26.4 with four)
+ *   "no_tail_items" n        (default 40000) what counts as a SHORT frame: at most n item slots (tiles x 64-fragment chunks
+ *                            per tile: 1080p has 32 640).  A long frame's shading work list is built by a scan kernel
+ *                            (k_shade_items, screen order), its main launch is sized from the item count the frame slot
+ *                            produced one frame earlier and a small tail launch covers what that estimate misses.  A
+ *                            short frame is a chain of dependent kernels whose length is its rate: its raster tiles append
+ *                            their items themselves (no k_shade_items launch) and it is shaded at full coverage without
+ *                            the tail launch (C2: chain 95 -> 85 us, 27.3 -> 24.6 us per frame with four in flight)
  *   "ablate" bits            diagnostic builds only (make EXTRA=-DBB_ABLATE): skip parts of the pipeline */
 int bbr_set_option(bbr_context *ctx, const char *name, int64_t value);
 /* The stream layout in use (option "stream_layout"; 0 while only one frame is in flight).  *out_decided is always 1 and

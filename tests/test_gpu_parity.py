@@ -49,8 +49,12 @@ def test_c2_small(maps64, tile_mode):
 
 
 @pytest.mark.parametrize("tile_mode", [0, 1])
-def test_c3_small(maps256, tile_mode):
-    check(scenes.shaderball_scene(configs.C3.scaled(960, 540, 256), bbo.MaterialData(maps256)), tile_mode)
+@pytest.mark.parametrize("item_list", ["appended by k_raster (short frame)", "scanned by k_shade_items"])
+def test_c3_small(maps256, tile_mode, item_list):
+    """both ways a frame's item list comes about: a frame this small has its tiles append their items themselves; with
+    no_tail_items = 0 it takes the long frames' route (k_shade_items + main and tail launch)"""
+    opts = {} if item_list.startswith("appended") else {"no_tail_items": 0}
+    check(scenes.shaderball_scene(configs.C3.scaled(960, 540, 256), bbo.MaterialData(maps256)), tile_mode, **opts)
 
 
 def test_c5_small(maps64):
