@@ -1305,7 +1305,7 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
         if (tile_x0 + x < fp.width && tile_y0 + y < fp.height) store_background(x, y);
       }
       if (tid == 0) frag_count[tile] = 0u;
-      BB_RSTAMP(5);
+      BB_RSTAMP(1); BB_RSTAMP(2); BB_RSTAMP(3); BB_RSTAMP(4);   // (diagnostic build: a light tile's phases all end here)
       return;
     }
     if (__popcll(m_ok) == 1 && __ballot(full) == m_ok) {
@@ -1318,7 +1318,7 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
         if (item_groups) atomicAdd(&item_groups[(slot / kItemGroupSlots) * kItemGroupStride], (uint32_t)(TILE_PIXELS / 64));
       }
       if (item_head && wave == 0) append_items((uint32_t)(TILE_PIXELS / 64), kFullTile);
-      BB_RSTAMP(5);
+      BB_RSTAMP(1); BB_RSTAMP(2); BB_RSTAMP(3); BB_RSTAMP(4);   // (diagnostic build: a light tile's phases all end here)
       return;
     }
   }
