@@ -69,6 +69,19 @@ def committed_trace_ms(workload, kernel="k_shade"):
     return None, None, None
 
 
+def committed_texel_lines(workload):
+    """distinct 128-byte lines of the packed material a frame of this workload touches (tools/texel_lines.py, CPU, committed as
+    profiles/*_texel_lines.txt): the compulsory texel reads -- the lower bound of what the fetch counters can be DRAM traffic"""
+    import glob
+    import re
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_texel_lines.txt")), reverse=True):
+        txt = open(f).read()
+        m = re.search(rf"^{workload.upper()}:.*?distinct 128-byte lines touched:\s+(\d+) = ([0-9.]+) MB", txt, re.S | re.M)
+        if m:
+            return int(m.group(1)) * 128, os.path.relpath(f, ROOT)
+    return None, None
+
+
 def profiled_traffic(workload, kernel="k_shade"):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/*_pmc_hbm.json, written by
     tools/profile_summary.py: FETCH_SIZE and WRITE_SIZE collected in separate passes, FETCH_SIZE doubled as
@@ -558,6 +571,12 @@ def main():
                     "frame_frac": round(balg["total"] / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                     "n_shaded": int(n_shaded_total),
                     "limiter": None}   # filled in below from this run's own figures
+        lines_bytes, lines_src = committed_texel_lines(args.workload)
+        roofline["traffic_is"] = ("bytes through the L2s' memory side (FETCH_SIZE x 2 + WRITE_SIZE): Infinity-Cache hits are included -- gfx950 "
+                                  "exposes no counter behind the L2 -- so it is an UPPER bound of the DRAM bytes")
+        if lines_bytes:
+            roofline["distinct_texel_line_bytes"] = lines_bytes
+            roofline["distinct_texel_line_source"] = lines_src
         t_ms, t_alone_ms, t_src = committed_trace_ms(args.workload)
         roofline["avg_kernel_ms_is"] = (f"HIP events around k_shade on its own stream with {args.frames_in_flight} frames in flight: an "
                                         "OVERLAPPED latency (the kernel shares the GPU with the other frames' kernels and the events also "
