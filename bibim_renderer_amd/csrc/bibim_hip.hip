@@ -2101,10 +2101,10 @@ int bbr_push_shard(bbr_context *c, int32_t form, void *const *peer_gathered, con
     const int dev = peer_devices[p];
     if (dev == c->device || c->peer_mapped.count(dev)) continue;
     int can = 0;
-    if (hipDeviceCanAccessPeer(&can, c->device, dev) != hipSuccess || !can) { direct = false; break; }
-    const hipError_t e = hipDeviceEnablePeerAccess(dev, 0);
-    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { direct = false; break; }
-    (void)hipGetLastError();
+    hipError_t e = hipDeviceCanAccessPeer(&can, c->device, dev);
+    if (e == hipSuccess && can) e = hipDeviceEnablePeerAccess(dev, 0);
+    (void)hipGetLastError();  // (neither outcome may linger as the runtime's "last error": the copies below are a full substitute)
+    if (!can || (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)) { direct = false; break; }
     c->peer_mapped.insert(dev);
   }
   if (direct) {
