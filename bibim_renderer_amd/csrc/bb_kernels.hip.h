@@ -1739,7 +1739,9 @@ __global__ __launch_bounds__(kItemsThreads) void k_shade_items(FrameParams fp, c
 //    each list to a multiple of 64 with copies of its first fragment), and no count has to be read before the fragments.
 //    The main launch is sized on the host from the item count the same frame slot produced one frame earlier (pinned
 //    word written by k_shade_items) plus 3 % + 64; a second, 32-workgroup instantiation (TAIL) walks whatever lies beyond
-//    that estimate in a loop, so a frame that suddenly has more fragments is still complete.
+//    that estimate in a loop, so a frame that suddenly has more fragments is still complete.  (A SHORT frame -- 1080p --
+//    has neither: its raster tiles append their items themselves, k_raster above, the count is read through `item_count`,
+//    and it is launched at full coverage.)
 //  * the chain is cut to three round trips per item (item word -> fragment words -> record + texels): the fragment
 //    word carries the clip-arena slot of a clipped sub-triangle, so its planes are fetched together with the primitive
 //    record instead of after it; a wave whose 64 fragments share one primitive fetches the record through the scalar
