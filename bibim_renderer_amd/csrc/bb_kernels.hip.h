@@ -469,23 +469,25 @@ BB_DEV void clip_primitive_wave(ClipWork &w, int owner, const float (*clip)[4], 
   // primitive instead of two (the ground plane's two primitives are k_geometry's critical path at 1080p: in-kernel stamps).
   bool ok = false;
   ClipSlot s;
+  RasterTri tri = {};
   if (lane < n_slots) {
     const int i = lane + 1;
-    s.tri.X0 = w.X[0]; s.tri.Y0 = w.Y[0];
-    s.tri.X1 = w.X[i]; s.tri.Y1 = w.Y[i];
-    s.tri.X2 = w.X[i + 1]; s.tri.Y2 = w.Y[i + 1];
-    s.tri.rw0 = w.rw[0]; s.tri.rw1 = w.rw[i]; s.tri.rw2 = w.rw[i + 1];
+    tri.X0 = w.X[0]; tri.Y0 = w.Y[0];
+    tri.X1 = w.X[i]; tri.Y1 = w.Y[i];
+    tri.X2 = w.X[i + 1]; tri.Y2 = w.Y[i + 1];
+    tri.rw0 = w.rw[0]; tri.rw1 = w.rw[i]; tri.rw2 = w.rw[i + 1];
     const ClipVert v0 = w.poly[cur][0], v1 = w.poly[cur][i], v2 = w.poly[cur][i + 1];
     for (int c = 0; c < 3; ++c) {
       s.bary[0][c] = v0.b[c];
       s.bary[1][c] = v1.b[c];
       s.bary[2][c] = v2.b[c];
     }
-    s.pad[0] = s.pad[1] = 0;
-    ok = setup_tri(s.tri, w.z[0], w.z[i], w.z[i + 1]);
+    s.pad = 0;
+    ok = setup_tri(tri, w.z[0], w.z[i], w.z[i + 1]);
     TileRange tr;
-    ok = ok && tile_range<TILE_W, TILE_H>(s.tri, fp, tr);
+    ok = ok && tile_range<TILE_W, TILE_H>(tri, fp, tr);
     s.valid = ok ? 1u : 0u;
+    s.h = PlaneHead{tri.X0, tri.Y0, tri.l1dx, tri.l1dy, tri.l2dx, tri.l2dy, tri.rw0, tri.rw1, tri.rw2};
   }
   const unsigned long long m = __ballot(ok);
   const int n_valid = (int)__popcll(m);
@@ -508,7 +510,7 @@ BB_DEV void clip_primitive_wave(ClipWork &w, int owner, const float (*clip)[4], 
     // no room for the sub-triangles, and the frame is rendered again anyway -- an entry no tile can touch (all zero)
     BroadTri b = {};
     if (arena_fits) {
-      b.tri = s.tri;
+      b.tri = tri;
       b.ref = (w.prim << 3) | (uint32_t)lane;  // the OWNER's primitive (prim is per lane)
       b.pad[0] = base + (uint32_t)lane + 1u;     // its clip-arena slot + 1: travels into the fragment word (k_raster)
     }
@@ -522,10 +524,11 @@ BB_DEV void clip_primitive_wave(ClipWork &w, int owner, const float (*clip)[4], 
 // per-primitive viewport, everything downstream of the vertex stage shared.
 template <int TILE_W, int TILE_H, bool OVERLAY = false>
 __global__ __launch_bounds__(256) void k_geometry(const DrawDesc *__restrict__ draws, uint32_t n_draws, uint32_t n_prims,
-                                                  Mat4 pv, Mat4 view, FrameParams fp, RasterTri *__restrict__ tris,
-                                                  ShadeRec *__restrict__ recs, ClipSlot *__restrict__ clip_arena,
-                                                  Counters *__restrict__ ctr, uint32_t *__restrict__ tile_count,
-                                                  uint32_t *__restrict__ bins, BroadTri *__restrict__ broad_list,
+                                                  RasterTri *__restrict__ tris, ShadeRec *__restrict__ recs,
+                                                  uint32_t *__restrict__ tile_count, uint32_t *__restrict__ bins,
+                                                  Counters *__restrict__ ctr,
+                                                  Mat4 pv, Mat4 view, FrameParams fp, ClipSlot *__restrict__ clip_arena,
+                                                  BroadTri *__restrict__ broad_list,
                                                   const MaterialDesc *__restrict__ materials,
                                                   BlockStats *__restrict__ block_stats) {
 #ifdef BB_STAMPS
@@ -635,7 +638,7 @@ __global__ __launch_bounds__(256) void k_geometry(const DrawDesc *__restrict__ d
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         const Vertex &v = vtx[k];
-        float *o = pa.vary[k];
+        float o[kNumVary];
         if (OVERLAY) {
           // ib.inv_model row 0 = the light's colour, or the gizmo's viewMat whose upper 3x3 turns the normals
           // (gizmo.vert:27).  draw.material is the program: 1 marker, 2 gizmo.
@@ -664,6 +667,10 @@ __global__ __launch_bounds__(256) void k_geometry(const DrawDesc *__restrict__ d
           o[8] = T.x; o[9] = T.y; o[10] = T.z;
           o[11] = B.x; o[12] = B.y; o[13] = B.z;
         }
+        // varying j of vertex k: 0, 1 in the record's head (the texture coordinates), the rest in its body
+        pa.uv[k][0] = o[0]; pa.uv[k][1] = o[1];
+#pragma unroll
+        for (int j = 0; j < kNumBodyVary; ++j) pa.vary[j][k] = o[2 + j];
       }
       pa.material = draw.material;  // (overlay pass: the overlay program, not an index into the material table)
       pa.packed = nullptr;
@@ -675,13 +682,8 @@ __global__ __launch_bounds__(256) void k_geometry(const DrawDesc *__restrict__ d
       }
       pa.clip_base = kNotClipped;  // (a clipped primitive's is patched in once the clipper has its arena slots, below)
       // planes of the unclipped triangle; zero for a primitive that goes through the clipper (its sub-triangles have their own)
-      pa.X0 = t.X0; pa.Y0 = t.Y0;
-      pa.l1dx = t.l1dx; pa.l1dy = t.l1dy; pa.l2dx = t.l2dx; pa.l2dy = t.l2dy;
-      pa.rw0 = t.rw0; pa.rw1 = t.rw1; pa.rw2 = t.rw2;
-      if (needs_clip) {
-        pa.X0 = pa.Y0 = 0;
-        pa.l1dx = pa.l1dy = pa.l2dx = pa.l2dy = pa.rw0 = pa.rw1 = pa.rw2 = 0.0f;
-      }
+      pa.h = PlaneHead{t.X0, t.Y0, t.l1dx, t.l1dy, t.l2dx, t.l2dy, t.rw0, t.rw1, t.rw2};
+      if (needs_clip) pa.h = PlaneHead{0, 0, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
       if (!BB_ABLATE(64u)) {
         recs[prim] = pa;
         if (survives) tris[prim] = t;
@@ -1128,6 +1130,7 @@ BB_DEV bool tile_row(const FrameParams &fp, int grid_y, int &ty, int &out_tile_r
 // "large" entries after a per-tile accept/reject test.
 // ------------------------------------------------------------------------------------------------
 constexpr int kStage = kTileThreads;  // staged entries per chunk (one per thread)
+constexpr uint32_t kBroadSpec = 16;    // every-tile-list entries a light tile fetches before it knows the count
 
 struct StagedTri {  // struct-of-arrays in LDS: thread j owns column j when filling
   int X0[kStage], Y0[kStage], X1[kStage], Y1[kStage], X2[kStage], Y2[kStage];
@@ -1181,10 +1184,12 @@ BB_DEV CookedLight cook_light(const Light &l) {
 // wins are left alone (no background fill).  OVERLAY = false with depth_io != nullptr stores the resolved depth.
 template <int TILE_W, int TILE_H, bool OVERLAY = false>
 __global__ __launch_bounds__(kTileThreads) void k_raster(
+    // (first: what a tile needs before its first load -- these arrive in scalar registers with the wave, "kernarg preload";
+    //  the Makefile asks for it.  Everything behind them comes with one scalar load from the kernel-argument segment.)
+    uint32_t *__restrict__ tile_count, Counters *__restrict__ ctr, const BroadTri *__restrict__ broad_list,
+    uint32_t *__restrict__ frag_count, unsigned long long *__restrict__ frags, float4 *__restrict__ out,
     FrameParams fp, const RasterTri *__restrict__ tris, const ClipSlot *__restrict__ clip_arena,
-    Counters *__restrict__ ctr, uint32_t *__restrict__ tile_count,
-    const uint32_t *__restrict__ bins, const BroadTri *__restrict__ broad_list,
-    unsigned long long *__restrict__ frags, uint32_t *__restrict__ frag_count, float4 *__restrict__ out,
+    const uint32_t *__restrict__ bins,
     uint32_t *__restrict__ vis_prim, float *__restrict__ vis_depth,
     const float4 *__restrict__ background, float *__restrict__ depth_io, uint32_t *__restrict__ host_flags,
     uint32_t *__restrict__ out8, uint32_t *__restrict__ item_groups, uint32_t *__restrict__ item_head,
@@ -1257,7 +1262,11 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
   // A frame whose every-tile list overflowed (bit 1 of ctr->overflow, final since k_geometry ended) is rendered again after
   // the host has grown the list: the clip path reserves a run of entries and writes none of them when the run does not
   // fit, so a prefix of the list may hold entries never written this frame -- the overflowed frame takes none of it.
-  const uint32_t n_broad = (BB_ABLATE(5u) || (ctr->overflow & 2u)) ? 0u : min(ctr->n_broad, fp.broad_cap);
+  // (Both counter words are read unconditionally and combined without a branch -- ONE round trip, together with the bin
+  //  counts above, in front of the tile's first decision.  As `overflow & 2 ? 0 : n_broad` the compiler made the second
+  //  load wait for the first.)
+  const uint32_t ctr_overflow = ctr->overflow, ctr_n_broad = ctr->n_broad;
+  const uint32_t n_broad = BB_ABLATE(5u) ? 0u : (min(ctr_n_broad, fp.broad_cap) & (((ctr_overflow >> 1) & 1u) - 1u));
 
   // the pixel's colour when no geometry covers it.  forward: the clear colour (src/main.cpp:84); deferred: brdf.frag on the
   // cleared G-buffer texel (k_deferred_background); fused presentation: the same colours as presented pixels (the clear
@@ -1279,11 +1288,18 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
   // and the workgroup is gone after two memory round trips.  Through the general path below these tiles lived 4.8 us each
   // (8 KB of keys cleared, a barrier, one staged entry, another barrier: in-kernel stamps) and held 28 % of the frame's
   // wave-slot time between them.  Anything else falls through.
+  // (The first kBroadSpec entries of the every-tile list are fetched BEFORE the counts have arrived -- the list always has
+  //  that many entries allocated, and zero-filled ones can touch no tile -- so that a light tile is ONE memory round trip:
+  //  counts and entries come back together.  A frame with more entries fetches the rest behind the count.)
+  BroadTri spec;
+  if (!OVERLAY && (uint32_t)lane < kBroadSpec) spec = broad_list[lane];
   if (!OVERLAY && !vis_prim && !depth_io && (n_cls[0] | n_cls[1] | n_cls[2]) == 0u && n_broad <= 64u) {
     bool ok = false, full = false;
     uint32_t ref = 0u, clip_slot1 = 0u;
     if ((uint32_t)lane < n_broad) {
-      const BroadTri &b = broad_list[lane];
+      BroadTri b;
+      if ((uint32_t)lane < kBroadSpec) b = spec;
+      else b = broad_list[lane];
       const RasterTri t = b.tri;
       ref = b.ref;
       clip_slot1 = b.pad[0];
@@ -1755,6 +1771,9 @@ __global__ __launch_bounds__(kItemsThreads) void k_shade_items(FrameParams fp, c
 #ifndef BB_SHADE_THREADS
 #define BB_SHADE_THREADS 256
 #endif
+#ifndef BB_SHADE_WAVES
+#define BB_SHADE_WAVES 8  // waves per SIMD the main forward instantiation is compiled for (64 registers)
+#endif
 constexpr int kShadeThreads = BB_SHADE_THREADS;
 #ifdef BB_STAMPS
 __device__ unsigned long long g_shade_stamps[4096 * 8];  // diagnostic build: per-wave phase cycles of k_shade
@@ -1784,15 +1803,20 @@ struct ItemFrag {
 // keeps ~100 live around a loop where the straight-line body fits 64 -- four waves per SIMD instead of eight.  The main
 // instantiation asks for eight waves per SIMD (amdgpu_waves_per_eu): the allocator then gets from 67 registers to 64
 // without a spill, and the eighth wave is worth 3.4 us of the kernel's 76 at C3 (latency hiding is what this kernel runs on).
-template <int TILE_W, int TILE_H, bool DEFERRED, bool PRESENT = false, bool TAIL = false>
-__global__ __launch_bounds__(kShadeThreads) __attribute__((amdgpu_waves_per_eu(TAIL ? 1 : (DEFERRED ? 7 : 8)))) void k_shade(
-    FrameParams fp, ShadeParams sp, const CookedLight *__restrict__ cooked, const ShadeRec *__restrict__ recs,
-    const ClipSlot *__restrict__ clip_arena, const unsigned long long *__restrict__ frags,
-    const uint32_t *__restrict__ frag_count, const uint32_t *__restrict__ items, uint32_t first_item,
+// MIXED = false: every material of the frame is packed (its five shaded maps share one size, or are the uniform defaults:
+// what bbr_upload_material produces for every ShaderBall material) -- the instantiation then has no per-map sampling path
+// at all, and that path's registers and code are not the main launch's problem.  The host knows (upload_material_table).
+template <int TILE_W, int TILE_H, bool DEFERRED, bool PRESENT = false, bool TAIL = false, bool MIXED = true>
+__global__ __launch_bounds__(kShadeThreads) __attribute__((amdgpu_waves_per_eu(TAIL ? 1 : ((DEFERRED || MIXED) ? 7 : BB_SHADE_WAVES)))) void k_shade(
+    // (first: what stands between a wave's launch and its first loads -- the item word, the item count, then the fragment
+    //  words and the record: these pointers arrive in scalar registers with the wave, "kernarg preload", 14 dwords at most)
+    const uint32_t *__restrict__ items, const uint32_t *__restrict__ item_count, uint32_t first_item,
+    const unsigned long long *__restrict__ frags, const uint32_t *__restrict__ frag_count,
+    const ShadeRec *__restrict__ recs, const ClipSlot *__restrict__ clip_arena,
+    FrameParams fp, ShadeParams sp, const CookedLight *__restrict__ cooked,
     const MaterialDesc *__restrict__ materials, float4 *__restrict__ out,
     uint2 *__restrict__ gbuffer, const SrgbTables *__restrict__ tables, uint32_t *__restrict__ out8,
-    Counters *__restrict__ ctr, Counters *__restrict__ ctr_done, uint32_t *__restrict__ item_groups,
-    const uint32_t *__restrict__ item_count) {
+    Counters *__restrict__ ctr, Counters *__restrict__ ctr_done, uint32_t *__restrict__ item_groups) {
   constexpr int TILE_PIXELS = TILE_W * TILE_H;
   const ConstLights lights_c{(ConstCooked)cooked};
   // The frame's counter block has done its job (k_geometry filled it, k_raster read it): keep a copy for the host's
@@ -1821,7 +1845,10 @@ __global__ __launch_bounds__(kShadeThreads) __attribute__((amdgpu_waves_per_eu(T
   //  eight; runs of 4 / 16 / 64 workgroups per XCD: 87 / 89 / 94 us, no traffic gain.  Plain round-robin stays.)
   uint32_t j = first_item + (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * (uint32_t)kShadeWaves + (threadIdx.x >> 6)));
   uint32_t item = items[1u + (TAIL ? 0u : j)];
-  const uint32_t n_items = *item_count;  // (items[0], or the head word k_raster's tiles appended through: short frames)
+  uint32_t n_items = *item_count;  // (items[0], or the head word k_raster's tiles appended through: short frames)
+  // (both loads are in flight before either is waited for: left to itself the compiler reads the count, branches, and only
+  //  then asks for the item word -- one more dependent round trip in front of every wave's fragments)
+  asm volatile("" : "+s"(item), "+s"(n_items));
   if (BB_ABLATE(2048u)) sp.num_lights = 0;
   if (j >= n_items) return;  // a wave without an item (the kernel has no barrier: waves come and go on their own)
   do {  // (a loop only in the TAIL instantiation)
@@ -1851,90 +1878,197 @@ __global__ __launch_bounds__(kShadeThreads) __attribute__((amdgpu_waves_per_eu(T
   int x, y;
   tile_pixel<TILE_W>((int)(frag >> 32) & (TILE_PIXELS - 1), x, y);
   const int gx = tx * TILE_W + x, gy = ty * TILE_H + y;
-  const size_t o = (size_t)(out_tile_row * TILE_H + y) * (size_t)fp.width + (size_t)gx;
+  // the pixel's index in the output (32 bits: a frame has at most 2^30 pixels) -- formed here, so that ONE register, not the
+  // pixel's coordinates, lives through the two load groups below (the kernel runs at the 64 registers of eight waves per SIMD)
+  uint32_t opix = (uint32_t)(out_tile_row * TILE_H + y) * (uint32_t)fp.width + (uint32_t)gx;
+  asm volatile("" : "+v"(opix));
+  const size_t o = (size_t)opix;
 
-  // The primitive record (224 bytes) and, for a clipped primitive, its sub-triangle's clip slot: barycentrics and the
-  // fourteen varyings.  Two forms of the same statements:
-  //  * every fragment of the wave belongs to ONE (sub-)triangle -- the ground plane's waves, about half of C3's: the
-  //    record is fetched ONCE through the scalar cache (s_load) instead of 64 lanes gathering 16 x 16 bytes each.
-  //    That takes 20 of a wave's 26 vector loads -- 20 KB of register-file traffic through the texture-address unit
-  //    -- out of the memory pipeline, whose queues were what made a round trip cost 3-4 thousand cycles under load
-  //    (in-kernel stamps); the price is that operands coming from scalar registers halve the issue rate of the ~60
-  //    instructions that read them.
-  //  * otherwise each lane gathers the record of its own fragment's primitive (neighbouring pixels share primitives,
-  //    so the loads of a wave hit few L1 lines).
+  // ---- The dependent loads between a fragment and its colour, in TWO round trips ----
+  //   A  the HEAD of the primitive record (planes, 1/w, the three texture coordinates, the material binding: 80 bytes) and,
+  //      for a fragment of a clipped primitive, its sub-triangle's clip slot -- whose index the fragment word carries, so
+  //      nothing has to be read first to know whether and where
+  //   B  the texels (four 12-byte taps, addressed from the interpolated uv) TOGETHER WITH the body of the record (the other
+  //      twelve varyings of each vertex: 144 bytes)
+  // Written as one sequence the compiler serialised it into five (round 3's build, by its listing: clip_base -> planes ->
+  // barycentrics -> varyings -> material pointer -> texels; it sinks every load to its first use to stay within 64
+  // registers): each group below ends in a fence -- an empty asm that takes every loaded value -- so that all loads of the
+  // group are in flight before the first of them is waited for.
+  // Two forms of the same statements:
+  //  * every fragment of the wave belongs to ONE (sub-)triangle -- the ground plane's waves, about half of C3's: record and
+  //    clip slot come ONCE through the scalar cache (s_load; constant address space) instead of 64 lanes gathering them;
+  //  * otherwise each lane gathers the record of its own fragment's primitive (neighbouring pixels share primitives, so
+  //    the loads of a wave hit few L1 lines).
   float a[kNumVary];
   uint32_t packed_dims, material;
   const uint8_t *packed_texels;
-  auto interpolate = [&](const auto &pa, const auto *clips, uint32_t clip1, uint32_t sub) {
-    // perspective-correct barycentrics from the screen-space planes of the (sub-)triangle
-    int X0 = pa.X0, Y0 = pa.Y0;
-    float l1dx = pa.l1dx, l1dy = pa.l1dy, l2dx = pa.l2dx, l2dy = pa.l2dy, rw0 = pa.rw0, rw1 = pa.rw1, rw2 = pa.rw2;
-    // A sub-triangle of a clipped primitive (the ground plane, mostly) has its own planes, in the clip arena.  The
-    // fragment word usually carries the slot, so these loads go out together with the record's; when k_raster did not
-    // know it (more than 32 clipped sub-triangles on one tile) the slot comes from the record, one round trip later.
-    const uint32_t clip_base = pa.clip_base;
-    const bool clipped = clip1 != 0u || clip_base != kNotClipped;
-    float cb[3][3];
-    if (clipped) {
-      const auto &cs = clips[clip1 != 0u ? clip1 - 1u : clip_base + sub];
-      X0 = cs.tri.X0; Y0 = cs.tri.Y0;
-      l1dx = cs.tri.l1dx; l1dy = cs.tri.l1dy; l2dx = cs.tri.l2dx; l2dy = cs.tri.l2dy;
-      rw0 = cs.tri.rw0; rw1 = cs.tri.rw1; rw2 = cs.tri.rw2;
-#pragma unroll
-      for (int jj = 0; jj < 3; ++jj)
-#pragma unroll
-        for (int k = 0; k < 3; ++k) cb[jj][k] = cs.bary[jj][k];
-    }
+  float b0, b1, b2;  // perspective-correct barycentrics with respect to the (unclipped) primitive
+  // perspective-correct barycentrics from the screen-space planes of the (sub-)triangle
+  auto barycentrics = [&](const PlaneHead &h, bool clipped, const float (&cb)[3][3]) {
     const int Xc = gx * 256 + 128, Yc = gy * 256 + 128;
-    const float dxp = (float)(Xc - X0), dyp = (float)(Yc - Y0);
-    const float l1 = fmaf(l1dx, dxp, l1dy * dyp);
-    const float l2 = fmaf(l2dx, dxp, l2dy * dyp);
+    const float dxp = (float)(Xc - h.X0), dyp = (float)(Yc - h.Y0);
+    const float l1 = fmaf(h.l1dx, dxp, h.l1dy * dyp);
+    const float l2 = fmaf(h.l2dx, dxp, h.l2dy * dyp);
     const float l0 = (1.0f - l1) - l2;
-    const float u0 = l0 * rw0, u1 = l1 * rw1, u2 = l2 * rw2;
+    const float u0 = l0 * h.rw0, u1 = l1 * h.rw1, u2 = l2 * h.rw2;
     const float r = bb_rcp((u0 + u1) + u2);
-    float b0 = u0 * r, b1 = u1 * r, b2 = u2 * r;
+    b0 = u0 * r; b1 = u1 * r; b2 = u2 * r;
     if (clipped) {  // barycentrics with respect to the unclipped primitive
       const float c0 = fmaf(b2, cb[2][0], fmaf(b1, cb[1][0], b0 * cb[0][0]));
       const float c1 = fmaf(b2, cb[2][1], fmaf(b1, cb[1][1], b0 * cb[0][1]));
       const float c2 = fmaf(b2, cb[2][2], fmaf(b1, cb[1][2], b0 * cb[0][2]));
       b0 = c0; b1 = c1; b2 = c2;
     }
-#pragma unroll
-    for (int k = 0; k < kNumVary; ++k) a[k] = fmaf(b2, pa.vary[2][k], fmaf(b1, pa.vary[1][k], b0 * pa.vary[0][k]));
-    packed_dims = pa.packed_dims;
-    material = pa.material;
-    packed_texels = (const uint8_t *)pa.packed;
+  };
+  // texels of the packed material (one set of taps, four 12-byte loads of 9-byte records) -- global loads, issued in group B
+  BilinearTaps tp = {};
+  uint32_t t00[3] = {}, t10[3] = {}, t01[3] = {}, t11[3] = {};
+  // (Issued by EVERY lane, without a branch around them: a lane whose material is not packed -- maps of different sizes, the
+  //  per-map path further down -- reads twelve bytes of its own record instead and ignores them.  Behind a branch the loads
+  //  still in flight at the join are unknown to the compiler, and it waits for all of them where the record's first part
+  //  would do.)
+  auto issue_taps = [&](const void *harmless) {
+    const float u = BB_ABLATE(8u) ? 0.5f : a[0], v = BB_ABLATE(8u) ? 0.5f : a[1];
+    const bool packed = !MIXED || packed_dims != 0u;
+    tp = bilinear_taps<true>(u, v, packed ? (int)(packed_dims & 0xFFFFu) : 1, packed ? (int)(packed_dims >> 16) : 1);
+    const GlobalBytes tb = packed ? (GlobalBytes)packed_texels : (GlobalBytes)harmless;
+    const u32x3 q00 = *(GlobalTap)(tb + texel_offset(tp.o00)), q10 = *(GlobalTap)(tb + texel_offset(tp.o10));
+    const u32x3 q01 = *(GlobalTap)(tb + texel_offset(tp.o01)), q11 = *(GlobalTap)(tb + texel_offset(tp.o11));
+    t00[0] = q00.x; t00[1] = q00.y; t00[2] = q00.z;
+    t10[0] = q10.x; t10[1] = q10.y; t10[2] = q10.z;
+    t01[0] = q01.x; t01[1] = q01.y; t01[2] = q01.z;
+    t11[0] = q11.x; t11[1] = q11.y; t11[2] = q11.z;
   };
   {
-    const uint32_t clip1 = (uint32_t)(frag >> (32 + kFragPixBits));
+    const uint32_t clip1 = (uint32_t)(frag >> (32 + kFragPixBits));  // clip-arena slot + 1 of a clipped sub-triangle, 0: none / unknown
     const uint32_t ref_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)ref);
     if ((__ballot(ref != ref_u) == 0ull && !BB_ABLATE(4096u)) || BB_ABLATE(8192u)) {
-      // (the constant address space is what makes these scalar loads -- and keeps the compiler from merging the two
-      //  forms back into one that gathers: both buffers were written by k_geometry and are read-only here)
-      typedef const ShadeRec __attribute__((address_space(4))) *ConstRecs;
-      typedef const ClipSlot __attribute__((address_space(4))) *ConstClips;
-      interpolate(((ConstRecs)recs)[BB_ABLATE(16u) ? 0u : (ref_u >> 3)], (ConstClips)clip_arena,
-                  (uint32_t)__builtin_amdgcn_readfirstlane((int)clip1), ref_u & 7u);
+      // ---- uniform wave: scalar loads (the constant address space is what makes them scalar -- and keeps the compiler from
+      // merging the two forms back into one that gathers: both buffers were written by k_geometry and are read-only here) ----
+      typedef const ShadeRec __attribute__((address_space(4))) *ConstRec;
+      typedef const ClipSlot __attribute__((address_space(4))) *ConstClip;
+      typedef const PlaneHead __attribute__((address_space(4))) *ConstHead;
+      const ConstRec rp = (ConstRec)recs + (BB_ABLATE(16u) ? 0u : (ref_u >> 3));
+      const uint32_t clip1_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)clip1);
+      bool clipped = clip1_u != 0u;
+      const ConstClip cp = (ConstClip)clip_arena + (clipped ? clip1_u - 1u : 0u);
+      const ConstHead hp = clipped ? &cp->h : &rp->h;
+      // group A
+      PlaneHead h;
+      h.X0 = hp->X0; h.Y0 = hp->Y0; h.l1dx = hp->l1dx; h.l1dy = hp->l1dy; h.l2dx = hp->l2dx; h.l2dy = hp->l2dy;
+      h.rw0 = hp->rw0; h.rw1 = hp->rw1; h.rw2 = hp->rw2;
+      float uv[3][2], cb[3][3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { uv[k][0] = rp->uv[k][0]; uv[k][1] = rp->uv[k][1]; }
+#pragma unroll
+      for (int jj = 0; jj < 3; ++jj)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) cb[jj][k] = cp->bary[jj][k];  // (slot 0 when the fragment is not clipped: loaded, not used)
+      packed_dims = rp->packed_dims;
+      material = rp->material;
+      unsigned long long packed_bits = (unsigned long long)(uintptr_t)rp->packed;
+      uint32_t clip_base = rp->clip_base;
+      asm volatile("" :: "s"(h.X0), "s"(h.Y0), "s"(h.l1dx), "s"(h.l1dy), "s"(h.l2dx), "s"(h.l2dy), "s"(h.rw0), "s"(h.rw1), "s"(h.rw2), "s"(uv[0][0]), "s"(uv[0][1]), "s"(uv[1][0]), "s"(uv[1][1]), "s"(uv[2][0]), "s"(uv[2][1]), "s"(packed_dims), "s"(material), "s"(packed_bits), "s"(clip_base), "s"(cb[0][0]), "s"(cb[0][1]), "s"(cb[0][2]), "s"(cb[1][0]), "s"(cb[1][1]), "s"(cb[1][2]), "s"(cb[2][0]), "s"(cb[2][1]), "s"(cb[2][2]) : "memory");
+      packed_texels = (const uint8_t *)(uintptr_t)packed_bits;
+      if (!clipped && clip_base != kNotClipped) {
+        // a clipped primitive whose slot k_raster could not put into the fragment word (more than 32 clipped sub-triangles
+        // on one tile): found through the record, one round trip later
+        const ConstClip cq = (ConstClip)clip_arena + (clip_base + (ref_u & 7u));
+        h.X0 = cq->h.X0; h.Y0 = cq->h.Y0; h.l1dx = cq->h.l1dx; h.l1dy = cq->h.l1dy; h.l2dx = cq->h.l2dx; h.l2dy = cq->h.l2dy;
+        h.rw0 = cq->h.rw0; h.rw1 = cq->h.rw1; h.rw2 = cq->h.rw2;
+#pragma unroll
+        for (int jj = 0; jj < 3; ++jj)
+#pragma unroll
+          for (int k = 0; k < 3; ++k) cb[jj][k] = cq->bary[jj][k];
+        clipped = true;
+      }
+      barycentrics(h, clipped, cb);
+      a[0] = fmaf(b2, uv[2][0], fmaf(b1, uv[1][0], b0 * uv[0][0]));
+      a[1] = fmaf(b2, uv[2][1], fmaf(b1, uv[1][1], b0 * uv[0][1]));
+      BB_KSTAMP(2);  // head (+ clip slot) arrived, barycentrics and uv done
+      // group B: the texel taps first (vector loads, the long pole), the body of the record behind them (scalar loads)
+      issue_taps((const void *)(const ShadeRec *)(uintptr_t)rp);
+      float body[kNumBodyVary][3];
+#pragma unroll
+      for (int jj = 0; jj < kNumBodyVary; ++jj)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) body[jj][k] = rp->vary[jj][k];
+#pragma unroll
+      for (int q = 0; q < kNumBodyVary; q += 4)
+        asm volatile("" :: "s"(body[q][0]), "s"(body[q][1]), "s"(body[q][2]), "s"(body[q + 1][0]), "s"(body[q + 1][1]), "s"(body[q + 1][2]), "s"(body[q + 2][0]), "s"(body[q + 2][1]), "s"(body[q + 2][2]), "s"(body[q + 3][0]), "s"(body[q + 3][1]), "s"(body[q + 3][2]) : "memory");
+#pragma unroll
+      for (int jj = 0; jj < kNumBodyVary; ++jj) a[2 + jj] = fmaf(b2, body[jj][2], fmaf(b1, body[jj][1], b0 * body[jj][0]));
     } else {
-      interpolate(recs[prim], clip_arena, clip1, ref & 7u);
+      // ---- each lane gathers the record of its own fragment's primitive ----
+      const ShadeRec *rp = recs + prim;
+      bool clipped = clip1 != 0u;
+      const ClipSlot *cp = clip_arena + (clipped ? clip1 - 1u : 0u);
+      const PlaneHead *hp = clipped ? &cp->h : &rp->h;
+      // group A: three loads of the head (from the record or the clip slot), three of the rest of the record's head,
+      // and, for the lanes of clipped fragments, three of the slot's barycentrics
+      PlaneHead h = *hp;
+      float uv[3][2], cb[3][3] = {};
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { uv[k][0] = rp->uv[k][0]; uv[k][1] = rp->uv[k][1]; }
+      packed_dims = rp->packed_dims;
+      material = rp->material;
+      unsigned long long packed_bits = (unsigned long long)(uintptr_t)rp->packed;
+      uint32_t clip_base = rp->clip_base;
+      if (clipped) {
+#pragma unroll
+        for (int jj = 0; jj < 3; ++jj)
+#pragma unroll
+          for (int k = 0; k < 3; ++k) cb[jj][k] = cp->bary[jj][k];
+      }
+      asm volatile("" :: "v"(h.X0), "v"(h.Y0), "v"(h.l1dx), "v"(h.l1dy), "v"(h.l2dx), "v"(h.l2dy), "v"(h.rw0), "v"(h.rw1), "v"(h.rw2), "v"(uv[0][0]), "v"(uv[0][1]), "v"(uv[1][0]), "v"(uv[1][1]), "v"(uv[2][0]), "v"(uv[2][1]), "v"(packed_dims), "v"(material), "v"(packed_bits), "v"(clip_base), "v"(cb[0][0]), "v"(cb[0][1]), "v"(cb[0][2]), "v"(cb[1][0]), "v"(cb[1][1]), "v"(cb[1][2]), "v"(cb[2][0]), "v"(cb[2][1]), "v"(cb[2][2]) : "memory");
+      packed_texels = (const uint8_t *)(uintptr_t)packed_bits;
+      const bool late = !clipped && clip_base != kNotClipped;  // (see the uniform form)
+      if (__builtin_expect(__ballot(late) != 0ull, 0)) {
+        if (late) {
+          const ClipSlot cs = clip_arena[clip_base + (ref & 7u)];
+          h = cs.h;
+#pragma unroll
+          for (int jj = 0; jj < 3; ++jj)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) cb[jj][k] = cs.bary[jj][k];
+          clipped = true;
+        }
+      }
+      barycentrics(h, clipped, cb);
+      a[0] = fmaf(b2, uv[2][0], fmaf(b1, uv[1][0], b0 * uv[0][0]));
+      a[1] = fmaf(b2, uv[2][1], fmaf(b1, uv[1][1], b0 * uv[0][1]));
+      BB_KSTAMP(2);  // head (+ clip slot) arrived, barycentrics and uv done
+      // group B: the first 80 bytes of the record's body (varyings 0..5 whole and two thirds of the sixth), the four texel
+      // taps behind them, and -- as soon as the first part has arrived and its six varyings are interpolated, their eighteen
+      // registers free again -- the other 64 bytes of the body.  Loads return in order: the second part (the same cache
+      // lines as the first: L1 hits) comes back behind the taps, so the group is still one round trip long, and its peak is
+      // 20 + 12 loaded registers instead of 36 + 12 (the kernel has 64).
+      const float *bp = &rp->vary[0][0];
+      float p1[20];
+#pragma unroll
+      for (int q = 0; q < 20; ++q) p1[q] = bp[q];
+      issue_taps(rp);
+      asm volatile("" :: "v"(p1[0]), "v"(p1[1]), "v"(p1[2]), "v"(p1[3]), "v"(p1[4]), "v"(p1[5]), "v"(p1[6]), "v"(p1[7]), "v"(p1[8]), "v"(p1[9]), "v"(p1[10]), "v"(p1[11]), "v"(p1[12]), "v"(p1[13]), "v"(p1[14]), "v"(p1[15]), "v"(p1[16]), "v"(p1[17]), "v"(p1[18]), "v"(p1[19]) : "memory");
+#pragma unroll
+      for (int jj = 0; jj < 6; ++jj) a[2 + jj] = fmaf(b2, p1[3 * jj + 2], fmaf(b1, p1[3 * jj + 1], b0 * p1[3 * jj]));
+      asm volatile("" :: "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]) : "memory");  // (the second part is asked for HERE, not earlier)
+      float p2[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) p2[q] = bp[20 + q];
+      asm volatile("" :: "v"(p2[0]), "v"(p2[1]), "v"(p2[2]), "v"(p2[3]), "v"(p2[4]), "v"(p2[5]), "v"(p2[6]), "v"(p2[7]), "v"(p2[8]), "v"(p2[9]), "v"(p2[10]), "v"(p2[11]), "v"(p2[12]), "v"(p2[13]), "v"(p2[14]), "v"(p2[15]) : "memory");
+      a[8] = fmaf(b2, p2[0], fmaf(b1, p1[19], b0 * p1[18]));
+#pragma unroll
+      for (int jj = 7; jj < kNumBodyVary; ++jj) a[2 + jj] = fmaf(b2, p2[3 * jj - 18], fmaf(b1, p2[3 * jj - 19], b0 * p2[3 * jj - 20]));
     }
   }
+  // the taps are used from here on: pin them behind the body's fence (they were issued in front of it)
+  asm volatile("" :: "v"(t00[0]), "v"(t00[1]), "v"(t00[2]), "v"(t10[0]), "v"(t10[1]), "v"(t10[2]), "v"(t01[0]), "v"(t01[1]), "v"(t01[2]), "v"(t11[0]), "v"(t11[1]), "v"(t11[2]) : "memory");
 
-  BB_KSTAMP(2);  // record (+ clip slot) arrived, varyings interpolated
-  // texture fetches, forward_brdf.frag:16-22
+  // texture filtering, forward_brdf.frag:16-22
   const float u = BB_ABLATE(8u) ? 0.5f : a[0], v = BB_ABLATE(8u) ? 0.5f : a[1];
   f3 albedo, normal;
   float metallic, roughness, ao;
-  if (packed_dims != 0u) {
-    // packed material: one set of taps, four 12-byte loads of 9-byte records
-    const BilinearTaps tp = bilinear_taps<true>(u, v, (int)(packed_dims & 0xFFFFu), (int)(packed_dims >> 16));
-    const uint8_t *tb = packed_texels;
-    uint32_t t00[3], t10[3], t01[3], t11[3];
-    __builtin_memcpy(t00, tb + texel_offset(tp.o00), 12);
-    __builtin_memcpy(t10, tb + texel_offset(tp.o10), 12);
-    __builtin_memcpy(t01, tb + texel_offset(tp.o01), 12);
-    __builtin_memcpy(t11, tb + texel_offset(tp.o11), 12);
+  if (!MIXED || packed_dims != 0u) {
     albedo.x = filter_channel(t00[0], t10[0], t01[0], t11[0], 0, tp.fx, tp.fy);
     albedo.y = filter_channel(t00[0], t10[0], t01[0], t11[0], 8, tp.fx, tp.fy);
     albedo.z = filter_channel(t00[0], t10[0], t01[0], t11[0], 16, tp.fx, tp.fy);
@@ -2232,19 +2366,13 @@ __global__ __launch_bounds__(kShadeThreads) void k_shade_overlay(
   // perspective-correct barycentrics: the same statements as k_shade
   const bool clipped = pa.clip_base != kNotClipped;
   const ClipSlot *cs = clipped ? &clip_arena[pa.clip_base + (ref & 7u)] : nullptr;
-  int X0 = pa.X0, Y0 = pa.Y0;
-  float l1dx = pa.l1dx, l1dy = pa.l1dy, l2dx = pa.l2dx, l2dy = pa.l2dy, rw0 = pa.rw0, rw1 = pa.rw1, rw2 = pa.rw2;
-  if (clipped) {
-    X0 = cs->tri.X0; Y0 = cs->tri.Y0;
-    l1dx = cs->tri.l1dx; l1dy = cs->tri.l1dy; l2dx = cs->tri.l2dx; l2dy = cs->tri.l2dy;
-    rw0 = cs->tri.rw0; rw1 = cs->tri.rw1; rw2 = cs->tri.rw2;
-  }
+  const PlaneHead h = clipped ? cs->h : pa.h;
   const int Xc = gx * 256 + 128, Yc = gy * 256 + 128;
-  const float dxp = (float)(Xc - X0), dyp = (float)(Yc - Y0);
-  const float l1 = fmaf(l1dx, dxp, l1dy * dyp);
-  const float l2 = fmaf(l2dx, dxp, l2dy * dyp);
+  const float dxp = (float)(Xc - h.X0), dyp = (float)(Yc - h.Y0);
+  const float l1 = fmaf(h.l1dx, dxp, h.l1dy * dyp);
+  const float l2 = fmaf(h.l2dx, dxp, h.l2dy * dyp);
   const float l0 = (1.0f - l1) - l2;
-  const float u0 = l0 * rw0, u1 = l1 * rw1, u2 = l2 * rw2;
+  const float u0 = l0 * h.rw0, u1 = l1 * h.rw1, u2 = l2 * h.rw2;
   const float r = bb_rcp((u0 + u1) + u2);
   float b0 = u0 * r, b1 = u1 * r, b2 = u2 * r;
   if (clipped) {
@@ -2253,9 +2381,12 @@ __global__ __launch_bounds__(kShadeThreads) void k_shade_overlay(
     const float c2 = fmaf(b2, cs->bary[2][2], fmaf(b1, cs->bary[1][2], b0 * cs->bary[0][2]));
     b0 = c0; b1 = c1; b2 = c2;
   }
+  // varyings 0..5 of the overlay programs (k_geometry<..., OVERLAY>): 0, 1 sit in the record's head, 2..5 in its body
   float a[6];
 #pragma unroll
-  for (int k = 0; k < 6; ++k) a[k] = fmaf(b2, pa.vary[2][k], fmaf(b1, pa.vary[1][k], b0 * pa.vary[0][k]));
+  for (int k = 0; k < 2; ++k) a[k] = fmaf(b2, pa.uv[2][k], fmaf(b1, pa.uv[1][k], b0 * pa.uv[0][k]));
+#pragma unroll
+  for (int k = 0; k < 4; ++k) a[2 + k] = fmaf(b2, pa.vary[k][2], fmaf(b1, pa.vary[k][1], b0 * pa.vary[k][0]));
   float col[3] = {a[0], a[1], a[2]};  // light.frag: outColor = vec4(vColor, 1)
   if (pa.material == 2u) {             // gizmo.frag:10-17: L = -(0,0,1); diff = max(dot(L, normalize(vNormal)), 0)
     const f3 N = normalize3(mk3(a[3], a[4], a[5]));

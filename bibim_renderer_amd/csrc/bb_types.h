@@ -93,14 +93,25 @@ struct RasterTri {
 };
 static_assert(sizeof(RasterTri) == 64, "RasterTri");
 
-// Sub-triangle produced by the polygon clipper.  112 B.
+// What k_shade needs of a (sub-)triangle before it can interpolate anything: vertex 0 in 24.8, the screen-space
+// barycentric planes relative to it, 1/w at the three vertices.  36 B.  A primitive record and a clip-arena slot both START
+// with one, so that a lane fetches it from either place with the same three loads.
+struct PlaneHead {
+  int32_t X0, Y0;
+  float l1dx, l1dy, l2dx, l2dy;
+  float rw0, rw1, rw2;
+};
+static_assert(sizeof(PlaneHead) == 36, "PlaneHead");
+
+// Sub-triangle produced by the polygon clipper, as k_shade reads it (k_raster gets its copy of the triangle through the
+// every-tile list).  80 B.
 struct ClipSlot {
-  RasterTri tri;
+  PlaneHead h;
   float bary[3][3];  // own vertex j -> barycentrics with respect to the unclipped primitive
   uint32_t valid;
-  uint32_t pad[2];
+  uint32_t pad;
 };
-static_assert(sizeof(ClipSlot) == 112, "ClipSlot");
+static_assert(sizeof(ClipSlot) == 80 && offsetof(ClipSlot, bary) == 36, "ClipSlot");
 
 // Entry of the every-tile list: the triangle itself travels with the reference so that the raster kernel's
 // per-tile classification is one load deep.  80 B.
@@ -122,21 +133,26 @@ static_assert(sizeof(BroadTri) == 80, "BroadTri");
 constexpr uint32_t kPackedTexelBytes = BB_PACKED_STRIDE;
 constexpr uint32_t kPackedTexelPad = 16;  // bytes allocated behind the last record (the 12-byte load of the last texel)
 
-// Everything k_shade needs about one primitive, in ONE 224-byte record (56 dwords): the post-vertex-stage varyings
-// of its three vertices, the screen-space barycentric planes and 1/w of the (unclipped) triangle, and its material
-// binding.  Every lane gathers the record of its own fragment's primitive (neighbouring pixels share primitives, so
-// the loads of a wave hit few L1 lines).
+// Everything k_shade needs about one primitive, in ONE 224-byte record (56 dwords), in the order it is needed:
+//   head (80 B)  what stands in front of the texel fetch: the planes and 1/w of the (unclipped) triangle, the texture
+//                coordinates of its three vertices, its material binding
+//   body (144 B) the other twelve varyings, varying-major ([varying][vertex]) -- fetched together WITH the texels, not in
+//                front of them, in two parts (80 + 64 bytes): the first five 16-byte loads hold varyings 0..5 whole, so their
+//                registers are free again before the second part is asked for
+// Every lane gathers the record of its own fragment's primitive (neighbouring pixels share primitives, so the loads of a
+// wave hit few L1 lines); a wave whose fragments share one primitive reads it through the scalar cache.
+constexpr int kNumBodyVary = kNumVary - 2;  // posWorld(3) N(3) T(3) B(3)
 struct ShadeRec {
-  float vary[3][kNumVary];
-  int32_t X0, Y0;                // vertex 0 of the triangle, 24.8 (planes are relative to it)
-  float l1dx, l1dy, l2dx, l2dy;  // screen-space barycentric planes
-  float rw0, rw1, rw2;           // 1/w at the vertices
-  uint32_t material;
-  const uint8_t *packed;         // packed material texels, 9-byte records (nullptr: use the material table)
+  PlaneHead h;                   // (zero for a primitive that went through the clipper: its sub-triangles have their own)
+  float uv[3][2];
   uint32_t packed_dims;          // width | height << 16, 0 = not packed
+  const uint8_t *packed;         // packed material texels, 9-byte records (nullptr: use the material table)
+  uint32_t material;
   uint32_t clip_base;            // first clip-arena slot of a clipped primitive, kNotClipped otherwise
+  float vary[kNumBodyVary][3];   // [varying][vertex]
 };
-static_assert(sizeof(ShadeRec) == 224 && offsetof(ShadeRec, packed) == 208, "ShadeRec");
+static_assert(sizeof(ShadeRec) == 224 && offsetof(ShadeRec, uv) == 36 && offsetof(ShadeRec, packed) == 64 &&
+                  offsetof(ShadeRec, vary) == 80, "ShadeRec");
 constexpr uint32_t kNotClipped = 0xFFFFFFFFu;
 constexpr int kShadeRecDwords = sizeof(ShadeRec) / 4;
 

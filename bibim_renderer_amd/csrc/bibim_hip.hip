@@ -188,6 +188,7 @@ struct bbr_context {
   uint8_t *d_default_texels = nullptr;  // 6 x RGBA8 (1x1 default maps)
   DeviceBuffer<MaterialDesc> d_materials;
   bool materials_dirty = true;
+  bool all_packed = true;  // every live material has a packed form (k_shade's MIXED = false instantiation may be used)
 
   FrameUniformBlock frame_u = {};
   ViewUniformBlock view_u = {};
@@ -375,7 +376,8 @@ int ensure_slot_buffers(bbr_context *c, FrameSlot &s) {
   HIP_TRY(c, s.d_block_stats.ensure(std::max<size_t>((c->n_prims + 255) / 256, 1) * 4, true));
   HIP_TRY(c, s.d_tile_count.ensure(tiles * kBinClasses, true));
   HIP_TRY(c, s.d_bins.ensure(tiles * kBinClasses * c->bin_cap));
-  HIP_TRY(c, s.d_broad.ensure(c->broad_cap, true));
+  // (at least kBroadSpec entries: k_raster's light-tile path reads that many before it knows how many the frame wrote)
+  HIP_TRY(c, s.d_broad.ensure(std::max<size_t>(c->broad_cap, kBroadSpec), true));
   HIP_TRY(c, s.d_frags.ensure(tiles * (size_t)(c->tile_w() * c->tile_h())));
 #ifdef BB_STAMPS
   HIP_TRY(c, s.d_frag_count.ensure(tiles * 17, true));  // diagnostic build: 8 x u64 raster stamps per tile behind the counts
@@ -416,7 +418,11 @@ int upload_material_table(bbr_context *c) {
   if (!c->materials_dirty) return BBR_OK;
   size_t n = std::max<size_t>(c->materials.size(), 1);
   std::vector<MaterialDesc> h(n);
-  for (size_t i = 0; i < c->materials.size(); ++i) h[i] = c->materials[i].desc;
+  c->all_packed = true;
+  for (size_t i = 0; i < c->materials.size(); ++i) {
+    h[i] = c->materials[i].desc;
+    if (c->materials[i].alive && !c->materials[i].desc.packed) c->all_packed = false;
+  }
   int rc = drain(c);
   if (rc) return rc;
   HIP_TRY(c, c->d_materials.ensure(n));
@@ -435,8 +441,8 @@ void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const Fra
   hipEvent_t *ev = c->timing_this ? &c->ring[bbr_context::kRingEvents * (c->ring_frames % bbr_context::kRingCap)] : nullptr;
   if (c->n_prims)
     hipLaunchKernelGGL((k_geometry<TW, TH>), dim3((c->n_prims + 255) / 256), dim3(256), 0, sg, d_draws, n_draws,
-                       c->n_prims, pv, view, fp, s.d_tris.ptr, s.d_attrs.ptr, s.d_clip.ptr, ctr, s.d_tile_count.ptr,
-                       s.d_bins.ptr, s.d_broad.ptr, c->d_materials.ptr, s.d_block_stats.ptr);
+                       c->n_prims, s.d_tris.ptr, s.d_attrs.ptr, s.d_tile_count.ptr, s.d_bins.ptr, ctr, pv, view, fp, s.d_clip.ptr,
+                       s.d_broad.ptr, c->d_materials.ptr, s.d_block_stats.ptr);
   if (ev && c->timing == 1) (void)hipEventRecord(ev[1], sg);
   if (sr != sg) {
     (void)hipEventRecord(s.ev_geom_done, sg);
@@ -463,9 +469,9 @@ void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const Fra
   const uint32_t max_items = (uint32_t)(fp.tiles_x * grid_y) * (uint32_t)(TW * TH / 64);
   const bool short_frame = max_items <= (uint32_t)c->no_tail_items;
   uint32_t *item_head = short_frame ? d_item_head : nullptr;
-  hipLaunchKernelGGL((k_raster<TW, TH>), dim3(fp.tiles_x, grid_y), dim3(kTileThreads), 0, sr, fp, s.d_tris.ptr,
-                     s.d_clip.ptr, ctr, s.d_tile_count.ptr, s.d_bins.ptr, s.d_broad.ptr, s.d_frags.ptr,
-                     s.d_frag_count.ptr, out, c->dump_vis ? c->d_vis_prim.ptr : nullptr,
+  hipLaunchKernelGGL((k_raster<TW, TH>), dim3(fp.tiles_x, grid_y), dim3(kTileThreads), 0, sr, s.d_tile_count.ptr, ctr,
+                     s.d_broad.ptr, s.d_frag_count.ptr, s.d_frags.ptr, out, fp, s.d_tris.ptr, s.d_clip.ptr, s.d_bins.ptr,
+                     c->dump_vis ? c->d_vis_prim.ptr : nullptr,
                      c->dump_vis ? c->d_vis_depth.ptr : nullptr,
                      fp.deferred ? s.d_background.ptr : nullptr, (c->overlays && c->world == 1) ? s.d_depth.ptr : nullptr,
                      s.h_flags, out8, short_frame ? nullptr : s.d_item_groups.ptr, item_head, s.d_items.ptr, d_lights, sp.num_lights,
@@ -500,15 +506,20 @@ void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const Fra
   const bool tail = main_wgs * kShadeWaves < max_items;
   auto shade = [&](auto deferred, auto present) {
     if (tail) {
-      hipLaunchKernelGGL((k_shade<TW, TH, decltype(deferred)::value, decltype(present)::value, true>), dim3(32), dim3(kShadeThreads),
-                         0, sr, fp, sp, s.d_cooked.ptr, s.d_attrs.ptr, s.d_clip.ptr, s.d_frags.ptr, s.d_frag_count.ptr, s.d_items.ptr,
-                         main_wgs * (uint32_t)kShadeWaves, c->d_materials.ptr, out, gbuf, tables, out8, ctr, ctr_done, nullptr, item_count);
+      hipLaunchKernelGGL((k_shade<TW, TH, decltype(deferred)::value, decltype(present)::value, true, true>), dim3(32), dim3(kShadeThreads),
+                         0, sr, s.d_items.ptr, item_count, main_wgs * (uint32_t)kShadeWaves, s.d_frags.ptr, s.d_frag_count.ptr, s.d_attrs.ptr,
+                         s.d_clip.ptr, fp, sp, s.d_cooked.ptr, c->d_materials.ptr, out, gbuf, tables, out8, ctr, ctr_done, nullptr);
       if (ss != sr) (void)hipEventRecord(s.ev_tail_done, sr);
     }
-    hipLaunchKernelGGL((k_shade<TW, TH, decltype(deferred)::value, decltype(present)::value, false>), dim3(main_wgs),
-                       dim3(kShadeThreads), 0, ss, fp, sp, s.d_cooked.ptr, s.d_attrs.ptr, s.d_clip.ptr, s.d_frags.ptr,
-                       s.d_frag_count.ptr, s.d_items.ptr, 0u, c->d_materials.ptr, out, gbuf, tables, out8, ctr, ctr_done,
-                       short_frame ? nullptr : s.d_item_groups.ptr, item_count);
+    // (the main launch without the per-map sampling path when every material is packed: k_shade, MIXED)
+    auto main_launch = [&](auto mixed) {
+      hipLaunchKernelGGL((k_shade<TW, TH, decltype(deferred)::value, decltype(present)::value, false, decltype(mixed)::value>), dim3(main_wgs),
+                         dim3(kShadeThreads), 0, ss, s.d_items.ptr, item_count, 0u, s.d_frags.ptr, s.d_frag_count.ptr, s.d_attrs.ptr,
+                         s.d_clip.ptr, fp, sp, s.d_cooked.ptr, c->d_materials.ptr, out, gbuf, tables, out8, ctr, ctr_done,
+                         short_frame ? nullptr : s.d_item_groups.ptr);
+    };
+    if (c->all_packed) main_launch(std::false_type{});
+    else main_launch(std::true_type{});
     if (tail && ss != sr) (void)hipStreamWaitEvent(ss, s.ev_tail_done, 0);
   };
   if (fp.deferred) {
@@ -644,7 +655,7 @@ int submit_frame_into(bbr_context *c, int slot_index) {
   float4 *out = c->ext_out ? reinterpret_cast<float4 *>(c->ext_out) : s.d_frame.ptr;
   const FrameSlot *prev = (c->last_slot >= 0 && c->last_slot != slot_index) ? &c->slots[c->last_slot] : nullptr;
 
-  (void)hipMemcpyAsync(s.d_staging.ptr, s.h_staging, total, hipMemcpyHostToDevice, sg);
+  HIP_TRY(c, hipMemcpyAsync(s.d_staging.ptr, s.h_staging, total, hipMemcpyHostToDevice, sg));
   if (c->tile_mode == 0) launch_frame<64, 64>(c, s, prev, fp, pv, view, sp, d_lights, d_draws, c->n_live_draws, out, d_item_head);
   else launch_frame<32, 32>(c, s, prev, fp, pv, view, sp, d_lights, d_draws, c->n_live_draws, out, d_item_head);
   HIP_TRY(c, hipGetLastError());
@@ -949,7 +960,8 @@ extern "C" int bbr_draw_overlays(bbr_context *c, int32_t gizmo_extent) {
     HIP_TRY(c, s.d_block_stats.ensure(((n_prims + 255) / 256) * 4, true));
     HIP_TRY(c, s.d_tile_count.ensure(tiles * kBinClasses, true));
     HIP_TRY(c, s.d_bins.ensure(tiles * kBinClasses * c->bin_cap));
-    HIP_TRY(c, s.d_broad.ensure(c->broad_cap, true));
+    // (at least kBroadSpec entries: k_raster's light-tile path reads that many before it knows how many the frame wrote)
+  HIP_TRY(c, s.d_broad.ensure(std::max<size_t>(c->broad_cap, kBroadSpec), true));
     HIP_TRY(c, s.d_frags.ensure(tiles * (size_t)(c->tile_w() * c->tile_h())));
     HIP_TRY(c, s.d_frag_count.ensure(tiles, true));
     FrameParams fp = make_params(c);
@@ -968,11 +980,11 @@ extern "C" int bbr_draw_overlays(bbr_context *c, int32_t gizmo_extent) {
     auto launch = [&](auto tw, auto th) {
       constexpr int TW = decltype(tw)::value, TH = decltype(th)::value;
       hipLaunchKernelGGL((k_geometry<TW, TH, true>), dim3((n_prims + 255) / 256), dim3(256), 0, st, d_draws, (uint32_t)draws.size(),
-                         n_prims, ident, ident, fp, s.d_tris.ptr, s.d_attrs.ptr, s.d_clip.ptr, ctr, s.d_tile_count.ptr,
-                         s.d_bins.ptr, s.d_broad.ptr, c->d_materials.ptr, s.d_block_stats.ptr);
-      hipLaunchKernelGGL((k_raster<TW, TH, true>), dim3(fp.tiles_x, fp.tiles_y), dim3(kTileThreads), 0, st, fp, s.d_tris.ptr,
-                         s.d_clip.ptr, ctr, s.d_tile_count.ptr, s.d_bins.ptr, s.d_broad.ptr, s.d_frags.ptr, s.d_frag_count.ptr,
-                         (float4 *)nullptr, (uint32_t *)nullptr, (float *)nullptr,
+                         n_prims, s.d_tris.ptr, s.d_attrs.ptr, s.d_tile_count.ptr, s.d_bins.ptr, ctr, ident, ident, fp, s.d_clip.ptr,
+                         s.d_broad.ptr, c->d_materials.ptr, s.d_block_stats.ptr);
+      hipLaunchKernelGGL((k_raster<TW, TH, true>), dim3(fp.tiles_x, fp.tiles_y), dim3(kTileThreads), 0, st, s.d_tile_count.ptr, ctr,
+                         s.d_broad.ptr, s.d_frag_count.ptr, s.d_frags.ptr, (float4 *)nullptr, fp, s.d_tris.ptr, s.d_clip.ptr,
+                         s.d_bins.ptr, (uint32_t *)nullptr, (float *)nullptr,
                          (const float4 *)nullptr, fs.d_depth.ptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
                          (uint32_t *)nullptr, (uint32_t *)nullptr, (const Light *)nullptr, 0, (CookedLight *)nullptr);
       constexpr int kChunks = TW * TH / kShadeThreads;
