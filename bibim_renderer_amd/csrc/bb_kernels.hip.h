@@ -196,7 +196,8 @@ BB_DEV void store_pixel(uint32_t *p, uint32_t v) { __builtin_nontemporal_store(v
 // (The intermediates that are written once and read once -- fragment words, RasterTri records -- stay ordinary accesses:
 //  non-temporal they made the frame 2 % slower, 112.1 -> 114.8 / 113.8 us: their one reader does find them in the L2.)
 
-BB_DEV f4 mat4_mul(const Mat4 &m, f4 v) {
+template <typename M4>  // (Mat4 in any address space)
+BB_DEV f4 mat4_mul(const M4 &m, f4 v) {
   f4 r;
   r.x = fmaf(m.M[3][0], v.w, fmaf(m.M[2][0], v.z, fmaf(m.M[1][0], v.y, m.M[0][0] * v.x)));
   r.y = fmaf(m.M[3][1], v.w, fmaf(m.M[2][1], v.z, fmaf(m.M[1][1], v.y, m.M[0][1] * v.x)));
@@ -558,16 +559,29 @@ __global__ __launch_bounds__(256) void k_geometry(const DrawDesc *__restrict__ d
     const uint32_t tri = local - inst * draw.tris_per_instance;
 
     BB_STAMP(1);
-    const InstanceBlock &ib = draw.instances[inst];
+    typedef const InstanceBlock __attribute__((address_space(1))) *GlobalInstance;  // (global, not flat, loads)
+    const auto &ib = ((GlobalInstance)draw.instances)[inst];
     // The three 44-byte vertices as few, wide loads (a non-indexed triangle is 132 contiguous bytes: nine
     // dwordx4/x3/x2 loads instead of 33 dword loads).  Lanes are 132 bytes apart, so every load instruction touches
     // ~64 cache lines and the L1's tag rate, not HBM, bounds this phase: fewer instructions is what counts.
-    Vertex vtx[3];
+    // (One shape of loads for indexed and non-indexed meshes -- three 44-byte vertices at three indices, through pointers the
+    //  compiler knows to be global memory: left as an if / else of two copies into the same array it merged them into 33
+    //  flat dword loads with 33 selected addresses.)
+    typedef const Vertex __attribute__((address_space(1))) *GlobalVertex;
+    typedef const uint32_t __attribute__((address_space(1))) *GlobalIndex;
+    uint32_t vi[3] = {3u * tri, 3u * tri + 1u, 3u * tri + 2u};
     if (draw.indices) {
+      const GlobalIndex ix = (GlobalIndex)draw.indices + 3u * tri;
+      vi[0] = ix[0]; vi[1] = ix[1]; vi[2] = ix[2];
+    }
+    const GlobalVertex gv = (GlobalVertex)draw.vertices;
+    Vertex vtx[3];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) __builtin_memcpy(&vtx[k], &draw.vertices[draw.indices[3 * tri + k]], sizeof(Vertex));
-    } else {
-      __builtin_memcpy(vtx, &draw.vertices[3 * tri], 3 * sizeof(Vertex));
+    for (int k = 0; k < 3; ++k) {
+      const GlobalVertex q = gv + vi[k];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { vtx[k].pos[c] = q->pos[c]; vtx[k].normal[c] = q->normal[c]; vtx[k].tangent[c] = q->tangent[c]; }
+      vtx[k].uv[0] = q->uv[0]; vtx[k].uv[1] = q->uv[1];
     }
 #ifdef BB_STAMPS
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -647,7 +661,7 @@ __global__ __launch_bounds__(256) void k_geometry(const DrawDesc *__restrict__ d
           if (draw.material == 1u) {
             o[0] = ib.inv_model.M[0][0]; o[1] = ib.inv_model.M[0][1]; o[2] = ib.inv_model.M[0][2];
           } else {
-            const Mat4 &gv = ib.inv_model;
+            const auto &gv = ib.inv_model;
             f3 n = ld3(v.normal);
             o[0] = v.tangent[0]; o[1] = v.tangent[1]; o[2] = v.tangent[2];  // the gizmo mesh keeps its colour there
             o[3] = fmaf(gv.M[2][0], n.z, fmaf(gv.M[1][0], n.y, gv.M[0][0] * n.x));
@@ -657,9 +671,11 @@ __global__ __launch_bounds__(256) void k_geometry(const DrawDesc *__restrict__ d
         } else {
           // :31-36  normalMat = transpose(mat3(aInvModel))
           f3 n = ld3(v.normal), tg = ld3(v.tangent);
-          const Mat4 &im = ib.inv_model;
-          f3 N = normalize3(mk3(dot3(ld3(im.M[0]), n), dot3(ld3(im.M[1]), n), dot3(ld3(im.M[2]), n)));
-          f3 T = normalize3(mk3(dot3(ld3(im.M[0]), tg), dot3(ld3(im.M[1]), tg), dot3(ld3(im.M[2]), tg)));
+          const auto &im = ib.inv_model;
+          const f3 im0 = mk3(im.M[0][0], im.M[0][1], im.M[0][2]), im1 = mk3(im.M[1][0], im.M[1][1], im.M[1][2]),
+                   im2 = mk3(im.M[2][0], im.M[2][1], im.M[2][2]);
+          f3 N = normalize3(mk3(dot3(im0, n), dot3(im1, n), dot3(im2, n)));
+          f3 T = normalize3(mk3(dot3(im0, tg), dot3(im1, tg), dot3(im2, tg)));
           f3 B = cross3(N, T);
           o[0] = v.uv[0]; o[1] = v.uv[1];
           o[2] = pw[k][0]; o[3] = pw[k][1]; o[4] = pw[k][2];
@@ -676,9 +692,12 @@ __global__ __launch_bounds__(256) void k_geometry(const DrawDesc *__restrict__ d
       pa.packed = nullptr;
       pa.packed_dims = 0u;
       if (!OVERLAY) {
+        // (pointer and sizes read together and combined without a branch: as `packed ? dims : 0` the sizes waited for the pointer)
         const MaterialDesc &md = materials[draw.material];
-        pa.packed = md.packed;
-        pa.packed_dims = md.packed ? ((uint32_t)md.pw | ((uint32_t)md.ph << 16)) : 0u;
+        const uint8_t *const mp = md.packed;
+        const uint32_t mdims = (uint32_t)md.pw | ((uint32_t)md.ph << 16);
+        pa.packed = mp;
+        pa.packed_dims = mdims & (mp ? ~0u : 0u);
       }
       pa.clip_base = kNotClipped;  // (a clipped primitive's is patched in once the clipper has its arena slots, below)
       // planes of the unclipped triangle; zero for a primitive that goes through the clipper (its sub-triangles have their own)
