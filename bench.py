@@ -30,6 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+XGMI_LINK_GBS_PER_DIRECTION = 76.8  # one direction of one xGMI link (153.6 GB/s both ways; seven links per MI355X)
 
 
 def _committed_summary(pattern, workload, kernel):
@@ -184,21 +185,190 @@ def cpu_baseline(cfg, maps, budget_s=20.0):
             "single_thread_value": round(mpix / t_single, 3), "n_shaded": int(n1)}, rgba
 
 
-def self_launch(n_ranks):
-    """Run this very command line as n_ranks ranks under torch.distributed.run (one process per GPU, RCCL over xGMI; rendezvous on
-    127.0.0.1 at a free port).  Returns the launcher's exit code.  Nothing here imports torch or touches a GPU."""
-    import socket
+# ------------------------------------------------------------------------------------------------
+# N > 1: every attempt runs in FRESH child processes under a supervisor that never touches torch or the GPU
+# ------------------------------------------------------------------------------------------------
+# The exchange of an N > 1 run is the one part of this file no single-GPU box can execute (RCCL between two devices, peer
+# stores over xGMI).  If it hangs on real hardware, the run must still end with a line: the supervisor watches the workers'
+# milestones, kills the whole process group of an attempt that stops making progress (or exits non-zero) and starts the next
+# rung of the ladder in NEW processes -- a process that has initialised the GPU is never re-executed or reused:
+#     as asked (default: native, the library's own ncclAllGather)  ->  torch.distributed all-gather  ->  the same, plain RGBA32F
+# The line of the attempt that completes carries `exchange.attempts`: what was tried before it and why it was given up.
+# Two launch forms, one supervisor:
+#   * `python bench.py --gpus N` (no launcher): the parent starts `torch.distributed.run ... bench.py ... --worker` per attempt;
+#   * under a launcher (WORLD_SIZE set, the driver's N > 1 form): every rank process is the supervisor of its own worker, the
+#     ranks agree on "this attempt failed" through a flag file, and each attempt meets on its own rendezvous port.
+MILESTONES = ("spawned", "imported", "group", "first_frame", "warm", "timed", "done")
+
+
+def attempt_ladder(exchange, gather, present):
+    """[(exchange, gather), ...]: the attempt as asked, then the fallbacks (each only once)"""
+    first = (exchange or "native", gather)
+    ladder = [first]
+    for rung in (("torch", gather), ("torch", "rgba32f")):
+        if rung not in ladder and not (present and rung[1] != gather):
+            ladder.append(rung)
+    return ladder
+
+
+def stall_limit_s(waiting_for, steps, warmup, cpu_budget):
+    """seconds without a new milestone before an attempt is given up (BBR_BENCH_STALL_LIMIT: one number for every phase)"""
+    if os.environ.get("BBR_BENCH_STALL_LIMIT"):
+        return float(os.environ["BBR_BENCH_STALL_LIMIT"])
+    return {"imported": 300.0,                                   # the first `import torch` on a fresh box takes minutes
+            "group": 120.0, "first_frame": 180.0,                # rendezvous; textures, uploads, communicator, first exchange
+            "warm": 120.0 + 0.05 * warmup, "timed": 60.0 + 0.05 * steps,
+            "done": 240.0 + 3.0 * cpu_budget}.get(waiting_for, 120.0)
+
+
+def _kill_group(p):
+    import signal
+    for sig, wait in ((signal.SIGTERM, 10.0), (signal.SIGKILL, 10.0)):
+        try:
+            os.killpg(p.pid, sig)
+        except (ProcessLookupError, PermissionError):
+            pass
+        try:
+            p.wait(timeout=wait)
+            return
+        except Exception:   # noqa: BLE001  (subprocess.TimeoutExpired: escalate)
+            continue
+
+
+def run_attempt(cmd, env, watch_ranks, limits, fail_flag=None):
+    """One attempt in its own session (process group).  Returns (ok, stdout_text, why): ok = every watched rank reached
+    "done" (or the group exited 0); why = what was seen otherwise."""
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what this pool's driver supports (RCCL, peer pushes)
-    env.setdefault("OMP_NUM_THREADS", "1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    sys.stdout.flush()
-    return subprocess.call(cmd, env=env)
+    import tempfile
+    import threading
+    fd, ms_path = tempfile.mkstemp(prefix="bbr_bench_ms_")
+    os.close(fd)
+    env = dict(env, BBR_BENCH_MILESTONES=ms_path)
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, start_new_session=True)
+    chunks = []
+    t = threading.Thread(target=lambda: chunks.append(p.stdout.read()), daemon=True)
+    t.start()
+    stage, last, why = 0, time.monotonic(), None
+    reached = {}
+    while True:
+        rc = p.poll()
+        try:
+            for line in open(ms_path).read().splitlines():
+                parts = line.split()
+                if len(parts) == 2 and parts[1] in MILESTONES:
+                    reached[parts[0]] = max(reached.get(parts[0], 0), MILESTONES.index(parts[1]))
+        except OSError:
+            pass
+        now_stage = min([reached.get(str(r), 0) for r in watch_ranks]) if watch_ranks else 0
+        if now_stage > stage:
+            stage, last = now_stage, time.monotonic()
+        if rc is not None:
+            break
+        if stage == len(MILESTONES) - 1:
+            try:
+                p.wait(timeout=60.0)     # everything is done: teardown only
+            except Exception:            # noqa: BLE001
+                _kill_group(p)
+            break
+        waiting_for = MILESTONES[stage + 1]
+        if time.monotonic() - last > limits(waiting_for):
+            why = f"no progress for {limits(waiting_for):.0f} s while waiting for milestone '{waiting_for}' (ranks at {dict(sorted(reached.items()))})"
+            _kill_group(p)
+            break
+        if fail_flag and os.path.exists(fail_flag):
+            why = "another rank gave this attempt up"
+            _kill_group(p)
+            break
+        time.sleep(0.2)
+    t.join(timeout=5.0)
+    try:
+        os.unlink(ms_path)
+    except OSError:
+        pass
+    out = (chunks[0] if chunks else b"").decode(errors="replace")
+    ok = why is None and (stage == len(MILESTONES) - 1 or p.returncode == 0)
+    if not ok and why is None:
+        why = f"exit code {p.returncode} after milestone '{MILESTONES[stage]}'"
+    return ok, out, why
+
+
+def _worker_argv(argv, exchange, gather):
+    """the command line of an attempt: the caller's arguments with --exchange / --gather of this rung, marked --worker"""
+    out, skip = [], False
+    for a in argv:
+        if skip:
+            skip = False
+            continue
+        if a in ("--exchange", "--gather"):
+            skip = True
+            continue
+        if a.startswith("--exchange=") or a.startswith("--gather=") or a == "--worker":
+            continue
+        out.append(a)
+    return out + ["--exchange", exchange, "--gather", gather, "--worker"]
+
+
+def _emit_first_json_line(text):
+    for line in text.splitlines():
+        if line.startswith("{"):
+            sys.stdout.write(line + "\n")
+            sys.stdout.flush()
+            return True
+    return False
+
+
+def supervise(args, argv):
+    """Run the N > 1 bench as a ladder of attempts (see above).  Returns the exit code.  Nothing here imports torch or
+    touches a GPU."""
+    import socket
+    # (the one-GPU rehearsal gathers through gloo, where the library's RCCL communicator cannot come up with two ranks per device)
+    first = args.exchange or ("native" if os.environ.get("BBR_BENCH_BACKEND", "nccl") == "nccl" else "torch")
+    ladder = attempt_ladder(first, args.gather, args.present)
+    limits = lambda name: stall_limit_s(name, args.steps, args.warmup, args.cpu_budget)   # noqa: E731
+    under_launcher = "WORLD_SIZE" in os.environ
+    rank = int(os.environ.get("RANK", "0"))
+    base_env = dict(os.environ)
+    base_env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what this pool's driver supports (RCCL, peer pushes)
+    base_env.setdefault("OMP_NUM_THREADS", "1")
+    attempts = []
+    for k, (exchange, gather) in enumerate(ladder):
+        env = dict(base_env, BBR_BENCH_ATTEMPTS=json.dumps(attempts))
+        wargv = _worker_argv(argv, exchange, gather)
+        flag = None
+        if under_launcher:
+            # this process is rank `rank` of a launcher's group: supervise OUR worker; attempt k meets on its own port
+            port = int(os.environ.get("MASTER_PORT", "29533"))
+            env["MASTER_PORT"] = str(port + 1 + k)
+            # (the launcher's agent hosts the store of ITS rendezvous and tells its children to use it; an attempt's workers
+            #  meet on their own port, where rank 0's worker has to host the store itself)
+            env["TORCHELASTIC_USE_AGENT_STORE"] = "False"
+            flag = os.path.join("/tmp", f"bbr_bench_{os.getppid()}_{port}_attempt{k}.failed")
+            cmd = [sys.executable, os.path.abspath(__file__)] + wargv
+            watch = [rank]
+        else:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + wargv
+            watch = list(range(args.gpus))
+        sys.stdout.flush()
+        ok, out, why = run_attempt(cmd, env, watch, limits, flag)
+        if ok:
+            if rank == 0 and not _emit_first_json_line(out):
+                ok, why = False, "the attempt ended without a JSON line"
+            else:
+                return 0
+        attempts.append({"exchange": exchange, "gather": gather, "gave_up_because": why})
+        print(f"[bench supervisor rank {rank}] attempt {k + 1}/{len(ladder)} ({exchange}, {gather}) given up: {why}", file=sys.stderr, flush=True)
+        if flag:
+            try:
+                open(flag, "w").close()   # tell the other ranks' supervisors
+            except OSError:
+                pass
+            time.sleep(1.0)               # let them see it before the next attempt's rendezvous starts
+    print(f"[bench supervisor rank {rank}] every attempt failed: {attempts}", file=sys.stderr, flush=True)
+    return 1
 
 
 def main():
@@ -219,22 +389,28 @@ def main():
     ap.add_argument("--frames-in-flight", type=int, default=None, choices=[1, 2, 3, 4],
                     help="frames queued on the GPU at once (the reference keeps 2).  Default 3, and 4 for c2: a 1080p frame is a "
                          "chain of dependent kernels ~95 us long that fills a fraction of the GPU, so its rate is chain length / "
-                         "frames in flight (C2: 48 / 34 / 28 us per frame with 2 / 3 / 4); at 4K three frames fill the machine "
-                         "(C3: 147 / 134 / 135 us)")
+                         "frames in flight (C2, round 4: 45 / 31 / 24 us per frame with 2 / 3 / 4); at 4K three frames fill the "
+                         "machine (C3, round 4: 120 / 108 / 108 us with 2 / 3 / 4 on the round's first build; "
+                         "profiles/r04_scheduling_experiments.txt)")
     ap.add_argument("--stream-layout", type=int, default=2, choices=[0, 1, 2],
                     help="option stream_layout of the library (include/bibim_hip.h); 2 (one stream per frame slot) is its default")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="any other option of the library (bbr_set_option), e.g. --opt no_tail_items=0; recorded in config.options")
-    ap.add_argument("--gather", default="packed", choices=["packed", "rgba32f"],
+    ap.add_argument("--gather", default="packed", choices=["packed", "rgba32f", "rgba16f"],
                     help="N > 1: what the all-gather moves -- the shard as rgb + one alpha bit per pixel (lossless, 12.1 B per "
-                         "pixel; default) or as plain RGBA32F (16 B); the reassembled frame is the same, bit for bit")
+                         "pixel; default) or as plain RGBA32F (16 B); the reassembled frame is the same, bit for bit.  rgba16f: "
+                         "every channel rounded to binary16, the reference's own HDR attachment format (8 B per pixel, LOSSY: a "
+                         "different output, reported as such in config.output, never the default)")
+    ap.add_argument("--worker", action="store_true",
+                    help="(internal) this process is one rank of one attempt, started by the supervisor (see `supervise`)")
     ap.add_argument("--exchange", default=None, choices=["torch", "native", "peer"],
                     help="N > 1: who runs the exchange.  native (default): bbr_allgather_frame -- the library packs, calls "
                          "ncclAllGather (RCCL over xGMI) on the frame's own stream and un-interleaves (the id travels through "
                          "torch.distributed once).  torch: torch.distributed all_gather_into_tensor (RCCL) on a stream of the "
                          "harness + the library's un-interleave kernel.  peer: bbr_push_shard -- one kernel stores this rank's "
                          "block into every rank's gather buffer (IPC handles; all xGMI links at once), a host barrier orders "
-                         "the landing.  None of the three has run on more than one GPU (DESIGN.md section 5)")
+                         "the landing.  None of the three has run on more than one GPU (DESIGN.md section 5): every N > 1 run is "
+                         "a ladder of attempts in fresh processes (as asked -> torch -> torch rgba32f), see `supervise`")
     ap.add_argument("--force-dist", action="store_true", help="exercise the all-gather path with WORLD_SIZE = 1")
     ap.add_argument("--render-pass", default="forward", choices=["forward", "deferred"],
                     help="forward_brdf.* (the path BASELINE measures) or the reference's deferred path, gbuffer.* + brdf.*")
@@ -251,12 +427,25 @@ def main():
     if args.frames_in_flight is None:
         args.frames_in_flight = 4 if args.workload == "c2" else 3
 
-    # `python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves, as CHILD processes of
-    # torch.distributed.run, before this process has imported torch or made any HIP call (a process that has touched the
-    # GPU must never be replaced or re-executed on this pool).  Rank 0's JSON line reaches the caller through the
-    # inherited stdout; the exit code is the launcher's (non-zero if any rank failed).
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        raise SystemExit(self_launch(args.gpus))
+    # N > 1: this process is a SUPERVISOR unless it was started as a worker (--worker).  It starts the ranks of one attempt
+    # after the other as CHILD processes -- before it has imported torch or made any HIP call (a process that has touched
+    # the GPU must never be replaced or re-executed on this pool) -- and relays the JSON line of the attempt that completes.
+    if args.gpus > 1 and not args.worker:
+        raise SystemExit(supervise(args, sys.argv[1:]))
+
+    # milestones for the supervisor (N > 1) and the rehearsal hook that makes a rank stall at one of them
+    ms_path = os.environ.get("BBR_BENCH_MILESTONES")
+    my_rank = int(os.environ.get("RANK", "0"))
+
+    def mark(name):
+        hook = os.environ.get("BBR_BENCH_STALL", "").split(":")   # "exchange:rank:milestone", e.g. native:1:first_frame
+        if len(hook) == 3 and hook[0] == (args.exchange or "native") and hook[1] == str(my_rank) and hook[2] == name:
+            print(f"[bench rank {my_rank}] BBR_BENCH_STALL: stalling in front of '{name}'", file=sys.stderr, flush=True)
+            time.sleep(1e6)
+        if ms_path:
+            with open(ms_path, "a") as f:
+                f.write(f"{my_rank} {name}\n")
+    mark("spawned")
 
     # The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints a version banner when its
     # communicator comes up): from here on file descriptor 1 is stderr, and the JSON line goes to the real stdout.
@@ -265,6 +454,7 @@ def main():
     os.dup2(2, 1)
 
     import torch
+    mark("imported")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -292,6 +482,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    mark("group")
 
     from bibim_renderer_amd import Renderer, configs, textures
     from bibim_renderer_amd import scene as S
@@ -329,30 +520,37 @@ def main():
         gathered_t = [torch.empty((world * shard_rows, W, 4), dtype=torch.float32, device="cuda") for _ in range(2)]  # [rank][shard row]
         frame_t = [torch.empty((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
         packed = args.gather == "packed" and not args.present
+        half = args.gather == "rgba16f" and not args.present
         from bibim_renderer_amd import partition as P
-        form = P.SHARD_RGBA8 if args.present else (P.SHARD_PACKED if packed else P.SHARD_RGBA32F)
+        form = P.SHARD_RGBA8 if args.present else (P.SHARD_PACKED if packed else (P.SHARD_RGBA16F if half else P.SHARD_RGBA32F))
         exchange_note = None
         if args.exchange == "native":
             # the 128-byte id: made by rank 0's library, handed round by the harness, one ncclCommInitRank per rank.  If any
             # rank cannot open its communicator (no librccl for dlopen, ...) ALL ranks fall back to the torch exchange -- a
             # collective must be entered by everybody or by nobody.
-            ok, why = 1, ""
+            # First a vote on something that is NOT collective -- can this rank load librccl and make an id at all? -- and only
+            # if every rank says yes do they enter ncclCommInitRank together: a rank that failed locally and went straight to
+            # the vote would leave the others waiting inside the collective.
+            ok, why, box = 1, "", [None]
             try:
-                box = [r.comm_unique_id() if rank == 0 else None]
+                r.comm_probe()
+                if rank == 0:
+                    box = [r.comm_unique_id()]
             except Exception as e:   # noqa: BLE001  (reported below)
-                box, ok, why = [None], 0, f"bbr_comm_unique_id: {e}"
-            if world > 1:
-                dist.broadcast_object_list(box, src=0)
-            if ok and box[0] is not None:
-                try:
-                    r.comm_init(rank, world, box[0])
-                except Exception as e:   # noqa: BLE001
-                    ok, why = 0, f"bbr_comm_init: {e}"
-            else:
-                ok = 0
+                ok, why = 0, f"bbr_comm_probe / bbr_comm_unique_id: {e}"
             flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
             if world > 1:
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                if world > 1:
+                    dist.broadcast_object_list(box, src=0)
+                try:
+                    r.comm_init(rank, world, box[0])     # collective; a failure here is the supervisor's to catch (stall / exit code)
+                except Exception as e:   # noqa: BLE001
+                    ok, why = 0, f"bbr_comm_init: {e}"
+                flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+                if world > 1:
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()) == 0:
                 exchange_note = f"native exchange unavailable on some rank ({why or 'another rank'}): torch.distributed all-gather instead"
                 print(f"[bench rank {rank}] {exchange_note}", file=sys.stderr, flush=True)
@@ -373,8 +571,8 @@ def main():
             peer_ptrs = [[mine[b] if p == rank else r.ipc_open(handles[p][1][b]) for p in range(world)] for b in range(2)]
             pushed = [torch.cuda.Event(), torch.cuda.Event()]
             pending = []
-        if packed:
-            pb = r.packed_shard_bytes()
+        if packed or half:   # (a staged block: made by the library from the shard, un-made by bbr_unpack_whole)
+            pb = r.exchange_block_bytes(form)
             packed_t = [torch.empty((pb,), dtype=torch.uint8, device="cuda") for _ in range(2)]
             gathered_packed_t = [torch.empty((world * pb,), dtype=torch.uint8, device="cuda") for _ in range(2)]
         if args.present:
@@ -427,11 +625,11 @@ def main():
             r.present(shard8_t[b].data_ptr())
         r.stream_wait_frame(ag_stream.cuda_stream)
         with torch.cuda.stream(ag_stream):
-            if packed:
-                r.pack_shard(packed_t[b].data_ptr(), ag_stream.cuda_stream)
+            if packed or half:
+                r.stage_shard(form, packed_t[b].data_ptr(), ag_stream.cuda_stream)
                 consumed[b].record(ag_stream)
             src, dst = (shard8_t[b], gathered8_t[b]) if args.present else (
-                (packed_t[b], gathered_packed_t[b]) if packed else (shard_t[b], gathered_t[b]))
+                (packed_t[b], gathered_packed_t[b]) if (packed or half) else (shard_t[b], gathered_t[b]))
             if n >= 2:
                 ag_stream.wait_event(unpacked[b])                # un-interleave n-2 has finished reading dst
             if backend == "nccl":
@@ -441,15 +639,15 @@ def main():
                 h_dst = torch.empty(dst.shape, dtype=dst.dtype)
                 dist.all_gather_into_tensor(h_dst, h_src)
                 dst.copy_(h_dst)
-            if not packed:
+            if not (packed or half):
                 consumed[b].record(ag_stream)
             gathered_ev[b].record(ag_stream)
         with torch.cuda.stream(up_stream):
             up_stream.wait_event(gathered_ev[b])
             if args.present:
                 r.unpack_gathered_rgba8(gathered8_t[b].data_ptr(), frame8_t[b].data_ptr(), up_stream.cuda_stream)
-            elif packed:
-                r.unpack_gathered_packed(gathered_packed_t[b].data_ptr(), frame_t[b].data_ptr(), up_stream.cuda_stream)
+            elif packed or half:
+                r.unpack_whole(form, gathered_packed_t[b].data_ptr(), frame_t[b].data_ptr(), up_stream.cuda_stream)
             else:
                 r.unpack_gathered(gathered_t[b].data_ptr(), frame_t[b].data_ptr(), up_stream.cuda_stream)
             unpacked[b].record(up_stream)
@@ -476,6 +674,7 @@ def main():
     # first frame sizes every capacity (bins etc.); synchronize() re-renders if one overflowed
     step()
     fence()
+    mark("first_frame")
     stats = r.stats()
     # The host side of a step is one ctypes call into the C++ shim; a cyclic-GC pass of the interpreter (tens of ms with
     # torch's object graph loaded) inside the timed region would be a stall of the harness, not of the renderer.  Collect
@@ -514,6 +713,7 @@ def main():
         torch.cuda.synchronize()
     if use_events:
         r.timing_reset()   # (host-side after the synchronize: the samples of the warm-up steps are dropped)
+    mark("warm")
     overflow_before = r.capacity_growths()   # host-side counter
     frames_before = step_no[0] + overflow_before   # frames submitted so far (incl. the re-renders after overflows)
     t0 = time.perf_counter()
@@ -530,6 +730,7 @@ def main():
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     fence()
+    mark("timed")
     if r.capacity_growths() != overflow_before:   # (overflows healed during the warm-up frames do not count)
         raise SystemExit("a capacity overflowed inside the timed region: the frames timed were incomplete")
     gc.enable()
@@ -588,10 +789,28 @@ def main():
         if world == 1 and not args.force_dist:
             roofline["valu"] = valu_roofline(args.workload, "k_shade", avg_shade_ms, n_cus)
         if dist is not None:
-            # every rank's own k_shade figures (its bands of the frame), gathered to rank 0's line
+            # every rank's own figures (its bands of the frame), gathered to rank 0's line: k_shade inside the timed region,
+            # and -- after it, one frame in flight, no exchange -- what each of the rank's three kernels costs by itself
+            r.set_option("frames_in_flight", 1)
+            r.set_option("timing_stride", 1)
+            r.set_option("timing", 1)
+            if not (args.exchange == "native"):
+                r.set_output_device_ptr(shard_t[0].data_ptr(), shard_t[0].numel() * 4)
+            for _ in range(4):
+                S.draw_frame(r, scene, cam, settings, material)
+            r.synchronize()
+            r.timing_reset()
+            for _ in range(20):
+                S.draw_frame(r, scene, cam, settings, material)
+            r.synchronize()
+            _, f1r, g1r, ra1r, s1r = r.timing_summary()
+            r.set_option("timing", 0)
+            r.set_option("frames_in_flight", args.frames_in_flight)
             mine = {"rank": rank, "device": local_rank, "n_shaded": int(stats["n_shaded"]), "avg_kernel_ms": round(avg_shade_ms, 5),
                     "algorithmic_bytes_per_launch": int(shade_bytes), "achieved": round(achieved, 2),
-                    "frac": round(achieved / HBM_PEAK_GBS, 4)}
+                    "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "alone": {"avg_geometry_ms": round(g1r, 5), "avg_raster_ms": round(ra1r, 5), "avg_shade_ms": round(s1r, 5),
+                              "avg_device_frame_latency_ms": round(f1r, 5)}}
             per_rank = [None] * world
             dist.all_gather_object(per_rank, mine)
             roofline["per_rank"] = per_rank
@@ -666,6 +885,35 @@ def main():
             "what": "binary16 HDR -> tone map (on, exposure 1) -> sRGB UNORM8 of the whole frame"}
         r.set_option("frames_in_flight", args.frames_in_flight)
 
+    # north_star asks for 1080p AND 4K figures: after the timed region of the default (C3) run, C2 -- ShaderBall, one point
+    # light, 1920x1080 -- for a hundred steps with ITS four frames in flight, in a context of its own
+    also = None
+    if args.workload == "c3" and not dist_path and not args.present and args.render_pass == "forward" and not args.opt:
+        cfg2 = configs.CONFIGS["c2"]
+        r.synchronize()
+        rb = Renderer(cfg2.width, cfg2.height, device=local_rank)
+        rb.set_option("frames_in_flight", 4)
+        mb = rb.upload_material(textures.make_material(cfg2.texture_size))
+        sb, cb, setb = S.config_scene(rb, cfg2, ball)
+        S.draw_frame(rb, sb, cb, setb, mb)
+        rb.synchronize()
+        for _ in range(60):
+            S.draw_frame(rb, sb, cb, setb, mb)
+        rb.synchronize()
+        torch.cuda.synchronize()
+        n_c2 = 100
+        tb = time.perf_counter()
+        for _ in range(n_c2):
+            S.draw_frame(rb, sb, cb, setb, mb)
+        torch.cuda.synchronize()
+        tb = time.perf_counter() - tb
+        rb.synchronize()
+        also = {"c2_1080p": {"workload": f"{cfg2.name}: {cfg2.description}", "steps": n_c2, "frames_in_flight": 4,
+                             "ms_per_step": round(tb / n_c2 * 1e3, 5), "value": round(cfg2.width * cfg2.height * n_c2 / tb / 1e6, 2),
+                             "unit": "Mpixels/s", "n_shaded": int(rb.stats()["n_shaded"])}}
+        sb.close()
+        rb.close()
+
     verified = None
     if args.verify and dist_path:
         last = (step_no[0] - 1) & 1
@@ -684,6 +932,9 @@ def main():
             want = r2.read_presented()
         else:
             want = r2.read_framebuffer()
+            if half:   # the binary16 wire form: every channel of the unpartitioned frame to the nearest binary16 value
+                with np.errstate(over="ignore"):
+                    want = want.astype(np.float16).astype(np.float32)
         verified = bool(np.array_equal(got.view(np.uint8), want.view(np.uint8)))
         if not verified and os.environ.get("BBR_BENCH_DEBUG"):
             S.draw_frame(r2, scene2, cam2, settings2, m2)
@@ -710,7 +961,7 @@ def main():
                              f"(first {rows[:8].tolist()}, last {rows[-3:].tolist()}){extra}")
 
     cpu, parity, parity_literal = None, None, None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline:   # (N > 1: on rank 0's host cores, while the other ranks wait at the final barrier)
         cpu, oracle_frame = cpu_baseline(cfg, maps, args.cpu_budget)
         if cpu["n_shaded"] != n_shaded_total:
             raise SystemExit(f"GPU shaded {n_shaded_total} pixels, oracle {cpu['n_shaded']}: parity broken")
@@ -752,13 +1003,16 @@ def main():
                        "partition": "single GPU" if world == 1 else f"interleaved {args.band_rows or r.tile_height()}-row bands, "
                                     f"{world} ranks, " + {"torch": "ncclAllGather (torch.distributed) of ",
                                                           "native": "bbr_allgather_frame (ncclAllGather on the frame's stream) of ",
-                                                          "peer": "bbr_push_shard (hipMemcpyPeerAsync into every rank's buffer) of "}[args.exchange] + (
+                                                          "peer": "bbr_push_shard (one kernel storing to every rank's buffer; copies if a peer cannot be mapped) of "}[args.exchange] + (
                                         "RGBA8 shards" if args.present else
                                         "shards packed as rgb + alpha bit (lossless, 12.1 B/pixel)" if args.gather == "packed"
+                                        else "shards rounded to binary16 (8 B/pixel, lossy)" if args.gather == "rgba16f"
                                         else "RGBA32F shards") + " + un-interleave",
                        "tile": f"{stats['tile_w']}x{stats['tile_h']}",
                        "output": ("presented RGBA8 (fused)" if args.present_fused else "RGBA32F frame + presented RGBA8")
-                                 if args.present else "RGBA32F frame",
+                                 if args.present else ("RGBA32F frame" if not (dist_path and half) else
+                                                       "frame of binary16 values (R16G16B16A16_SFLOAT, the reference's HDR attachment format, "
+                                                       "src/render.h:94), widened to RGBA32F -- LOSSY, not the default metric's output"),
                        "render_pass": args.render_pass,
                        "stream_layout": layout, **({"options": args.opt} if args.opt else {})},
             "roofline": roofline, "cpu_baseline": cpu,
@@ -768,13 +1022,43 @@ def main():
             "shaded_fraction_of_frame": round(n_shaded_total / float(W * H), 4),
         }
         if dist_path:
+            block_bytes = int(r.exchange_block_bytes(form))
+            # what the links allow, so that a reader of a scaling record can hold the measurement against it: every rank has to
+            # RECEIVE world - 1 blocks per frame.  On the node's full mesh each of them can arrive over its own xGMI link (the
+            # direct pattern: bbr_push_shard, or RCCL when it picks a direct algorithm): block / link rate; a ring passes every
+            # block through every link in turn: (world - 1) x block / link rate.
+            link = XGMI_LINK_GBS_PER_DIRECTION
+            direct_ms = block_bytes / (link * 1e9) * 1e3 if world > 1 else 0.0
+            ring_ms = direct_ms * (world - 1)
+            rccl_ranks = None
+            if args.exchange == "native":
+                try:
+                    rccl_ranks = r.comm_count()   # ncclCommCount on the library's own communicator
+                except Exception as e:            # noqa: BLE001
+                    rccl_ranks = f"unavailable: {e}"
+            try:
+                attempts_before = json.loads(os.environ.get("BBR_BENCH_ATTEMPTS", "[]"))
+            except ValueError:
+                attempts_before = []
             out["exchange"] = {"who": args.exchange, "form": {P.SHARD_RGBA8: "rgba8", P.SHARD_PACKED: "packed rgb + alpha bit",
-                                                              P.SHARD_RGBA32F: "rgba32f"}[form],
-                               "bytes_per_rank_block": int(r.exchange_block_bytes(form)),
-                               "bytes_received_per_rank_per_frame": int(r.exchange_block_bytes(form)) * (world - 1),
-                               "ranks_in_communicator": int(dist.get_world_size()), "backend": backend,
+                                                              P.SHARD_RGBA32F: "rgba32f", P.SHARD_RGBA16F: "rgba16f"}[form],
+                               "bytes_per_rank_block": block_bytes,
+                               "bytes_received_per_rank_per_frame": block_bytes * (world - 1),
+                               "ranks_in_communicator": int(dist.get_world_size()),
+                               "ranks_in_communicator_is": "torch.distributed's world size; rccl_ranks is what the library's own communicator reports",
+                               "rccl_ranks": rccl_ranks, "backend": backend,
                                "band_rows": int(args.band_rows or r.tile_height()), "shard_rows": int(r.shard_rows()),
+                               "link_rate_gbs_assumed": link,
+                               "link_rate_is": "xGMI, one direction of one link: half of the 153.6 GB/s a link carries both ways; seven links per GPU",
+                               "link_bound_ms_estimate": round(direct_ms, 4), "link_bound_ms_estimate_ring": round(ring_ms, 4),
+                               "link_bound_mpixels_per_s_estimate": (round(W * H / (direct_ms * 1e-3) / 1e6, 1) if direct_ms > 0 else None),
+                               "link_bound_is": "block / link rate: every rank receives world - 1 blocks per frame, each over its own link of the "
+                                                "full mesh at best (ring: x (world - 1)); with frames in flight the exchange of frame n overlaps "
+                                                "the rendering of n + 1, so the frame period is at least max(this, a rank's rendering time)",
+                               "attempts": attempts_before,
                                **({"note": exchange_note} if exchange_note else {})}
+        if also is not None:
+            out["also"] = also
         if verified is not None:
             out["verified_against_unpartitioned_render"] = verified
         if parity is not None:
@@ -784,6 +1068,9 @@ def main():
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
+    if dist is not None:
+        dist.barrier()   # (rank 0 may have spent a while on the CPU baseline)
+    mark("done")
     scene.close()
     r.close()
     if dist is not None:

@@ -91,6 +91,9 @@ SIGNATURES = {
     "bbr_comm_unique_id": (C.c_int, [_P, _P]),
     "bbr_comm_init": (C.c_int, [_P, C.c_int32, C.c_int32, _P]),
     "bbr_comm_destroy": (C.c_int, [_P]),
+    "bbr_comm_probe": (C.c_int, [_P]),
+    "bbr_comm_count": (C.c_int, [_P, C.POINTER(C.c_int32)]),
+    "bbr_stage_shard": (C.c_int, [_P, C.c_int32, _P, _P]),
     "bbr_exchange_block_bytes": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_uint64)]),
     "bbr_allgather_frame": (C.c_int, [_P, C.c_int32, _P, _P, _P]),
     "bbr_push_shard": (C.c_int, [_P, C.c_int32, C.POINTER(_P), C.POINTER(C.c_int32), _P]),
@@ -107,7 +110,7 @@ SIGNATURES = {
     "bbr_ipc_close": (C.c_int, [_P, _P]),
 }
 COMM_ID_BYTES, IPC_HANDLE_BYTES = 128, 64
-SHARD_RGBA32F, SHARD_PACKED, SHARD_RGBA8 = 0, 1, 2
+SHARD_RGBA32F, SHARD_PACKED, SHARD_RGBA8, SHARD_RGBA16F = 0, 1, 2, 3
 
 # every symbol include/bibim_scene.h declares (C surface of the C++ Scene/Camera/drawFrame shim)
 _F = C.c_float

@@ -2327,6 +2327,34 @@ __global__ void k_unpack_gathered_packed(const uint8_t *__restrict__ gathered, f
   frame[i] = make_float4(rgb[0], rgb[1], rgb[2], ((m >> (j & 63)) & 1ull) ? 1.0f : 0.0f);
 }
 
+// The reference's own HDR attachment format as a wire form (R16G16B16A16_SFLOAT, src/render.h:94, src/main.cpp:463-472):
+// 8 bytes per pixel, half of the fp32 shard.  Lossy -- every channel is rounded to the nearest binary16 value (ties to even,
+// the rounding an attachment write performs: bb_half_round) -- and therefore a separate output, never the default.
+__global__ void k_pack_shard_half(const float4 *__restrict__ shard, uint2 *__restrict__ out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = shard[i];
+  const _Float16 h[4] = {(_Float16)p.x, (_Float16)p.y, (_Float16)p.z, (_Float16)p.w};
+  uint2 w;
+  __builtin_memcpy(&w, h, 8);
+  out[i] = w;
+}
+
+// [world][shard_rows][width] RGBA16F -> row-major frame, widened to RGBA32F (every binary16 value is a binary32 value)
+__global__ void k_unpack_gathered_half(const uint2 *__restrict__ gathered, float4 *__restrict__ frame, int width, int height,
+                                       int world, int band_rows, int shard_rows) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t n = (size_t)width * (size_t)height;
+  if (i >= n) return;
+  int y = (int)(i / (size_t)width), x = (int)(i - (size_t)y * width);
+  int band = y / band_rows, r = y - band * band_rows;
+  int rank = band % world, lb = band / world;
+  const uint2 w = gathered[((size_t)rank * shard_rows + (size_t)lb * band_rows + r) * (size_t)width + x];
+  _Float16 h[4];
+  __builtin_memcpy(h, &w, 8);
+  frame[i] = make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+}
+
 // [world][shard_rows][width] RGBA8 -> row-major presented frame (same un-interleave as k_unpack_gathered)
 __global__ void k_unpack_gathered_rgba8(const uint32_t *__restrict__ gathered, uint32_t *__restrict__ frame, int width,
                                         int height, int world, int band_rows, int shard_rows) {

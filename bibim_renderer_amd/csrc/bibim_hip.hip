@@ -37,6 +37,7 @@ struct Rccl {
   decltype(&ncclCommInitRank) comm_init_rank = nullptr;
   decltype(&ncclAllGather) all_gather = nullptr;
   decltype(&ncclCommDestroy) comm_destroy = nullptr;
+  decltype(&ncclCommCount) comm_count = nullptr;
   decltype(&ncclGetErrorString) error_string = nullptr;
 };
 Rccl g_rccl;
@@ -1928,8 +1929,10 @@ namespace {
 
 size_t exchange_block_bytes(const bbr_context *c, int form) {
   const size_t n = (size_t)c->width * c->shard_rows();
-  return form == BBR_SHARD_RGBA32F ? n * 16 : (form == BBR_SHARD_PACKED ? packed_block_bytes(c) : n * 4);
+  return form == BBR_SHARD_RGBA32F ? n * 16 : (form == BBR_SHARD_PACKED ? packed_block_bytes(c) : (form == BBR_SHARD_RGBA16F ? n * 8 : n * 4));
 }
+// bytes per pixel of the whole frame an exchange of this form leaves behind (the binary16 form is widened to fp32)
+size_t whole_pixel_bytes(int form) { return form == BBR_SHARD_RGBA8 ? 4 : 16; }
 
 int open_rccl(bbr_context *c) {
   std::lock_guard<std::mutex> lock(g_rccl_mutex);
@@ -1945,8 +1948,9 @@ int open_rccl(bbr_context *c) {
   r.comm_init_rank = (decltype(r.comm_init_rank))dlsym(lib, "ncclCommInitRank");
   r.all_gather = (decltype(r.all_gather))dlsym(lib, "ncclAllGather");
   r.comm_destroy = (decltype(r.comm_destroy))dlsym(lib, "ncclCommDestroy");
+  r.comm_count = (decltype(r.comm_count))dlsym(lib, "ncclCommCount");
   r.error_string = (decltype(r.error_string))dlsym(lib, "ncclGetErrorString");
-  if (!r.get_unique_id || !r.comm_init_rank || !r.all_gather || !r.comm_destroy || !r.error_string)
+  if (!r.get_unique_id || !r.comm_init_rank || !r.all_gather || !r.comm_destroy || !r.comm_count || !r.error_string)
     return fail(c, BBR_ERR_HIP, "librccl lacks an entry point");
   r.lib = lib;
   g_rccl = r;
@@ -1969,14 +1973,19 @@ int stage_block(bbr_context *c, FrameSlot &s, int form, void *dst, hipStream_t s
     HIP_TRY(c, hipGetLastError());
     return BBR_OK;
   }
+  if (form == BBR_SHARD_RGBA16F) {
+    hipLaunchKernelGGL(k_pack_shard_half, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float4 *)s.out_used, (uint2 *)dst, n);
+    HIP_TRY(c, hipGetLastError());
+    return BBR_OK;
+  }
   const void *src = form == BBR_SHARD_RGBA32F ? (const void *)s.out_used : (const void *)s.present.out;
   if (src != dst) HIP_TRY(c, hipMemcpyAsync(dst, src, exchange_block_bytes(c, form), hipMemcpyDeviceToDevice, st));
   return BBR_OK;
 }
 
 int check_exchange(bbr_context *c, int form, const char *who) {
-  if (form != BBR_SHARD_RGBA32F && form != BBR_SHARD_PACKED && form != BBR_SHARD_RGBA8)
-    return fail(c, BBR_ERR_INVALID_ARGUMENT, std::string(who) + ": form must be BBR_SHARD_RGBA32F, _PACKED or _RGBA8");
+  if (form != BBR_SHARD_RGBA32F && form != BBR_SHARD_PACKED && form != BBR_SHARD_RGBA8 && form != BBR_SHARD_RGBA16F)
+    return fail(c, BBR_ERR_INVALID_ARGUMENT, std::string(who) + ": form must be BBR_SHARD_RGBA32F, _PACKED, _RGBA8 or _RGBA16F");
   if (!c->have_frame || c->last_slot < 0) return fail(c, BBR_ERR_NOT_IN_FRAME, std::string(who) + ": nothing rendered");
   const FrameSlot &s = c->slots[c->last_slot];
   if (form == BBR_SHARD_RGBA8) {
@@ -1996,6 +2005,9 @@ int unpack_whole(bbr_context *c, int form, const void *gathered, void *whole, hi
   else if (form == BBR_SHARD_PACKED)
     hipLaunchKernelGGL(k_unpack_gathered_packed, grid, block, 0, st, (const uint8_t *)gathered, (float4 *)whole, c->width, c->height,
                        c->world, c->eff_band_rows(), c->shard_rows(), packed_block_bytes(c), packed_mask_offset(c));
+  else if (form == BBR_SHARD_RGBA16F)
+    hipLaunchKernelGGL(k_unpack_gathered_half, grid, block, 0, st, (const uint2 *)gathered, (float4 *)whole, c->width, c->height,
+                       c->world, c->eff_band_rows(), c->shard_rows());
   else
     hipLaunchKernelGGL(k_unpack_gathered_rgba8, grid, block, 0, st, (const uint32_t *)gathered, (uint32_t *)whole, c->width, c->height,
                        c->world, c->eff_band_rows(), c->shard_rows());
@@ -2033,6 +2045,33 @@ int bbr_comm_init(bbr_context *c, int32_t rank, int32_t world, const uint8_t *un
   return BBR_OK;
 }
 
+int bbr_comm_probe(bbr_context *c) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  BBR_ON_DEVICE(c);
+  return open_rccl(c);  // dlopen + dlsym only: nothing collective, safe to call on one rank alone
+}
+
+int bbr_comm_count(bbr_context *c, int32_t *out_ranks) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  if (!out_ranks) return fail(c, BBR_ERR_INVALID_ARGUMENT, "comm_count: NULL");
+  if (!c->comm) return fail(c, BBR_ERR_NOT_IN_FRAME, "comm_count: no communicator (bbr_comm_init)");
+  int n = 0;
+  RCCL_TRY(c, g_rccl.comm_count(c->comm, &n));
+  *out_ranks = n;
+  return BBR_OK;
+}
+
+int bbr_stage_shard(bbr_context *c, int32_t form, void *block_device, void *stream) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  BBR_ON_DEVICE(c);
+  int rc = check_exchange(c, form, "stage_shard");
+  if (rc) return rc;
+  if (!block_device) return fail(c, BBR_ERR_INVALID_ARGUMENT, "stage_shard: NULL");
+  FrameSlot &s = c->slots[c->last_slot];
+  hipStream_t st = stream ? (hipStream_t)stream : s.stream_used;  // a caller's stream must already wait for the frame
+  return stage_block(c, s, form, block_device, st);
+}
+
 int bbr_comm_destroy(bbr_context *c) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
   BBR_ON_DEVICE(c);
@@ -2048,7 +2087,7 @@ int bbr_comm_destroy(bbr_context *c) {
 }
 
 int bbr_exchange_block_bytes(const bbr_context *c, int32_t form, uint64_t *out_bytes) {
-  if (!c || !out_bytes || form < 0 || form > BBR_SHARD_RGBA8) return BBR_ERR_INVALID_ARGUMENT;
+  if (!c || !out_bytes || form < 0 || form > BBR_SHARD_RGBA16F) return BBR_ERR_INVALID_ARGUMENT;
   *out_bytes = exchange_block_bytes(c, form);
   return BBR_OK;
 }
@@ -2068,7 +2107,7 @@ int bbr_allgather_frame(bbr_context *c, int32_t form, void *gathered, void *whol
     gathered = s.d_gathered.ptr;
   }
   if (!whole) {
-    HIP_TRY(c, s.d_whole.ensure((size_t)c->width * c->height * (form == BBR_SHARD_RGBA8 ? 4 : 16)));
+    HIP_TRY(c, s.d_whole.ensure((size_t)c->width * c->height * whole_pixel_bytes(form)));
     whole = s.d_whole.ptr;
   }
   hipStream_t st = stream ? (hipStream_t)stream : s.stream_used;
@@ -2156,11 +2195,11 @@ int bbr_push_state(const bbr_context *c, int32_t *out_direct) {
 int bbr_unpack_whole(bbr_context *c, int32_t form, const void *gathered, void *whole, void *stream) {
   if (!c) return BBR_ERR_INVALID_ARGUMENT;
   BBR_ON_DEVICE(c);
-  if (form < 0 || form > BBR_SHARD_RGBA8 || !gathered) return fail(c, BBR_ERR_INVALID_ARGUMENT, "unpack_whole: bad form / NULL");
+  if (form < 0 || form > BBR_SHARD_RGBA16F || !gathered) return fail(c, BBR_ERR_INVALID_ARGUMENT, "unpack_whole: bad form / NULL");
   if (c->last_slot < 0) return fail(c, BBR_ERR_NOT_IN_FRAME, "unpack_whole: nothing rendered");
   FrameSlot &s = c->slots[c->last_slot];
   if (!whole) {
-    HIP_TRY(c, s.d_whole.ensure((size_t)c->width * c->height * (form == BBR_SHARD_RGBA8 ? 4 : 16)));
+    HIP_TRY(c, s.d_whole.ensure((size_t)c->width * c->height * whole_pixel_bytes(form)));
     whole = s.d_whole.ptr;
   }
   int rc = unpack_whole(c, form, gathered, whole, stream ? (hipStream_t)stream : s.stream_used);

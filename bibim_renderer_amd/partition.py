@@ -91,7 +91,9 @@ def unpack_gathered_packed(gathered, height, width, world, band_rows):
 
 # ---- the native exchange (bbr_allgather_frame / bbr_push_shard, include/bibim_hip.h): block sizes and copy order ----
 
-SHARD_RGBA32F, SHARD_PACKED, SHARD_RGBA8 = 0, 1, 2
+SHARD_RGBA32F, SHARD_PACKED, SHARD_RGBA8, SHARD_RGBA16F = 0, 1, 2, 3
+# bytes per pixel of the forms with a fixed pixel size (the packed form: packed_layout)
+_PIXEL_BYTES = {SHARD_RGBA32F: 16, SHARD_RGBA8: 4, SHARD_RGBA16F: 8}
 
 
 def exchange_block_bytes(form, height, width, world, band_rows):
@@ -99,7 +101,7 @@ def exchange_block_bytes(form, height, width, world, band_rows):
     rows = shard_rows(height, world, band_rows)
     if form == SHARD_PACKED:
         return packed_layout(rows, width)[0]
-    return rows * width * (16 if form == SHARD_RGBA32F else 4)
+    return rows * width * _PIXEL_BYTES[form]
 
 
 def push_order(rank, world):
@@ -131,9 +133,12 @@ def push_offset(rank, block_bytes):
 
 
 def encode_block(shard, form):
-    """a rank's shard [rows, W, 4] as the bytes that travel (uint8): float32 RGBA, the packed form, or RGBA8"""
+    """a rank's shard [rows, W, 4] as the bytes that travel (uint8): float32 RGBA, the packed form, RGBA8, or binary16 RGBA"""
     if form == SHARD_PACKED:
         return pack_shard_bits(shard)
+    if form == SHARD_RGBA16F:   # every channel to the nearest binary16 value, ties to even (numpy's conversion; = the oracle's bbo_half_round)
+        with np.errstate(over="ignore"):
+            return np.ascontiguousarray(shard, np.float32).astype(np.float16).view(np.uint8).reshape(-1)
     return np.ascontiguousarray(shard, np.float32 if form == SHARD_RGBA32F else np.uint8).view(np.uint8).reshape(-1)
 
 
@@ -143,5 +148,7 @@ def decode_gathered(gathered, form, height, width, world, band_rows):
     if form == SHARD_PACKED:
         return unpack_gathered_packed(g, height, width, world, band_rows)
     rows = shard_rows(height, world, band_rows)
+    if form == SHARD_RGBA16F:   # widened back to RGBA32F (every binary16 value is a binary32 value)
+        return unpack_gathered(g.view(np.float16).reshape(world, rows, width, 4), height, band_rows).astype(np.float32)
     dt = np.float32 if form == SHARD_RGBA32F else np.uint8
     return unpack_gathered(g.view(dt).reshape(world, rows, width, 4), height, band_rows)

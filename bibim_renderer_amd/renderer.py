@@ -267,6 +267,20 @@ class Renderer:
     def comm_destroy(self):
         self._check(self._L.bbr_comm_destroy(self._ctx))
 
+    def comm_probe(self):
+        """can this process load librccl?  Not collective: ranks vote on it before they enter comm_init together."""
+        self._check(self._L.bbr_comm_probe(self._ctx))
+
+    def comm_count(self):
+        """ranks in the context's communicator, as RCCL reports them (ncclCommCount)"""
+        n = C.c_int32()
+        self._check(self._L.bbr_comm_count(self._ctx, C.byref(n)))
+        return int(n.value)
+
+    def stage_shard(self, form, block_ptr, stream_handle=None):
+        """this rank's block of the last frame in `form` -> block_ptr (exchange_block_bytes(form) bytes)"""
+        self._check(self._L.bbr_stage_shard(self._ctx, form, C.c_void_p(block_ptr), C.c_void_p(stream_handle) if stream_handle else None))
+
     def exchange_block_bytes(self, form):
         n = C.c_uint64()
         self._check(self._L.bbr_exchange_block_bytes(self._ctx, form, C.byref(n)))

@@ -286,7 +286,8 @@ int bbr_tone_map(bbr_context *ctx, int32_t enable_tone_mapping, float exposure);
  *               buffer a peer is still un-interleaving frame n from: two gather buffers per rank, used in turn.
  * Block forms (what travels per rank; bbr_exchange_block_bytes): BBR_SHARD_RGBA32F the fp32 shard (16 B/pixel),
  * BBR_SHARD_PACKED rgb + one alpha bit per pixel (12.1 B, lossless: alpha is 0 or 1; = bbr_pack_shard), BBR_SHARD_RGBA8
- * the presented shard (4 B; needs bbr_present).  `gathered` / `whole` = NULL use buffers owned by the frame's slot
+ * the presented shard (4 B; needs bbr_present), BBR_SHARD_RGBA16F the shard rounded to binary16 (8 B, lossy: a separate
+ * output, see the define).  `gathered` / `whole` = NULL use buffers owned by the frame's slot
  * (bbr_whole_frame_device_ptr, bbr_read_whole_frame).  An exchange never re-renders (one rank alone must not repeat a
  * collective): let the capacities settle with one synchronised frame first, as after any scene change.
  * Not yet run on more than one GPU: see DESIGN.md section 6. */
@@ -295,9 +296,20 @@ int bbr_tone_map(bbr_context *ctx, int32_t enable_tone_mapping, float exposure);
 #define BBR_SHARD_RGBA32F 0
 #define BBR_SHARD_PACKED 1
 #define BBR_SHARD_RGBA8 2
+#define BBR_SHARD_RGBA16F 3 /* every channel rounded to binary16 -- the reference's own HDR attachment format, R16G16B16A16_SFLOAT
+                             * (src/render.h:94, src/main.cpp:463-472): 8 B/pixel, LOSSY; the whole frame is widened back to RGBA32F */
 int bbr_comm_unique_id(bbr_context *ctx, uint8_t *out_id /* BBR_COMM_ID_BYTES */);
 int bbr_comm_init(bbr_context *ctx, int32_t rank, int32_t world, const uint8_t *unique_id /* BBR_COMM_ID_BYTES */);
 int bbr_comm_destroy(bbr_context *ctx);
+/* opens librccl (dlopen + symbol lookup) and nothing else: NOT collective.  Hosts vote on this before they enter
+ * bbr_comm_init together -- a rank that cannot load the library must not leave the others waiting inside ncclCommInitRank */
+int bbr_comm_probe(bbr_context *ctx);
+/* ranks in the context's communicator as RCCL itself reports them (ncclCommCount) */
+int bbr_comm_count(bbr_context *ctx, int32_t *out_ranks);
+/* this rank's block of the last frame in `form`, written to `block_device` (bbr_exchange_block_bytes bytes) on `hip_stream`
+ * (NULL = the frame's own stream): what bbr_allgather_frame / bbr_push_shard do first, for hosts that run the collective
+ * themselves and finish with bbr_unpack_whole */
+int bbr_stage_shard(bbr_context *ctx, int32_t form, void *block_device, void *hip_stream);
 int bbr_exchange_block_bytes(const bbr_context *ctx, int32_t form, uint64_t *out_bytes);
 int bbr_allgather_frame(bbr_context *ctx, int32_t form, void *gathered_device /* world blocks, or NULL */,
                         void *whole_device /* height*width pixels, or NULL */, void *hip_stream);

@@ -518,6 +518,10 @@ float bbo_half_round(float x) {
   return u2f(sign | r);
 }
 
+void bbo_half_round_n(const float *in, float *out, size_t n) {
+  for (size_t i = 0; i < n; ++i) out[i] = bbo_half_round(in[i]);
+}
+
 /* exp as a fixed sequence of binary32 operations: Cody-Waite reduction by ln2 (hi/lo), degree-7 Taylor/Horner in
  * fma, scaling by 2^n in two exact-until-the-last multiplications.  Max error measured over 2^24 points: < 1 ulp. */
 float bbo_exp(float x) {

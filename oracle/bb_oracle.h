@@ -17,6 +17,7 @@
 #ifndef BB_ORACLE_H
 #define BB_ORACLE_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -205,6 +206,7 @@ void bbo_tone_map(float *rgba, uint64_t n_pixels, int32_t enable, float exposure
  * hdr_tone_mapping.frag:9-18, src/render.h:94, src/render.cpp:242-254.  See bb_oracle.c for the contract. */
 void bbo_present(const float *rgba, uint64_t n_pixels, int32_t enable, float exposure, int32_t hdr16, uint8_t *out_rgba8);
 float bbo_half_round(float x);
+void bbo_half_round_n(const float *in, float *out, size_t n); /* the same, element by element */
 float bbo_exp(float x);
 void bbo_srgb_thresholds(float *out255);
 

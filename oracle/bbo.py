@@ -118,6 +118,8 @@ def lib():
         L.bbo_present.restype = None
         L.bbo_half_round.argtypes = [C.c_float]
         L.bbo_half_round.restype = C.c_float
+        L.bbo_half_round_n.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.bbo_half_round_n.restype = None
         L.bbo_exp.argtypes = [C.c_float]
         L.bbo_exp.restype = C.c_float
         L.bbo_srgb_thresholds.argtypes = [C.c_void_p]
@@ -432,7 +434,13 @@ def present(rgba, enable, exposure, hdr16=True):
 
 
 def half_round(x):
-    return np.array([lib().bbo_half_round(float(v)) for v in np.ravel(x)], np.float32).reshape(np.shape(x))
+    """every value to the nearest binary16 value, ties to even (bbo_half_round, the rounding of an RGBA16F attachment write)"""
+    a = np.ascontiguousarray(x, np.float32)
+    if a.size > 64:
+        out = np.empty_like(a)
+        lib().bbo_half_round_n(_p(a), _p(out), a.size)
+        return out.reshape(np.shape(x))
+    return np.array([lib().bbo_half_round(float(v)) for v in np.ravel(a)], np.float32).reshape(np.shape(x))
 
 
 def exp(x):

@@ -2,6 +2,7 @@
 MI355X; r03_bench_under_rocprof.json: the same command under rocprofv3) carry every field of the measurement contract,
 and their numbers hang together with the committed kernel table and counter summaries."""
 import json
+import time
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -75,35 +76,113 @@ def test_traffic_and_valu_come_from_summaries_of_the_same_kernel_sources():
 
 
 def test_bench_with_gpus_n_and_no_launcher_starts_its_own_ranks_before_touching_torch():
-    """`python bench.py --gpus 8 ...` (the driver's N = 1 command form with another N): the ranks are started as children of
-    torch.distributed.run before this process has imported torch or made a HIP call, with the same arguments, rendezvous
-    on 127.0.0.1, and the launcher's exit code is handed on."""
+    """`python bench.py --gpus 8 ...` (the driver's N = 1 command form with another N): the ranks of an attempt are started as
+    children of torch.distributed.run before this process has imported torch or made a HIP call, with the same arguments
+    (+ the attempt's --exchange / --gather and --worker), rendezvous on 127.0.0.1; the JSON line of the attempt that
+    completes is relayed and the exit code is 0."""
     import subprocess
     import sys
     code = r'''
-import os, subprocess, sys
-os.environ.pop("WORLD_SIZE", None)
-seen = {}
-def fake_call(cmd, env=None):
-    seen["cmd"], seen["env"] = cmd, env
-    return 7
-subprocess.call = fake_call
+import json, os, sys
+for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "BBR_BENCH_BACKEND"):
+    os.environ.pop(k, None)
 sys.argv = ["bench.py", "--gpus", "8", "--steps", "20", "--warmup", "5"]
 import bench
+seen = []
+def fake_attempt(cmd, env, watch, limits, flag=None):
+    seen.append((cmd, env, watch, flag))
+    return True, '[rccl banner]\n{"metric": "m", "n_gpus": 8}\n', None
+bench.run_attempt = fake_attempt
 try:
     bench.main()
     raise AssertionError("main() returned")
 except SystemExit as e:
-    assert e.code == 7, e.code
+    assert e.code == 0, e.code
 assert "torch" not in sys.modules, "torch was imported before the ranks were started"
-c = seen["cmd"]
+(c, env, watch, flag), = seen
 assert c[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in c and c[c.index("--nproc-per-node") + 1] == "8"
-assert c[c.index("--master-addr") + 1] == "127.0.0.1" and c[-6:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
-assert c[-7].endswith("bench.py") and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+assert c[c.index("--master-addr") + 1] == "127.0.0.1"
+tail = c[c.index([x for x in c if x.endswith("bench.py")][0]) + 1:]
+assert tail == ["--gpus", "8", "--steps", "20", "--warmup", "5", "--exchange", "native", "--gather", "packed", "--worker"], tail
+assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and json.loads(env["BBR_BENCH_ATTEMPTS"]) == [] and watch == list(range(8)) and flag is None
 print("ok")
 '''
     p = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=120)
-    assert p.returncode == 0 and p.stdout.strip() == "ok", p.stderr[-2000:]
+    assert p.returncode == 0 and p.stdout.strip().splitlines()[-1] == "ok" and '{"metric": "m", "n_gpus": 8}' in p.stdout, p.stderr[-2000:]
+
+
+def test_attempt_ladder_falls_back_in_fresh_processes_and_reports_what_failed():
+    """native hangs -> the supervisor gives the attempt up and starts torch in new processes; that attempt is told (and its
+    line says) what was tried before.  Every attempt failing is exit code 1 and no line."""
+    import bench
+    assert bench.attempt_ladder(None, "packed", False) == [("native", "packed"), ("torch", "packed"), ("torch", "rgba32f")]
+    assert bench.attempt_ladder("torch", "rgba32f", False) == [("torch", "rgba32f")]
+    assert bench.attempt_ladder("peer", "rgba16f", False) == [("peer", "rgba16f"), ("torch", "rgba16f"), ("torch", "rgba32f")]
+    assert bench.attempt_ladder("native", "packed", True) == [("native", "packed"), ("torch", "packed")]   # --present gathers RGBA8 either way
+    assert bench._worker_argv(["--gpus", "2", "--exchange", "peer", "--gather=packed", "--verify"], "torch", "rgba32f") == \
+        ["--gpus", "2", "--verify", "--exchange", "torch", "--gather", "rgba32f", "--worker"]
+    import argparse
+    args = argparse.Namespace(gpus=2, exchange=None, gather="packed", present=False, steps=20, warmup=5, cpu_budget=20.0)
+    calls = []
+
+    def fake(outcomes):
+        def run(cmd, env, watch, limits, flag=None):
+            calls.append((cmd[cmd.index("--exchange") + 1], cmd[cmd.index("--gather") + 1], json.loads(env["BBR_BENCH_ATTEMPTS"])))
+            return outcomes[len(calls) - 1]
+        return run
+    real, env0 = bench.run_attempt, dict(os.environ)
+    try:
+        for k in ("WORLD_SIZE", "RANK", "BBR_BENCH_BACKEND"):
+            os.environ.pop(k, None)
+        bench.run_attempt = fake([(False, "", "no progress for 60 s while waiting for milestone 'first_frame'"), (True, '{"ok": 1}\n', None)])
+        assert bench.supervise(args, ["--gpus", "2"]) == 0
+        assert [c[:2] for c in calls] == [("native", "packed"), ("torch", "packed")]
+        assert calls[0][2] == [] and calls[1][2] == [{"exchange": "native", "gather": "packed",
+                                                      "gave_up_because": "no progress for 60 s while waiting for milestone 'first_frame'"}]
+        calls.clear()
+        bench.run_attempt = fake([(False, "", "exit code 1 after milestone 'group'")] * 3)
+        assert bench.supervise(args, ["--gpus", "2"]) == 1 and len(calls) == 3 and len(calls[2][2]) == 2
+    finally:
+        bench.run_attempt = real
+        os.environ.clear()
+        os.environ.update(env0)
+
+
+def test_supervisor_kills_a_stalled_attempt_and_lets_a_finished_one_through(tmp_path):
+    """run_attempt on real child processes (no GPU, no torch): milestones arrive through the file named by
+    BBR_BENCH_MILESTONES; a child that stops making progress is killed with its whole process group, one that reaches
+    'done' is a success even if it then dawdles"""
+    import bench
+    import sys
+    child = tmp_path / "child.py"
+    child.write_text(
+        "import os, sys, time\n"
+        "ms = os.environ['BBR_BENCH_MILESTONES']\n"
+        "def mark(n):\n"
+        "    open(ms, 'a').write('0 %s\\n' % n)\n"
+        "mode = sys.argv[1]\n"
+        "for n in ('spawned', 'imported', 'group'):\n"
+        "    mark(n); time.sleep(0.05)\n"
+        "if mode == 'stall':\n"
+        "    time.sleep(600)\n"
+        "if mode == 'crash':\n"
+        "    sys.exit(3)\n"
+        "for n in ('first_frame', 'warm', 'timed'):\n"
+        "    mark(n)\n"
+        "print('{\"metric\": \"x\"}', flush=True)\n"
+        "mark('done')\n")
+    limits = lambda name: 1.5   # noqa: E731
+    t0 = time.monotonic()
+    ok, out, why = bench.run_attempt([sys.executable, str(child), "stall"], dict(os.environ), [0], limits)
+    assert not ok and "first_frame" in why and "no progress" in why and time.monotonic() - t0 < 30
+    ok, out, why = bench.run_attempt([sys.executable, str(child), "crash"], dict(os.environ), [0], limits)
+    assert not ok and "exit code 3" in why and "group" in why
+    ok, out, why = bench.run_attempt([sys.executable, str(child), "fine"], dict(os.environ), [0], limits)
+    assert ok and why is None and out.strip() == '{"metric": "x"}'
+    flag = tmp_path / "flag"
+    flag.write_text("")
+    ok, out, why = bench.run_attempt([sys.executable, str(child), "stall"], dict(os.environ), [0], lambda n: 60.0, str(flag))
+    assert not ok and "another rank" in why
 
 
 def test_trace_durations_quoted_in_the_bench_line_come_from_the_committed_phases_file():

@@ -26,15 +26,21 @@ def _line(proc):
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize("extra", [[], ["--gather", "rgba32f"], ["--present"]])
+@pytest.mark.parametrize("extra", [[], ["--gather", "rgba32f"], ["--present"], ["--gather", "rgba16f"]])
 def test_native_collective_with_one_rank(extra):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
     out = _line(subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--force-dist", "--exchange", "native"] + COMMON + extra,
                                cwd=ROOT, capture_output=True, text=True, timeout=600, env=env))
     assert out["verified_against_unpartitioned_render"] is True and out["n_gpus"] == 1
+    ex = out["exchange"]
+    assert ex["who"] == "native" and ex["rccl_ranks"] == 1 and ex["attempts"] == []      # ncclCommCount on the library's communicator
+    assert ex["link_bound_ms_estimate"] == 0.0 and ex["link_rate_gbs_assumed"] > 0       # (one rank receives nothing)
+    if extra == ["--gather", "rgba16f"]:
+        assert ex["form"] == "rgba16f" and "binary16" in out["config"]["output"] and "LOSSY" in out["config"]["output"]
+        assert ex["bytes_per_rank_block"] == 1920 * 1080 * 8   # (half of the RGBA32F block)
 
 
-@pytest.mark.parametrize("exchange,extra", [("peer", []), ("peer", ["--present"]), ("torch", [])])
+@pytest.mark.parametrize("exchange,extra", [("peer", []), ("peer", ["--present"]), ("torch", []), ("torch", ["--gather", "rgba16f"])])
 def test_two_ranks_on_one_gpu(exchange, extra):
     env = dict(os.environ, BBR_BENCH_BACKEND="gloo", BBR_BENCH_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
@@ -43,6 +49,30 @@ def test_two_ranks_on_one_gpu(exchange, extra):
     assert out["verified_against_unpartitioned_render"] is True and out["n_gpus"] == 2
     assert out["scaling"] == "strong"
     assert ("bbr_push_shard" if exchange == "peer" else "torch.distributed") in out["config"]["partition"]
+    ex = out["exchange"]
+    assert ex["attempts"] == [] and ex["who"] == exchange and ex["rccl_ranks"] is None
+    # the ceiling a scaling record can be held against: a block over one link (two ranks: ring and direct are the same)
+    assert ex["link_bound_ms_estimate"] == pytest.approx(ex["bytes_per_rank_block"] / (ex["link_rate_gbs_assumed"] * 1e9) * 1e3, rel=1e-3)
+    assert ex["link_bound_ms_estimate_ring"] == pytest.approx(ex["link_bound_ms_estimate"], rel=1e-3)
+    for pr in out["roofline"]["per_rank"]:
+        assert pr["alone"]["avg_geometry_ms"] > 0 and pr["alone"]["avg_raster_ms"] > 0 and pr["alone"]["avg_shade_ms"] > 0
+
+
+def test_a_stalled_exchange_is_given_up_and_the_torch_attempt_completes():
+    """the one combination no rehearsal can reach is a native / peer exchange that HANGS on real
+    hardware.  Here rank 1 is made to stall (BBR_BENCH_STALL) in the peer attempt: the supervisor -- the parent, which never
+    touches the GPU -- sees no milestone for BBR_BENCH_STALL_LIMIT seconds, kills that attempt's whole process group and
+    starts the torch attempt in fresh processes; its line says what was given up and why.  Exit code 0, ONE JSON line."""
+    env = dict(os.environ, BBR_BENCH_BACKEND="gloo", BBR_BENCH_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               BBR_BENCH_STALL="peer:1:first_frame", BBR_BENCH_STALL_LIMIT="100")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = _line(subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--exchange", "peer"] + COMMON,
+                               cwd=ROOT, capture_output=True, text=True, timeout=900, env=env))
+    ex = out["exchange"]
+    assert out["n_gpus"] == 2 and out["verified_against_unpartitioned_render"] is True and ex["who"] == "torch"
+    assert len(ex["attempts"]) == 1 and ex["attempts"][0]["exchange"] == "peer"
+    assert "no progress" in ex["attempts"][0]["gave_up_because"] and "first_frame" in ex["attempts"][0]["gave_up_because"]
 
 
 def test_bare_bench_command_with_two_gpus_launches_its_own_ranks():
@@ -55,5 +85,6 @@ def test_bare_bench_command_with_two_gpus_launches_its_own_ranks():
                                 "--verify"], cwd=ROOT, capture_output=True, text=True, timeout=900, env=env))
     assert out["n_gpus"] == 2 and out["verified_against_unpartitioned_render"] is True
     assert out["exchange"]["ranks_in_communicator"] == 2 and out["exchange"]["bytes_per_rank_block"] > 0
+    assert out["exchange"]["who"] == "torch" and out["exchange"]["attempts"] == []   # (gloo rehearsal: the ladder starts at torch)
     assert [p["rank"] for p in out["roofline"]["per_rank"]] == [0, 1]
     assert sum(p["n_shaded"] for p in out["roofline"]["per_rank"]) == out["roofline"]["n_shaded"]

@@ -41,7 +41,9 @@ def test_collective_form_with_a_one_rank_communicator(scene_and_frames):
     r.comm_init(0, 1, uid)
     with pytest.raises(BibimError):
         r.comm_init(0, 1, uid)                             # already has one
-    for form, want in ((P.SHARD_RGBA32F, ref), (P.SHARD_PACKED, ref)):
+    assert r.comm_count() == 1                             # what RCCL itself says about the communicator
+    ref16 = bbo.half_round(ref)                            # the binary16 wire form: the oracle's rounding of every channel
+    for form, want in ((P.SHARD_RGBA32F, ref), (P.SHARD_PACKED, ref), (P.SHARD_RGBA16F, ref16)):
         assert r.exchange_block_bytes(form) == P.exchange_block_bytes(form, cfg.height, cfg.width, 1, 32)
         h = r.render_scene(sc, h)
         r.allgather_frame(form)                            # library-owned gather buffer and whole frame
@@ -71,7 +73,8 @@ def test_collective_form_with_a_one_rank_communicator(scene_and_frames):
 
 
 @pytest.mark.parametrize("world,form,push_mode", [(2, P.SHARD_PACKED, 1), (3, P.SHARD_RGBA32F, 1), (4, P.SHARD_RGBA8, 1),
-                                                   (8, P.SHARD_PACKED, 1), (8, P.SHARD_RGBA32F, 0), (3, P.SHARD_RGBA8, 0)])
+                                                   (8, P.SHARD_PACKED, 1), (8, P.SHARD_RGBA32F, 0), (3, P.SHARD_RGBA8, 0),
+                                                   (2, P.SHARD_RGBA16F, 1), (4, P.SHARD_RGBA16F, 0), (8, P.SHARD_RGBA16F, 1)])
 def test_peer_form_among_contexts_on_one_device(scene_and_frames, world, form, push_mode):
     """every rank pushes its block into every rank's gather buffer -- with ONE kernel storing to all peers (push_mode 1, the
     default) or with copies queued one behind the other (0); afterwards all buffers hold the same bytes (the layout
@@ -101,7 +104,7 @@ def test_peer_form_among_contexts_on_one_device(scene_and_frames, world, form, p
     host = [b.cpu().numpy() for b in bufs]
     for hb in host[1:]:
         assert np.array_equal(hb, host[0])
-    want = ref8 if form == P.SHARD_RGBA8 else ref
+    want = ref8 if form == P.SHARD_RGBA8 else (bbo.half_round(ref) if form == P.SHARD_RGBA16F else ref)
     assert np.array_equal(P.decode_gathered(host[0], form, cfg.height, cfg.width, world, band).view(np.uint8), want.view(np.uint8))
     for r, b in zip(rs, bufs):
         r.unpack_whole(form, b.data_ptr())

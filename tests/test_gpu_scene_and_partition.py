@@ -195,17 +195,29 @@ def test_c4_full_size_4k_split_over_2_4_8_ranks(c4_whole_frame, world):
     for rank, r in enumerate(rs):
         r.pack_shard(packed[rank * pb:].data_ptr())
         r.synchronize()
-    for form in ("rgba32f", "packed"):
+    # ... and in the reference's own HDR attachment format as a wire form (BBR_SHARD_RGBA16F, 8 bytes per pixel, lossy):
+    # every channel of the frame rounded to binary16 exactly as the oracle rounds it
+    hb = rs[0].exchange_block_bytes(P.SHARD_RGBA16F)
+    assert hb == shard_rows * cfg.width * 8
+    halves = torch.full((world * hb,), 0xAB, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    for rank, r in enumerate(rs):
+        r.stage_shard(P.SHARD_RGBA16F, halves[rank * hb:].data_ptr())
+        r.synchronize()
+    for form in ("rgba32f", "packed", "rgba16f"):
         frame = torch.full((cfg.height, cfg.width, 4), 3.0, dtype=torch.float32, device="cuda")
         torch.cuda.synchronize()
         if form == "rgba32f":
             rs[-1].unpack_gathered(gathered.data_ptr(), frame.data_ptr())
-        else:
+        elif form == "packed":
             rs[-1].unpack_gathered_packed(packed.data_ptr(), frame.data_ptr())
+        else:
+            rs[-1].unpack_whole(P.SHARD_RGBA16F, halves.data_ptr(), frame.data_ptr())
         rs[-1].synchronize()
         torch.cuda.synchronize()
         got = frame.cpu().numpy()
-        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), form
+        expect = bbo.half_round(want) if form == "rgba16f" else want
+        assert np.array_equal(got.view(np.uint32), expect.view(np.uint32)), form
     for r in rs:
         r.close()
 

@@ -80,6 +80,33 @@ def test_direct_push_drives_every_link_of_the_mesh_at_once(world):
         assert sorted(d for st in P.push_steps(r, world, True) for d in st) == sorted(d for st in P.push_steps(r, world, False) for d in st)
 
 
+def test_binary16_wire_form_rounds_like_the_oracle():
+    """BBR_SHARD_RGBA16F (the reference's HDR attachment format, src/render.h:94): the host model's conversion (numpy's
+    float32 -> float16) is the oracle's bbo_half_round for every class of value -- every binary16 value, every midpoint
+    between two of them and its neighbours, the overflow threshold, subnormals, infinities -- and a frame survives
+    encode -> gather -> decode as its rounded self at 8 bytes per pixel"""
+    from oracle import bbo
+    h = np.arange(0, 0x7C00, dtype=np.uint16).view(np.float16).astype(np.float32)            # every finite binary16 value >= 0
+    mid = ((h[:-1].astype(np.float64) + h[1:].astype(np.float64)) / 2).astype(np.float32)    # exact in binary32
+    vals = np.concatenate([h, mid, np.nextafter(mid, np.float32(np.inf)), np.nextafter(mid, np.float32(-np.inf)),
+                           np.float32([65504.0, 65519.99, 65520.0, 65536.0, 1e9, np.inf, 2.0 ** -25, 2.0 ** -24 * 1.5, 0.0])])
+    vals = np.concatenate([vals, -vals]).astype(np.float32)
+    with np.errstate(over="ignore"):
+        via_numpy = vals.astype(np.float16).astype(np.float32)
+    assert np.array_equal(via_numpy.view(np.uint32), bbo.half_round(vals).view(np.uint32))
+    rng = np.random.Generator(np.random.PCG64(16))
+    H, W, world, band = 130, 70, 3, 32
+    frame = (rng.standard_normal((H, W, 4)) * np.float32(50)).astype(np.float32)
+    frame[..., 3] = rng.integers(0, 2, (H, W)).astype(np.float32)
+    block = P.exchange_block_bytes(P.SHARD_RGBA16F, H, W, world, band)
+    assert block == P.shard_rows(H, world, band) * W * 8
+    blocks = [P.encode_block(P.pack_shard(frame, r, world, band), P.SHARD_RGBA16F) for r in range(world)]
+    assert all(b.size == block for b in blocks)
+    back = P.decode_gathered(np.concatenate(blocks), P.SHARD_RGBA16F, H, W, world, band)
+    assert back.dtype == np.float32 and np.array_equal(back.view(np.uint32), bbo.half_round(frame).view(np.uint32))
+    assert np.array_equal(back[..., 3], frame[..., 3])                                        # alpha 0 / 1 is exact
+
+
 @pytest.mark.parametrize("form", [P.SHARD_RGBA32F, P.SHARD_PACKED, P.SHARD_RGBA8])
 @pytest.mark.parametrize("H,W,world,band", [(270, 17, 4, 32), (130, 390, 3, 64), (2160, 64, 8, 32), (64, 64, 1, 32)])
 def test_peer_exchange_model_leaves_the_same_gather_buffer_on_every_rank(form, H, W, world, band):
