@@ -55,19 +55,28 @@ def _committed_summary(pattern, workload, kernel):
 def committed_trace_ms(workload, kernel="k_shade"):
     """mean duration of `kernel`'s timed launches by the kernel trace of the same command under rocprofv3
     (profiles/*bench_kernel_phases.txt, newest round first): what `roofline.frac` can be reproduced from.  Returns
-    (timed_region_ms, alone_ms, file) or (None, None, None)."""
+    (timed_region_ms, alone_ms, file) or (None, None, why).  Only a file that was measured on the kernel sources of THIS tree
+    counts (its `# kernel_source_sha256` line, written by tools/profile_summary.py): durations of other kernels beside this
+    run's bytes would be a mixed figure."""
     import glob
     import re
+    from bibim_renderer_amd.build_id import kernel_source_sha256
+    mine, stale = kernel_source_sha256(), None
     pat = "*_bench_kernel_phases.txt" if workload == "c3" else f"*_{workload}_bench_kernel_phases.txt"
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", pat)), reverse=True):
         if workload == "c3" and re.search(r"_c\d_bench_kernel_phases", f):
             continue
-        for line in open(f):
+        text = open(f).read()
+        sha = re.search(r"^# kernel_source_sha256 ([0-9a-f]{64})", text, re.M)
+        if not sha or sha.group(1) != mine:
+            stale = stale or os.path.relpath(f, ROOT)
+            continue
+        for line in text.splitlines():
             if line.split() and line.split()[0] == kernel:
                 m = re.findall(r"mean=\s*([0-9.]+) us", line)
                 if len(m) >= 2:
                     return float(m[0]) * 1e-3, float(m[1]) * 1e-3, os.path.relpath(f, ROOT)
-    return None, None, None
+    return None, None, (f"{stale}: measured on other kernel sources than this tree's" if stale else None)
 
 
 def committed_texel_lines(workload):
@@ -782,6 +791,8 @@ def main():
         roofline["avg_kernel_ms_is"] = (f"HIP events around k_shade on its own stream with {args.frames_in_flight} frames in flight: an "
                                         "OVERLAPPED latency (the kernel shares the GPU with the other frames' kernels and the events also "
                                         "bracket the dispatch gaps), so it can exceed ms_per_step; `frac` uses it and is the conservative figure")
+        if not t_ms and t_src:
+            roofline["trace_source"] = t_src   # (why there are no trace_* figures: the committed trace is of other kernels)
         if t_ms:
             roofline.update({"trace_kernel_ms": round(t_ms, 5), "trace_kernel_alone_ms": round(t_alone_ms, 5), "trace_source": t_src,
                              "trace_frac": round(shade_bytes / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),

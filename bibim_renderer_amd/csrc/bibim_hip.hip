@@ -1919,8 +1919,10 @@ int bbr_unpack_gathered_packed(bbr_context *c, const void *gathered, void *frame
 // ================================================================================================
 // native exchange (BASELINE config #4): the step in which every rank gets the whole frame
 //   collective form: RCCL all-gather of the ranks' blocks (ring over xGMI), one process per GPU
-//   peer form:       every rank copies its block into every rank's gather buffer (hipMemcpyPeerAsync); for one process
-//                    that drives several GPUs, or several processes that exchanged IPC handles
+//   peer form:       every rank puts its block into every rank's gather buffer -- ONE kernel that stores to all peers at once
+//                    (option push_mode 1, the default: every xGMI link of the mesh busy together), or hipMemcpyPeerAsync
+//                    copies one behind the other (push_mode 0, and the fallback when a peer cannot be mapped); for one
+//                    process that drives several GPUs, or several processes that exchanged IPC handles
 // Both run on the stream of the frame's slot, right behind its k_shade: with stream layout 2 a frame's kernels share a
 // stream with nothing else, so the exchange is simply the frame's last step, the next frame of the same slot is ordered
 // behind it without an event, and the frames of the other slots render while the links are busy.

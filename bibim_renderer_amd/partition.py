@@ -136,7 +136,7 @@ def encode_block(shard, form):
     """a rank's shard [rows, W, 4] as the bytes that travel (uint8): float32 RGBA, the packed form, RGBA8, or binary16 RGBA"""
     if form == SHARD_PACKED:
         return pack_shard_bits(shard)
-    if form == SHARD_RGBA16F:   # every channel to the nearest binary16 value, ties to even (numpy's conversion; = the oracle's bbo_half_round)
+    if form == SHARD_RGBA16F:   # every channel to the nearest binary16 value, ties to even (numpy's conversion; the tests pin it to the CPU checker's rounding)
         with np.errstate(over="ignore"):
             return np.ascontiguousarray(shard, np.float32).astype(np.float16).view(np.uint8).reshape(-1)
     return np.ascontiguousarray(shard, np.float32 if form == SHARD_RGBA32F else np.uint8).view(np.uint8).reshape(-1)

@@ -3,6 +3,7 @@
 from __future__ import annotations
 
 import ctypes as C
+import os
 import weakref
 
 import numpy as np
@@ -26,6 +27,11 @@ class Renderer:
             raise BibimError(rc, (self._L.bbr_last_error(None) or b"").decode())
         self.width, self.height = int(width), int(height)
         self._scenes = weakref.WeakSet()  # host-shim scenes hold meshes of this context: they must go first
+        # test hook: BBR_OPTIONS="name=value,..." is applied to every context this process creates (the GPU suite runs its
+        # small frames through the long frames' route with no_tail_items=0: tests/conftest.py, fixture item_route)
+        for kv in filter(None, os.environ.get("BBR_OPTIONS", "").split(",")):
+            k, v = kv.split("=")
+            self.set_option(k.strip(), int(v))
 
     # -- plumbing --
     def _check(self, rc):

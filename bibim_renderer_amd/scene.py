@@ -25,8 +25,9 @@ def _p(a):
 
 
 def load_shaderball_vertices():
-    """bb::Vertex[29328] float32 [n, 11]: the committed conversion of ShaderBall.fbx (tests/golden)."""
-    return np.ascontiguousarray(np.load(os.path.join(ROOT, "tests", "golden", "shaderball_vertices.npz"))["vertices"])
+    """bb::Vertex[29328] float32 [n, 11]: the committed conversion of ShaderBall.fbx -- package data (its sha256 is pinned by
+    tests/golden/shaderball_vertices.json; minted by tools/make_fixtures.py from the reference's asset)."""
+    return np.ascontiguousarray(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "shaderball_vertices.npz"))["vertices"])
 
 
 @dataclass

@@ -160,10 +160,10 @@ int bbr_unpack_gathered_packed(bbr_context *ctx, const void *gathered_device, vo
 int bbr_tile_height(const bbr_context *ctx, int32_t *out_tile_h);
 
 /* ---- diagnostics ---- */
-int bbr_get_stats(bbr_context *ctx, bbr_stats *out);
+int bbr_get_stats(bbr_context *ctx, bbr_stats *out);                            /* synchronises (and re-renders an overflowed frame) */
 /* How often a capacity (bins, every-tile list, clip arena) has been grown since bbr_create (= bbr_stats.bin_overflow), without
  * synchronising or touching the GPU: a host that times frames can tell afterwards whether one of them overflowed. */
-int bbr_capacity_growths(const bbr_context *ctx, uint32_t *out_count);          /* synchronises */
+int bbr_capacity_growths(const bbr_context *ctx, uint32_t *out_count);          /* host-side counter: does NOT synchronise */
 /* winning primitive (global API-order index, 0xFFFFFFFF = none) and depth per pixel; synchronises.
  * Re-runs the frame once with the visibility dump enabled. */
 int bbr_read_visibility(bbr_context *ctx, uint32_t *prim_host, float *depth_host);

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def load_shaderball_vertices():
-    v = np.load(os.path.join(ROOT, "tests", "golden", "shaderball_vertices.npz"))["vertices"]
+    v = np.load(os.path.join(ROOT, "bibim_renderer_amd", "data", "shaderball_vertices.npz"))["vertices"]  # (a data file; no product code)
     out = np.zeros(len(v), bbo.VERTEX_DTYPE)
     out["pos"], out["uv"], out["normal"], out["tangent"] = v[:, 0:3], v[:, 3:5], v[:, 5:8], v[:, 8:11]
     return out

@@ -15,7 +15,7 @@ import zlib
 import numpy as np
 import pytest
 
-from conftest import GOLDEN
+from conftest import GOLDEN, ROOT
 from bibim_renderer_amd import assets
 
 REF = os.environ.get("BB_REFERENCE", "/root/reference")
@@ -321,10 +321,20 @@ def test_fbx_reader_errors(tmp_path):
         assets.load_fbx_vertices(str(tmp_path / "t.fbx"))
 
 
+def test_packaged_shaderball_mesh_is_the_pinned_conversion():
+    """the benchmark mesh ships as package data (bibim_renderer_amd/data), not as a file of the test tree; what pins it is
+    the hash minted with it (tests/golden/shaderball_vertices.json, tools/make_fixtures.py)"""
+    from bibim_renderer_amd import scene as S
+    v = S.load_shaderball_vertices()
+    info = json.load(open(os.path.join(GOLDEN, "shaderball_vertices.json")))
+    assert v.shape == (29328, 11) and v.dtype == np.float32
+    assert hashlib.sha256(v.tobytes()).hexdigest() == info["sha256_f32le"]
+
+
 @pytest.mark.skipif(not have_ref, reason="reference assets are only mounted in the authoring container")
 def test_fbx_reader_on_shaderball_matches_the_committed_fixture():
     v = assets.load_fbx_vertices(os.path.join(REF, "resources", "ShaderBall.fbx"))
-    want = np.load(os.path.join(GOLDEN, "shaderball_vertices.npz"))["vertices"]
+    want = np.load(os.path.join(ROOT, "bibim_renderer_amd", "data", "shaderball_vertices.npz"))["vertices"]   # package data, hash pinned below
     info = json.load(open(os.path.join(GOLDEN, "shaderball_vertices.json")))
     assert v.shape == (29328, 11) and np.array_equal(v.view(np.uint32), want.view(np.uint32))
     assert hashlib.sha256(v.tobytes()).hexdigest() == info["sha256_f32le"]

@@ -42,7 +42,7 @@ def check(sc, tile_mode=None, **opts):
 
 
 @pytest.mark.parametrize("tile_mode", [0, 1])
-def test_c2_and_c3_small(maps64, tile_mode):
+def test_c2_and_c3_small(maps64, tile_mode, item_route):
     check(scenes.shaderball_scene(configs.C2.scaled(320, 180, 64), bbo.MaterialData(maps64)), tile_mode)
     check(scenes.shaderball_scene(configs.C3.scaled(640, 360, 64), bbo.MaterialData(maps64)), tile_mode)
 
@@ -76,7 +76,7 @@ def test_mixed_map_sizes_with_a_height_map():
     check(sc)
 
 
-def test_heavy_clipping_overflow_replay_and_frames_in_flight(maps64):
+def test_heavy_clipping_overflow_replay_and_frames_in_flight(maps64, item_route):
     cfg = configs.C3.scaled(384, 216, 64)
     sc = scenes.shaderball_scene(cfg, bbo.MaterialData(maps64))
     check(sc, bin_cap=8, frames_in_flight=3)
@@ -84,7 +84,7 @@ def test_heavy_clipping_overflow_replay_and_frames_in_flight(maps64):
     check(sc)
 
 
-def test_partition_and_present_on_the_deferred_image(maps64):
+def test_partition_and_present_on_the_deferred_image(maps64, item_route):
     cfg = configs.C3.scaled(512, 300, 64)
     sc = scenes.shaderball_scene(cfg, bbo.MaterialData(maps64))
     sc.frame["enable_tone_mapping"], sc.frame["exposure"] = 1, 1.4
@@ -153,3 +153,25 @@ def test_gbuffer_views_show_the_attachments(maps64, fused):
     if not fused:
         assert np.array_equal(r.read_framebuffer().view(np.uint32), bbo.render(sc)[0].view(np.uint32))
     r.close()
+
+
+def test_full_size_c3_deferred_frame_against_the_literal_form():
+    """The deferred pass at BASELINE's 4K size (C3: 16 balls, 4 lights, 2048^2 maps) against the oracle's LITERAL light loop
+    -- brdf.frag:26-72 statement by statement on the binary16 G-buffer values -- not only against the contract form the
+    kernel shares with the checker.  Tolerance, stated: absolute 1e-4 per channel (BASELINE.json)."""
+    from bibim_renderer_amd import textures
+    cfg = configs.C3
+    sc = scenes.shaderball_scene(cfg, bbo.MaterialData(textures.make_material(cfg.texture_size)))
+    literal, _, _, _, rst = bbo.render_deferred(sc, want_gbuffer=False, flags=bbo.FLAG_LITERAL)
+    contract, _, _, _, _ = bbo.render_deferred(sc, want_gbuffer=False)
+    r = Renderer(sc.width, sc.height)
+    r.set_option("render_pass", 1)
+    r.render_scene(sc)
+    img = r.read_framebuffer()
+    st = r.stats()
+    r.close()
+    assert st["n_shaded"] == rst["n_shaded"] and np.isfinite(literal).all() and np.isfinite(img).all()
+    assert np.array_equal(img.view(np.uint32), contract.view(np.uint32)), "the deferred frame is no longer bit-exact at 4K"
+    d = np.abs(img.astype(np.float64) - literal.astype(np.float64))
+    assert d.max() <= 1e-4, float(d.max())
+    assert np.array_equal(img[..., 3], literal[..., 3])

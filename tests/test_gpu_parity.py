@@ -90,7 +90,7 @@ def test_c3_full_size_4k():
     assert st["n_shaded"] == json.load(open(os.path.join(GOLDEN, "n_shaded.json")))["c3"]["n_shaded"]
 
 
-@pytest.mark.parametrize("name", ["c2", "c3"])
+@pytest.mark.parametrize("name", ["c2", "c3", "c5"])
 def test_full_size_frame_against_the_literal_glsl_form(name):
     """The HIP frame against the oracle's LITERAL form -- forward_brdf.frag:29-70 / brdf.glsl statement by statement, no
     re-association -- at BASELINE's full sizes with 2048^2 maps.  `check` above is bit-exact against the CONTRACT form, which
@@ -174,7 +174,7 @@ def test_default_material_fallback_has_nans_in_the_same_places():
     assert np.array_equal(np.isnan(img), np.isnan(ref))
 
 
-def test_mixed_map_sizes_non_power_of_two_and_partial_material():
+def test_mixed_map_sizes_non_power_of_two_and_partial_material(item_route):
     rng = np.random.Generator(np.random.PCG64(11))
     maps = {"albedo": rng.integers(0, 256, (48, 80, 4), dtype=np.uint8),
             "roughness": rng.integers(60, 256, (17, 5, 4), dtype=np.uint8),
@@ -218,7 +218,7 @@ def test_empty_frame_and_culled_geometry():
     assert (img == 0).all() and st["n_raster_tris"] == 0
 
 
-def test_camera_inside_geometry_heavy_clipping(maps64):
+def test_camera_inside_geometry_heavy_clipping(maps64, item_route):
     """camera between the balls, looking along the lattice: many primitives cross the near plane and the guard band"""
     cfg = configs.C3.scaled(256, 144, 64)
     sc = scenes.shaderball_scene(cfg, bbo.MaterialData(maps64))
@@ -284,7 +284,7 @@ def test_depth_ties_follow_api_order():
     check(quad_scene(70, 50, 2.0, 4.0, "ba"))
 
 
-def test_bin_capacity_overflow_is_recovered(maps64):
+def test_bin_capacity_overflow_is_recovered(maps64, item_route):
     """tiny bins force the overflow path: the frame is re-rendered with larger bins, result unchanged"""
     sc = scenes.shaderball_scene(configs.C3.scaled(320, 180, 64), bbo.MaterialData(maps64))
     _, _, st = check(sc, bin_cap=8)
@@ -298,7 +298,7 @@ def test_broad_list_threshold_extremes(maps64):
 
 
 @pytest.mark.parametrize("caps", [{"broad_cap": 1}, {"clip_cap": 1}, {"broad_cap": 2, "clip_cap": 2, "broad_threshold": 1}])
-def test_every_tile_list_and_clip_arena_overflow_through_a_clipped_primitive(maps64, caps):
+def test_every_tile_list_and_clip_arena_overflow_through_a_clipped_primitive(maps64, caps, item_route):
     """The clip path reserves a RUN of list entries / arena slots per primitive and writes none of them when the run
     does not fit: the overflowed frame must not consume the unwritten part (it takes no every-tile entry at all), and the
     frame rendered after the growth is the oracle's.  Once with a synchronising call right after the first frame, once
@@ -322,7 +322,7 @@ def test_every_tile_list_and_clip_arena_overflow_through_a_clipped_primitive(map
 
 
 @pytest.mark.parametrize("frames_in_flight", [1, 2, 3])
-def test_frames_in_flight_streams_of_different_frames(maps64, frames_in_flight):
+def test_frames_in_flight_streams_of_different_frames(maps64, frames_in_flight, item_route):
     """two frames in flight on two streams: alternating scenes back to back, no synchronisation in between,
     every frame must still come out exactly as when rendered alone"""
     sa = scenes.shaderball_scene(configs.C3.scaled(448, 252, 64), bbo.MaterialData(maps64))
@@ -497,7 +497,7 @@ def test_present_buffer_on_every_rounding_boundary():
     r.close()
 
 
-def test_present_after_an_overflow_replay_and_into_a_caller_buffer(maps64):
+def test_present_after_an_overflow_replay_and_into_a_caller_buffer(maps64, item_route):
     import torch
     sc = scenes.shaderball_scene(configs.C3.scaled(320, 180, 64), bbo.MaterialData(maps64))
     sc.frame["enable_tone_mapping"], sc.frame["exposure"] = 1, 1.0
@@ -608,7 +608,7 @@ def test_api_lifecycle_user_stream_frees_and_timing(maps64):
 
 @pytest.mark.parametrize("deferred", [0, 1])
 @pytest.mark.parametrize("enable,exposure", [(0, 1.0), (1, 1.6)])
-def test_fused_presentation_writes_the_same_bytes(maps64, deferred, enable, exposure):
+def test_fused_presentation_writes_the_same_bytes(maps64, deferred, enable, exposure, item_route):
     """option present_fused: the raster / shade kernels produce the presented RGBA8 image themselves (no fp32 frame, no
     k_present): byte-identical to rendering + bbr_present, i.e. to the oracle's bbo_present of the oracle's frame"""
     import torch
@@ -636,7 +636,7 @@ def test_fused_presentation_writes_the_same_bytes(maps64, deferred, enable, expo
     r.close()
 
 
-def test_fused_presentation_special_values_partition_and_overlays(maps64):
+def test_fused_presentation_special_values_partition_and_overlays(maps64, item_route):
     from bibim_renderer_amd import partition as P
     tri = scenes.triangle_scene(96, 96)                  # default material: NaN where N.H = 1
     ref, _, _, _ = bbo.render(tri)

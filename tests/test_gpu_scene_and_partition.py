@@ -74,7 +74,7 @@ def test_triangle_scene_through_the_shim():
 
 
 @pytest.mark.parametrize("world,band_rows,tile_mode", [(2, 64, 0), (3, 64, 0), (8, 64, 0), (4, 32, 1), (8, 128, 0), (5, 96, 1)])
-def test_partitioned_render_reassembles_to_the_single_gpu_frame(maps64, world, band_rows, tile_mode):
+def test_partitioned_render_reassembles_to_the_single_gpu_frame(maps64, world, band_rows, tile_mode, item_route):
     """every rank's shard rendered on this one GPU in turn; host-side all-gather + un-interleave == full frame"""
     cfg = configs.C3.scaled(512, 300, 64)
     sc = scenes.shaderball_scene(cfg, bbo.MaterialData(maps64))
@@ -373,7 +373,7 @@ def test_frames_stay_identical_while_other_processes_share_the_gpu(maps64):
             p.wait(timeout=60)
 
 
-def test_a_host_that_never_synchronises_still_outgrows_an_overflow(maps64):
+def test_a_host_that_never_synchronises_still_outgrows_an_overflow(maps64, item_route):
     """bins far too small, frames only streamed into a caller buffer: the first frames are incomplete (and stay so),
     but within a few frames the capacities have grown by themselves and every later frame is exact"""
     import torch
@@ -437,7 +437,7 @@ def test_two_and_a_half_million_triangles_at_4k(maps256):
 
 @pytest.mark.parametrize("width,height,world,band,deferred", [(384, 200, 4, 64, 0), (390, 203, 3, 32, 0), (384, 200, 2, 32, 1),
                                                               (1000, 70, 8, 32, 0)])
-def test_packed_shards_reassemble_the_same_frame(maps64, width, height, world, band, deferred):
+def test_packed_shards_reassemble_the_same_frame(maps64, width, height, world, band, deferred, item_route):
     """the all-gather payload as rgb + one alpha bit per pixel (bbr_pack_shard / bbr_unpack_gathered_packed): the frame
     every rank ends up with is the unpartitioned frame, bit for bit -- forward (alpha 0 on cleared pixels, 1 on shaded
     ones) and deferred (1 everywhere), widths off the 64-pixel mask grid, more ranks than bands"""

@@ -28,7 +28,7 @@ def shaderball():
     from tools.fbx_geometry import load_vertices
     v, info = load_vertices(os.path.join(REF, "resources", "ShaderBall.fbx"))
     info["sha256_f32le"] = hashlib.sha256(np.ascontiguousarray(v).tobytes()).hexdigest()
-    np.savez_compressed(os.path.join(GOLD, "shaderball_vertices.npz"), vertices=v)
+    np.savez_compressed(os.path.join(ROOT, "bibim_renderer_amd", "data", "shaderball_vertices.npz"), vertices=v)  # package data
     json.dump(info, open(os.path.join(GOLD, "shaderball_vertices.json"), "w"), indent=1)
     print("shaderball", info)
 
@@ -303,7 +303,11 @@ def contract_manifest():
     old = json.load(open(path)) if os.path.exists(path) else {"history": []}
     rev = bbo.contract_revision()
     files = {f: hashlib.sha256(open(os.path.join(GOLD, f), "rb").read()).hexdigest() for f in frozen}
-    if old.get("contract_revision") != rev or old.get("files") != files:
+    if old.get("files") not in (None, files) and old.get("contract_revision") == rev:
+        # frozen frames that changed WITHOUT a new revision: exactly what this manifest exists to make impossible
+        raise SystemExit(f"the frozen frames differ from the ones contract revision {rev} minted: bump BBO_CONTRACT_REVISION "
+                         "(oracle/bb_oracle.h, with a line in its history) before re-minting, or restore the fixtures")
+    if old.get("contract_revision") != rev:
         old["history"] = old.get("history", []) + [{"contract_revision": rev, "files": files}]
     old.update({"contract_revision": rev, "files": files,
                 "note": "frames frozen from the oracle's CONTRACT (default) form; keys *_literal_rgba_bits inside them are the "

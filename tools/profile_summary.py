@@ -88,6 +88,7 @@ elif mode == "phases":
     with open(sys.argv[4], "w") as f:
         f.write(f"# {skip} frames before the timed region, {steps} timed steps ({bench['config']['workload'].split(':')[0]}, "
                 f"{bench['roofline']['frames_in_flight']} frames in flight); durations from the kernel trace\n")
+        f.write(f"# kernel_source_sha256 {source_hash()}\n")   # (bench.py quotes these durations only for the kernels of its own tree)
         for k, v in sorted(per.items()):
             if not k.startswith("k_"):
                 continue
