@@ -693,8 +693,13 @@ def main():
     gc.disable()
     # a few dozen frames bring the GPU up to speed and let every frame slot learn its item count (the shading launch of a
     # slot is sized from the slot's previous frame); the untimed warm-up steps follow
-    for _ in range(40):
+    # ... and a quarter of a second: the GPU's clocks take that long to come up under this load (20 frames timed after 40 warm
+    # frames read 117-119 us, the same 20 frames 100 ms of rendering later 105-110: gpurun_out/r4/drv_style.txt, round 4), and
+    # the driver's run is 20 steps.  Untimed, like the W warm-up steps that follow; the timed region is still exactly K steps.
+    n_pre, t_pre = 0, time.perf_counter()
+    while n_pre < 40 or time.perf_counter() - t_pre < 0.25:
         step()
+        n_pre += 1
     fence()
     layout, layout_decided, layout_ms = r.stream_layout_state()
     use_events = not args.no_timing_events

@@ -1867,7 +1867,8 @@ __global__ __launch_bounds__(kShadeThreads) __attribute__((amdgpu_waves_per_eu(T
   uint32_t n_items = *item_count;  // (items[0], or the head word k_raster's tiles appended through: short frames)
   // (both loads are in flight before either is waited for: left to itself the compiler reads the count, branches, and only
   //  then asks for the item word -- one more dependent round trip in front of every wave's fragments)
-  asm volatile("" : "+s"(item), "+s"(n_items));
+  //  -- and the frame parameters the item is decoded with arrive in the same round trip, not in one of their own behind it)
+  asm volatile("" : "+s"(item), "+s"(n_items), "+s"(fp.tiles_x), "+s"(fp.world), "+s"(fp.rank), "+s"(fp.band_tiles), "+s"(fp.width));
   if (BB_ABLATE(2048u)) sp.num_lights = 0;
   if (j >= n_items) return;  // a wave without an item (the kernel has no barrier: waves come and go on their own)
   do {  // (a loop only in the TAIL instantiation)
