@@ -410,6 +410,9 @@ def main():
                          "pixel; default) or as plain RGBA32F (16 B); the reassembled frame is the same, bit for bit.  rgba16f: "
                          "every channel rounded to binary16, the reference's own HDR attachment format (8 B per pixel, LOSSY: a "
                          "different output, reported as such in config.output, never the default)")
+    ap.add_argument("--no-also", action="store_true",
+                    help="skip the 1080p figure the default C3 run adds to its line (`also.c2_1080p`): the counter passes of "
+                         "tools/profile_round.sh average every launch of a kernel in the process")
     ap.add_argument("--worker", action="store_true",
                     help="(internal) this process is one rank of one attempt, started by the supervisor (see `supervise`)")
     ap.add_argument("--exchange", default=None, choices=["torch", "native", "peer"],
@@ -904,7 +907,7 @@ def main():
     # north_star asks for 1080p AND 4K figures: after the timed region of the default (C3) run, C2 -- ShaderBall, one point
     # light, 1920x1080 -- for a hundred steps with ITS four frames in flight, in a context of its own
     also = None
-    if args.workload == "c3" and not dist_path and not args.present and args.render_pass == "forward" and not args.opt:
+    if args.workload == "c3" and not dist_path and not args.present and args.render_pass == "forward" and not args.opt and not args.no_also:
         cfg2 = configs.CONFIGS["c2"]
         r.synchronize()
         rb = Renderer(cfg2.width, cfg2.height, device=local_rank)
