@@ -699,10 +699,19 @@ def main():
     # ... and a quarter of a second: the GPU's clocks take that long to come up under this load (20 frames timed after 40 warm
     # frames read 117-119 us, the same 20 frames 100 ms of rendering later 105-110: gpurun_out/r4/drv_style.txt, round 4), and
     # the driver's run is 20 steps.  Untimed, like the W warm-up steps that follow; the timed region is still exactly K steps.
-    n_pre, t_pre = 0, time.perf_counter()
-    while n_pre < 40 or time.perf_counter() - t_pre < 0.25:
+    # (The NUMBER of such frames is agreed between the ranks: every step of an N > 1 run contains collectives.)
+    t_pre = time.perf_counter()
+    for _ in range(40):
         step()
-        n_pre += 1
+    fence()
+    per_frame = max((time.perf_counter() - t_pre) / 40.0, 1e-6)
+    n_more = max(0, min(20000, int(0.25 / per_frame) - 40))
+    if dist is not None:
+        nm = torch.tensor([n_more], dtype=torch.int64, device="cuda")
+        dist.all_reduce(nm, op=dist.ReduceOp.MAX)
+        n_more = int(nm.item())
+    for _ in range(n_more):
+        step()
     fence()
     layout, layout_decided, layout_ms = r.stream_layout_state()
     use_events = not args.no_timing_events

@@ -525,6 +525,7 @@ BB_DEV void clip_primitive_wave(ClipWork &w, int owner, const float (*clip)[4], 
 // per-primitive viewport, everything downstream of the vertex stage shared.
 template <int TILE_W, int TILE_H, bool OVERLAY = false>
 __global__ __launch_bounds__(256) void k_geometry(const DrawDesc *__restrict__ draws, uint32_t n_draws, uint32_t n_prims,
+                                                  FirstPrims first_prims,
                                                   RasterTri *__restrict__ tris, ShadeRec *__restrict__ recs,
                                                   uint32_t *__restrict__ tile_count, uint32_t *__restrict__ bins,
                                                   Counters *__restrict__ ctr,
@@ -551,8 +552,12 @@ __global__ __launch_bounds__(256) void k_geometry(const DrawDesc *__restrict__ d
   uint32_t clipped_raster = 0;  // wave-uniform: sub-triangles of this wave's clipped primitives that reached the every-tile list
   Viewport vp = {fp.half_w, fp.half_h, fp.half_w, fp.half_h};
   if (prim < n_prims) {
+    // which draw: the first few draws' first_prim are kernel arguments (no load); more draws than that: the table
     uint32_t d = 0;
-    while (d + 1 < n_draws && prim >= draws[d + 1].first_prim) ++d;
+#pragma unroll
+    for (int q = 0; q < kInlineFirstPrims; ++q) d += prim >= first_prims.v[q] ? 1u : 0u;
+    if (n_draws > (uint32_t)kInlineFirstPrims + 1u)
+      while (d + 1 < n_draws && prim >= draws[d + 1].first_prim) ++d;
     const DrawDesc draw = draws[d];
     const uint32_t local = prim - draw.first_prim;
     const uint32_t inst = local / draw.tris_per_instance;
@@ -583,6 +588,25 @@ __global__ __launch_bounds__(256) void k_geometry(const DrawDesc *__restrict__ d
       for (int c = 0; c < 3; ++c) { vtx[k].pos[c] = q->pos[c]; vtx[k].normal[c] = q->normal[c]; vtx[k].tangent[c] = q->tangent[c]; }
       vtx[k].uv[0] = q->uv[0]; vtx[k].uv[1] = q->uv[1];
     }
+    // The upper 3 x 3 of the instance's inverse model matrix (the survivors' normal matrix; the overlay programs' colour /
+    // view rows) is asked for in the SAME batch as the vertices and the model matrix: every lane of an instance reads the
+    // same 128 bytes (L1 hits), and asked for only behind the cull it was one more dependent round trip in a kernel that is
+    // nothing but a chain of them.  The fence keeps the compiler from sinking the loads back to their first use.
+    float im_[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) im_[r][cc] = ib.inv_model.M[r][cc];
+    Mat4 model;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) model.M[r][cc] = ib.model.M[r][cc];
+    asm volatile("" :: "v"(im_[0][0]), "v"(im_[0][1]), "v"(im_[0][2]), "v"(im_[1][0]), "v"(im_[1][1]), "v"(im_[1][2]), "v"(im_[2][0]),
+                 "v"(im_[2][1]), "v"(im_[2][2]), "v"(vtx[0].pos[0]), "v"(vtx[1].pos[0]), "v"(vtx[2].pos[0]), "v"(model.M[0][0]),
+                 "v"(model.M[0][1]), "v"(model.M[0][2]), "v"(model.M[0][3]), "v"(model.M[1][0]), "v"(model.M[1][1]), "v"(model.M[1][2]),
+                 "v"(model.M[1][3]), "v"(model.M[2][0]), "v"(model.M[2][1]), "v"(model.M[2][2]), "v"(model.M[2][3]), "v"(model.M[3][0]),
+                 "v"(model.M[3][1]), "v"(model.M[3][2]), "v"(model.M[3][3]) : "memory");
 #ifdef BB_STAMPS
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     BB_STAMP(6);
@@ -598,11 +622,11 @@ __global__ __launch_bounds__(256) void k_geometry(const DrawDesc *__restrict__ d
       if (OVERLAY) {
         // The host folds the matrices: ib.model = (P*V)*modelMat of the light (light.vert:11-14) or the gizmo's own
         // projMat*viewMat (gizmo.vert:13-24)
-        c = mat4_mul(ib.model, f4{v.pos[0], v.pos[1], v.pos[2], 1.0f});
+        c = mat4_mul(model, f4{v.pos[0], v.pos[1], v.pos[2], 1.0f});
         pw[k][0] = pw[k][1] = pw[k][2] = 0.0f;
       } else {
         // forward_brdf.vert:25,27
-        const f4 w = mat4_mul(ib.model, f4{v.pos[0], v.pos[1], v.pos[2], 1.0f});
+        const f4 w = mat4_mul(model, f4{v.pos[0], v.pos[1], v.pos[2], 1.0f});
         // forward_brdf.vert:27 multiplies (P*V) * posWorld (pv = P*V); gbuffer.vert:19-22 P * (V * posWorld) (pv = P)
         c = fp.deferred ? mat4_mul(pv, mat4_mul(view, w)) : mat4_mul(pv, w);
         pw[k][0] = w.x; pw[k][1] = w.y; pw[k][2] = w.z;
@@ -659,21 +683,19 @@ __global__ __launch_bounds__(256) void k_geometry(const DrawDesc *__restrict__ d
 #pragma unroll
           for (int j = 0; j < kNumVary; ++j) o[j] = 0.0f;
           if (draw.material == 1u) {
-            o[0] = ib.inv_model.M[0][0]; o[1] = ib.inv_model.M[0][1]; o[2] = ib.inv_model.M[0][2];
+            o[0] = im_[0][0]; o[1] = im_[0][1]; o[2] = im_[0][2];
           } else {
-            const auto &gv = ib.inv_model;
             f3 n = ld3(v.normal);
             o[0] = v.tangent[0]; o[1] = v.tangent[1]; o[2] = v.tangent[2];  // the gizmo mesh keeps its colour there
-            o[3] = fmaf(gv.M[2][0], n.z, fmaf(gv.M[1][0], n.y, gv.M[0][0] * n.x));
-            o[4] = fmaf(gv.M[2][1], n.z, fmaf(gv.M[1][1], n.y, gv.M[0][1] * n.x));
-            o[5] = fmaf(gv.M[2][2], n.z, fmaf(gv.M[1][2], n.y, gv.M[0][2] * n.x));
+            o[3] = fmaf(im_[2][0], n.z, fmaf(im_[1][0], n.y, im_[0][0] * n.x));
+            o[4] = fmaf(im_[2][1], n.z, fmaf(im_[1][1], n.y, im_[0][1] * n.x));
+            o[5] = fmaf(im_[2][2], n.z, fmaf(im_[1][2], n.y, im_[0][2] * n.x));
           }
         } else {
           // :31-36  normalMat = transpose(mat3(aInvModel))
           f3 n = ld3(v.normal), tg = ld3(v.tangent);
-          const auto &im = ib.inv_model;
-          const f3 im0 = mk3(im.M[0][0], im.M[0][1], im.M[0][2]), im1 = mk3(im.M[1][0], im.M[1][1], im.M[1][2]),
-                   im2 = mk3(im.M[2][0], im.M[2][1], im.M[2][2]);
+          const f3 im0 = mk3(im_[0][0], im_[0][1], im_[0][2]), im1 = mk3(im_[1][0], im_[1][1], im_[1][2]),
+                   im2 = mk3(im_[2][0], im_[2][1], im_[2][2]);
           f3 N = normalize3(mk3(dot3(im0, n), dot3(im1, n), dot3(im2, n)));
           f3 T = normalize3(mk3(dot3(im0, tg), dot3(im1, tg), dot3(im2, tg)));
           f3 B = cross3(N, T);
@@ -692,12 +714,9 @@ __global__ __launch_bounds__(256) void k_geometry(const DrawDesc *__restrict__ d
       pa.packed = nullptr;
       pa.packed_dims = 0u;
       if (!OVERLAY) {
-        // (pointer and sizes read together and combined without a branch: as `packed ? dims : 0` the sizes waited for the pointer)
-        const MaterialDesc &md = materials[draw.material];
-        const uint8_t *const mp = md.packed;
-        const uint32_t mdims = (uint32_t)md.pw | ((uint32_t)md.ph << 16);
-        pa.packed = mp;
-        pa.packed_dims = mdims & (mp ? ~0u : 0u);
+        // (the material's packed form travels in the draw descriptor: no load of the material table here)
+        pa.packed = draw.packed;
+        pa.packed_dims = draw.packed ? draw.packed_dims : 0u;
       }
       pa.clip_base = kNotClipped;  // (a clipped primitive's is patched in once the clipper has its arena slots, below)
       // planes of the unclipped triangle; zero for a primitive that goes through the clipper (its sub-triangles have their own)

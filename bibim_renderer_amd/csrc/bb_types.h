@@ -164,6 +164,18 @@ struct DrawDesc {
   uint32_t tris_per_instance;
   uint32_t first_prim;
   uint32_t material;
+  // the material's packed form as the primitive records carry it (nullptr / 0: maps of different sizes, the material table):
+  // filled in by the host, so that k_geometry has no dependent load of the material table in front of its record stores
+  const uint8_t *packed;
+  uint32_t packed_dims;  // width | height << 16
+  uint32_t pad;
+};
+static_assert(sizeof(DrawDesc) == 56, "DrawDesc");
+// first_prim of draws 1 .. kInlineFirstPrims travel as kernel arguments (0xFFFFFFFF: no such draw): k_geometry finds its
+// draw without a load for frames of up to kInlineFirstPrims + 1 draws
+constexpr int kInlineFirstPrims = 3;
+struct FirstPrims {
+  uint32_t v[kInlineFirstPrims];
 };
 
 struct TexDesc {

@@ -199,6 +199,7 @@ struct bbr_context {
   std::vector<InstanceBlock> host_instances;
   uint32_t n_prims = 0;
   uint32_t n_live_draws = 0;
+  FirstPrims first_prims = {{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}};  // of the recorded frame's draws 1 .. 3 (k_geometry)
 
   static constexpr int kMaxSlots = 4;
   static constexpr int kCounterBlocks = kMaxSlots + 1;  // one per frame slot + one for the overlay pass
@@ -442,7 +443,7 @@ void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const Fra
   hipEvent_t *ev = c->timing_this ? &c->ring[bbr_context::kRingEvents * (c->ring_frames % bbr_context::kRingCap)] : nullptr;
   if (c->n_prims)
     hipLaunchKernelGGL((k_geometry<TW, TH>), dim3((c->n_prims + 255) / 256), dim3(256), 0, sg, d_draws, n_draws,
-                       c->n_prims, s.d_tris.ptr, s.d_attrs.ptr, s.d_tile_count.ptr, s.d_bins.ptr, ctr, pv, view, fp, s.d_clip.ptr,
+                       c->n_prims, c->first_prims, s.d_tris.ptr, s.d_attrs.ptr, s.d_tile_count.ptr, s.d_bins.ptr, ctr, pv, view, fp, s.d_clip.ptr,
                        s.d_broad.ptr, c->d_materials.ptr, s.d_block_stats.ptr);
   if (ev && c->timing == 1) (void)hipEventRecord(ev[1], sg);
   if (sr != sg) {
@@ -619,8 +620,15 @@ int submit_frame_into(bbr_context *c, int slot_index) {
       d.tris_per_instance = rd.tris_per_instance;
       d.first_prim = rd.first_prim;
       d.material = (uint32_t)rd.material;
+      const MaterialDesc &md = c->materials[rd.material].desc;
+      d.packed = md.packed;
+      d.packed_dims = md.packed ? ((uint32_t)md.pw | ((uint32_t)md.ph << 16)) : 0u;
+      d.pad = 0;
+      if (k >= 1 && k <= (uint32_t)kInlineFirstPrims) c->first_prims.v[k - 1] = d.first_prim;
       hd[k++] = d;
     }
+    for (uint32_t q = k; q <= (uint32_t)kInlineFirstPrims; ++q)
+      if (q >= 1) c->first_prims.v[q - 1] = 0xFFFFFFFFu;
     c->n_live_draws = k;
   }
   if (inst_bytes) std::memcpy((uint8_t *)s.h_staging + lights_bytes + draws_bytes, c->host_instances.data(), inst_bytes);
@@ -951,6 +959,8 @@ extern "C" int bbr_draw_overlays(bbr_context *c, int32_t gizmo_extent) {
   HIP_TRY(c, upload_sync(s.d_staging.ptr, draws.data(), draws.size() * sizeof(DrawDesc)));
   HIP_TRY(c, upload_sync(s.d_staging.ptr + draws_bytes, inst.data(), inst_bytes));
   const DrawDesc *d_draws = reinterpret_cast<const DrawDesc *>(s.d_staging.ptr);
+  FirstPrims ov_first = {{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}};
+  for (size_t q = 1; q < draws.size() && q <= (size_t)kInlineFirstPrims; ++q) ov_first.v[q - 1] = draws[q].first_prim;
 
   for (int attempt = 0; attempt < 8; ++attempt) {
     const size_t tiles = (size_t)c->tiles_x() * c->tiles_y();
@@ -981,7 +991,7 @@ extern "C" int bbr_draw_overlays(bbr_context *c, int32_t gizmo_extent) {
     auto launch = [&](auto tw, auto th) {
       constexpr int TW = decltype(tw)::value, TH = decltype(th)::value;
       hipLaunchKernelGGL((k_geometry<TW, TH, true>), dim3((n_prims + 255) / 256), dim3(256), 0, st, d_draws, (uint32_t)draws.size(),
-                         n_prims, s.d_tris.ptr, s.d_attrs.ptr, s.d_tile_count.ptr, s.d_bins.ptr, ctr, ident, ident, fp, s.d_clip.ptr,
+                         n_prims, ov_first, s.d_tris.ptr, s.d_attrs.ptr, s.d_tile_count.ptr, s.d_bins.ptr, ctr, ident, ident, fp, s.d_clip.ptr,
                          s.d_broad.ptr, c->d_materials.ptr, s.d_block_stats.ptr);
       hipLaunchKernelGGL((k_raster<TW, TH, true>), dim3(fp.tiles_x, fp.tiles_y), dim3(kTileThreads), 0, st, s.d_tile_count.ptr, ctr,
                          s.d_broad.ptr, s.d_frag_count.ptr, s.d_frags.ptr, (float4 *)nullptr, fp, s.d_tris.ptr, s.d_clip.ptr,

@@ -23,7 +23,10 @@ def _line(proc):
     assert proc.returncode == 0, proc.stderr[-3000:]
     lines = [l for l in proc.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, proc.stdout[-2000:]
-    return json.loads(lines[0])
+    out = json.loads(lines[0])
+    # what the supervisor said about attempts it gave up travels with the line, so that a failing assertion shows it
+    out["_supervisor_stderr"] = [l for l in proc.stderr.splitlines() if "bench supervisor" in l or "Error" in l or "differs" in l][-12:]
+    return out
 
 
 @pytest.mark.parametrize("extra", [[], ["--gather", "rgba32f"], ["--present"], ["--gather", "rgba16f"]])
@@ -48,7 +51,7 @@ def test_two_ranks_on_one_gpu(exchange, extra):
     out = _line(subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env))
     assert out["verified_against_unpartitioned_render"] is True and out["n_gpus"] == 2
     assert out["scaling"] == "strong"
-    assert ("bbr_push_shard" if exchange == "peer" else "torch.distributed") in out["config"]["partition"]
+    assert ("bbr_push_shard" if exchange == "peer" else "torch.distributed") in out["config"]["partition"], out["_supervisor_stderr"]
     ex = out["exchange"]
     assert ex["attempts"] == [] and ex["who"] == exchange and ex["rccl_ranks"] is None
     # the ceiling a scaling record can be held against: a block over one link (two ranks: ring and direct are the same)
