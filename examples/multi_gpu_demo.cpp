@@ -39,7 +39,9 @@ int main(int argc, char **argv) {
     else if (a == "--tone-map" && i + 1 < argc) { tone = true; exposure = (float)std::atof(argv[++i]); }
     else if (a == "--form" && i + 1 < argc) {
       std::string f = argv[++i];
-      form = f == "rgba32f" ? BBR_SHARD_RGBA32F : (f == "rgba8" ? BBR_SHARD_RGBA8 : BBR_SHARD_PACKED);
+      // rgba16f: the reference's own HDR attachment format on the wire (8 bytes per pixel); presenting the widened frame
+      // gives the same image, because presentation starts by rounding to binary16 anyway
+      form = f == "rgba32f" ? BBR_SHARD_RGBA32F : (f == "rgba8" ? BBR_SHARD_RGBA8 : (f == "rgba16f" ? BBR_SHARD_RGBA16F : BBR_SHARD_PACKED));
     }
     else if (a == "--out" && i + 1 < argc) out = argv[++i];
     else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
@@ -118,7 +120,7 @@ int main(int argc, char **argv) {
     if (bbr_synchronize(k.ctx) != BBR_OK) return die("bbr_synchronize", k.ctx);
   const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   std::printf("%dx%d over %d ranks on %d GPU(s), %s blocks of %llu bytes: %.1f us/frame = %.0f Mpixels/s (simple loop, one frame at a time)\n",
-              width, height, ranks, n_gpus < ranks ? n_gpus : ranks, form == BBR_SHARD_PACKED ? "packed" : (form == BBR_SHARD_RGBA8 ? "RGBA8" : "RGBA32F"),
+              width, height, ranks, n_gpus < ranks ? n_gpus : ranks, form == BBR_SHARD_PACKED ? "packed" : (form == BBR_SHARD_RGBA8 ? "RGBA8" : (form == BBR_SHARD_RGBA16F ? "RGBA16F" : "RGBA32F")),
               (unsigned long long)block, frames ? dt / frames * 1e6 : 0.0, frames ? (double)width * height * frames / dt / 1e6 : 0.0);
 
   // the LAST rank's whole frame -> PPM (fp32 forms: presented on the host side of this demo with the library's own step)

@@ -31,6 +31,11 @@ def test_collective_form_with_a_one_rank_communicator(scene_and_frames):
     r = Renderer(cfg.width, cfg.height)
     with pytest.raises(BibimError):
         r.allgather_frame(P.SHARD_RGBA32F)                 # nothing rendered
+    with pytest.raises(BibimError):
+        r.stage_shard(P.SHARD_RGBA16F, 1)                  # nothing rendered either
+    with pytest.raises(BibimError):
+        r.comm_count()                                     # no communicator yet
+    r.comm_probe()                                         # librccl loads: NOT collective, safe on one rank alone
     r.set_partition(0, 1, 32)
     h = r.render_scene(sc)
     r.synchronize()                                        # first frame of a scene: sizes the capacities (re-renders)

@@ -60,11 +60,12 @@ def test_native_demo_writes_the_oracles_image(tmp_path, deferred):
     assert np.array_equal(got, want[..., :3])
 
 
-@pytest.mark.parametrize("ranks,form", [(3, "packed"), (8, "rgba8"), (2, "rgba32f")])
+@pytest.mark.parametrize("ranks,form", [(3, "packed"), (8, "rgba8"), (2, "rgba32f"), (4, "rgba16f")])
 def test_multi_gpu_demo_completes_the_frame_with_peer_pushes(tmp_path, ranks, form):
     """examples/multi_gpu_demo.cpp: one C++ process, `ranks` contexts (all on this box's one GPU), every rank renders its
     bands and pushes its block into every rank's gather buffer (bbr_push_shard), bbr_unpack_whole: the last rank's whole
-    frame, presented, must be the oracle's presented image of the unpartitioned frame"""
+    frame, presented, must be the oracle's presented image of the unpartitioned frame.  (rgba16f -- the reference's HDR
+    attachment format on the wire -- gives the SAME image: presentation rounds to binary16 first, and that is idempotent.)"""
     exe = tmp_path / "mgdemo"
     subprocess.check_call(["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "examples", "multi_gpu_demo.cpp"), "-L" + os.path.join(ROOT, "bibim_renderer_amd"),
