@@ -1309,10 +1309,17 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
   // the pixel's colour when no geometry covers it.  forward: the clear colour (src/main.cpp:84); deferred: brdf.frag on the
   // cleared G-buffer texel (k_deferred_background); fused presentation: the same colours as presented pixels (the clear
   // colour presents as (0, 0, 0, 255))
+  // (read ONCE, with the tile's first loads: inside store_background it was a scalar load and a wait per pixel pass)
+  float4 bg = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  uint32_t bg8 = 0xFF000000u;
+  if (background) {
+    bg = background[0];
+    bg8 = __float_as_uint(background[1].x);
+  }
   auto store_background = [&](int x, int y) {
     const size_t o = (size_t)(out_y0 + y) * (size_t)fp.width + (size_t)(tile_x0 + x);
-    if (out8) store_pixel(&out8[o], background ? __float_as_uint(background[1].x) : 0xFF000000u);
-    else store_pixel(&out[o], background ? background[0] : make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+    if (out8) store_pixel(&out8[o], bg8);
+    else store_pixel(&out[o], bg);
   };
 
   // ---- light tiles: no LDS, no barrier ----
@@ -1353,9 +1360,16 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
     }
     const unsigned long long m_ok = __ballot(ok);
     if (m_ok == 0ull) {
-      for (int p = tid; p < TILE_PIXELS; p += kTileThreads) {
-        int x, y;
-        tile_pixel<TILE_W>(p, x, y);
+      // the same pixels in the same order as `for (p = tid; p < TILE_PIXELS; p += kTileThreads) tile_pixel(p)` would visit them,
+      // without that function's arithmetic per pixel: pass k of thread tid is pixel (x, y + k * STEP) of the tile
+      // (kTileThreads = 256 pixels = 4 blocks of 8 x 8 = a strip TILE_W wide or, for 64-pixel tiles, half of one)
+      constexpr int BX = TILE_W / 8;                      // 8 x 8 blocks per row of blocks
+      constexpr int PASSES = TILE_PIXELS / kTileThreads;
+      static_assert((kTileThreads / 64) % BX == 0 || BX % (kTileThreads / 64) == 0, "fill pattern");
+#pragma unroll
+      for (int k = 0; k < PASSES; ++k) {
+        const int block = (tid >> 6) + k * (kTileThreads / 64);
+        const int x = (block % BX) * 8 + (tid & 7), y = (block / BX) * 8 + ((tid >> 3) & 7);
         if (tile_x0 + x < fp.width && tile_y0 + y < fp.height) store_background(x, y);
       }
       if (tid == 0) frag_count[tile] = 0u;
