@@ -386,6 +386,7 @@ BB_DEV void broad_insert(const RasterTri &t, uint32_t ref, const FrameParams &fp
 struct BinTicket {
   uint32_t base;   // valid in the group's leader lane until redeemed
   uint32_t rank;
+  uint32_t gsize;  // slots the leader reserved (leader lane only)
   int leader;
 };
 
@@ -410,12 +411,27 @@ BB_DEV BinTicket wave_bin_reserve(bool has, uint32_t seg, uint32_t *tile_count) 
     pending &= ~m;
   }
   if (has && lane == t.leader) t.base = atomicAdd(&tile_count[seg], gsize);
+  t.gsize = gsize;
   return t;
 }
 
+// heavy: the frame's heavy-tile list (fp.heavy_threshold != 0).  The ONE reservation that takes a bin's count across the
+// threshold appends the tile -- as the launch slot k_raster's screen order gives it, and the class of the bin -- so a tile
+// is listed at most once per class, and which of its entries does the work follows from the final counts (k_raster).
 BB_DEV void wave_bin_write(bool has, uint32_t seg, uint32_t ref, const BinTicket &t, const FrameParams &fp, Counters *ctr,
-                           uint32_t *bins) {
+                           uint32_t *bins, uint32_t *heavy) {
   const uint32_t base = (uint32_t)__shfl((int)t.base, t.leader);
+  if (heavy && has && (int)(threadIdx.x & 63) == t.leader && t.base < fp.heavy_threshold && t.base + t.gsize >= fp.heavy_threshold) {
+    const uint32_t tile = seg / kBinClasses, c = seg - tile * kBinClasses;
+    const uint32_t ty = tile / (uint32_t)fp.tiles_x, tx = tile - ty * (uint32_t)fp.tiles_x;
+    uint32_t gy = ty;  // owned tile row -> grid row: the inverse of tile_row
+    if (fp.world > 1) {
+      const uint32_t band = ty / (uint32_t)fp.band_tiles;
+      gy = (band / (uint32_t)fp.world) * (uint32_t)fp.band_tiles + (ty - band * (uint32_t)fp.band_tiles);
+    }
+    const uint32_t k = atomicAdd(&ctr->n_heavy, 1u);
+    if (k < kBinClasses * (uint32_t)(fp.tiles_x * fp.tiles_y)) heavy[k] = (gy * (uint32_t)fp.tiles_x + tx) | (c << 30);
+  }
   if (has) {
     uint32_t slot = base + t.rank;
     if (slot < fp.bin_cap) {
@@ -532,7 +548,7 @@ __global__ __launch_bounds__(256) void k_geometry(const DrawDesc *__restrict__ d
                                                   Mat4 pv, Mat4 view, FrameParams fp, ClipSlot *__restrict__ clip_arena,
                                                   BroadTri *__restrict__ broad_list,
                                                   const MaterialDesc *__restrict__ materials,
-                                                  BlockStats *__restrict__ block_stats) {
+                                                  BlockStats *__restrict__ block_stats, uint32_t *__restrict__ heavy) {
 #ifdef BB_STAMPS
 #define BB_STAMP(i) do { if (threadIdx.x == 0) reinterpret_cast<unsigned long long *>(clip_arena + fp.clip_cap)[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
 #else
@@ -757,7 +773,7 @@ __global__ __launch_bounds__(256) void k_geometry(const DrawDesc *__restrict__ d
         refs += (uint32_t)__popcll(__ballot(has[j]));
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) wave_bin_write(has[j], seg[j], prim << 3, tk[j], fp, ctr, bins);
+      for (int j = 0; j < 4; ++j) wave_bin_write(has[j], seg[j], prim << 3, tk[j], fp, ctr, bins, (OVERLAY || !fp.heavy_threshold) ? nullptr : heavy);
     }
   }
   BB_STAMP(3);
@@ -1231,7 +1247,8 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
     uint32_t *__restrict__ vis_prim, float *__restrict__ vis_depth,
     const float4 *__restrict__ background, float *__restrict__ depth_io, uint32_t *__restrict__ host_flags,
     uint32_t *__restrict__ out8, uint32_t *__restrict__ item_groups, uint32_t *__restrict__ item_head,
-    uint32_t *__restrict__ items, const Light *__restrict__ lights, int num_lights, CookedLight *__restrict__ cooked) {
+    uint32_t *__restrict__ items, const Light *__restrict__ lights, int num_lights, CookedLight *__restrict__ cooked,
+    const uint32_t *__restrict__ heavy) {
   constexpr int TILE_PIXELS = TILE_W * TILE_H;
   __shared__ unsigned long long keys[TILE_PIXELS];
   __shared__ StagedTri st;
@@ -1246,6 +1263,7 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
     host_flags[1] = ctr->bin_need;
     host_flags[3] = ctr->n_broad;
     host_flags[4] = ctr->n_clip_slots;
+    host_flags[5] = ctr->n_heavy;   // sizes the heavy rows of this slot's next frame
   }
   // SHORT FRAMES (item_head != nullptr; the host decides by the frame's tile count): there is no k_shade_items launch.  The
   // tiles append their items to the frame's list themselves -- one returning atomic per tile on the list's head word, which
@@ -1262,12 +1280,35 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
     at = (uint32_t)__shfl((int)at, 0);
     if ((uint32_t)lane < chunks)
       items[1u + at + (uint32_t)lane] = flag | ((uint32_t)blockIdx.y << (kItemChunkBits + kItemTxBits)) | ((uint32_t)blockIdx.x << kItemChunkBits) | (uint32_t)lane;
-  };
+  };  // (short frames only: they have no heavy rows, blockIdx is the tile's launch slot)
   static_assert(TILE_PIXELS / 64 <= 64, "a tile's items are written by one wave");
-  // launch slot -> tile: plain row order
-  const uint32_t slot = blockIdx.y * gridDim.x + blockIdx.x;
-  const int grid_row = (int)blockIdx.y;
-  const int tx = (int)blockIdx.x;
+  // launch slot -> tile: plain row order ...
+  uint32_t slot = blockIdx.y * gridDim.x + blockIdx.x;
+  // ... behind fp.heavy_rows rows of HEAVY SLOTS (long frames only).  A tile's life is 1.6 us when nothing is binned to it and
+  // 14-39 us when a ball is; in plain screen order the last heavy tile starts when the kernel's work is half done and the
+  // launch ends in a tail as long as that tile.  k_geometry lists the tiles whose bins reach fp.heavy_threshold references
+  // (launch slot | class << 30, at most one entry per class and tile); the workgroups of the first rows take one entry each
+  // and rasterise THAT tile, and the tile's own workgroup, which sees the same final counts, leaves at once.  Which entry
+  // of a tile listed twice does the work follows from the counts too (the highest class at the threshold), so nobody has to
+  // claim anything.  The rows are sized by the host from the list length of the slot's previous frame; a list longer than
+  // the rows is not used at all -- every decision is all-or-nothing on values that are final since k_geometry ended.
+  const uint32_t heavy_slots = (uint32_t)fp.heavy_rows * gridDim.x;
+  bool heavy_slot = false;
+  uint32_t heavy_class = 0u;
+  if (!OVERLAY && fp.heavy_rows) {
+    if (blockIdx.y < (uint32_t)fp.heavy_rows) {
+      const uint32_t n_heavy = ctr->n_heavy;
+      if (slot >= n_heavy || n_heavy > heavy_slots) return;
+      const uint32_t e = heavy[slot];
+      heavy_class = e >> 30;
+      slot = e & 0x3FFFFFFFu;
+      heavy_slot = true;
+    } else {
+      slot -= heavy_slots;
+    }
+  }
+  const int grid_row = (int)(slot / gridDim.x);
+  const int tx = (int)(slot - (uint32_t)grid_row * gridDim.x);
   int ty, out_tile_row;
   const bool live = tile_row(fp, grid_row, ty, out_tile_row);
   if (!live) return;
@@ -1294,17 +1335,29 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
   // late wave disagreed with its workgroup about the loop bounds: ~100 wrong pixels in one frame of a few hundred
   // whenever other processes shared the GPU.)
   uint32_t n_cls[kBinClasses];
+  bool at_threshold[kBinClasses];
 #pragma unroll
-  for (uint32_t c = 0; c < kBinClasses; ++c)
-    n_cls[c] = BB_ABLATE(1u | (256u << c)) ? 0u : min(tile_count[tile * kBinClasses + c], fp.bin_cap);
+  for (uint32_t c = 0; c < kBinClasses; ++c) {
+    const uint32_t raw = tile_count[tile * kBinClasses + c];
+    at_threshold[c] = raw >= fp.heavy_threshold;
+    n_cls[c] = BB_ABLATE(1u | (256u << c)) ? 0u : min(raw, fp.bin_cap);
+  }
   // A frame whose every-tile list overflowed (bit 1 of ctr->overflow, final since k_geometry ended) is rendered again after
   // the host has grown the list: the clip path reserves a run of entries and writes none of them when the run does not
   // fit, so a prefix of the list may hold entries never written this frame -- the overflowed frame takes none of it.
   // (Both counter words are read unconditionally and combined without a branch -- ONE round trip, together with the bin
   //  counts above, in front of the tile's first decision.  As `overflow & 2 ? 0 : n_broad` the compiler made the second
   //  load wait for the first.)
-  const uint32_t ctr_overflow = ctr->overflow, ctr_n_broad = ctr->n_broad;
+  const uint32_t ctr_overflow = ctr->overflow, ctr_n_broad = ctr->n_broad, ctr_n_heavy = ctr->n_heavy;
   const uint32_t n_broad = BB_ABLATE(5u) ? 0u : (min(ctr_n_broad, fp.broad_cap) & (((ctr_overflow >> 1) & 1u) - 1u));
+  if (!OVERLAY && fp.heavy_rows) {
+    if (heavy_slot) {   // (the list is in use, or this workgroup had left above)
+      const uint32_t top = at_threshold[2] ? 2u : (at_threshold[1] ? 1u : 0u);
+      if (heavy_class != top) return;                          // the tile's other entry does it
+    } else if ((at_threshold[0] || at_threshold[1] || at_threshold[2]) && ctr_n_heavy <= heavy_slots) {
+      return;                                                  // a heavy slot does it (or has done it)
+    }
+  }
 
   // the pixel's colour when no geometry covers it.  forward: the clear colour (src/main.cpp:84); deferred: brdf.frag on the
   // cleared G-buffer texel (k_deferred_background); fused presentation: the same colours as presented pixels (the clear
@@ -1407,7 +1460,9 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
     s_n_clip_refs = 0;
   }
   __syncthreads();  // keys cleared; every wave has its copy of the counts
-  if (tid < (int)kBinClasses && (tid == 0 ? n_cls[0] : (tid == 1 ? n_cls[1] : n_cls[2])))
+  // (a tile rasterised from a heavy slot keeps its counts: its own workgroup may not have looked at them yet.  k_shade_items
+  //  clears them.)
+  if (!heavy_slot && tid < (int)kBinClasses && (tid == 0 ? n_cls[0] : (tid == 1 ? n_cls[1] : n_cls[2])))
     tile_count[tile * kBinClasses + tid] = 0;  // ready for the slot's next frame
 
   // entry order: class 0 | class 1 | class 2 | every-tile list
@@ -1748,9 +1803,27 @@ __global__ __launch_bounds__(kItemsThreads) void k_shade_items(FrameParams fp, c
                                                                uint32_t *__restrict__ items, int grid_x, int grid_y,
                                                                uint32_t *__restrict__ host_count,
                                                                const Light *__restrict__ lights, int num_lights,
-                                                               CookedLight *__restrict__ cooked) {
+                                                               CookedLight *__restrict__ cooked,
+                                                               uint32_t *__restrict__ tile_count, const Counters *__restrict__ ctr,
+                                                               const uint32_t *__restrict__ heavy) {
   __shared__ uint32_t s_wave[2][kItemsThreads / 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // tiles that k_raster rasterised from a heavy slot still have their bin counts (their own workgroups had to see them):
+  // cleared here for the slot's next frame
+  if (fp.heavy_rows) {
+    const uint32_t n_heavy = ctr->n_heavy;
+    if (n_heavy <= (uint32_t)fp.heavy_rows * (uint32_t)grid_x)
+      for (uint32_t i = blockIdx.x * (uint32_t)kItemsThreads + (uint32_t)tid; i < n_heavy; i += gridDim.x * (uint32_t)kItemsThreads) {
+        const uint32_t hs = heavy[i] & 0x3FFFFFFFu;
+        const int gy = (int)(hs / (uint32_t)grid_x), tx = (int)(hs - (uint32_t)gy * (uint32_t)grid_x);
+        int ty, out_tile_row;
+        if (tile_row(fp, gy, ty, out_tile_row)) {
+          const uint32_t tile = (uint32_t)ty * (uint32_t)fp.tiles_x + (uint32_t)tx;
+#pragma unroll
+          for (uint32_t c = 0; c < kBinClasses; ++c) tile_count[tile * kBinClasses + c] = 0u;
+        }
+      }
+  }
   // the frame's cooked light table (k_shade reads it through the scalar cache): once per frame, by the last workgroup
   // (the one with the fewest slots to scan)
   if (blockIdx.x == gridDim.x - 1)

@@ -196,7 +196,8 @@ struct Counters {
   uint32_t n_clip_slots;
   uint32_t overflow;  // bit0 bins, bit1 broad list, bit2 clip arena
   uint32_t bin_need;  // largest per-tile reference count seen when a bin overflowed
-  uint32_t pad[28];
+  uint32_t n_heavy;   // entries of the frame's heavy-tile list (k_geometry appends, k_raster starts those tiles first)
+  uint32_t pad[27];
 };
 static_assert(sizeof(Counters) == 128, "Counters");
 
@@ -214,6 +215,11 @@ struct FrameParams {
   // screen-band partition (band = band_tiles tile rows; band b belongs to rank b % world)
   int32_t rank, world, band_tiles;
   int32_t shard_rows;                // rows of the compact output when world > 1
+  // heavy tiles first (k_raster): a tile one of whose bins reaches heavy_threshold references is appended to the frame's
+  // heavy list by k_geometry (launch slot | class << 30), and the first heavy_rows grid rows of k_raster's launch work
+  // through that list before the screen-ordered rest starts.  0 / 0: off.
+  uint32_t heavy_threshold;
+  int32_t heavy_rows;
   uint32_t ablate;                   // diagnostics only: bit0 skip raster, bit1 skip shading, bit2 skip broad list
   int32_t deferred;                  // 1: the reference's deferred path (gbuffer.vert/.frag + brdf.frag), 0: forward
   int32_t gbuffer_view;              // deferred only: -1 the lit scene, 0..3 buffer_visualize.frag on that G-buffer attachment

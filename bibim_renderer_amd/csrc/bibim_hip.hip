@@ -124,6 +124,7 @@ struct FrameSlot {
   DeviceBuffer<uint32_t> d_frag_count;
   DeviceBuffer<uint32_t> d_items;       // k_shade's work list: [0] = count, then slot << 6 | chunk of 64 fragments
   DeviceBuffer<CookedLight> d_cooked;   // the frame's light table as the light loop consumes it (k_shade_items -> k_shade)
+  DeviceBuffer<uint32_t> d_heavy;       // the frame's heavy-tile list (k_geometry -> k_raster; option "heavy_tiles")
   DeviceBuffer<uint32_t> d_item_groups; // 64-fragment chunks per group of 256 launch slots (k_raster -> k_shade_items)
   DeviceBuffer<float4> d_frame;
   DeviceBuffer<float4> d_background;  // deferred path: colour of the pixels no geometry covers
@@ -149,7 +150,7 @@ struct FrameSlot {
   uint32_t n_prims = 0;
 
   void release_tile_buffers() {
-    d_tile_count.release(); d_bins.release(); d_frags.release(); d_frag_count.release(); d_items.release(); d_item_groups.release(); d_cooked.release();
+    d_tile_count.release(); d_bins.release(); d_frags.release(); d_frag_count.release(); d_items.release(); d_item_groups.release(); d_cooked.release(); d_heavy.release();
   }
   // native exchange (bbr_allgather_frame / bbr_push_shard) with library-owned buffers: every rank's block, the whole frame
   DeviceBuffer<uint8_t> d_gathered, d_whole;
@@ -266,6 +267,13 @@ struct bbr_context {
   std::unordered_set<int> peer_mapped;  // devices whose memory this context's device can store to (peer access enabled)
   bool last_push_direct = false;
   int64_t no_tail_items = 40000;  // option "no_tail_items": frames with at most this many item slots get no tail launch
+  // option "heavy_tiles": k_raster starts the tiles one of whose bins holds at least this many references before the
+  // screen-ordered rest (long frames only; 0: plain screen order; -1, the default: 64 while ONE frame is in flight, 0
+  // otherwise).  Measured at C3: k_raster alone 61.9 -> 51.0 us and a frame's latency 177 -> 167 us with 64 (48: the same;
+  // 96 / 128 / 256: 58.7 / 61.0 / 61.4; 1 / 16 / 32: 55 / 54 / 53.5 and k_geometry +9 / +10 / +6 us for its appends) -- and
+  // with three frames in flight the frame period 1-2 % LONGER (32: 7 %): the other frames' kernels fill the tail that
+  // the order removes, and the light tiles' background stores then come in one burst instead of spread over the launch.
+  int64_t heavy_tiles = -1;
   static constexpr int kLayouts = 3;
   int layout_mode = 2;  // the option
   int layout = 2;       // layout of the frame being submitted
@@ -392,6 +400,7 @@ int ensure_slot_buffers(bbr_context *c, FrameSlot &s) {
     return fail(c, BBR_ERR_INVALID_ARGUMENT, "frame too large for this tile size: set option tile_mode to 0 (64 x 64 tiles)");
   HIP_TRY(c, s.d_item_groups.ensure((size_t)kItemGroups * kItemGroupStride, true));
   HIP_TRY(c, s.d_cooked.ensure(kMaxNumLights));
+  HIP_TRY(c, s.d_heavy.ensure(tiles * kBinClasses, true));
   if (c->deferred) HIP_TRY(c, s.d_background.ensure(2));
   if (c->overlays && &s != &c->ov) HIP_TRY(c, s.d_depth.ensure((size_t)c->width * c->height));
   if (c->present_fused && &s != &c->ov) {
@@ -434,17 +443,35 @@ int upload_material_table(bbr_context *c) {
 }
 
 template <int TW, int TH>
-void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const FrameParams &fp, const Mat4 &pv,
+void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const FrameParams &fp_in, const Mat4 &pv,
                   const Mat4 &view, const ShadeParams &sp, const Light *d_lights, const DrawDesc *d_draws, uint32_t n_draws, float4 *out,
                   uint32_t *d_item_head) {
   const int slot_index = (int)(&s - c->slots);
+  FrameParams fp = fp_in;
+  // a rank without bands (more ranks than bands) still launches one row: its blocks fall off tiles_y and exit
+  const int grid_y = std::max(1, c->world > 1 ? c->local_bands() * fp.band_tiles : fp.tiles_y);
+  // A SHORT frame (at most option "no_tail_items" item slots: 1080p has 32 640) has no k_shade_items launch: k_raster's tiles
+  // append their items themselves through the head word the staging copy has just zeroed, and its first workgroup cooks
+  // the lights.  One kernel and one kernel boundary less on the frame's chain of dependent kernels; such a frame is also
+  // shaded at full coverage, without the tail launch (below).
+  const uint32_t max_items = (uint32_t)(fp.tiles_x * grid_y) * (uint32_t)(TW * TH / 64);
+  const bool short_frame = max_items <= (uint32_t)c->no_tail_items;
+  // Heavy tiles first (long frames; k_raster): the heavy rows in front of the launch are sized from the length of the list
+  // the slot's previous frame produced (pinned word 5, written by k_raster) + 1/8 + 8.  A list that does not fit them is not
+  // used by that frame at all (plain screen order), so the first frame of a slot, or one after a jump, is merely slower.
+  const int64_t heavy_tiles = c->heavy_tiles >= 0 ? c->heavy_tiles : (c->pipelined() ? 0 : 64);
+  if (!short_frame && heavy_tiles > 0 && !c->dump_vis) {
+    fp.heavy_threshold = (uint32_t)heavy_tiles;
+    const uint32_t seen_heavy = s.h_flags ? s.h_flags[5] : 0u;
+    if (seen_heavy) fp.heavy_rows = (int32_t)((seen_heavy + seen_heavy / 8u + 8u + (uint32_t)fp.tiles_x - 1u) / (uint32_t)fp.tiles_x);
+  }
   hipStream_t sg = c->frame_geom_stream(slot_index), sr = c->raster_stream(slot_index), ss = c->frame_shade_stream(slot_index);
   Counters *ctr = c->d_counters.ptr + s.ctr_index, *ctr_done = c->d_counters_done.ptr + s.ctr_index;
   hipEvent_t *ev = c->timing_this ? &c->ring[bbr_context::kRingEvents * (c->ring_frames % bbr_context::kRingCap)] : nullptr;
   if (c->n_prims)
     hipLaunchKernelGGL((k_geometry<TW, TH>), dim3((c->n_prims + 255) / 256), dim3(256), 0, sg, d_draws, n_draws,
                        c->n_prims, c->first_prims, s.d_tris.ptr, s.d_attrs.ptr, s.d_tile_count.ptr, s.d_bins.ptr, ctr, pv, view, fp, s.d_clip.ptr,
-                       s.d_broad.ptr, c->d_materials.ptr, s.d_block_stats.ptr);
+                       s.d_broad.ptr, c->d_materials.ptr, s.d_block_stats.ptr, s.d_heavy.ptr);
   if (ev && c->timing == 1) (void)hipEventRecord(ev[1], sg);
   if (sr != sg) {
     (void)hipEventRecord(s.ev_geom_done, sg);
@@ -457,33 +484,26 @@ void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const Fra
   (void)prev;
   for (const FrameSlot &o : c->slots)
     if (&o != &s && o.in_flight && o.out_used == out && o.stream_used != sr) (void)hipStreamWaitEvent(sr, o.ev_shade_done, 0);
-  // a rank without bands (more ranks than bands) still launches one row: its blocks fall off tiles_y and exit
-  int grid_y = std::max(1, c->world > 1 ? c->local_bands() * fp.band_tiles : fp.tiles_y);
   // option "present_fused": k_raster / k_shade write presented pixels into the slot's RGBA8 image
   uint32_t *out8 = c->present_fused ? s.d_present.ptr : nullptr;
   const SrgbTables *tables = c->present_fused ? c->d_srgb_tables.ptr : nullptr;
   if (fp.deferred)
     hipLaunchKernelGGL(k_deferred_background, dim3(1), dim3(kBackgroundThreads), 0, sr, sp, d_lights, s.d_background.ptr, tables, fp.gbuffer_view);
-  // A SHORT frame (at most option "no_tail_items" item slots: 1080p has 32 640) has no k_shade_items launch: k_raster's tiles
-  // append their items themselves through the head word the staging copy has just zeroed, and its first workgroup cooks
-  // the lights.  One kernel and one kernel boundary less on the frame's chain of dependent kernels; such a frame is also
-  // shaded at full coverage, without the tail launch (below).
-  const uint32_t max_items = (uint32_t)(fp.tiles_x * grid_y) * (uint32_t)(TW * TH / 64);
-  const bool short_frame = max_items <= (uint32_t)c->no_tail_items;
   uint32_t *item_head = short_frame ? d_item_head : nullptr;
-  hipLaunchKernelGGL((k_raster<TW, TH>), dim3(fp.tiles_x, grid_y), dim3(kTileThreads), 0, sr, s.d_tile_count.ptr, ctr,
+  hipLaunchKernelGGL((k_raster<TW, TH>), dim3(fp.tiles_x, fp.heavy_rows + grid_y), dim3(kTileThreads), 0, sr, s.d_tile_count.ptr, ctr,
                      s.d_broad.ptr, s.d_frag_count.ptr, s.d_frags.ptr, out, fp, s.d_tris.ptr, s.d_clip.ptr, s.d_bins.ptr,
                      c->dump_vis ? c->d_vis_prim.ptr : nullptr,
                      c->dump_vis ? c->d_vis_depth.ptr : nullptr,
                      fp.deferred ? s.d_background.ptr : nullptr, (c->overlays && c->world == 1) ? s.d_depth.ptr : nullptr,
                      s.h_flags, out8, short_frame ? nullptr : s.d_item_groups.ptr, item_head, s.d_items.ptr, d_lights, sp.num_lights,
-                     s.d_cooked.ptr);
+                     s.d_cooked.ptr, s.d_heavy.ptr);
   s.has_depth = c->overlays && c->world == 1;
   // k_shade's work list (64 fragments per item), built from the per-tile fragment counts as soon as k_raster is done; the
   // same launch cooks the frame's light table
   if (!short_frame)
     hipLaunchKernelGGL((k_shade_items<TW, TH>), dim3((unsigned)((fp.tiles_x * grid_y + kItemsThreads - 1) / kItemsThreads)), dim3(kItemsThreads), 0, sr, fp, s.d_frag_count.ptr, s.d_item_groups.ptr, s.d_items.ptr,
-                       fp.tiles_x, grid_y, s.h_flags ? s.h_flags + 2 : nullptr, d_lights, sp.num_lights, s.d_cooked.ptr);
+                       fp.tiles_x, grid_y, s.h_flags ? s.h_flags + 2 : nullptr, d_lights, sp.num_lights, s.d_cooked.ptr,
+                       s.d_tile_count.ptr, ctr, s.d_heavy.ptr);
   const uint32_t *item_count = short_frame ? item_head : s.d_items.ptr;   // where k_shade finds the number of items
   if (ev && c->timing == 1) (void)hipEventRecord(ev[2], sr);
   if (ss != sr) {
@@ -992,12 +1012,13 @@ extern "C" int bbr_draw_overlays(bbr_context *c, int32_t gizmo_extent) {
       constexpr int TW = decltype(tw)::value, TH = decltype(th)::value;
       hipLaunchKernelGGL((k_geometry<TW, TH, true>), dim3((n_prims + 255) / 256), dim3(256), 0, st, d_draws, (uint32_t)draws.size(),
                          n_prims, ov_first, s.d_tris.ptr, s.d_attrs.ptr, s.d_tile_count.ptr, s.d_bins.ptr, ctr, ident, ident, fp, s.d_clip.ptr,
-                         s.d_broad.ptr, c->d_materials.ptr, s.d_block_stats.ptr);
+                         s.d_broad.ptr, c->d_materials.ptr, s.d_block_stats.ptr, (uint32_t *)nullptr);
       hipLaunchKernelGGL((k_raster<TW, TH, true>), dim3(fp.tiles_x, fp.tiles_y), dim3(kTileThreads), 0, st, s.d_tile_count.ptr, ctr,
                          s.d_broad.ptr, s.d_frag_count.ptr, s.d_frags.ptr, (float4 *)nullptr, fp, s.d_tris.ptr, s.d_clip.ptr,
                          s.d_bins.ptr, (uint32_t *)nullptr, (float *)nullptr,
                          (const float4 *)nullptr, fs.d_depth.ptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
-                         (uint32_t *)nullptr, (uint32_t *)nullptr, (const Light *)nullptr, 0, (CookedLight *)nullptr);
+                         (uint32_t *)nullptr, (uint32_t *)nullptr, (const Light *)nullptr, 0, (CookedLight *)nullptr,
+                         (const uint32_t *)nullptr);
       constexpr int kChunks = TW * TH / kShadeThreads;
       hipLaunchKernelGGL((k_shade_overlay<TW, TH>), dim3(fp.tiles_x * kChunks, fp.tiles_y), dim3(kShadeThreads), 0, st, fp,
                          s.d_attrs.ptr, s.d_clip.ptr, s.d_frags.ptr, s.d_frag_count.ptr, c->d_srgb_tables.ptr, fs.present.out);
@@ -1764,6 +1785,9 @@ int bbr_set_option(bbr_context *c, const char *name, int64_t value) {
   } else if (n == "no_tail_items") {
     if (value < 0) return fail(c, BBR_ERR_INVALID_ARGUMENT, "no_tail_items must be >= 0");
     c->no_tail_items = value;
+  } else if (n == "heavy_tiles") {
+    if (value < -1 || value > (1 << 24)) return fail(c, BBR_ERR_INVALID_ARGUMENT, "heavy_tiles: -1 (automatic), 0 (off) or a reference count");
+    c->heavy_tiles = value;
   } else if (n == "broad_cap" || n == "clip_cap") {
     // starting capacity of the every-tile list / the clip arena (entries); both double when a frame overflows them
     if (value < 1 || value > (1 << 24)) return fail(c, BBR_ERR_INVALID_ARGUMENT, n + " out of range (1 .. 2^24)");

@@ -210,6 +210,10 @@ int bbr_timing_summary(bbr_context *ctx, uint32_t *out_frames, float *out_avg_fr
  *                            short frame is a chain of dependent kernels whose length is its rate: its raster tiles append
  *                            their items themselves (no k_shade_items launch) and it is shaded at full coverage without
  *                            the tail launch (C2: chain 95 -> 85 us, 27.3 -> 24.6 us per frame with four in flight)
+ *   "heavy_tiles" n          long frames: the raster kernel starts the tiles one of whose bins holds at least n triangle
+ *                            references before the screen-ordered rest.  Same pixels.  0: plain screen order; -1 (default):
+ *                            64 while one frame is in flight, 0 otherwise -- it shortens a single frame (C3: k_raster alone
+ *                            61.9 -> 51.0 us, frame latency 177 -> 167 us) and costs 1-2 % of the pipelined frame rate
  *   "ablate" bits            diagnostic builds only (make EXTRA=-DBB_ABLATE): skip parts of the pipeline */
 int bbr_set_option(bbr_context *ctx, const char *name, int64_t value);
 /* The stream layout in use (option "stream_layout"; 0 while only one frame is in flight).  *out_decided is always 1 and

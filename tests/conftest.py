@@ -59,13 +59,17 @@ def assert_frame_close(img, ref, tol=1e-4):
     assert bad == 0, f"{bad} channel values outside {tol}*max(1,|ref|); max |diff| = {float(d.max())}"
 
 
-@pytest.fixture(params=["short-frame route", "long-frame route"])
+@pytest.fixture(params=["short-frame route", "long-frame route", "long-frame route, heavy tiles first"])
 def item_route(request, monkeypatch):
     """Both ways a frame's shading work list comes about.  A frame with at most `no_tail_items` item slots --
     nearly every frame of this suite -- has its raster tiles append their items themselves and is shaded by one full-coverage
     launch; BASELINE's 4K / 8K frames take the other route: k_shade_items scans the tiles in screen order, the main launch
     is sized from the slot's previous frame and a tail launch covers the rest.  With no_tail_items = 0 (applied to every
-    context the test creates, bibim_renderer_amd.Renderer) a small frame takes the long route too."""
-    if request.param.startswith("long"):
+    context the test creates, bibim_renderer_amd.Renderer) a small frame takes the long route too.  Third form (round 4):
+    the long route with k_raster starting its heavy tiles first (option heavy_tiles; the automatic choice while one frame is
+    in flight), with a threshold low enough (4 references in a bin) for these small frames to have heavy tiles."""
+    if request.param.endswith("heavy tiles first"):
+        monkeypatch.setenv("BBR_OPTIONS", "no_tail_items=0,heavy_tiles=4")
+    elif request.param.startswith("long"):
         monkeypatch.setenv("BBR_OPTIONS", "no_tail_items=0")
     return request.param

@@ -756,11 +756,15 @@ def test_stream_layouts_render_the_same_frames(maps64, mode):
     r.close()
 
 
+@pytest.mark.parametrize("heavy", [0, 4])
 @pytest.mark.parametrize("layout", [0, 2])
-def test_a_frame_with_many_more_fragments_than_the_one_before(maps64, layout):
+def test_a_frame_with_many_more_fragments_than_the_one_before(maps64, layout, heavy):
     """k_shade's main launch is sized from the item count of the frame the slot rendered before; whatever lies behind it
     is shaded by the small persistent tail launch.  A nearly empty frame followed by a full one (and back) in every
-    frame slot, with frames in flight: every frame is the oracle's, bit for bit"""
+    frame slot, with frames in flight: every frame is the oracle's, bit for bit.
+    heavy = 4: k_raster's heavy rows are sized from the previous frame of the slot too -- the first big frame's list does
+    not fit the rows the small frame left (it is rasterised in plain screen order), the next one's does, and the small
+    frame that follows has far more rows than entries."""
     big = scenes.shaderball_scene(configs.C3.scaled(960, 540, 64), bbo.MaterialData(maps64))
     small = scenes.triangle_scene(960, 540)
     ref_big, _, _, st_big = bbo.render(big)
@@ -770,6 +774,7 @@ def test_a_frame_with_many_more_fragments_than_the_one_before(maps64, layout):
     r.set_option("frames_in_flight", 3)
     r.set_option("stream_layout", layout)
     r.set_option("no_tail_items", 0)             # (a frame this small would otherwise be launched at full coverage, without a tail)
+    r.set_option("heavy_tiles", heavy)
     hb = hs = None
     for rep in range(3):
         for _ in range(4):                       # every slot has seen the small frame

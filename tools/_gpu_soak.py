@@ -33,7 +33,7 @@ last = None            # (ref, ref8) of the last frame rendered into the interna
 t_end, n_frames, n_checks, ops = time.time() + seconds, 0, 0, {}
 ext_buf = None
 while time.time() < t_end:
-    op = rng.choice(["render"] * 12 + ["check"] * 3 + ["layout", "fif", "resize", "pass", "fused", "present", "extbuf", "sync"])
+    op = rng.choice(["render"] * 12 + ["check"] * 3 + ["layout", "fif", "resize", "pass", "fused", "present", "extbuf", "sync", "route"])
     ops[op] = ops.get(op, 0) + 1
     if op == "render":
         sc, ref, ref8 = scene_and_ref(rng.choice(list(bases)), ext, deferred)
@@ -82,6 +82,9 @@ while time.time() < t_end:
         else:
             r.set_output_device_ptr(None, 0); ext_buf = None
         last = None
+    elif op == "route":   # short / long frames' work list, k_raster's heavy tiles first or in screen order (same pixels)
+        r.set_option("no_tail_items", rng.choice([0, 40000]))
+        r.set_option("heavy_tiles", rng.choice([-1, 0, 4, 64]))
     elif op == "sync":
         r.synchronize()
 r.synchronize()
