@@ -323,23 +323,28 @@ def test_frames_stay_identical_while_other_processes_share_the_gpu(maps64):
     """Regression for two races that only showed with other processes on the GPU (waves of a workgroup starting far
     apart): k_raster reading a tile's bin counts after another wave had cleared them, and zero fills on the NULL stream
     landing after the first kernels.  Two contender processes render in a loop; this one renders 300 partitioned frames
-    into two alternating caller buffers (bench.py's N > 1 pattern) and every frame must have the same bits."""
+    into two alternating caller buffers (bench.py's N > 1 pattern) and every frame must have the same bits.
+    Third pass (round 4): the long frames' route with k_raster's heavy slots, where a tile's bin counts are read by two
+    workgroups that may start far apart."""
     import subprocess, sys, time, torch
     contender = ("import sys; sys.path.insert(0, '.');\n"
                  "from bibim_renderer_amd import configs, textures, Renderer; from bibim_renderer_amd import scene as S\n"
                  "cfg = configs.C3.scaled(1920, 1080, 256); r = Renderer(cfg.width, cfg.height)\n"
                  "m = r.upload_material(textures.make_material(256)); sc, cam, st = S.config_scene(r, cfg)\n"
                  "import time; t = time.time()\n"
-                 "while time.time() - t < 12: [S.draw_frame(r, sc, cam, st, m) for _ in range(50)]; r.synchronize()\n")
+                 "while time.time() - t < 16: [S.draw_frame(r, sc, cam, st, m) for _ in range(50)]; r.synchronize()\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     procs = [subprocess.Popen([sys.executable, "-c", contender], cwd=root, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
              for _ in range(2)]
     try:
         time.sleep(4.0)  # let the contenders get going (their first import of torch-free modules is quick)
         cfg = configs.C3.scaled(1920, 1080, 64)
-        for fif in (1, 3):
+        for fif, heavy in ((1, 0), (3, 0), (3, 4)):
             r = Renderer(cfg.width, cfg.height)
             r.set_option("frames_in_flight", fif)
+            if heavy:
+                r.set_option("no_tail_items", 0)
+                r.set_option("heavy_tiles", heavy)
             material = r.upload_material(maps64)
             scene, cam, settings = S.config_scene(r, cfg)
             r.set_partition(1, 4, r.tile_height())
@@ -366,7 +371,7 @@ def test_frames_stay_identical_while_other_processes_share_the_gpu(maps64):
             torch.cuda.synchronize()
             k = keep.view(torch.int32)
             bad = [n for n in range(steps) if not torch.equal(k[n], k[0])]
-            assert not bad, (fif, bad[:10])
+            assert not bad, (fif, heavy, bad[:10])
             scene.close(); r.close()
     finally:
         for p in procs:
