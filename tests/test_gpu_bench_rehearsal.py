@@ -78,6 +78,22 @@ def test_a_stalled_exchange_is_given_up_and_the_torch_attempt_completes():
     assert "no progress" in ex["attempts"][0]["gave_up_because"] and "first_frame" in ex["attempts"][0]["gave_up_because"]
 
 
+def test_a_stalled_rank_under_a_launcher_is_given_up_by_every_ranks_supervisor():
+    """The same hang in the form the DRIVER starts N > 1 runs: `python -m torch.distributed.run ... bench.py --gpus 2`.  There
+    is no common parent then: every rank is its own supervisor of its own worker.  Rank 1's worker stalls in the peer attempt;
+    its supervisor gives the attempt up and leaves a flag file, rank 0's supervisor -- whose worker hangs in the exchange
+    waiting for rank 1 -- sees the flag (or its own stall limit), kills its worker too, and both start the torch attempt,
+    which meets on the attempt's own port.  Rank 0 prints the ONE line."""
+    env = dict(os.environ, BBR_BENCH_BACKEND="gloo", BBR_BENCH_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               BBR_BENCH_STALL="peer:1:first_frame", BBR_BENCH_STALL_LIMIT="100")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--exchange", "peer"] + COMMON
+    out = _line(subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env))
+    ex = out["exchange"]
+    assert out["n_gpus"] == 2 and out["verified_against_unpartitioned_render"] is True and ex["who"] == "torch", out["_supervisor_stderr"]
+    assert len(ex["attempts"]) == 1 and ex["attempts"][0]["exchange"] == "peer"
+
+
 def test_bare_bench_command_with_two_gpus_launches_its_own_ranks():
     """`python3 bench.py --gpus 2 --steps 20 --warmup 5` with no launcher around it (what a driver that reuses its N = 1
     command form would run): bench.py starts the two ranks itself and relays rank 0's line.  Rehearsed on the one GPU."""
