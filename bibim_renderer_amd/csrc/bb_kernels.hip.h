@@ -554,6 +554,11 @@ __global__ __launch_bounds__(256) void k_geometry(const DrawDesc *__restrict__ d
 #else
 #define BB_STAMP(i) do { } while (0)
 #endif
+  // This kernel's waves issue one instruction in ~18 cycles and wait for memory most of their lives; with frames in flight
+  // they share their SIMDs with k_shade's, which want to issue all the time.  At the highest issue priority their few
+  // instructions go out when they are ready and the wave gives its slot back sooner (k_raster does the same; C3 frame
+  // -2 % on two boxes of three, 0 on the third; C5 the same as without).
+  __builtin_amdgcn_s_setprio(3);
   BB_STAMP(0);
   __shared__ ClipWork s_clip[4];  // one per wave
   // (No workgroup barrier anywhere in this kernel: the four waves of a workgroup share nothing -- each has its own clip
@@ -1254,6 +1259,7 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
   __shared__ StagedTri st;
   __shared__ uint32_t s_count;
 
+  __builtin_amdgcn_s_setprio(3);  // (as k_geometry: a latency-bound wave's instruction goes out when it is ready)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // {overflow bits, bin_need, -, every-tile entries asked for, clip slots asked for} of this frame straight into pinned host
   // memory (final since k_geometry ended): the host looks at them when it reuses the frame's slot -- a few stores instead
@@ -1900,6 +1906,7 @@ __global__ __launch_bounds__(kItemsThreads) void k_shade_items(FrameParams fp, c
 #define BB_SHADE_WAVES 8  // waves per SIMD the main forward instantiation is compiled for (64 registers)
 #endif
 constexpr int kShadeThreads = BB_SHADE_THREADS;
+constexpr int kFrontPriorityLights = 6;  // k_shade: from this many lights on, a wave's load phases run at a raised issue priority
 #ifdef BB_STAMPS
 __device__ unsigned long long g_shade_stamps[4096 * 8];  // diagnostic build: per-wave phase cycles of k_shade
 #endif
@@ -1960,6 +1967,11 @@ __global__ __launch_bounds__(kShadeThreads) __attribute__((amdgpu_waves_per_eu(T
 #else
 #define BB_KSTAMP(i) do { } while (0)
 #endif
+  // With a LONG light loop (C5's eight lights: two thirds of a wave's instructions) the waves that are still asking for their
+  // fragments, records and texels go first: their loads are out sooner and there is always another wave's light loop to
+  // issue behind them (C5 frame 509-514 -> 500-503 us on two boxes).  With four lights the same priority costs 2-3 %
+  // (C3 101 -> 104 us): there the waves in their light loops are the ones about to give their slots back.
+  if (sp.num_lights >= kFrontPriorityLights) __builtin_amdgcn_s_setprio(2);
   const int lane = (int)(threadIdx.x & 63u);
   // this wave's (first) item: wave-uniform, everything derived from it lives in scalar registers.  The item word is read
   // together with the item count, not after it (the list has room for every index a launch can produce): one dependent
@@ -2189,6 +2201,7 @@ __global__ __launch_bounds__(kShadeThreads) __attribute__((amdgpu_waves_per_eu(T
   }
   // the taps are used from here on: pin them behind the body's fence (they were issued in front of it)
   asm volatile("" :: "v"(t00[0]), "v"(t00[1]), "v"(t00[2]), "v"(t10[0]), "v"(t10[1]), "v"(t10[2]), "v"(t01[0]), "v"(t01[1]), "v"(t01[2]), "v"(t11[0]), "v"(t11[1]), "v"(t11[2]) : "memory");
+  __builtin_amdgcn_s_setprio(0);  // (the loads are out: filtering and the light loop at the default priority)
 
   // texture filtering, forward_brdf.frag:16-22
   const float u = BB_ABLATE(8u) ? 0.5f : a[0], v = BB_ABLATE(8u) ? 0.5f : a[1];
