@@ -710,18 +710,17 @@ def main():
         nm = torch.tensor([n_more], dtype=torch.int64, device="cuda")
         dist.all_reduce(nm, op=dist.ReduceOp.MAX)
         n_more = int(nm.item())
-    for _ in range(n_more):
-        step()
-    fence()
     layout, layout_decided, layout_ms = r.stream_layout_state()
     use_events = not args.no_timing_events
     # HIP events around k_shade on sampled steps of the timed region: ten samples of a long run, but never closer than every
     # fourth step (a pair on every step costs ~6 % of the rate it describes; the driver's 20-step run gets five samples)
     event_stride = max(1, min(args.event_stride, args.steps)) if args.event_stride > 0 else max(min(4, max(1, args.steps // 2)), args.steps // 10)
-    # Everything that synchronises or idles the GPU happens BEFORE the warm-up steps: switching the timing events on (their
-    # creation takes half a millisecond), the statistics read-back.  Between the last warm-up step and the clock there is
-    # only what the contract asks for -- barrier + synchronize -- so the timed steps start on a GPU that was busy a moment
-    # ago, as the frames of a running application do, not on one that has idled through a millisecond of bookkeeping.
+    # Everything that synchronises or idles the GPU happens BEFORE the quarter second of frames below: switching the timing
+    # events on (the library drains and creates 2560 events: the GPU idles for a millisecond, and its clocks need ~100 ms
+    # of load to come back -- with the switch BEHIND those frames the default run read 109-110 us per C3 frame, 102 with
+    # --warmup 200, 100.7 without events: gpurun_out/r4/cmp1.txt, cmp3.txt), the statistics read-back.  Between the last
+    # warm-up step and the clock there is only what the contract asks for -- barrier + synchronize -- so the timed steps start
+    # on a GPU that was busy a moment ago, as the frames of a running application do.
     fence()
     if use_events:
         # timed region: only the two events that bracket the dominant kernel (the full five-event breakdown costs
@@ -729,6 +728,8 @@ def main():
         r.set_option("timing", 2)
         r.set_option("timing_stride", event_stride)
     fence()
+    for _ in range(n_more):
+        step()
     for _ in range(args.warmup):
         step()
     if dist_path and args.exchange == "peer" and pending:
