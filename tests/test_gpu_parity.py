@@ -753,6 +753,9 @@ def test_stream_layouts_render_the_same_frames(maps64, mode):
         r.set_option("stream_layout", 3)
     with pytest.raises(BibimError):
         r.set_option("stream_layout", -1)
+    with pytest.raises(BibimError):
+        r.set_option("heavy_tiles", -2)      # (-1 = automatic, 0 = off, n = a bin's reference count)
+    r.set_option("heavy_tiles", -1)
     r.close()
 
 
