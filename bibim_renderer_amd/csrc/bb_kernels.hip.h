@@ -1072,96 +1072,38 @@ constexpr int kFragPixBits = 12;  // pixel-in-tile field of a fragment's high wo
 constexpr int kTileThreads = 256;
 constexpr int kTileWaves = kTileThreads / 64;
 
-// One lane rasterises one small triangle into the tile's LDS keys.  Bounding box <= 16 px in each direction
-// => every edge-function term fits 32 bits and steps are plain adds.
+// ONE ROW of a small triangle (raster classes 0 and 1: spans <= 64 px, so every edge-function term fits 32 bits and a
+// step is a plain add) by one lane: the row's pixels of bounding box ^ tile, left to right.  k_raster hands the rows of all
+// small triangles of a chunk out as one list (see there), so a lane's work is a row whatever the triangle's size.
+// Same values as the 64-bit form (edge_eval) at every pixel centre: E' = E + (top-left ? 0 : -1), covered <=> all E' >= 0.
+// The depth is depth_max's expression with its row-constant half hoisted: z = fma(dzdx, dxp, fma(dzdy, dyp, z0)), and
+// dxp = float(Xc - X0) is stepped by 256.0f (exact: |Xc - X0| <= 2^14 + 2^8 inside the bounding box).
 template <int TILE_W, int TILE_H>
-BB_DEV void raster_triangle_lane(const RasterTri &t, uint32_t ref, int px0, int px1, int py0, int py1, int tile_x0,
-                                 int tile_y0, unsigned long long *keys, uint32_t zbias = 0u) {
-  const int dx0 = t.X1 - t.X0, dy0 = t.Y1 - t.Y0;
-  const int dx1 = t.X2 - t.X1, dy1 = t.Y2 - t.Y1;
-  const int dx2 = t.X0 - t.X2, dy2 = t.Y0 - t.Y2;
-  const int Xc0 = px0 * 256 + 128, Yc0 = py0 * 256 + 128;
-  // top-left rule folded into the edge value: E' = E + (top-left ? 0 : -1); covered <=> all E' >= 0
-  int r0 = dx0 * (Yc0 - t.Y0) - dy0 * (Xc0 - t.X0) + ((dy0 < 0 || (dy0 == 0 && dx0 > 0)) ? 0 : -1);
-  int r1 = dx1 * (Yc0 - t.Y1) - dy1 * (Xc0 - t.X1) + ((dy1 < 0 || (dy1 == 0 && dx1 > 0)) ? 0 : -1);
-  int r2 = dx2 * (Yc0 - t.Y2) - dy2 * (Xc0 - t.X2) + ((dy2 < 0 || (dy2 == 0 && dx2 > 0)) ? 0 : -1);
+BB_DEV void raster_triangle_row(int X0, int Y0, int X1, int Y1, int X2, int Y2, float z0, float dzdx, float dzdy, uint32_t ref,
+                                int px0, int px1, int py, int tile_x0, int tile_y0, unsigned long long *keys, uint32_t zbias) {
+  const int dx0 = X1 - X0, dy0 = Y1 - Y0;
+  const int dx1 = X2 - X1, dy1 = Y2 - Y1;
+  const int dx2 = X0 - X2, dy2 = Y0 - Y2;
+  const int Xc0 = px0 * 256 + 128, Yc = py * 256 + 128;
+  int e0 = mul32(dx0, Yc - Y0) - mul32(dy0, Xc0 - X0) + ((dy0 < 0 || (dy0 == 0 && dx0 > 0)) ? 0 : -1);
+  int e1 = mul32(dx1, Yc - Y1) - mul32(dy1, Xc0 - X1) + ((dy1 < 0 || (dy1 == 0 && dx1 > 0)) ? 0 : -1);
+  int e2 = mul32(dx2, Yc - Y2) - mul32(dy2, Xc0 - X2) + ((dy2 < 0 || (dy2 == 0 && dx2 > 0)) ? 0 : -1);
   const int sx0 = dy0 * 256, sx1 = dy1 * 256, sx2 = dy2 * 256;  // E(x+1) = E - sx
-  const int sy0 = dx0 * 256, sy1 = dx1 * 256, sy2 = dx2 * 256;  // E(y+1) = E + sy
-  const int w = px1 - px0 + 1, n = w * (py1 - py0 + 1);
-  int e0 = r0, e1 = r1, e2 = r2, x = 0, py = py0;
-  for (int i = 0; i < n; ++i) {
+  const float zrow = fmaf(dzdy, (float)(Yc - Y0), z0);
+  float dxp = (float)(Xc0 - X0);
+  const int y = py - tile_y0;
+  constexpr int BX = TILE_W / 8;
+  const int row_index = (((y >> 3) * BX) << 6) | ((y & 7) << 3);  // tile_index<TILE_W>(x, y) = row_index + (x >> 3 << 6 | x & 7)
+  const unsigned long long key_lo = (unsigned long long)(ref + 1u);
+  for (int x = px0 - tile_x0; x <= px1 - tile_x0; ++x) {
     if ((e0 | e1 | e2) >= 0) {
-      int px = px0 + x;
-      depth_max(t, px, py, ref, keys, tile_index<TILE_W>(px - tile_x0, py - tile_y0), zbias);
+      float z = fmaf(dzdx, dxp, zrow);
+      if (!(z >= 0.0f)) z = 0.0f;
+      if (z > 1.0f) z = 1.0f;
+      atomicMax(&keys[row_index + (((x >> 3) << 6) | (x & 7))], ((unsigned long long)(__float_as_uint(z) + zbias) << 32) | key_lo);
     }
-    ++x;
     e0 -= sx0; e1 -= sx1; e2 -= sx2;
-    if (x == w) {
-      x = 0;
-      ++py;
-      r0 += sy0; r1 += sy1; r2 += sy2;
-      e0 = r0; e1 = r1; e2 = r2;
-    }
-  }
-}
-
-// The same triangle shared by L lanes (L = 2 or 4, consecutive lanes): lane `sub` takes the bounding box's rows sub, sub + L,
-// ...  A tile with a few dozen tiny triangles keeps a few dozen lanes busy for up to 64 pixels each in the one-lane form
-// -- the workgroup's critical path, and k_raster's at 1080p, where the ball's tiles finish last; the other lanes of
-// those waves are idle anyway.  (C2: k_raster 34.4 -> 30.6 us, C3: -3.9 us.)
-template <int TILE_W, int TILE_H>
-BB_DEV void raster_triangle_rows(const RasterTri &t, uint32_t ref, int px0, int px1, int py0, int py1, int tile_x0, int tile_y0,
-                                 unsigned long long *keys, int sub, int L, uint32_t zbias = 0u) {
-  const int dx0 = t.X1 - t.X0, dy0 = t.Y1 - t.Y0;
-  const int dx1 = t.X2 - t.X1, dy1 = t.Y2 - t.Y1;
-  const int dx2 = t.X0 - t.X2, dy2 = t.Y0 - t.Y2;
-  const int Xc0 = px0 * 256 + 128, Yc0 = (py0 + sub) * 256 + 128;
-  int r0 = dx0 * (Yc0 - t.Y0) - dy0 * (Xc0 - t.X0) + ((dy0 < 0 || (dy0 == 0 && dx0 > 0)) ? 0 : -1);
-  int r1 = dx1 * (Yc0 - t.Y1) - dy1 * (Xc0 - t.X1) + ((dy1 < 0 || (dy1 == 0 && dx1 > 0)) ? 0 : -1);
-  int r2 = dx2 * (Yc0 - t.Y2) - dy2 * (Xc0 - t.X2) + ((dy2 < 0 || (dy2 == 0 && dx2 > 0)) ? 0 : -1);
-  const int sx0 = dy0 * 256, sx1 = dy1 * 256, sx2 = dy2 * 256;              // E(x+1) = E - sx
-  const int sy0 = dx0 * 256 * L, sy1 = dx1 * 256 * L, sy2 = dx2 * 256 * L;  // E(y+L) = E + sy
-  for (int py = py0 + sub; py <= py1; py += L) {
-    int e0 = r0, e1 = r1, e2 = r2;
-    for (int px = px0; px <= px1; ++px) {
-      if ((e0 | e1 | e2) >= 0) depth_max(t, px, py, ref, keys, tile_index<TILE_W>(px - tile_x0, py - tile_y0), zbias);
-      e0 -= sx0; e1 -= sx1; e2 -= sx2;
-    }
-    r0 += sy0; r1 += sy1; r2 += sy2;
-  }
-}
-
-// Sixteen lanes rasterise one small triangle (spans <= 64 px): 4x4 pixel blocks over bounding box ^ tile, one pixel
-// per lane, 32-bit edge functions evaluated with 24-bit multiply-adds (exact: |step| < 2^23, offsets < 64).
-template <int TILE_W, int TILE_H>
-BB_DEV void raster_triangle_group16(const RasterTri &t, uint32_t ref, int px0, int px1, int py0, int py1, int tile_x0,
-                                    int tile_y0, unsigned long long *keys, int gl, uint32_t zbias = 0u) {
-  const EdgeSetup e = edge_setup(t);
-  const int Xc0 = px0 * 256 + 128, Yc0 = py0 * 256 + 128;
-  const int w = px1 - px0 + 1, h = py1 - py0 + 1;
-  int o[3], sx[3], sy[3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    o[i] = e.dx[i] * (Yc0 - e.Y[i]) - e.dy[i] * (Xc0 - e.X[i]) + e.bias[i];
-    sx[i] = -e.dy[i] * 256;
-    sy[i] = e.dx[i] * 256;
-  }
-  const int lx = gl & 3, ly = gl >> 2;
-  // this lane's pixel of the first block; stepping a block to the right / down is an add (exact: same values as the
-  // multiply-add form, all terms < 2^30)
-  int r0 = mul32(lx, sx[0]) + mul32(ly, sy[0]) + o[0];
-  int r1 = mul32(lx, sx[1]) + mul32(ly, sy[1]) + o[1];
-  int r2 = mul32(lx, sx[2]) + mul32(ly, sy[2]) + o[2];
-  const int bx0 = 4 * sx[0], bx1 = 4 * sx[1], bx2 = 4 * sx[2];
-  const int by0 = 4 * sy[0], by1 = 4 * sy[1], by2 = 4 * sy[2];
-  for (int y = ly; y < h; y += 4) {
-    int e0 = r0, e1 = r1, e2 = r2;
-    for (int x = lx; x < w; x += 4) {
-      if ((e0 | e1 | e2) >= 0)
-        depth_max(t, px0 + x, py0 + y, ref, keys, tile_index<TILE_W>(px0 + x - tile_x0, py0 + y - tile_y0), zbias);
-      e0 += bx0; e1 += bx1; e2 += bx2;
-    }
-    r0 += by0; r1 += by1; r2 += by2;
+    dxp += 256.0f;
   }
 }
 
@@ -1241,8 +1183,14 @@ BB_DEV CookedLight cook_light(const Light &l) {
 // OVERLAY = true (overlay subpass): the keys start from the scene's resolved depth (`depth_io`, read) instead of 0,
 // gizmo primitives are scissored to their rectangle and biased above everything else, pixels no overlay primitive
 // wins are left alone (no background fill).  OVERLAY = false with depth_io != nullptr stores the resolved depth.
+#ifndef BB_RASTER_WAVES
+#define BB_RASTER_WAVES 8
+#endif
+#ifndef BB_RASTER_PREFETCH
+#define BB_RASTER_PREFETCH 1
+#endif
 template <int TILE_W, int TILE_H, bool OVERLAY = false>
-__global__ __launch_bounds__(kTileThreads) void k_raster(
+__global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(OVERLAY ? 7 : BB_RASTER_WAVES))) void k_raster(
     // (first: what a tile needs before its first load -- these arrive in scalar registers with the wave, "kernarg preload";
     //  the Makefile asks for it.  Everything behind them comes with one scalar load from the kernel-argument segment.)
     uint32_t *__restrict__ tile_count, Counters *__restrict__ ctr, const BroadTri *__restrict__ broad_list,
@@ -1258,6 +1206,9 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
   __shared__ unsigned long long keys[TILE_PIXELS];
   __shared__ StagedTri st;
   __shared__ uint32_t s_count;
+  // the row list of the chunk's small triangles (see the chunk loop)
+  __shared__ uint16_t s_row0[kStage];          // first row of staged entry j in its wave's list
+  __shared__ uint32_t s_wave_rows[kTileWaves];  // rows in each wave's list
 
   __builtin_amdgcn_s_setprio(3);  // (as k_geometry: a latency-bound wave's instruction goes out when it is ready)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1374,6 +1325,12 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
   if (background) {
     bg = background[0];
     bg8 = __float_as_uint(background[1].x);
+    // (uniform values: kept in scalar registers -- five vector registers that would otherwise live through the whole chunk loop)
+    bg.x = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(bg.x)));
+    bg.y = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(bg.y)));
+    bg.z = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(bg.z)));
+    bg.w = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(bg.w)));
+    bg8 = (uint32_t)__builtin_amdgcn_readfirstlane((int)bg8);
   }
   auto store_background = [&](int x, int y) {
     const size_t o = (size_t)(out_y0 + y) * (size_t)fp.width + (size_t)(tile_x0 + x);
@@ -1480,90 +1437,94 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
     return (OVERLAY && (ref >> 3) >= fp.ov_first_gizmo_prim) ? 0x40000000u : 0u;
   };
   BB_RSTAMP(1);
+  // ---- the chunk loop: up to kStage entries at a time ----
+  // An entry is fetched in two dependent trips (bin reference -> triangle record; an every-tile entry in one).  Both run
+  // AHEAD of the chunk they belong to: the references of chunk k + 2 and the triangles of chunk k + 1 are asked for before
+  // chunk k is rasterised, so a tile with several chunks (a far ball puts 2500 tiny triangles into one tile: ten chunks)
+  // pays the two trips once, not once per chunk -- they had been the critical path of the frame's heaviest tiles.
+  struct Fetched {  // what the staging keeps of an entry (the first 36 bytes of its RasterTri)
+    int X0, Y0, X1, Y1, X2, Y2;
+    float z0, dzdx, dzdy;
+    uint32_t ref, clip_slot1;
+  };
+  auto fetch_ref = [&](uint32_t e) -> uint32_t {  // bin reference of entry e (0 for the every-tile list and past the end)
+    if (e >= e3) return 0u;
+    const uint32_t c = e < e1 ? 0u : (e < e2 ? 1u : 2u);
+    const uint32_t i = e - (c == 0u ? 0u : (c == 1u ? e1 : e2));
+    return bin0[(size_t)c * fp.bin_cap + i];
+  };
+  auto fetch_tri = [&](uint32_t e, uint32_t ref) -> Fetched {
+    Fetched f = {};
+    if (e >= e_end) return f;
+    const RasterTri *t = e < e3 ? &tris[ref >> 3] : &broad_list[e - e3].tri;  // binned triangles are never clipped
+    f.X0 = t->X0; f.Y0 = t->Y0; f.X1 = t->X1; f.Y1 = t->Y1; f.X2 = t->X2; f.Y2 = t->Y2;
+    f.z0 = t->z0; f.dzdx = t->dzdx; f.dzdy = t->dzdy;
+    f.ref = ref;
+    if (e >= e3) {
+      f.ref = broad_list[e - e3].ref;
+      f.clip_slot1 = broad_list[e - e3].pad[0];
+    }
+    return f;
+  };
+  uint32_t ref_next = fetch_ref((uint32_t)tid + (uint32_t)kStage);
+  Fetched cur = fetch_tri((uint32_t)tid, fetch_ref((uint32_t)tid));
   for (uint32_t base = 0; base < e_end; base += kStage) {
     if (base) __syncthreads();  // previous chunk consumed
-    // ---- stage: every thread fetches one entry (reference -> triangle record), all loads in flight together ----
+    // ---- stage: every thread files one entry; the rows of the small triangles (classes 0 and 1) are counted ----
     {
       const uint32_t e = base + (uint32_t)tid;
       uint32_t box = 0xFFFFFFFFu;
+      int rows = 0;
       if (e < e_end) {
-        RasterTri t;
-        uint32_t ref, clip_slot1 = 0u;
-        if (e < e3) {
-          const uint32_t c = e < e1 ? 0u : (e < e2 ? 1u : 2u);
-          const uint32_t i = e - (c == 0u ? 0u : (c == 1u ? e1 : e2));
-          ref = bin0[(size_t)c * fp.bin_cap + i];
-          t = tris[ref >> 3];  // binned triangles are never clipped
-        } else {
-          const BroadTri &b = broad_list[e - e3];
-          t = b.tri;
-          ref = b.ref;
-          clip_slot1 = b.pad[0];
-        }
+        const Fetched &t = cur;
         int32_t minX = min(t.X0, min(t.X1, t.X2)), maxX = max(t.X0, max(t.X1, t.X2));
         int32_t minY = min(t.Y0, min(t.Y1, t.Y2)), maxY = max(t.Y0, max(t.Y1, t.Y2));
         int px0 = max((minX - 128 + 255) >> 8, tile_x0), px1 = min((maxX - 128) >> 8, rx1);
         int py0 = max((minY - 128 + 255) >> 8, tile_y0), py1 = min((maxY - 128) >> 8, ry1);
-        if (OVERLAY && (ref >> 3) >= fp.ov_first_gizmo_prim) {  // the gizmo's scissor rectangle (src/main.cpp:767-772)
+        if (OVERLAY && (t.ref >> 3) >= fp.ov_first_gizmo_prim) {  // the gizmo's scissor rectangle (src/main.cpp:767-772)
           px0 = max(px0, fp.ov_x0); px1 = min(px1, fp.ov_x1 - 1);
           py0 = max(py0, fp.ov_y0); py1 = min(py1, fp.ov_y1 - 1);
         }
         bool ok = px0 <= px1 && py0 <= py1;
-        if (ok && e >= e3) ok = classify_rect(edge_setup(t), px0, px1, py0, py1) != 0;  // every-tile list: accept / reject
+        if (ok && e >= e3) {  // every-tile list: accept / reject
+          RasterTri rt;
+          rt.X0 = t.X0; rt.Y0 = t.Y0; rt.X1 = t.X1; rt.Y1 = t.Y1; rt.X2 = t.X2; rt.Y2 = t.Y2;
+          ok = classify_rect(edge_setup(rt), px0, px1, py0, py1) != 0;
+        }
         if (ok) {
-          if (clip_slot1) {
+          if (t.clip_slot1) {
             const uint32_t k = atomicAdd(&s_n_clip_refs, 1u);
             if (k < kClipRefs) {
-              s_clip_ref[k] = ref;
-              s_clip_slot[k] = clip_slot1;
+              s_clip_ref[k] = t.ref;
+              s_clip_slot[k] = t.clip_slot1;
             }
           }
           box = (uint32_t)(px0 - tile_x0) | ((uint32_t)(px1 - tile_x0) << 8) | ((uint32_t)(py0 - tile_y0) << 16) |
                 ((uint32_t)(py1 - tile_y0) << 24);
           st.X0[tid] = t.X0; st.Y0[tid] = t.Y0; st.X1[tid] = t.X1; st.Y1[tid] = t.Y1; st.X2[tid] = t.X2; st.Y2[tid] = t.Y2;
           st.z0[tid] = t.z0; st.dzdx[tid] = t.dzdx; st.dzdy[tid] = t.dzdy;
-          st.ref[tid] = ref;
+          st.ref[tid] = t.ref;
+          if (e < e2) rows = py1 - py0 + 1;
         }
       }
       st.box[tid] = box;
+      // The rows of the wave's small triangles, as one list per wave: lane l's rows are items [first, first + rows) of it.
+      // (exclusive prefix sum over the wave, bit-sliced: rows <= TILE_H needs seven ballots and mbcnt pairs -- no LDS traffic, no
+      //  shuffle addresses to keep in registers)
+      int first = 0;
+      uint32_t wave_rows = 0u;
+#pragma unroll
+      for (int b = 0; (1 << b) <= TILE_H; ++b) {
+        const unsigned long long m = __ballot(((rows >> b) & 1) != 0);
+        first += (int)(__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) << b);
+        wave_rows += (uint32_t)__popcll(m) << b;
+      }
+      s_row0[tid] = (uint16_t)first;
+      if (lane == 0) s_wave_rows[wave] = wave_rows;
     }
     __syncthreads();
     if (base == 0) BB_RSTAMP(2);
     const uint32_t hi = min(base + (uint32_t)kStage, e_end);
-    // ---- class 0: one tiny triangle per lane ----
-    // (with few of them in the chunk, two or four lanes share a triangle row by row: raster_triangle_rows)
-    {
-      const uint32_t lo = base, h0 = min(hi, e1);
-      const uint32_t n0 = h0 > lo ? h0 - lo : 0u;
-      const int shift = n0 <= (uint32_t)(kTileThreads / 4) ? 2 : (n0 <= (uint32_t)(kTileThreads / 2) ? 1 : 0);  // uniform
-      const uint32_t e = lo + ((uint32_t)tid >> shift);
-      if (e < h0) {
-        const int j = (int)(e - base);
-        const uint32_t box = st.box[j];
-        if (box != 0xFFFFFFFFu) {
-          const RasterTri t = staged_tri(st, j);
-          const int bx0 = tile_x0 + (int)(box & 255u), bx1 = tile_x0 + (int)((box >> 8) & 255u);
-          const int by0 = tile_y0 + (int)((box >> 16) & 255u), by1 = tile_y0 + (int)(box >> 24);
-          if (shift == 0)
-            raster_triangle_lane<TILE_W, TILE_H>(t, st.ref[j], bx0, bx1, by0, by1, tile_x0, tile_y0, keys, zbias_of(st.ref[j]));
-          else
-            raster_triangle_rows<TILE_W, TILE_H>(t, st.ref[j], bx0, bx1, by0, by1, tile_x0, tile_y0, keys, tid & ((1 << shift) - 1),
-                                                 1 << shift, zbias_of(st.ref[j]));
-        }
-      }
-    }
-    // ---- class 1: sixteen lanes per small triangle ----
-    // (one lane per triangle, as for class 0, was measured 2.6x slower here: bounding boxes of up to 64x64 pixels
-    //  make the per-lane loops long and divergent)
-    for (uint32_t e = max(base, e1) + (uint32_t)(tid >> 4); e < min(hi, e2); e += kTileThreads / 16) {
-      const int j = (int)(e - base);
-      const uint32_t box = st.box[j];
-      if (box == 0xFFFFFFFFu) continue;
-      const RasterTri t = staged_tri(st, j);
-      raster_triangle_group16<TILE_W, TILE_H>(t, st.ref[j], tile_x0 + (int)(box & 255u), tile_x0 + (int)((box >> 8) & 255u),
-                                              tile_y0 + (int)((box >> 16) & 255u), tile_y0 + (int)(box >> 24), tile_x0,
-                                              tile_y0, keys, tid & 15, zbias_of(st.ref[j]));
-    }
     // ---- class 2 and the every-tile list: one wave per large triangle ----
     {
       const uint32_t lo = max(base, e2);
@@ -1578,6 +1539,49 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
           raster_triangle_wave<TILE_W, TILE_H>(t, st.ref[j], tile_x0, tile_y0, fp, keys, lane);
       }
     }
+    // (behind the wave-per-triangle loop, whose 64-bit edge functions need the registers)
+    // the next chunk's triangles and the references of the one after it: in flight while this chunk is rasterised
+#if BB_RASTER_PREFETCH
+    {
+      const uint32_t e_next = base + (uint32_t)kStage + (uint32_t)tid;
+      cur = fetch_tri(e_next, ref_next);
+      ref_next = fetch_ref(e_next + (uint32_t)kStage);
+    }
+#endif
+    // ---- classes 0 and 1 (small triangles): one ROW of one triangle per lane ----
+    // Round 4 gave a tiny triangle one lane (its whole bounding box, pixel by pixel: 16 % of the lanes busy) and a small one
+    // sixteen lanes (4 x 4 pixel blocks over its box, a 70-instruction edge setup repeated in each of them: 56 % busy); a tile's
+    // life was the life of its unluckiest lane group.  Now the rows of all of them are one list and the 256 threads take rows
+    // from it in turn: every lane has work of the same kind whatever the triangle's size, consecutive lanes hold consecutive
+    // rows of one triangle (the triangle's words are LDS broadcasts, the rows about equally long), and a row's setup is
+    // paid once per row, not per 4 x 4 block.  Same pixels, same keys: the edge functions and the depth expression are
+    // the ones of the 64-bit form.
+    {
+      const uint32_t r0 = s_wave_rows[0], r1 = r0 + s_wave_rows[1], r2 = r1 + s_wave_rows[2], r3 = r2 + s_wave_rows[3];
+      static_assert(kTileWaves == 4, "row list: four wave regions");
+      for (uint32_t i = (uint32_t)tid; i < r3; i += kTileThreads) {
+        const uint32_t w = (i >= r0 ? 1u : 0u) + (i >= r1 ? 1u : 0u) + (i >= r2 ? 1u : 0u);
+        const uint32_t local = i - (w == 0u ? 0u : (w == 1u ? r0 : (w == 2u ? r1 : r2)));
+        // whose row: the last entry of wave w's 64 whose first row is <= local (entries without rows share their successor's
+        // first row, so the last one is the one that has it)
+        int j = (int)(w * 64u);
+#pragma unroll
+        for (int step = 32; step; step >>= 1)
+          if ((uint32_t)s_row0[j + step] <= local) j += step;
+        const uint32_t box = st.box[j];
+        const int py = tile_y0 + (int)((box >> 16) & 255u) + (int)(local - (uint32_t)s_row0[j]);
+        const uint32_t ref = st.ref[j];
+        raster_triangle_row<TILE_W, TILE_H>(st.X0[j], st.Y0[j], st.X1[j], st.Y1[j], st.X2[j], st.Y2[j], st.z0[j], st.dzdx[j],
+                                            st.dzdy[j], ref, tile_x0 + (int)(box & 255u), tile_x0 + (int)((box >> 8) & 255u), py,
+                                            tile_x0, tile_y0, keys, zbias_of(ref));
+      }
+    }
+#if !BB_RASTER_PREFETCH
+    if (base + (uint32_t)kStage < e_end) {
+      const uint32_t e_next = base + (uint32_t)kStage + (uint32_t)tid;
+      cur = fetch_tri(e_next, fetch_ref(e_next));
+    }
+#endif
   }
   __syncthreads();
   BB_RSTAMP(3);
@@ -1586,19 +1590,35 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
   // fragment = ((clip slot + 1) << kFragPixBits | pixel in tile) << 32 | reference
   unsigned long long *my_frags = frags + (size_t)tile * TILE_PIXELS;
   const uint32_t n_clip_refs = s_n_clip_refs <= kClipRefs ? s_n_clip_refs : 0u;  // too many: k_shade looks the slots up
-  for (int base = 0; base < TILE_PIXELS; base += kTileThreads) {
-    int p = base + tid;
+  // (ONE returning LDS atomic per wave: the wave counts the covered pixels of all its passes first -- round 4 reserved per pass,
+  //  four dependent LDS round trips per wave of every ball tile)
+  constexpr int PASSES = TILE_PIXELS / kTileThreads;
+  unsigned long long pass_mask[PASSES];
+  uint32_t wave_total = 0u;
+#pragma unroll
+  for (int k = 0; k < PASSES; ++k) {
+    const int p = k * kTileThreads + tid;
+    int x, y;
+    tile_pixel<TILE_W>(p, x, y);
+    const bool in_frame = tile_x0 + x < fp.width && tile_y0 + y < fp.height;
+    const unsigned long long key = keys[p];
+    pass_mask[k] = __ballot(in_frame && (OVERLAY ? (uint32_t)key != 0u : key != 0ull));
+    wave_total += (uint32_t)__popcll(pass_mask[k]);
+  }
+  uint32_t wave_base = 0u;
+  if (lane == 0 && wave_total) wave_base = atomicAdd(&s_count, wave_total);
+  wave_base = (uint32_t)__shfl((int)wave_base, 0);
+#pragma unroll
+  for (int k = 0; k < PASSES; ++k) {
+    int p = k * kTileThreads + tid;
     int x, y;
     tile_pixel<TILE_W>(p, x, y);
     int gx = tile_x0 + x, gy = tile_y0 + y;
     bool in_frame = gx < fp.width && gy < fp.height;
     unsigned long long key = keys[p];
     // main passes: any key; overlay pass: only pixels an overlay primitive won (low word = reference + 1)
-    bool covered = in_frame && (OVERLAY ? (uint32_t)key != 0u : key != 0ull);
-    unsigned long long mask = __ballot(covered);
-    uint32_t wave_base = 0;
-    if (lane == 0 && mask) wave_base = atomicAdd(&s_count, (uint32_t)__popcll(mask));
-    wave_base = (uint32_t)__shfl((int)wave_base, 0);
+    const unsigned long long mask = pass_mask[k];
+    const bool covered = ((mask >> lane) & 1ull) != 0ull;
     if (covered) {
       uint32_t rank_in_wave = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
       const uint32_t ref = (uint32_t)key - 1u;
@@ -1612,6 +1632,7 @@ __global__ __launch_bounds__(kTileThreads) void k_raster(
     } else if (in_frame && !OVERLAY) {
       store_background(x, y);
     }
+    wave_base += (uint32_t)__popcll(mask);
     if (vis_prim && in_frame) {
       size_t o = (size_t)gy * (size_t)fp.width + (size_t)gx;
       vis_prim[o] = key ? (((uint32_t)key - 1u) >> 3) : 0xFFFFFFFFu;

@@ -3,7 +3,7 @@ sys.path.insert(0, '.')
 import numpy as np
 from bibim_renderer_amd import configs, textures, Renderer, _capi
 from bibim_renderer_amd import scene as S
-import os; _capi.LIB_PATH = os.path.abspath('tools/_keep/stamps.so')
+import os; _capi.LIB_PATH = os.path.abspath(os.environ.get('BBR_STAMPS_LIB', 'tools/_keep/stamps.so'))
 cfg = configs.CONFIGS[sys.argv[1]]
 r = Renderer(cfg.width, cfg.height)
 r.set_option('frames_in_flight', 1)
