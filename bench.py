@@ -148,6 +148,92 @@ def algorithmic_bytes(cfg, n_shaded, n_ball_vertices):
     return {"total": frame + tex + geom + uniforms, "tile_kernel": frame + tex + uniforms, "geometry": geom}
 
 
+class ClockSampler:
+    """sclk / mclk / socket power of ONE GPU read from sysfs on a thread of its own (plain file reads: hwmon freq1_input,
+    freq2_input, power1_input under /sys/class/drm/card*/device whose PCI address is the device's) -- no child process, no
+    rocm-smi, nothing that touches the HIP runtime.  The thread sleeps between samples (the interpreter lock is free while it
+    sleeps and while it reads), so it costs the frame loop a few tens of microseconds every `period_s`.  summary(t0, t1)
+    gives min / mean / max over the samples taken inside a window of time.perf_counter()."""
+
+    def __init__(self, pci_address, period_s=0.002):
+        import glob
+        import threading
+        self.files, self.samples, self.period_s, self.read_us = {}, [], period_s, None
+        self.card = None
+        for dev in sorted(glob.glob("/sys/class/drm/card*/device")):
+            try:
+                if os.path.basename(os.path.realpath(dev)).lower() != pci_address.lower():
+                    continue
+            except OSError:
+                continue
+            for key, name in (("sclk_mhz", "freq1_input"), ("mclk_mhz", "freq2_input"), ("power_w", "power1_input"),
+                              ("power_w", "power1_average")):
+                hits = glob.glob(os.path.join(dev, "hwmon", "hwmon*", name))
+                if hits and key not in self.files and os.access(hits[0], os.R_OK):
+                    self.files[key] = hits[0]
+            self.card = dev
+            break
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True) if self.files else None
+
+    def _read(self):
+        out = {}
+        for key, f in self.files.items():
+            try:
+                v = float(open(f).read().split()[0])
+            except (OSError, ValueError, IndexError):
+                continue
+            out[key] = v / 1e6   # Hz -> MHz, microwatt -> W
+        return out
+
+    def _run(self):
+        while not self._stop.is_set():
+            t = time.perf_counter()
+            v = self._read()
+            t1 = time.perf_counter()
+            self.read_us = (t1 - t) * 1e6 if self.read_us is None else 0.9 * self.read_us + 0.1 * (t1 - t) * 1e6
+            self.samples.append((0.5 * (t + t1), v))
+            self._stop.wait(self.period_s)
+
+    def start(self):
+        if self._thread:
+            self._thread.start()
+        return self
+
+    def stop(self):
+        self._stop.set()
+        if self._thread and self._thread.is_alive():
+            self._thread.join(timeout=1.0)
+
+    def summary(self, t0, t1):
+        if not self.files:
+            return {"available": False, "why": "no readable hwmon files for this device under /sys/class/drm"}
+        inside = [v for (t, v) in self.samples if t0 <= t <= t1]
+        if not inside:   # a region shorter than the sampling period: the nearest sample on either side
+            before = [x for x in self.samples if x[0] < t0][-1:]
+            after = [x for x in self.samples if x[0] > t1][:1]
+            inside = [v for (_, v) in before + after]
+        out = {"available": True, "samples": len(inside), "period_ms": self.period_s * 1e3,
+               "read_us": round(self.read_us or 0.0, 1), "source": self.card}
+        for key in ("sclk_mhz", "mclk_mhz", "power_w"):
+            vals = [v[key] for v in inside if key in v]
+            if vals:
+                out[key] = {"min": round(min(vals), 1), "mean": round(sum(vals) / len(vals), 1), "max": round(max(vals), 1)}
+        return out
+
+
+def device_pci_address(index):
+    """'0000:c1:00.0' of HIP device `index` (hipDeviceGetPCIBusId through the runtime torch has loaded); None if unavailable"""
+    try:
+        hip = C.CDLL("libamdhip64.so")
+        buf = C.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buf, 64, int(index)) == 0:
+            return buf.value.decode()
+    except OSError:
+        pass
+    return None
+
+
 def cpu_baseline(cfg, maps, budget_s=20.0):
     """Oracle (CPU restatement, kind "port") on the host cores: bounded sample of the same workload."""
     from concurrent.futures import ThreadPoolExecutor
@@ -187,11 +273,32 @@ def cpu_baseline(cfg, maps, budget_s=20.0):
             if reps >= 20 or t_single + t_multi + t_multi / reps > budget_s:
                 break
     mpix = W * H / 1e6
+    # the same frame on ALL the cores this process may use, one thread per 32-row band at most; at least
+    # five frames, bounded to about three seconds
+    all_cores = max(1, min(cores_available, len(bands)))
+    all_reps, t_all = 0, 0.0
+    if all_cores > cores:
+        with ThreadPoolExecutor(all_cores) as ex:
+            sum(ex.map(band, bands))   # (threads started, pages touched)
+            while all_reps < 5 or (t_all < 1.0 and all_reps < 50):
+                t0 = time.perf_counter()
+                n = sum(ex.map(band, bands))
+                t_all += time.perf_counter() - t0
+                assert n == n1
+                all_reps += 1
+                if t_all > 3.0 and all_reps >= 5:
+                    break
+    else:
+        all_reps, t_all = reps, t_multi
     return {"value": round(mpix * reps / t_multi, 3), "unit": "Mpixels/s", "cores": cores, "cores_available": cores_available,
             "host_logical_cpus": os.cpu_count(), "kind": "port",
             "sample": f"{reps} full {cfg.name} frame(s) ({W}x{H}), oracle/bb_oracle.c, {cores} threads over 32-row bands; "
-                      f"single-thread whole-frame run: {mpix / t_single:.3f} Mpixels/s",
-            "single_thread_value": round(mpix / t_single, 3), "n_shaded": int(n1)}, rgba
+                      f"single-thread whole-frame run: {mpix / t_single:.3f} Mpixels/s; all cores: {all_reps} frames on "
+                      f"{all_cores} threads",
+            "single_thread_value": round(mpix / t_single, 3),
+            "all_cores_value": round(mpix * all_reps / t_all, 3), "all_cores": all_cores, "all_cores_frames": all_reps,
+            "all_cores_is": "min(cores this process may use, 32-row bands of the frame) threads, one band per task",
+            "n_shaded": int(n1)}, rgba
 
 
 # ------------------------------------------------------------------------------------------------
@@ -208,6 +315,7 @@ def cpu_baseline(cfg, maps, budget_s=20.0):
 #   * under a launcher (WORLD_SIZE set, the driver's N > 1 form): every rank process is the supervisor of its own worker, the
 #     ranks agree on "this attempt failed" through a flag file, and each attempt meets on its own rendezvous port.
 MILESTONES = ("spawned", "imported", "group", "first_frame", "warm", "timed", "done")
+EXIT_FATAL = 3   # a worker's exit code for a failure that is not the exchange's: the supervisor does not try the next rung
 
 
 def attempt_ladder(exchange, gather, present):
@@ -244,16 +352,57 @@ def _kill_group(p):
             continue
 
 
-def run_attempt(cmd, env, watch_ranks, limits, fail_flag=None):
-    """One attempt in its own session (process group).  Returns (ok, stdout_text, why): ok = every watched rank reached
-    "done" (or the group exited 0); why = what was seen otherwise."""
+# The attempt that is running, for the supervisor's signal handlers: an attempt lives in a session of its own (so that its whole
+# process group can be killed when it stalls), which also means a signal sent to the supervisor's group does not reach it.
+# Whoever ends the supervisor -- the driver's timeout, a launcher tearing its ranks down, Ctrl-C -- must end the attempt too,
+# or its workers stay on the GPUs, possibly inside a hung collective.
+_RUNNING = {"p": None}
+
+
+def _end_running_attempt():
+    p = _RUNNING.get("p")
+    if p is not None and p.poll() is None:
+        _kill_group(p)
+    _RUNNING["p"] = None
+
+
+def _install_supervisor_handlers():
+    import atexit
+    import signal
+
+    def on_signal(signum, _frame):
+        print(f"[bench supervisor] signal {signum}: ending the running attempt's process group", file=sys.stderr, flush=True)
+        _end_running_attempt()
+        os._exit(128 + signum)
+    for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        try:
+            signal.signal(sig, on_signal)
+        except (ValueError, OSError):   # (not the main thread / not permitted: atexit still covers an orderly end)
+            pass
+    atexit.register(_end_running_attempt)
+
+
+def _die_with_parent():
+    """preexec of an attempt's first process: SIGTERM when the supervisor dies without running its handlers (SIGKILL, a crash)"""
+    try:
+        libc = C.CDLL("libc.so.6", use_errno=True)
+        libc.prctl(1, 15, 0, 0, 0)   # PR_SET_PDEATHSIG, SIGTERM
+    except OSError:
+        pass
+
+
+def run_attempt(cmd, env, watch_ranks, limits, fail_flag=None, deadline=None):
+    """One attempt in its own session (process group).  Returns (ok, stdout_text, why, fatal): ok = every watched rank reached
+    "done" (or the group exited 0); why = what was seen otherwise; fatal = a worker reported a failure that no other exchange
+    can cure (its message), the ladder stops.  `deadline` (time.monotonic()): the attempt is given up when it passes."""
     import subprocess
     import tempfile
     import threading
     fd, ms_path = tempfile.mkstemp(prefix="bbr_bench_ms_")
     os.close(fd)
     env = dict(env, BBR_BENCH_MILESTONES=ms_path)
-    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, start_new_session=True)
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, start_new_session=True, preexec_fn=_die_with_parent)
+    _RUNNING["p"] = p
     chunks = []
     t = threading.Thread(target=lambda: chunks.append(p.stdout.read()), daemon=True)
     t.start()
@@ -284,21 +433,34 @@ def run_attempt(cmd, env, watch_ranks, limits, fail_flag=None):
             why = f"no progress for {limits(waiting_for):.0f} s while waiting for milestone '{waiting_for}' (ranks at {dict(sorted(reached.items()))})"
             _kill_group(p)
             break
+        if deadline is not None and time.monotonic() > deadline:
+            why = f"the run's wall-time limit passed while waiting for milestone '{waiting_for}' (ranks at {dict(sorted(reached.items()))})"
+            _kill_group(p)
+            break
         if fail_flag and os.path.exists(fail_flag):
             why = "another rank gave this attempt up"
             _kill_group(p)
             break
         time.sleep(0.2)
+    _RUNNING["p"] = None
     t.join(timeout=5.0)
+    fatal = None
     try:
-        os.unlink(ms_path)
+        fatal = open(ms_path + ".fatal").read().strip() or None
     except OSError:
         pass
+    for f in (ms_path, ms_path + ".fatal"):
+        try:
+            os.unlink(f)
+        except OSError:
+            pass
     out = (chunks[0] if chunks else b"").decode(errors="replace")
-    ok = why is None and (stage == len(MILESTONES) - 1 or p.returncode == 0)
+    ok = why is None and fatal is None and (stage == len(MILESTONES) - 1 or p.returncode == 0)
+    if p.returncode == EXIT_FATAL and fatal is None:
+        fatal = "a worker left with the fatal exit code (its message is on stderr)"
     if not ok and why is None:
-        why = f"exit code {p.returncode} after milestone '{MILESTONES[stage]}'"
-    return ok, out, why
+        why = fatal or f"exit code {p.returncode} after milestone '{MILESTONES[stage]}'"
+    return ok, out, why, fatal
 
 
 def _worker_argv(argv, exchange, gather):
@@ -330,6 +492,7 @@ def supervise(args, argv):
     """Run the N > 1 bench as a ladder of attempts (see above).  Returns the exit code.  Nothing here imports torch or
     touches a GPU."""
     import socket
+    _install_supervisor_handlers()
     # (the one-GPU rehearsal gathers through gloo, where the library's RCCL communicator cannot come up with two ranks per device)
     first = args.exchange or ("native" if os.environ.get("BBR_BENCH_BACKEND", "nccl") == "nccl" else "torch")
     ladder = attempt_ladder(first, args.gather, args.present)
@@ -339,6 +502,31 @@ def supervise(args, argv):
     base_env = dict(os.environ)
     base_env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what this pool's driver supports (RCCL, peer pushes)
     base_env.setdefault("OMP_NUM_THREADS", "1")
+    # the whole ladder has a wall-time limit below the driver's own (1500 s for an N > 1 run): whatever happens, the supervisor
+    # ends by itself, having ended its workers
+    deadline = time.monotonic() + float(os.environ.get("BBR_BENCH_WALL_LIMIT", "1300"))
+    flag_base = None
+    if under_launcher:
+        port0 = int(os.environ.get("MASTER_PORT", "29533"))
+        flag_base = os.path.join("/tmp", f"bbr_bench_{os.getppid()}_{port0}")
+        if rank == 0:   # flags of an earlier run with the same parent and port must not decide this one
+            for k in range(len(ladder)):
+                for suffix in (f"_attempt{k}.failed", ".done"):
+                    try:
+                        os.unlink(flag_base + suffix)
+                    except OSError:
+                        pass
+    done_flag = flag_base + ".done" if flag_base else None
+
+    def cleanup_flags():
+        if flag_base and rank == 0:
+            time.sleep(2.0)   # (the other ranks' supervisors look at them for a moment longer)
+            for k in range(len(ladder)):
+                for suffix in (f"_attempt{k}.failed", ".done"):
+                    try:
+                        os.unlink(flag_base + suffix)
+                    except OSError:
+                        pass
     attempts = []
     for k, (exchange, gather) in enumerate(ladder):
         env = dict(base_env, BBR_BENCH_ATTEMPTS=json.dumps(attempts))
@@ -346,12 +534,11 @@ def supervise(args, argv):
         flag = None
         if under_launcher:
             # this process is rank `rank` of a launcher's group: supervise OUR worker; attempt k meets on its own port
-            port = int(os.environ.get("MASTER_PORT", "29533"))
-            env["MASTER_PORT"] = str(port + 1 + k)
+            env["MASTER_PORT"] = str(port0 + 1 + k)
             # (the launcher's agent hosts the store of ITS rendezvous and tells its children to use it; an attempt's workers
             #  meet on their own port, where rank 0's worker has to host the store itself)
             env["TORCHELASTIC_USE_AGENT_STORE"] = "False"
-            flag = os.path.join("/tmp", f"bbr_bench_{os.getppid()}_{port}_attempt{k}.failed")
+            flag = f"{flag_base}_attempt{k}.failed"
             cmd = [sys.executable, os.path.abspath(__file__)] + wargv
             watch = [rank]
         else:
@@ -362,12 +549,25 @@ def supervise(args, argv):
                    "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + wargv
             watch = list(range(args.gpus))
         sys.stdout.flush()
-        ok, out, why = run_attempt(cmd, env, watch, limits, flag)
+        ok, out, why, fatal = run_attempt(cmd, env, watch, limits, flag, deadline)
         if ok:
             if rank == 0 and not _emit_first_json_line(out):
                 ok, why = False, "the attempt ended without a JSON line"
             else:
+                if done_flag:
+                    try:
+                        open(done_flag, "w").close()   # "this run has its line": see below
+                    except OSError:
+                        pass
+                cleanup_flags()
                 return 0
+        # The ranks agree on SUCCESS too: if some rank's worker reached "done" -- rank 0's has then printed the
+        # line -- a rank whose own worker merely stalled in teardown must not walk the remaining rungs alone against
+        # rendezvous that can never complete.
+        if done_flag and os.path.exists(done_flag):
+            print(f"[bench supervisor rank {rank}] attempt {k + 1} ended here with '{why}', but another rank's worker completed it "
+                  "(the line is printed): leaving with 0", file=sys.stderr, flush=True)
+            return 0
         attempts.append({"exchange": exchange, "gather": gather, "gave_up_because": why})
         print(f"[bench supervisor rank {rank}] attempt {k + 1}/{len(ladder)} ({exchange}, {gather}) given up: {why}", file=sys.stderr, flush=True)
         if flag:
@@ -376,7 +576,15 @@ def supervise(args, argv):
             except OSError:
                 pass
             time.sleep(1.0)               # let them see it before the next attempt's rendezvous starts
+        if fatal:
+            print(f"[bench supervisor rank {rank}] not an exchange failure -- no further attempt: {fatal}", file=sys.stderr, flush=True)
+            cleanup_flags()
+            return 1
+        if time.monotonic() > deadline:
+            print(f"[bench supervisor rank {rank}] wall-time limit reached: no further attempt", file=sys.stderr, flush=True)
+            break
     print(f"[bench supervisor rank {rank}] every attempt failed: {attempts}", file=sys.stderr, flush=True)
+    cleanup_flags()
     return 1
 
 
@@ -410,6 +618,9 @@ def main():
                          "pixel; default) or as plain RGBA32F (16 B); the reassembled frame is the same, bit for bit.  rgba16f: "
                          "every channel rounded to binary16, the reference's own HDR attachment format (8 B per pixel, LOSSY: a "
                          "different output, reported as such in config.output, never the default)")
+    ap.add_argument("--no-clock-samples", action="store_true",
+                    help="do not sample this GPU's sclk / mclk / socket power from sysfs during the run (`clocks` in the line)")
+    ap.add_argument("--clock-period-ms", type=float, default=2.0, help="sampling period of the clock thread")
     ap.add_argument("--no-also", action="store_true",
                     help="skip the 1080p figure the default C3 run adds to its line (`also.c2_1080p`): the counter passes of "
                          "tools/profile_round.sh average every launch of a kernel in the process")
@@ -458,6 +669,19 @@ def main():
             with open(ms_path, "a") as f:
                 f.write(f"{my_rank} {name}\n")
     mark("spawned")
+
+    def fatal(message):
+        """a failure no other rung of the ladder can cure (parity, shaded-pixel count ...): say so where the supervisor looks, and
+        leave with EXIT_FATAL on every rank"""
+        print(f"[bench rank {my_rank}] FATAL: {message}", file=sys.stderr, flush=True)
+        if ms_path:
+            try:
+                with open(ms_path + ".fatal", "a") as f:
+                    f.write(f"rank {my_rank}: {message}\n")
+            except OSError:
+                pass
+        sys.stderr.flush()
+        os._exit(EXIT_FATAL)   # (not SystemExit: a process group that is being torn down must not wait in destructors of collectives)
 
     # The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints a version banner when its
     # communicator comes up): from here on file descriptor 1 is stderr, and the JSON line goes to the real stdout.
@@ -694,22 +918,16 @@ def main():
     import gc
     gc.collect()
     gc.disable()
-    # a few dozen frames bring the GPU up to speed and let every frame slot learn its item count (the shading launch of a
-    # slot is sized from the slot's previous frame); the untimed warm-up steps follow
-    # ... and a quarter of a second: the GPU's clocks take that long to come up under this load (20 frames timed after 40 warm
-    # frames read 117-119 us, the same 20 frames 100 ms of rendering later 105-110: gpurun_out/r4/drv_style.txt, round 4), and
-    # the driver's run is 20 steps.  Untimed, like the W warm-up steps that follow; the timed region is still exactly K steps.
-    # (The NUMBER of such frames is agreed between the ranks: every step of an N > 1 run contains collectives.)
-    t_pre = time.perf_counter()
+    # The clocks of this GPU, sampled from sysfs on a thread of its own from here to the end of the measurements
+    clocks = None
+    if not args.no_clock_samples:
+        addr = device_pci_address(local_rank)
+        clocks = ClockSampler(addr, args.clock_period_ms * 1e-3).start() if addr else None
+    # a few dozen frames let every frame slot learn its item count (the shading launch of a slot is sized from the slot's
+    # previous frame) ...
     for _ in range(40):
         step()
     fence()
-    per_frame = max((time.perf_counter() - t_pre) / 40.0, 1e-6)
-    n_more = max(0, min(20000, int(0.25 / per_frame) - 40))
-    if dist is not None:
-        nm = torch.tensor([n_more], dtype=torch.int64, device="cuda")
-        dist.all_reduce(nm, op=dist.ReduceOp.MAX)
-        n_more = int(nm.item())
     layout, layout_decided, layout_ms = r.stream_layout_state()
     use_events = not args.no_timing_events
     # HIP events around k_shade on sampled steps of the timed region: ten samples of a long run, but never closer than every
@@ -728,12 +946,51 @@ def main():
         r.set_option("timing", 2)
         r.set_option("timing_stride", event_stride)
     fence()
-    for _ in range(n_more):
-        step()
+    # ... and then the GPU is WARMED UNTIL ITS RATE IS STEADY (round 5): blocks of 50 frames, each closed by a device
+    # synchronisation, until two consecutive blocks agree within 1 % -- at most two seconds.  Round 4 rendered for a fixed quarter
+    # of a second; the driver's fresh-lease run read 116 us per frame where this harness's boxes read 103-110, and nothing in the
+    # line could say whether the GPU had still been coming up.  The block history is in the line now (`warm_up`).  Untimed, like
+    # the W warm-up steps that follow; the timed region is still exactly K steps.  (N > 1: every step holds collectives, so the
+    # ranks decide together -- the verdict is all-reduced -- and render the same number of blocks.)
+    warm_blocks, warm_why, t_warm0, warm_spans = [], None, time.perf_counter(), []
+    WARM_BLOCK, WARM_TOL, WARM_LIMIT_S, WARM_MIN_BLOCKS = 50, 0.01, 2.0, 3
+    while True:
+        tb = time.perf_counter()
+        for _ in range(WARM_BLOCK):
+            step()
+        if dist_path and args.exchange == "peer" and pending:
+            finish_peer(pending.pop())
+        torch.cuda.synchronize()
+        warm_blocks.append((time.perf_counter() - tb) / WARM_BLOCK * 1e3)
+        warm_spans.append((tb, time.perf_counter()))
+        steady = (len(warm_blocks) >= WARM_MIN_BLOCKS and
+                  abs(warm_blocks[-1] - warm_blocks[-2]) <= WARM_TOL * warm_blocks[-2])
+        out_of_time = time.perf_counter() - t_warm0 > WARM_LIMIT_S or len(warm_blocks) >= 400
+        stop = steady or out_of_time
+        if dist is not None:
+            v = torch.tensor([1 if stop else 0, 1 if steady else 0], dtype=torch.int32, device="cuda")
+            dist.all_reduce(v, op=dist.ReduceOp.MIN)   # everybody steady (or out of time) -> stop together
+            stop, steady = bool(int(v[0].item())), bool(int(v[1].item()))
+        if stop:
+            warm_why = "two consecutive blocks within 1 %" if steady else f"time limit ({WARM_LIMIT_S} s)"
+            break
     for _ in range(args.warmup):
         step()
     if dist_path and args.exchange == "peer" and pending:
         finish_peer(pending.pop())
+    # One guard for a whole class of hangs (round 4 found one by accident: ranks that had computed different numbers of
+    # pre-warm frames around collectives): every trip count around a collective must be the same on every rank.  Checked
+    # HERE, in front of the timed region, with one MIN and one MAX reduction -- a mismatch ends the run with a message instead of
+    # a stall that the supervisor can only time out.
+    if dist is not None:
+        trip = torch.tensor([args.steps, args.warmup, len(warm_blocks), event_stride, args.frames_in_flight, step_no[0]],
+                            dtype=torch.int64, device="cuda")
+        lo, hi = trip.clone(), trip.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if not torch.equal(lo, hi):
+            raise SystemExit(f"rank {rank}: the ranks disagree on a trip count around collectives -- (steps, warmup, warm-up blocks, "
+                             f"event stride, frames in flight, frames so far) = {trip.tolist()} here, min {lo.tolist()}, max {hi.tolist()}")
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -743,9 +1000,11 @@ def main():
     mark("warm")
     overflow_before = r.capacity_growths()   # host-side counter
     frames_before = step_no[0] + overflow_before   # frames submitted so far (incl. the re-renders after overflows)
+    r.host_timing_reset()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    t_submitted = time.perf_counter()
     # the closing bracket of the timed region: every stream of the device drained (hipDeviceSynchronize) and all ranks
     # there.  The library's own synchronising call additionally copies the frame's counter block to the host to look for
     # a capacity overflow; that check is not part of the K steps and runs right after the clock stops.
@@ -755,12 +1014,25 @@ def main():
     if dist is not None:
         dist.barrier()
         torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    t_end = time.perf_counter()
+    elapsed = t_end - t0
+    host_t = r.host_timing()
     fence()
     mark("timed")
     if r.capacity_growths() != overflow_before:   # (overflows healed during the warm-up frames do not count)
         raise SystemExit("a capacity overflowed inside the timed region: the frames timed were incomplete")
     gc.enable()
+    # The host's side of the timed region: if the host were the bottleneck it would never be blocked
+    # on a frame slot; if the GPU is, the host spends what is left of every frame period blocked.
+    host = {"submit_us_per_step": round(host_t["submit_ns"] / max(1, host_t["frames"]) / 1e3, 2),
+            "blocked_us_per_step": round(host_t["blocked_ns"] / max(1, host_t["frames"]) / 1e3, 2),
+            "blocked_steps": int(host_t["blocked_frames"]), "steps": int(host_t["frames"]),
+            "loop_us_per_step": round((t_submitted - t0) / args.steps * 1e6, 2),
+            "drain_us": round((t_end - t_submitted) * 1e6, 1),
+            "is": "submit = inside bbr_end_frame (staging, launches), of which blocked = waiting for the frame slot's previous frame "
+                  "(counted by the library, steady_clock, no GPU call); loop = the harness's step loop per step (Python + shim + "
+                  "submit); drain = from the last submit to the end of the timed region"}
+    clocks_timed = clocks.summary(t0, t_end) if clocks else None
 
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -884,14 +1156,21 @@ def main():
             step()
         fence()
         n2 = max(10, min(args.steps, 100))
-        t2 = time.perf_counter()
+        r.host_timing_reset()
+        t2a = time.perf_counter()
         for _ in range(n2):
             step()
         torch.cuda.synchronize()
-        t2 = time.perf_counter() - t2
+        t2b = time.perf_counter()
+        t2 = t2b - t2a
+        h2 = r.host_timing()
         fence()
         roofline["frames_in_flight_2"] = {"ms_per_step": round(t2 / n2 * 1e3, 5), "steps": n2,
                                           "value": round(W * H * n2 / t2 / 1e6, 2), "unit": "Mpixels/s",
+                                          "host": {"submit_us_per_step": round(h2["submit_ns"] / max(1, h2["frames"]) / 1e3, 2),
+                                                   "blocked_us_per_step": round(h2["blocked_ns"] / max(1, h2["frames"]) / 1e3, 2),
+                                                   "blocked_steps": int(h2["blocked_frames"])},
+                                          "clocks": clocks.summary(t2a, t2b) if clocks else None,
                                           "what": "the same step with the reference's two frames in flight (numFrames, src/main.cpp:38)"}
         roofline["single_frame_device_latency_ms"] = round(f1, 5)
         r.set_option("timing", 1)
@@ -943,6 +1222,8 @@ def main():
         sb.close()
         rb.close()
 
+    if clocks:
+        clocks.stop()
     verified = None
     if args.verify and dist_path:
         last = (step_no[0] - 1) & 1
@@ -990,35 +1271,50 @@ def main():
                              f"(first {rows[:8].tolist()}, last {rows[-3:].tolist()}){extra}")
 
     cpu, parity, parity_literal = None, None, None
-    if rank == 0 and not args.no_cpu_baseline:   # (N > 1: on rank 0's host cores, while the other ranks wait at the final barrier)
-        cpu, oracle_frame = cpu_baseline(cfg, maps, args.cpu_budget)
-        if cpu["n_shaded"] != n_shaded_total:
-            raise SystemExit(f"GPU shaded {n_shaded_total} pixels, oracle {cpu['n_shaded']}: parity broken")
-        # the frame the bench has been rendering, against the frame the oracle just rendered (forward pass only: the
-        # CPU baseline is the forward oracle)
-        if args.render_pass == "forward" and not dist_path and not args.present_fused:
-            gpu_frame = r.read_framebuffer()
-            tol = 1e-4 * np.maximum(1.0, np.abs(oracle_frame))
-            d = np.abs(gpu_frame - oracle_frame)
-            parity = {"bit_exact": bool(np.array_equal(gpu_frame.view(np.uint32), oracle_frame.view(np.uint32))),
-                      "within_1e-4_times_max_1_ref": bool((d <= tol).all()), "max_abs_diff": float(np.nanmax(d)),
-                      "pixels": int(W * H)}
-            if not parity["within_1e-4_times_max_1_ref"]:
-                raise SystemExit(f"GPU frame outside the 1e-4 tolerance of the oracle: {parity}")
-            parity["oracle_form"] = ("contract: the kernel's own evaluation order of the light loop (oracle/bb_oracle.c "
-                                     "light_surface_contract); bit_exact here is NOT parity with the GLSL -- see parity_vs_literal")
-            # ... and against the LITERAL form: forward_brdf.frag:29-70 / brdf.glsl statement by statement
-            from oracle import bbo, scenes
-            lit, _ = bbo.render_bands(scenes.shaderball_scene(cfg, bbo.MaterialData(maps)), flags=bbo.FLAG_LITERAL)
-            dl = np.abs(gpu_frame.astype(np.float64) - lit.astype(np.float64))
-            parity_literal = {"oracle_form": "literal: the GLSL statement by statement (BBO_FLAG_LITERAL)",
-                              "tolerance": "absolute 1e-4 per channel (BASELINE.json); also 1e-4 * max(1, |ref|) (BASELINE.md)",
-                              "within_abs_1e-4": bool((dl <= 1e-4).all()),
-                              "within_1e-4_times_max_1_ref": bool((dl <= 1e-4 * np.maximum(1.0, np.abs(lit))).all()),
-                              "max_abs_diff": float(np.nanmax(dl)), "max_abs_ref": float(np.nanmax(np.abs(lit))),
-                              "bit_exact": bool(np.array_equal(gpu_frame.view(np.uint32), lit.view(np.uint32))), "pixels": int(W * H)}
-            if not parity_literal["within_1e-4_times_max_1_ref"]:
-                raise SystemExit(f"GPU frame outside the 1e-4 tolerance of the literal GLSL form: {parity_literal}")
+    # Rank 0 times the CPU baseline and checks the frame against the oracle while the other ranks wait.  If that fails, it
+    # fails for EVERY rank, at once and with the message (the others sat in the final barrier until the
+    # supervisor timed them out, and the ladder then repeated a failure that no other exchange could cure).
+    failure = None
+    try:
+        if rank == 0 and not args.no_cpu_baseline:   # (N > 1: on rank 0's host cores, while the other ranks wait at the final barrier)
+            cpu, oracle_frame = cpu_baseline(cfg, maps, args.cpu_budget)
+            if cpu["n_shaded"] != n_shaded_total:
+                raise SystemExit(f"GPU shaded {n_shaded_total} pixels, oracle {cpu['n_shaded']}: parity broken")
+            # the frame the bench has been rendering, against the frame the oracle just rendered (forward pass only: the
+            # CPU baseline is the forward oracle)
+            if args.render_pass == "forward" and not dist_path and not args.present_fused:
+                gpu_frame = r.read_framebuffer()
+                tol = 1e-4 * np.maximum(1.0, np.abs(oracle_frame))
+                d = np.abs(gpu_frame - oracle_frame)
+                parity = {"bit_exact": bool(np.array_equal(gpu_frame.view(np.uint32), oracle_frame.view(np.uint32))),
+                          "within_1e-4_times_max_1_ref": bool((d <= tol).all()), "max_abs_diff": float(np.nanmax(d)),
+                          "pixels": int(W * H)}
+                if not parity["within_1e-4_times_max_1_ref"]:
+                    raise SystemExit(f"GPU frame outside the 1e-4 tolerance of the oracle: {parity}")
+                parity["oracle_form"] = ("contract: the kernel's own evaluation order of the light loop (oracle/bb_oracle.c "
+                                         "light_surface_contract); bit_exact here is NOT parity with the GLSL -- see parity_vs_literal")
+                # ... and against the LITERAL form: forward_brdf.frag:29-70 / brdf.glsl statement by statement
+                from oracle import bbo, scenes
+                lit, _ = bbo.render_bands(scenes.shaderball_scene(cfg, bbo.MaterialData(maps)), flags=bbo.FLAG_LITERAL)
+                dl = np.abs(gpu_frame.astype(np.float64) - lit.astype(np.float64))
+                parity_literal = {"oracle_form": "literal: the GLSL statement by statement (BBO_FLAG_LITERAL)",
+                                  "tolerance": "absolute 1e-4 per channel (BASELINE.json); also 1e-4 * max(1, |ref|) (BASELINE.md)",
+                                  "within_abs_1e-4": bool((dl <= 1e-4).all()),
+                                  "within_1e-4_times_max_1_ref": bool((dl <= 1e-4 * np.maximum(1.0, np.abs(lit))).all()),
+                                  "max_abs_diff": float(np.nanmax(dl)), "max_abs_ref": float(np.nanmax(np.abs(lit))),
+                                  "bit_exact": bool(np.array_equal(gpu_frame.view(np.uint32), lit.view(np.uint32))), "pixels": int(W * H)}
+                if not parity_literal["within_1e-4_times_max_1_ref"]:
+                    raise SystemExit(f"GPU frame outside the 1e-4 tolerance of the literal GLSL form: {parity_literal}")
+    except SystemExit as e:   # (the checks above end with a message)
+        failure = str(e.code)
+    except Exception as e:    # noqa: BLE001
+        failure = f"{type(e).__name__}: {e}"
+    if dist is not None:
+        box = [failure]
+        dist.broadcast_object_list(box, src=0)
+        failure = box[0]
+    if failure:
+        fatal(failure)
 
     if rank == 0:
         out = {
@@ -1045,6 +1341,13 @@ def main():
                        "render_pass": args.render_pass,
                        "stream_layout": layout, **({"options": args.opt} if args.opt else {})},
             "roofline": roofline, "cpu_baseline": cpu,
+            "host": host, "clocks": clocks_timed,
+            "warm_up": {"block_steps": WARM_BLOCK, "blocks_ms_per_step": [round(x, 5) for x in warm_blocks],
+                        "stopped_because": warm_why, "frames": WARM_BLOCK * len(warm_blocks),
+                        "clocks_first_block": clocks.summary(*warm_spans[0]) if clocks else None,
+                        "clocks_last_block": clocks.summary(*warm_spans[-1]) if clocks else None,
+                        "rule": f"blocks of {WARM_BLOCK} steps until two consecutive blocks agree within {WARM_TOL:.0%} (at least "
+                                f"{WARM_MIN_BLOCKS} blocks, at most {WARM_LIMIT_S} s), then the {args.warmup} warm-up steps"},
             # `value` is W*H / t: every pixel of the frame is produced, but only N_shaded of them run the PBR
             # shader (the rest get the clear colour from k_raster); the shaded-only rate:
             "shaded_mpixels_per_s": round(n_shaded_total * args.steps / elapsed / 1e6, 2),

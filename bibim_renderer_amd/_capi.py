@@ -99,6 +99,8 @@ SIGNATURES = {
     "bbr_push_shard": (C.c_int, [_P, C.c_int32, C.POINTER(_P), C.POINTER(C.c_int32), _P]),
     "bbr_push_state": (C.c_int, [_P, C.POINTER(C.c_int32)]),
     "bbr_capacity_growths": (C.c_int, [_P, C.POINTER(C.c_uint32)]),
+    "bbr_host_timing": (C.c_int, [_P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "bbr_host_timing_reset": (C.c_int, [_P]),
     "bbr_unpack_whole": (C.c_int, [_P, C.c_int32, _P, _P, _P]),
     "bbr_whole_frame_device_ptr": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint64)]),
     "bbr_read_whole_frame": (C.c_int, [_P, _P]),

@@ -10,6 +10,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <limits>
 #include <memory>
@@ -243,6 +244,10 @@ struct bbr_context {
   static constexpr uint32_t kRingCap = 512;
   static constexpr uint32_t kRingEvents = 5;
   int retries = 0;
+  // host side of the frame loop since the last bbr_host_timing_reset (steady_clock; no GPU call is made to keep them):
+  // frames submitted, time inside the submit (bbr_end_frame / bbr_replay_frame), and the part of it spent blocked because
+  // the frame slot's previous frame had not left the GPU yet
+  uint64_t host_frames = 0, host_submit_ns = 0, host_blocked_ns = 0, host_blocked_frames = 0;
 
   hipStream_t geom_stream() const { return user_stream ? user_stream : s_geom; }
   // k_raster on a stream of its own: geometry of frame N+1 (other slot, other counter block) need not wait for the
@@ -468,7 +473,15 @@ void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const Fra
   hipStream_t sg = c->frame_geom_stream(slot_index), sr = c->raster_stream(slot_index), ss = c->frame_shade_stream(slot_index);
   Counters *ctr = c->d_counters.ptr + s.ctr_index, *ctr_done = c->d_counters_done.ptr + s.ctr_index;
   hipEvent_t *ev = c->timing_this ? &c->ring[bbr_context::kRingEvents * (c->ring_frames % bbr_context::kRingCap)] : nullptr;
-  if (c->n_prims)
+#ifdef BB_ABLATE
+  // diagnostic builds only (tools/_gpu_overlap.py): bit 17 = launch nothing but k_shade -- the lists of the slot's last whole
+  // frame are shaded again -- which measures the shading's own pipelined rate.  (There is no "front half only" twin: k_shade is
+  // what clears the slot's counters and chunk totals, and a frame without it overruns the item list.)
+  const bool skip_front = (c->ablate & (1u << 17)) != 0u;
+#else
+  constexpr bool skip_front = false;
+#endif
+  if (c->n_prims && !skip_front)
     hipLaunchKernelGGL((k_geometry<TW, TH>), dim3((c->n_prims + 255) / 256), dim3(256), 0, sg, d_draws, n_draws,
                        c->n_prims, c->first_prims, s.d_tris.ptr, s.d_attrs.ptr, s.d_tile_count.ptr, s.d_bins.ptr, ctr, pv, view, fp, s.d_clip.ptr,
                        s.d_broad.ptr, c->d_materials.ptr, s.d_block_stats.ptr, s.d_heavy.ptr);
@@ -490,6 +503,7 @@ void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const Fra
   if (fp.deferred)
     hipLaunchKernelGGL(k_deferred_background, dim3(1), dim3(kBackgroundThreads), 0, sr, sp, d_lights, s.d_background.ptr, tables, fp.gbuffer_view);
   uint32_t *item_head = short_frame ? d_item_head : nullptr;
+  if (!skip_front)
   hipLaunchKernelGGL((k_raster<TW, TH>), dim3(fp.tiles_x, fp.heavy_rows + grid_y), dim3(kTileThreads), 0, sr, s.d_tile_count.ptr, ctr,
                      s.d_broad.ptr, s.d_frag_count.ptr, s.d_frags.ptr, out, fp, s.d_tris.ptr, s.d_clip.ptr, s.d_bins.ptr,
                      c->dump_vis ? c->d_vis_prim.ptr : nullptr,
@@ -500,7 +514,7 @@ void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const Fra
   s.has_depth = c->overlays && c->world == 1;
   // k_shade's work list (64 fragments per item), built from the per-tile fragment counts as soon as k_raster is done; the
   // same launch cooks the frame's light table
-  if (!short_frame)
+  if (!short_frame && !skip_front)
     hipLaunchKernelGGL((k_shade_items<TW, TH>), dim3((unsigned)((fp.tiles_x * grid_y + kItemsThreads - 1) / kItemsThreads)), dim3(kItemsThreads), 0, sr, fp, s.d_frag_count.ptr, s.d_item_groups.ptr, s.d_items.ptr,
                        fp.tiles_x, grid_y, s.h_flags ? s.h_flags + 2 : nullptr, d_lights, sp.num_lights, s.d_cooked.ptr,
                        s.d_tile_count.ptr, ctr, s.d_heavy.ptr);
@@ -592,7 +606,12 @@ int submit_frame_into(bbr_context *c, int slot_index) {
   FrameSlot &s = c->slots[slot_index];
   // the slot's previous frame (two frames ago) must have left the GPU before its buffers are reused
   if (s.in_flight) {
-    HIP_TRY(c, hipEventSynchronize(s.ev_shade_done));
+    if (hipEventQuery(s.ev_shade_done) != hipSuccess) {  // (hipErrorNotReady: still on the GPU -- the host waits, and says so)
+      const auto b0 = std::chrono::steady_clock::now();
+      HIP_TRY(c, hipEventSynchronize(s.ev_shade_done));
+      c->host_blocked_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - b0).count();
+      ++c->host_blocked_frames;
+    }
     s.in_flight = false;
   }
   // Self-healing for hosts that only stream frames: the frame that last used this slot reported an overflow.  Its
@@ -771,9 +790,12 @@ int queue_present(bbr_context *c, FrameSlot &s) {
 }
 
 int submit_frame(bbr_context *c) {
+  const auto t0 = std::chrono::steady_clock::now();
   int slot = (int)(c->frame_counter % (uint64_t)c->n_slots());
   int rc = submit_frame_into(c, slot);
   if (rc == BBR_OK) ++c->frame_counter;
+  c->host_submit_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+  ++c->host_frames;
   return rc;
 }
 
@@ -1653,6 +1675,22 @@ int bbr_last_frame_time_ms(bbr_context *c, float *out_frame_ms, float *out_shade
   HIP_TRY(c, hipEventElapsedTime(&b, e[3], e[4]));
   if (out_frame_ms) *out_frame_ms = a;
   if (out_shade_ms) *out_shade_ms = b;
+  return BBR_OK;
+}
+
+int bbr_host_timing(const bbr_context *c, uint64_t *out_frames, uint64_t *out_submit_ns, uint64_t *out_blocked_ns,
+                    uint64_t *out_blocked_frames) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  if (out_frames) *out_frames = c->host_frames;
+  if (out_submit_ns) *out_submit_ns = c->host_submit_ns;
+  if (out_blocked_ns) *out_blocked_ns = c->host_blocked_ns;
+  if (out_blocked_frames) *out_blocked_frames = c->host_blocked_frames;
+  return BBR_OK;
+}
+
+int bbr_host_timing_reset(bbr_context *c) {
+  if (!c) return BBR_ERR_INVALID_ARGUMENT;
+  c->host_frames = c->host_submit_ns = c->host_blocked_ns = c->host_blocked_frames = 0;
   return BBR_OK;
 }
 

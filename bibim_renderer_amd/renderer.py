@@ -3,7 +3,6 @@
 from __future__ import annotations
 
 import ctypes as C
-import os
 import weakref
 
 import numpy as np
@@ -27,11 +26,6 @@ class Renderer:
             raise BibimError(rc, (self._L.bbr_last_error(None) or b"").decode())
         self.width, self.height = int(width), int(height)
         self._scenes = weakref.WeakSet()  # host-shim scenes hold meshes of this context: they must go first
-        # test hook: BBR_OPTIONS="name=value,..." is applied to every context this process creates (the GPU suite runs its
-        # small frames through the long frames' route with no_tail_items=0: tests/conftest.py, fixture item_route)
-        for kv in filter(None, os.environ.get("BBR_OPTIONS", "").split(",")):
-            k, v = kv.split("=")
-            self.set_option(k.strip(), int(v))
 
     # -- plumbing --
     def _check(self, rc):
@@ -308,6 +302,16 @@ class Renderer:
         n = C.c_uint32()
         self._check(self._L.bbr_capacity_growths(self._ctx, C.byref(n)))
         return int(n.value)
+
+    def host_timing(self):
+        """host side of the frame loop since host_timing_reset (no GPU call): frames submitted, ns inside the submit calls, ns of
+        that spent blocked on a frame slot still in flight, frames in which the host was blocked"""
+        f, sub, blk, nb = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._check(self._L.bbr_host_timing(self._ctx, C.byref(f), C.byref(sub), C.byref(blk), C.byref(nb)))
+        return {"frames": int(f.value), "submit_ns": int(sub.value), "blocked_ns": int(blk.value), "blocked_frames": int(nb.value)}
+
+    def host_timing_reset(self):
+        self._check(self._L.bbr_host_timing_reset(self._ctx))
 
     def push_was_direct(self):
         """True if the last push_shard stored through the one-kernel direct form (option push_mode 1 and every peer mapped)"""

@@ -164,6 +164,14 @@ int bbr_get_stats(bbr_context *ctx, bbr_stats *out);                            
 /* How often a capacity (bins, every-tile list, clip arena) has been grown since bbr_create (= bbr_stats.bin_overflow), without
  * synchronising or touching the GPU: a host that times frames can tell afterwards whether one of them overflowed. */
 int bbr_capacity_growths(const bbr_context *ctx, uint32_t *out_count);          /* host-side counter: does NOT synchronise */
+/* The host's side of the frame loop since bbr_host_timing_reset, kept without touching the GPU (steady_clock around the
+ * submit): frames submitted by bbr_end_frame / bbr_replay_frame, nanoseconds spent inside those calls, and the part of
+ * it the host was BLOCKED because the frame slot it wanted to reuse was still on the GPU (and in how many frames).  A
+ * host that is never blocked is the bottleneck itself; one that is blocked every frame is waiting for the GPU.  This is
+ * the frame loop the reference paces with a fence per frame in flight (src/main.cpp:1277-1279). */
+int bbr_host_timing(const bbr_context *ctx, uint64_t *out_frames, uint64_t *out_submit_ns, uint64_t *out_blocked_ns,
+                    uint64_t *out_blocked_frames);
+int bbr_host_timing_reset(bbr_context *ctx);
 /* winning primitive (global API-order index, 0xFFFFFFFF = none) and depth per pixel; synchronises.
  * Re-runs the frame once with the visibility dump enabled. */
 int bbr_read_visibility(bbr_context *ctx, uint32_t *prim_host, float *depth_host);

@@ -59,17 +59,39 @@ def assert_frame_close(img, ref, tol=1e-4):
     assert bad == 0, f"{bad} channel values outside {tol}*max(1,|ref|); max |diff| = {float(d.max())}"
 
 
-@pytest.fixture(params=["short-frame route", "long-frame route", "long-frame route, heavy tiles first"])
+_ROUTES = {"short-frame route": {}, "long-frame route": {"no_tail_items": 0},
+           "long-frame route, heavy tiles first": {"no_tail_items": 0, "heavy_tiles": 4}}
+
+
+def _route(request, monkeypatch):
+    """every Renderer the test creates gets the route's options right after construction (a wrapper around the constructor, put
+    there by the fixture: the product code has no hook for it)"""
+    from bibim_renderer_amd import renderer as R
+    options = _ROUTES[request.param]
+    plain_init = R.Renderer.__init__
+
+    def init(self, *args, **kwargs):
+        plain_init(self, *args, **kwargs)
+        for name, value in options.items():
+            self.set_option(name, value)
+    monkeypatch.setattr(R.Renderer, "__init__", init)
+    return request.param
+
+
+@pytest.fixture(params=list(_ROUTES)[:2])
 def item_route(request, monkeypatch):
     """Both ways a frame's shading work list comes about.  A frame with at most `no_tail_items` item slots --
     nearly every frame of this suite -- has its raster tiles append their items themselves and is shaded by one full-coverage
     launch; BASELINE's 4K / 8K frames take the other route: k_shade_items scans the tiles in screen order, the main launch
-    is sized from the slot's previous frame and a tail launch covers the rest.  With no_tail_items = 0 (applied to every
-    context the test creates, bibim_renderer_amd.Renderer) a small frame takes the long route too.  Third form (round 4):
-    the long route with k_raster starting its heavy tiles first (option heavy_tiles; the automatic choice while one frame is
-    in flight), with a threshold low enough (4 references in a bin) for these small frames to have heavy tiles."""
-    if request.param.endswith("heavy tiles first"):
-        monkeypatch.setenv("BBR_OPTIONS", "no_tail_items=0,heavy_tiles=4")
-    elif request.param.startswith("long"):
-        monkeypatch.setenv("BBR_OPTIONS", "no_tail_items=0")
-    return request.param
+    is sized from the slot's previous frame and a tail launch covers the rest.  With no_tail_items = 0 a small frame takes the
+    long route too."""
+    return _route(request, monkeypatch)
+
+
+@pytest.fixture(params=list(_ROUTES))
+def item_route_heavy(request, monkeypatch):
+    """item_route plus a third form (round 4): the long route with k_raster starting its heavy tiles first (option heavy_tiles;
+    the automatic choice while one frame is in flight), with a threshold low enough (4 references in a bin) for these small
+    frames to have heavy tiles.  For the tests that reach k_raster's route decision -- the deferred pass, partitions, the
+    overflow / replay paths (round 5: the others ran it to no purpose, a third of the suite's time)."""
+    return _route(request, monkeypatch)

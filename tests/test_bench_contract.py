@@ -101,9 +101,9 @@ for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "BBR_BENCH_BACKEND"):
 sys.argv = ["bench.py", "--gpus", "8", "--steps", "20", "--warmup", "5"]
 import bench
 seen = []
-def fake_attempt(cmd, env, watch, limits, flag=None):
+def fake_attempt(cmd, env, watch, limits, flag=None, deadline=None):
     seen.append((cmd, env, watch, flag))
-    return True, '[rccl banner]\n{"metric": "m", "n_gpus": 8}\n', None
+    return True, '[rccl banner]\n{"metric": "m", "n_gpus": 8}\n', None, None
 bench.run_attempt = fake_attempt
 try:
     bench.main()
@@ -138,7 +138,7 @@ def test_attempt_ladder_falls_back_in_fresh_processes_and_reports_what_failed():
     calls = []
 
     def fake(outcomes):
-        def run(cmd, env, watch, limits, flag=None):
+        def run(cmd, env, watch, limits, flag=None, deadline=None):
             calls.append((cmd[cmd.index("--exchange") + 1], cmd[cmd.index("--gather") + 1], json.loads(env["BBR_BENCH_ATTEMPTS"])))
             return outcomes[len(calls) - 1]
         return run
@@ -146,14 +146,18 @@ def test_attempt_ladder_falls_back_in_fresh_processes_and_reports_what_failed():
     try:
         for k in ("WORLD_SIZE", "RANK", "BBR_BENCH_BACKEND"):
             os.environ.pop(k, None)
-        bench.run_attempt = fake([(False, "", "no progress for 60 s while waiting for milestone 'first_frame'"), (True, '{"ok": 1}\n', None)])
+        bench.run_attempt = fake([(False, "", "no progress for 60 s while waiting for milestone 'first_frame'", None), (True, '{"ok": 1}\n', None, None)])
         assert bench.supervise(args, ["--gpus", "2"]) == 0
         assert [c[:2] for c in calls] == [("native", "packed"), ("torch", "packed")]
         assert calls[0][2] == [] and calls[1][2] == [{"exchange": "native", "gather": "packed",
                                                       "gave_up_because": "no progress for 60 s while waiting for milestone 'first_frame'"}]
         calls.clear()
-        bench.run_attempt = fake([(False, "", "exit code 1 after milestone 'group'")] * 3)
+        bench.run_attempt = fake([(False, "", "exit code 1 after milestone 'group'", None)] * 3)
         assert bench.supervise(args, ["--gpus", "2"]) == 1 and len(calls) == 3 and len(calls[2][2]) == 2
+        # a failure that is not the exchange's (parity, shaded-pixel count: the worker says so) ends the ladder at once
+        calls.clear()
+        bench.run_attempt = fake([(False, "", "rank 0: GPU frame outside the 1e-4 tolerance", "rank 0: GPU frame outside the 1e-4 tolerance")] * 3)
+        assert bench.supervise(args, ["--gpus", "2"]) == 1 and len(calls) == 1
     finally:
         bench.run_attempt = real
         os.environ.clear()
@@ -178,23 +182,114 @@ def test_supervisor_kills_a_stalled_attempt_and_lets_a_finished_one_through(tmp_
         "if mode == 'stall':\n"
         "    time.sleep(600)\n"
         "if mode == 'crash':\n"
-        "    sys.exit(3)\n"
+        "    sys.exit(5)\n"
+        "if mode == 'fatal':\n"
+        "    open(ms + '.fatal', 'a').write('rank 0: parity broken\\n'); os._exit(3)\n"
         "for n in ('first_frame', 'warm', 'timed'):\n"
         "    mark(n)\n"
         "print('{\"metric\": \"x\"}', flush=True)\n"
         "mark('done')\n")
     limits = lambda name: 1.5   # noqa: E731
     t0 = time.monotonic()
-    ok, out, why = bench.run_attempt([sys.executable, str(child), "stall"], dict(os.environ), [0], limits)
-    assert not ok and "first_frame" in why and "no progress" in why and time.monotonic() - t0 < 30
-    ok, out, why = bench.run_attempt([sys.executable, str(child), "crash"], dict(os.environ), [0], limits)
-    assert not ok and "exit code 3" in why and "group" in why
-    ok, out, why = bench.run_attempt([sys.executable, str(child), "fine"], dict(os.environ), [0], limits)
-    assert ok and why is None and out.strip() == '{"metric": "x"}'
+    ok, out, why, fatal = bench.run_attempt([sys.executable, str(child), "stall"], dict(os.environ), [0], limits)
+    assert not ok and "first_frame" in why and "no progress" in why and time.monotonic() - t0 < 30 and fatal is None
+    ok, out, why, fatal = bench.run_attempt([sys.executable, str(child), "crash"], dict(os.environ), [0], limits)
+    assert not ok and "exit code 5" in why and "group" in why and fatal is None
+    ok, out, why, fatal = bench.run_attempt([sys.executable, str(child), "fatal"], dict(os.environ), [0], limits)
+    assert not ok and fatal == "rank 0: parity broken" and why == fatal
+    ok, out, why, fatal = bench.run_attempt([sys.executable, str(child), "fine"], dict(os.environ), [0], limits)
+    assert ok and why is None and fatal is None and out.strip() == '{"metric": "x"}'
     flag = tmp_path / "flag"
     flag.write_text("")
-    ok, out, why = bench.run_attempt([sys.executable, str(child), "stall"], dict(os.environ), [0], lambda n: 60.0, str(flag))
+    ok, out, why, fatal = bench.run_attempt([sys.executable, str(child), "stall"], dict(os.environ), [0], lambda n: 60.0, str(flag))
     assert not ok and "another rank" in why
+    # the run's wall-time limit ends an attempt that is still making progress slowly
+    ok, out, why, fatal = bench.run_attempt([sys.executable, str(child), "stall"], dict(os.environ), [0], lambda n: 60.0, None,
+                                            time.monotonic() + 1.0)
+    assert not ok and "wall-time limit" in why
+
+
+def test_a_supervisor_that_is_terminated_takes_its_attempt_with_it(tmp_path):
+    """an attempt runs in a session of its own, so a signal to the supervisor's process group does not reach
+    it.  SIGTERM to the supervisor (the driver's timeout, a launcher tearing its ranks down) must end the attempt's whole
+    process group -- workers left on the GPUs inside a hung collective are exactly the case the ladder exists for."""
+    import signal
+    import subprocess
+    import sys
+    pidfile = tmp_path / "pids"
+    worker = tmp_path / "worker.py"
+    worker.write_text(
+        "import os, subprocess, sys, time\n"
+        f"open({str(pidfile)!r}, 'a').write('%d\\n' % os.getpid())\n"
+        "if len(sys.argv) < 2:\n"
+        "    subprocess.Popen([sys.executable, __file__, 'grandchild'])\n"     # (a rank of the attempt: same process group)
+        "time.sleep(600)\n")
+    sup = tmp_path / "sup.py"
+    sup.write_text(
+        "import os, sys\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "import bench\n"
+        "bench._install_supervisor_handlers()\n"
+        f"bench.run_attempt([sys.executable, {str(worker)!r}], dict(os.environ), [0], lambda n: 600.0)\n")
+    p = subprocess.Popen([sys.executable, str(sup)], cwd=ROOT)
+    t0 = time.monotonic()
+    while (not pidfile.exists() or len(pidfile.read_text().split()) < 2) and time.monotonic() - t0 < 30:
+        time.sleep(0.1)
+    pids = [int(x) for x in pidfile.read_text().split()]
+    assert len(pids) == 2, pids
+    p.send_signal(signal.SIGTERM)
+    assert p.wait(timeout=40) == 128 + signal.SIGTERM
+
+    def alive(pid):
+        try:
+            os.kill(pid, 0)
+        except ProcessLookupError:
+            return False
+        try:   # a zombie still answers signal 0
+            return open(f"/proc/{pid}/stat").read().split(")")[1].split()[0] != "Z"
+        except OSError:
+            return False
+    t0 = time.monotonic()
+    while any(alive(q) for q in pids) and time.monotonic() - t0 < 20:
+        time.sleep(0.2)
+    assert not any(alive(q) for q in pids), "the attempt's processes outlived the supervisor"
+
+
+def test_ranks_agree_on_success_as_well(tmp_path, monkeypatch):
+    """under a launcher every rank supervises its own worker.  If rank 0's worker reached 'done' (the line is printed) while
+    rank 1's stalls in teardown, rank 1's supervisor must not walk the remaining rungs alone: it finds the run's .done flag and
+    leaves with 0."""
+    import argparse
+    import bench
+    args = argparse.Namespace(gpus=2, exchange=None, gather="packed", present=False, steps=20, warmup=5, cpu_budget=20.0)
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("MASTER_PORT", "29777")
+    monkeypatch.delenv("BBR_BENCH_BACKEND", raising=False)
+    flag_base = os.path.join("/tmp", f"bbr_bench_{os.getppid()}_29777")
+    calls = []
+    # rank 0: its worker completes -> the flag appears
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setattr(bench, "run_attempt", lambda *a, **k: (calls.append("r0") or (True, '{"ok": 1}\n', None, None)))
+    monkeypatch.setattr(bench.time, "sleep", lambda s: None)
+    seen = {}
+    real_unlink = os.unlink
+    monkeypatch.setattr(bench.os, "unlink", lambda f: (seen.update(done_existed=seen.get("done_existed") or os.path.exists(flag_base + ".done")),
+                                                       real_unlink(f))[1])
+    assert bench.supervise(args, ["--gpus", "2"]) == 0 and seen["done_existed"] and not os.path.exists(flag_base + ".done")
+    monkeypatch.setattr(bench.os, "unlink", real_unlink)
+    # rank 1: its worker stalls after the others are done; the flag is there
+    open(flag_base + ".done", "w").close()
+    try:
+        monkeypatch.setenv("RANK", "1")
+        monkeypatch.setattr(bench, "run_attempt", lambda *a, **k: (calls.append("r1") or (False, "", "no progress for 60 s while waiting for milestone 'done'", None)))
+        assert bench.supervise(args, ["--gpus", "2"]) == 0
+        assert calls == ["r0", "r1"]          # one attempt each: no walk down the ladder
+    finally:
+        for suffix in (".done", "_attempt0.failed"):
+            try:
+                os.unlink(flag_base + suffix)
+            except OSError:
+                pass
 
 
 def _latest(pattern):

@@ -42,7 +42,7 @@ def check(sc, tile_mode=None, **opts):
 
 
 @pytest.mark.parametrize("tile_mode", [0, 1])
-def test_c2_and_c3_small(maps64, tile_mode, item_route):
+def test_c2_and_c3_small(maps64, tile_mode, item_route_heavy):
     check(scenes.shaderball_scene(configs.C2.scaled(320, 180, 64), bbo.MaterialData(maps64)), tile_mode)
     check(scenes.shaderball_scene(configs.C3.scaled(640, 360, 64), bbo.MaterialData(maps64)), tile_mode)
 
@@ -76,7 +76,7 @@ def test_mixed_map_sizes_with_a_height_map():
     check(sc)
 
 
-def test_heavy_clipping_overflow_replay_and_frames_in_flight(maps64, item_route):
+def test_heavy_clipping_overflow_replay_and_frames_in_flight(maps64, item_route_heavy):
     cfg = configs.C3.scaled(384, 216, 64)
     sc = scenes.shaderball_scene(cfg, bbo.MaterialData(maps64))
     check(sc, bin_cap=8, frames_in_flight=3)
@@ -84,7 +84,7 @@ def test_heavy_clipping_overflow_replay_and_frames_in_flight(maps64, item_route)
     check(sc)
 
 
-def test_partition_and_present_on_the_deferred_image(maps64, item_route):
+def test_partition_and_present_on_the_deferred_image(maps64, item_route_heavy):
     cfg = configs.C3.scaled(512, 300, 64)
     sc = scenes.shaderball_scene(cfg, bbo.MaterialData(maps64))
     sc.frame["enable_tone_mapping"], sc.frame["exposure"] = 1, 1.4

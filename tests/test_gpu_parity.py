@@ -218,7 +218,7 @@ def test_empty_frame_and_culled_geometry():
     assert (img == 0).all() and st["n_raster_tris"] == 0
 
 
-def test_camera_inside_geometry_heavy_clipping(maps64, item_route):
+def test_camera_inside_geometry_heavy_clipping(maps64, item_route_heavy):
     """camera between the balls, looking along the lattice: many primitives cross the near plane and the guard band"""
     cfg = configs.C3.scaled(256, 144, 64)
     sc = scenes.shaderball_scene(cfg, bbo.MaterialData(maps64))
@@ -284,7 +284,7 @@ def test_depth_ties_follow_api_order():
     check(quad_scene(70, 50, 2.0, 4.0, "ba"))
 
 
-def test_bin_capacity_overflow_is_recovered(maps64, item_route):
+def test_bin_capacity_overflow_is_recovered(maps64, item_route_heavy):
     """tiny bins force the overflow path: the frame is re-rendered with larger bins, result unchanged"""
     sc = scenes.shaderball_scene(configs.C3.scaled(320, 180, 64), bbo.MaterialData(maps64))
     _, _, st = check(sc, bin_cap=8)
@@ -298,7 +298,7 @@ def test_broad_list_threshold_extremes(maps64):
 
 
 @pytest.mark.parametrize("caps", [{"broad_cap": 1}, {"clip_cap": 1}, {"broad_cap": 2, "clip_cap": 2, "broad_threshold": 1}])
-def test_every_tile_list_and_clip_arena_overflow_through_a_clipped_primitive(maps64, caps, item_route):
+def test_every_tile_list_and_clip_arena_overflow_through_a_clipped_primitive(maps64, caps, item_route_heavy):
     """The clip path reserves a RUN of list entries / arena slots per primitive and writes none of them when the run
     does not fit: the overflowed frame must not consume the unwritten part (it takes no every-tile entry at all), and the
     frame rendered after the growth is the oracle's.  Once with a synchronising call right after the first frame, once

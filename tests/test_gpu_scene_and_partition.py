@@ -74,7 +74,7 @@ def test_triangle_scene_through_the_shim():
 
 
 @pytest.mark.parametrize("world,band_rows,tile_mode", [(2, 64, 0), (3, 64, 0), (8, 64, 0), (4, 32, 1), (8, 128, 0), (5, 96, 1)])
-def test_partitioned_render_reassembles_to_the_single_gpu_frame(maps64, world, band_rows, tile_mode, item_route):
+def test_partitioned_render_reassembles_to_the_single_gpu_frame(maps64, world, band_rows, tile_mode, item_route_heavy):
     """every rank's shard rendered on this one GPU in turn; host-side all-gather + un-interleave == full frame"""
     cfg = configs.C3.scaled(512, 300, 64)
     sc = scenes.shaderball_scene(cfg, bbo.MaterialData(maps64))
@@ -378,7 +378,7 @@ def test_frames_stay_identical_while_other_processes_share_the_gpu(maps64):
             p.wait(timeout=60)
 
 
-def test_a_host_that_never_synchronises_still_outgrows_an_overflow(maps64, item_route):
+def test_a_host_that_never_synchronises_still_outgrows_an_overflow(maps64, item_route_heavy):
     """bins far too small, frames only streamed into a caller buffer: the first frames are incomplete (and stay so),
     but within a few frames the capacities have grown by themselves and every later frame is exact"""
     import torch
