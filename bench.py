@@ -519,14 +519,15 @@ def supervise(args, argv):
     done_flag = flag_base + ".done" if flag_base else None
 
     def cleanup_flags():
+        # (the .failed flags only: the run's .done flag stays for the ranks that are still on their way -- a rank whose worker
+        #  stalls in teardown looks for it a stall limit later -- and is removed by rank 0 of the next run with this parent and port)
         if flag_base and rank == 0:
             time.sleep(2.0)   # (the other ranks' supervisors look at them for a moment longer)
             for k in range(len(ladder)):
-                for suffix in (f"_attempt{k}.failed", ".done"):
-                    try:
-                        os.unlink(flag_base + suffix)
-                    except OSError:
-                        pass
+                try:
+                    os.unlink(f"{flag_base}_attempt{k}.failed")
+                except OSError:
+                    pass
     attempts = []
     for k, (exchange, gather) in enumerate(ladder):
         env = dict(base_env, BBR_BENCH_ATTEMPTS=json.dumps(attempts))

@@ -123,9 +123,12 @@ int bbr_framebuffer_device_ptr(bbr_context *ctx, void **out_device_ptr, uint64_t
 /* Render into caller-provided device memory instead (e.g. a torch tensor that RCCL all-gathers);
  * NULL restores the internal buffer.  bytes must cover the frame (or the shard when partitioned). */
 int bbr_set_output_device_ptr(bbr_context *ctx, void *device_ptr, uint64_t bytes);
-/* By default a context owns two HIP streams and keeps two frames in flight (geometry + raster of frame N+1
- * overlap the shading of frame N; option "frames_in_flight" = 1 turns that off).  Each in-flight frame has its own
- * internal framebuffer; bbr_read_framebuffer / bbr_framebuffer_device_ptr refer to the most recently submitted frame.
+/* By default a context owns four HIP streams and keeps two frames in flight, like the reference (numFrames,
+ * src/main.cpp:38): every frame slot has its own buffers, counter block and stream ("stream_layout" 2, the default: all
+ * kernels of a frame on the stream of its slot, so whole frames overlap and nothing inside a frame needs an event); the
+ * host blocks in bbr_end_frame only when the slot it wants to reuse is still on the GPU (bbr_host_timing counts that).
+ * Options "frames_in_flight" 1..4 and "stream_layout" change this.  bbr_read_framebuffer / bbr_framebuffer_device_ptr refer
+ * to the most recently submitted frame.
  * bbr_set_stream(stream != NULL) puts ALL of the context's work on the caller's stream instead (one frame in flight,
  * plain stream ordering with the caller's other work); NULL returns to the context's own streams. */
 int bbr_set_stream(bbr_context *ctx, void *hip_stream);
@@ -188,8 +191,9 @@ int bbr_timing_summary(bbr_context *ctx, uint32_t *out_frames, float *out_avg_fr
  *                            2: only the two around k_shade (frame/geometry/raster averages read 0); restarts the ring
  *   "timing_stride" n        with "timing" on, only every n-th frame carries events (default 1): the events themselves
  *                            perturb a pipelined frame stream (two per frame: ~4 % of the C3 frame rate)
- *   "frames_in_flight" 1..4  default 2
- *   "tile_mode" 0|1          0: 64x64 tiles, 1: 32x32 tiles (default)
+ *   "frames_in_flight" 1..4  default 2 (the reference's numFrames); bench.py runs 4K with 3 and 1080p with 4
+ *   "tile_mode" 0|1          1 (default): 32x32 screen tiles; 0: 64x64 tiles -- kept for frames beyond 8192 x 8192 pixels
+ *                            (65 536 tile slots), slower everywhere else (k_raster 120 vs 65 us at 4K, round 1)
  *   "bin_cap" n              initial references per (tile, raster class); grows by itself on overflow
  *   "broad_threshold" n      triangles touching more than n tiles go to the every-tile list
  *   "broad_cap" n            initial entries of the every-tile list (default 4096); doubles when a frame overflows it
@@ -302,7 +306,7 @@ int bbr_tone_map(bbr_context *ctx, int32_t enable_tone_mapping, float exposure);
  * output, see the define).  `gathered` / `whole` = NULL use buffers owned by the frame's slot
  * (bbr_whole_frame_device_ptr, bbr_read_whole_frame).  An exchange never re-renders (one rank alone must not repeat a
  * collective): let the capacities settle with one synchronised frame first, as after any scene change.
- * Not yet run on more than one GPU: see DESIGN.md section 6. */
+ * Not yet run on more than one GPU: see DESIGN.md section 5. */
 #define BBR_COMM_ID_BYTES 128
 #define BBR_IPC_HANDLE_BYTES 64
 #define BBR_SHARD_RGBA32F 0

@@ -67,7 +67,7 @@ def test_a_stalled_exchange_is_given_up_and_the_torch_attempt_completes():
     touches the GPU -- sees no milestone for BBR_BENCH_STALL_LIMIT seconds, kills that attempt's whole process group and
     starts the torch attempt in fresh processes; its line says what was given up and why.  Exit code 0, ONE JSON line."""
     env = dict(os.environ, BBR_BENCH_BACKEND="gloo", BBR_BENCH_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0",
-               BBR_BENCH_STALL="peer:1:first_frame", BBR_BENCH_STALL_LIMIT="100")
+               BBR_BENCH_STALL="peer:1:first_frame", BBR_BENCH_STALL_LIMIT="45")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     out = _line(subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--exchange", "peer"] + COMMON,
@@ -85,13 +85,28 @@ def test_a_stalled_rank_under_a_launcher_is_given_up_by_every_ranks_supervisor()
     waiting for rank 1 -- sees the flag (or its own stall limit), kills its worker too, and both start the torch attempt,
     which meets on the attempt's own port.  Rank 0 prints the ONE line."""
     env = dict(os.environ, BBR_BENCH_BACKEND="gloo", BBR_BENCH_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0",
-               BBR_BENCH_STALL="peer:1:first_frame", BBR_BENCH_STALL_LIMIT="100")
+               BBR_BENCH_STALL="peer:1:first_frame", BBR_BENCH_STALL_LIMIT="45")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--exchange", "peer"] + COMMON
     out = _line(subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env))
     ex = out["exchange"]
     assert out["n_gpus"] == 2 and out["verified_against_unpartitioned_render"] is True and ex["who"] == "torch", out["_supervisor_stderr"]
     assert len(ex["attempts"]) == 1 and ex["attempts"][0]["exchange"] == "peer"
+
+
+def test_a_rank_that_stalls_behind_the_line_does_not_walk_the_ladder_alone():
+    """under a launcher the ranks agree on success too.  Rank 1's worker stalls in front of its last
+    milestone -- behind the final barrier, i.e. after rank 0 has printed the line.  Rank 0's supervisor leaves the run's .done
+    flag; rank 1's supervisor gives its worker up after the stall limit, finds the flag and leaves with 0 instead of starting
+    the next rung against a rendezvous nobody else will join.  One line, exit code 0, no second attempt."""
+    env = dict(os.environ, BBR_BENCH_BACKEND="gloo", BBR_BENCH_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               BBR_BENCH_STALL="torch:1:done", BBR_BENCH_STALL_LIMIT="45")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--exchange", "torch"] + COMMON
+    proc = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    out = _line(proc)
+    assert out["n_gpus"] == 2 and out["verified_against_unpartitioned_render"] is True and out["exchange"]["attempts"] == []
+    assert "another rank's worker completed it" in proc.stderr and "attempt 2/" not in proc.stderr, proc.stderr[-2000:]
 
 
 def test_bare_bench_command_with_two_gpus_launches_its_own_ranks():

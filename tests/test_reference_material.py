@@ -1,0 +1,113 @@
+"""The reference's own complete material through the path.
+
+`resources/pbr_backup/light_gold` is the one set in the reference that holds albedo + normal + metallic + roughness: a smooth
+metal (roughness 46/255, metallic 255, mean albedo (243, 215, 148)) -- the corner of the BRDF where GGX's D peaks highest
+(1 / (pi a^2) with a = roughness^2 = 0.033: D up to ~300) and where the two evaluation orders of the light loop are furthest
+apart.  The seeded maps of the other tests never go below roughness 0.15.
+
+* CPU (authoring container only: the reference's PNGs cannot travel): the set is loaded with the product's own PNG decoder
+  and createPBRMaterialSet's rule for missing maps (src/render.cpp:1328-1336: the `default` material's map), C2 is rendered
+  by the oracle in contract and in literal form; BASELINE's tolerance and finiteness are asserted, and the statistics SURVEY
+  quotes are pinned.
+* GPU (travels): a seeded stand-in with the same statistics at full C3 size, HIP frame against the literal form and bit for
+  bit against the contract form.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from bibim_renderer_amd import configs, textures
+from oracle import bbo, scenes
+from tests.conftest import REFERENCE, assert_frame_close
+
+
+def assert_within_baseline(img, literal):
+    """BASELINE.md's tolerance |d| <= 1e-4 * max(1, |ref|) everywhere; BASELINE.json's absolute 1e-4 wherever binary32 can hold it.
+    This material's highlights reach ~1100 (the seeded maps' frames stop at 189): one unit in the last place of a value above
+    1024 is 1.2e-4, so an ABSOLUTE 1e-4 cannot be asked of any binary32 frame there -- the two forms are 4 ulp apart at most
+    (4.6e-7 relative), which is what is asserted instead for |ref| > 100."""
+    assert_frame_close(img, literal)
+    d = np.abs(img.astype(np.float64) - literal.astype(np.float64))
+    small = np.abs(literal) <= 100.0
+    assert d[small].max() <= 1e-4, float(d[small].max())
+    if (~small).any():
+        ulps = np.abs(img.view(np.int32).astype(np.int64) - literal.view(np.int32).astype(np.int64))
+        assert int(ulps[~small].max()) <= 16, int(ulps[~small].max())
+        assert float((d[~small] / np.abs(literal[~small])).max()) <= 2e-6
+
+
+LIGHT_GOLD = os.path.join(REFERENCE, "resources", "pbr_backup", "light_gold")
+DEFAULT = os.path.join(REFERENCE, "resources", "pbr", "default")
+
+
+def light_gold_stand_in(size=2048, seed=0x601D):
+    """maps with light_gold's statistics: roughness around 46/255 (never 0: brdf.glsl's 0/0 hazard is a separate test), metallic
+    255, albedo around (243, 215, 148), gentle normals, ao = the default map's 255"""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    m = textures.make_material(size)                 # (its normal map; everything else replaced)
+    noise = textures._value_noise(rng, size, 64)     # smooth, in [0, 1]
+
+    def rgba(r, g, b):
+        out = np.empty((size, size, 4), np.uint8)
+        out[..., 0], out[..., 1], out[..., 2], out[..., 3] = r, g, b, 255
+        return out
+    r8 = np.clip(np.rint(46 + 24 * (noise - 0.5)), 30, 70).astype(np.uint8)
+    tint = (noise - 0.5) * 10
+    return {"albedo": rgba(np.clip(np.rint(243 + tint), 0, 255).astype(np.uint8), np.clip(np.rint(215 + tint), 0, 255).astype(np.uint8),
+                           np.clip(np.rint(148 + tint), 0, 255).astype(np.uint8)),
+            "metallic": rgba(255, 255, 255), "roughness": rgba(r8, r8, r8), "ao": rgba(255, 255, 255), "normal": m["normal"]}
+
+
+@pytest.mark.skipif(not os.path.isdir(LIGHT_GOLD), reason="/root/reference is not present (authoring container only)")
+def test_light_gold_through_the_oracle_in_both_forms():
+    from bibim_renderer_amd import assets
+    maps = {}
+    for name in ("albedo", "metallic", "roughness", "ao", "normal", "height"):
+        f = os.path.join(LIGHT_GOLD, name + ".png")
+        if not os.path.exists(f):                    # src/render.cpp:1328-1336: the default material's map
+            f = os.path.join(DEFAULT, name + ".png")
+        maps[name] = assets.load_png(f)
+    assert not os.path.exists(os.path.join(LIGHT_GOLD, "ao.png")) and maps["ao"].shape[:2] == (16, 16)
+    # the statistics SURVEY 8(d) quotes for this set
+    assert abs(float(maps["roughness"][..., 0].mean()) - 46.0) < 1.5 and int(maps["metallic"][..., 0].min()) == 255
+    assert np.allclose(maps["albedo"][..., :3].reshape(-1, 3).mean(0), (243, 215, 148), atol=1.5)
+    sc = scenes.shaderball_scene(configs.C2, bbo.MaterialData(maps))
+    contract, n_c = bbo.render_bands(sc)
+    literal, n_l = bbo.render_bands(sc, flags=bbo.FLAG_LITERAL)
+    assert n_c == n_l > 0
+    assert np.isfinite(contract).all() and np.isfinite(literal).all()
+    assert float(literal[..., :3].max()) > 2.0      # a highlight is in the frame: this IS the smooth-metal corner
+    assert float(literal[..., :3].max()) > 500.0    # ... with values far above anything the seeded maps produce
+    assert_within_baseline(contract, literal)
+
+
+def test_the_stand_in_has_light_golds_statistics_and_both_forms_agree_on_it():
+    """what travels to the GPU box instead of the PNGs: same statistics, and the two forms within tolerance on it (reduced size)"""
+    maps = light_gold_stand_in(256)
+    assert abs(float(maps["roughness"][..., 0].mean()) - 46.0) < 2.0 and int(maps["roughness"].min()) >= 30
+    assert int(maps["metallic"][..., 0].min()) == 255
+    assert np.allclose(maps["albedo"][..., :3].reshape(-1, 3).mean(0), (243, 215, 148), atol=2.0)
+    sc = scenes.shaderball_scene(configs.C3.scaled(960, 540, 256), bbo.MaterialData(maps))
+    contract, _ = bbo.render_bands(sc)
+    literal, _ = bbo.render_bands(sc, flags=bbo.FLAG_LITERAL)
+    assert np.isfinite(literal).all()
+    assert_within_baseline(contract, literal)
+
+
+@pytest.mark.gpu
+def test_smooth_metal_at_full_c3_against_the_literal_form():
+    from bibim_renderer_amd import Renderer
+    cfg = configs.C3
+    maps = light_gold_stand_in(cfg.texture_size)
+    sc = scenes.shaderball_scene(cfg, bbo.MaterialData(maps))
+    literal, n_shaded = bbo.render_bands(sc, flags=bbo.FLAG_LITERAL)
+    contract, _ = bbo.render_bands(sc)
+    r = Renderer(sc.width, sc.height)
+    r.render_scene(sc)
+    img = r.read_framebuffer()
+    st = r.stats()
+    r.close()
+    assert st["n_shaded"] == n_shaded and np.isfinite(literal).all() and np.isfinite(img).all()
+    assert np.array_equal(img.view(np.uint32), contract.view(np.uint32))          # bit for bit the contract form
+    assert_within_baseline(img, literal)                                           # within BASELINE's tolerance of the GLSL as written
