@@ -1600,9 +1600,16 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(OV
   constexpr int PASSES = TILE_PIXELS / kTileThreads;
   unsigned long long pass_mask[PASSES];
   uint32_t wave_total = 0u;
+  // Which 8 x 8 block of the tile a wave takes in pass k: CONSECUTIVE blocks (for 32-pixel tiles a row of four, a 32 x 8 strip).
+  // The wave's covered pixels go into the fragment list as one run, 64 consecutive fragments are an item of k_shade and
+  // four consecutive items a workgroup (one CU; the next workgroup is on the next XCD): with the runs in wave order (below)
+  // workgroup j of a tile shades strip j, in every tile and every frame.  Measured with the runs in wave order, k_shade's
+  // fetch traffic per launch (FETCH_SIZE, KiB, C3): strips 53.8 k -- what round 4's one-atomic-per-pass compaction had --, a
+  // quarter of the tile per wave 62.2 k, a column of blocks per wave 67.1 k (gpurun_out/r5/t12_*).
+  auto pass_pixel = [&](int k) -> int { return (wave * PASSES + k) * 64 + lane; };
 #pragma unroll
   for (int k = 0; k < PASSES; ++k) {
-    const int p = k * kTileThreads + tid;
+    const int p = pass_pixel(k);
     int x, y;
     tile_pixel<TILE_W>(p, x, y);
     const bool in_frame = tile_x0 + x < fp.width && tile_y0 + y < fp.height;
@@ -1610,12 +1617,20 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(OV
     pass_mask[k] = __ballot(in_frame && (OVERLAY ? (uint32_t)key != 0u : key != 0ull));
     wave_total += (uint32_t)__popcll(pass_mask[k]);
   }
+  // The four runs stand in the list in WAVE order -- an exclusive prefix over the waves' totals through LDS, one more barrier
+  // -- not in the order in which four atomics happen to arrive: the fragment list of a tile is then the same from frame to
+  // frame, and so is which of k_shade's workgroups (which XCD, which L2) shades which part of the tile.  With a returning
+  // atomic per wave the runs came in any order and k_shade's fetch traffic rose by a fifth (the same L1 misses, more of them
+  // L2 misses: neighbouring tiles no longer sent their shared texel lines to the same L2s).
+  if (lane == 0) s_wave_rows[wave] = wave_total;   // (the row list's totals are done with: behind the chunk loop's last barrier)
+  __syncthreads();
   uint32_t wave_base = 0u;
-  if (lane == 0 && wave_total) wave_base = atomicAdd(&s_count, wave_total);
-  wave_base = (uint32_t)__shfl((int)wave_base, 0);
+#pragma unroll
+  for (int w = 0; w < kTileWaves; ++w) wave_base += w < wave ? s_wave_rows[w] : 0u;
+  if (tid == 0) s_count = s_wave_rows[0] + s_wave_rows[1] + s_wave_rows[2] + s_wave_rows[3];
 #pragma unroll
   for (int k = 0; k < PASSES; ++k) {
-    int p = k * kTileThreads + tid;
+    int p = pass_pixel(k);
     int x, y;
     tile_pixel<TILE_W>(p, x, y);
     int gx = tile_x0 + x, gy = tile_y0 + y;

@@ -1,7 +1,7 @@
 """Diagnostic (GPU box): the PIPELINED frame period of one rank of a screen-band partition -- three frames in flight, no
 exchange: what a rank can render per second before a byte moves -- for world 1 / 2 / 4 / 8, every rank index, and two band
 heights.  Beside it each kernel of that rank alone (one frame in flight, HIP events).  The 1 / world ideal is printed for
-comparison.   usage: _gpu_band_throughput.py [--workload c3] [--band-rows 0 256]   -> profiles/r04_band_throughput.txt"""
+comparison.   usage: _gpu_band_throughput.py [--workload c3] [--band-rows 0 256]   -> profiles/r05_band_throughput.txt"""
 import argparse, gc, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bibim_renderer_amd import configs, textures, Renderer
@@ -48,6 +48,7 @@ for band in a.band_rows:
             r.synchronize()
             n, f, g, ra, s = r.timing_summary()
             st = r.stats()
+            shard_rows = r.shard_rows() if world > 1 else cfg.height
             gc.enable()
             if world == 1:
                 base = best
@@ -58,3 +59,11 @@ for band in a.band_rows:
         if world > 1 and base:
             print(f"  -> world {world}, band rows {band or 32}: slowest rank {worst:6.1f} us/frame = {base / worst:4.2f}x one GPU's {base:5.1f} "
                   f"(ideal {world}x = {base / world:5.1f} us)", flush=True)
+            # what the links allow for the frame this rendering would have to be put together into: every rank receives world - 1
+            # blocks, each over its own xGMI link at best (76.8 GB/s per direction) -- block / link rate; a ring: x (world - 1)
+            px = cfg.width * shard_rows
+            forms = (("rgba32f", 16.0), ("packed rgb + alpha bit", 12.0 + 1.0 / 8), ("rgba16f (lossy)", 8.0), ("rgba8 presented", 4.0))
+            print("     exchange, link-bound (direct / ring) per frame: " + "; ".join(
+                f"{name} {px * b / 76.8e9 * 1e6:6.0f} / {px * b / 76.8e9 * 1e6 * (world - 1):6.0f} us" for name, b in forms) +
+                f"   -> which forms can beat one GPU's {base:5.1f} us at all: " +
+                (", ".join(name for name, b in forms if px * b / 76.8e9 * 1e6 < base) or "none"), flush=True)
