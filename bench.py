@@ -234,8 +234,28 @@ def device_pci_address(index):
     return None
 
 
+def cpu_quota():
+    """CPUs' worth of time the container may use (cgroup cpu.max / cfs quota), or None: a box may show 256 logical CPUs to
+    sched_getaffinity and still be held to a share of them"""
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(period)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        period = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / period
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(cfg, maps, budget_s=20.0):
-    """Oracle (CPU restatement, kind "port") on the host cores: bounded sample of the same workload."""
+    """Oracle (CPU restatement, kind "port") on the host cores: bounded sample of the same workload.
+    `value` = the oracle's threaded form (bbo_render_parallel: primitives set up once, in parallel, then 8-row bands from a
+    queue -- SURVEY 8(d)(ii)) on every core this process may use: its affinity mask, held to the container's CPU quota when there
+    is one (a one-GPU box shows 256 logical CPUs and grants 16).  Beside it the single-thread whole-frame run, whose frame the GPU
+    is compared with, and -- for continuity with rounds 1-4 -- the band-per-call form on at most 16 threads."""
     from concurrent.futures import ThreadPoolExecutor
 
     from oracle import bbo, scenes
@@ -243,6 +263,7 @@ def cpu_baseline(cfg, maps, budget_s=20.0):
     mat = bbo.MaterialData(maps)
     sc = scenes.shaderball_scene(cfg, mat)
     W, H = sc.width, sc.height
+    mpix = W * H / 1e6
     rgba = np.zeros((H, W, 4), np.float32)
     arr = (bbo.Draw * len(sc.draws))(*[d.c_struct() for d in sc.draws])
     L = bbo.lib()
@@ -255,49 +276,43 @@ def cpu_baseline(cfg, maps, budget_s=20.0):
         return st.n_shaded
 
     cores_available = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = max(1, min(cores_available, 16))  # threads used: at most a one-GPU box's CPU share
-    bands = [(y, min(y + 32, H)) for y in range(0, H, 32)]
+    quota = cpu_quota()
+    cores = max(1, cores_available if quota is None else min(cores_available, int(np.ceil(quota))))
     # single thread, whole frame in one call (the scalar port as written)
     t0 = time.perf_counter()
     n1 = band((0, H))
     t_single = time.perf_counter() - t0
-    # all cores, bands from a queue; repeat until the budget is used
-    reps, t_multi = 0, 0.0
-    with ThreadPoolExecutor(cores) as ex:
-        while True:
+    # every usable core, the threaded oracle: at least five frames, until about half of the budget is used
+    rgba_all = np.zeros((H, W, 4), np.float32)
+    _, st_all = bbo.render_parallel(sc, threads=cores, rows=8, out=rgba_all)   # (threads started, pages touched)
+    if st_all["n_shaded"] != n1 or not np.array_equal(rgba_all.view(np.uint32), rgba.view(np.uint32)):
+        raise SystemExit("the threaded oracle renders another frame than the scalar one")
+    reps, t_all = 0, 0.0
+    while reps < 5 or (t_all * cores < 0.5 * budget_s and reps < 200):
+        t0 = time.perf_counter()
+        bbo.render_parallel(sc, threads=cores, rows=8, out=rgba_all)
+        t_all += time.perf_counter() - t0
+        reps += 1
+    # rounds 1-4's form: one bbo_render call per 32-row band (each call sets every primitive up again) on <= 16 threads
+    band_threads = max(1, min(cores_available, 16))
+    bands = [(y, min(y + 32, H)) for y in range(0, H, 32)]
+    b_reps, t_bands = 0, 0.0
+    with ThreadPoolExecutor(band_threads) as ex:
+        while b_reps < 3:
             t0 = time.perf_counter()
             n = sum(ex.map(band, bands))
-            t_multi += time.perf_counter() - t0
+            t_bands += time.perf_counter() - t0
             assert n == n1
-            reps += 1
-            if reps >= 20 or t_single + t_multi + t_multi / reps > budget_s:
-                break
-    mpix = W * H / 1e6
-    # the same frame on ALL the cores this process may use, one thread per 32-row band at most; at least
-    # five frames, bounded to about three seconds
-    all_cores = max(1, min(cores_available, len(bands)))
-    all_reps, t_all = 0, 0.0
-    if all_cores > cores:
-        with ThreadPoolExecutor(all_cores) as ex:
-            sum(ex.map(band, bands))   # (threads started, pages touched)
-            while all_reps < 5 or (t_all < 1.0 and all_reps < 50):
-                t0 = time.perf_counter()
-                n = sum(ex.map(band, bands))
-                t_all += time.perf_counter() - t0
-                assert n == n1
-                all_reps += 1
-                if t_all > 3.0 and all_reps >= 5:
-                    break
-    else:
-        all_reps, t_all = reps, t_multi
-    return {"value": round(mpix * reps / t_multi, 3), "unit": "Mpixels/s", "cores": cores, "cores_available": cores_available,
-            "host_logical_cpus": os.cpu_count(), "kind": "port",
-            "sample": f"{reps} full {cfg.name} frame(s) ({W}x{H}), oracle/bb_oracle.c, {cores} threads over 32-row bands; "
-                      f"single-thread whole-frame run: {mpix / t_single:.3f} Mpixels/s; all cores: {all_reps} frames on "
-                      f"{all_cores} threads",
+            b_reps += 1
+    return {"value": round(mpix * reps / t_all, 3), "unit": "Mpixels/s", "cores": cores, "cores_available": cores_available,
+            "cpu_quota": quota, "host_logical_cpus": os.cpu_count(), "kind": "port",
+            "sample": f"{reps} full {cfg.name} frame(s) ({W}x{H}), oracle/bb_oracle.c bbo_render_parallel, {cores} threads, 8-row bands "
+                      f"from a queue ({t_all * cores:.1f} CPU-seconds); single-thread whole-frame run: {mpix / t_single:.3f} Mpixels/s",
             "single_thread_value": round(mpix / t_single, 3),
-            "all_cores_value": round(mpix * all_reps / t_all, 3), "all_cores": all_cores, "all_cores_frames": all_reps,
-            "all_cores_is": "min(cores this process may use, 32-row bands of the frame) threads, one band per task",
+            "all_cores_value": round(mpix * reps / t_all, 3), "all_cores": cores, "all_cores_frames": reps,
+            "all_cores_is": "= value: every core this process may use (affinity mask, held to the container's CPU quota `cpu_quota`)",
+            "band_calls_value": round(mpix * b_reps / t_bands, 3), "band_calls_threads": band_threads,
+            "band_calls_is": "rounds 1-4's figure: one bbo_render call per 32-row band, each repeating the set-up of every primitive",
             "n_shaded": int(n1)}, rgba
 
 
@@ -1079,9 +1094,10 @@ def main():
             roofline["distinct_texel_line_bytes"] = lines_bytes
             roofline["distinct_texel_line_source"] = lines_src
         t_ms, t_alone_ms, t_src = committed_trace_ms(args.workload)
-        roofline["avg_kernel_ms_is"] = (f"HIP events around k_shade on its own stream with {args.frames_in_flight} frames in flight: an "
-                                        "OVERLAPPED latency (the kernel shares the GPU with the other frames' kernels and the events also "
-                                        "bracket the dispatch gaps), so it can exceed ms_per_step; `frac` uses it and is the conservative figure")
+        roofline["avg_kernel_ms_is"] = (f"HIP events on the kernel's own stream right in front of and behind k_shade's main launch, with "
+                                        f"{args.frames_in_flight} frames in flight: the kernel shares the GPU with the other frames' kernels, so this is "
+                                        "its duration UNDER THAT LOAD (trace_kernel_ms is the same quantity from the kernel trace; "
+                                        "one_frame_in_flight / trace_kernel_alone_ms the kernel alone)")
         if not t_ms and t_src:
             roofline["trace_source"] = t_src   # (why there are no trace_* figures: the committed trace is of other kernels)
         if t_ms:

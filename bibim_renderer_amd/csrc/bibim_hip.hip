@@ -524,7 +524,8 @@ void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const Fra
     (void)hipEventRecord(s.ev_raster_done, sr);
     (void)hipStreamWaitEvent(ss, s.ev_raster_done, 0);
   }
-  if (ev) (void)hipEventRecord(ev[3], ss);  // completes when the shade stream has seen "raster done"
+  // (ev[3], the start of the shading interval, is recorded in front of the MAIN launch below -- behind the tail launch when
+  //  both are on one stream: the interval is then the dominant kernel's own, which the kernel trace can be held against)
   uint2 *gbuf = (fp.deferred && c->dump_gbuffer) ? c->d_gbuffer.ptr : nullptr;
   // Main launch: one item (64 fragments) per wave, four per workgroup, sized from the item count of the frame this slot
   // rendered last (k_shade_items leaves it in pinned host memory) plus 3 %; tail launch: a small persistent grid for
@@ -547,6 +548,7 @@ void launch_frame(bbr_context *c, FrameSlot &s, const FrameSlot *prev, const Fra
                          s.d_clip.ptr, fp, sp, s.d_cooked.ptr, c->d_materials.ptr, out, gbuf, tables, out8, ctr, ctr_done, nullptr);
       if (ss != sr) (void)hipEventRecord(s.ev_tail_done, sr);
     }
+    if (ev) (void)hipEventRecord(ev[3], ss);
     // (the main launch without the per-map sampling path when every material is packed: k_shade, MIXED)
     auto main_launch = [&](auto mixed) {
       hipLaunchKernelGGL((k_shade<TW, TH, decltype(deferred)::value, decltype(present)::value, false, decltype(mixed)::value>), dim3(main_wgs),

@@ -36,6 +36,8 @@
 #include "bb_oracle.h"
 
 #include <math.h>
+#include <pthread.h>
+#include <stdatomic.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -1039,6 +1041,223 @@ int bbo_render(const bbo_frame_uniforms *frame, const bbo_view_uniforms *view, c
                int32_t width, int32_t height, int32_t y0, int32_t y1, uint32_t flags, float *out_rgba,
                uint32_t *out_prim, float *out_depth, bbo_stats *stats) {
   return render_pbr(frame, view, draws, n_draws, width, height, y0, y1, flags, out_rgba, NULL, out_prim, out_depth, stats);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* the same forward frame on all cores ("std::thread over tile rows on all cores") */
+/* ------------------------------------------------------------------------------------------ */
+/* bbo_render called once per band repeats the vertex stage and the primitive setup of EVERY primitive in every call (22 ms of a
+ * 4K band's 30-80 ms): fine for a checker, a poor all-cores baseline.  Here the primitives are set up ONCE, in parallel
+ * (chunks of 1024 in API order), and the bands then walk the surviving sub-triangles of all chunks in that order -- so every
+ * pixel sees the same fragments in the same order, through the same covers / tri_depth / shade_pixel: the frame is bit for bit
+ * bbo_render's (tests/test_oracle_golden_frames.py). */
+#define PAR_CHUNK 1024u
+typedef struct {
+  raster_tri t;
+  uint32_t key;        /* ((prim << 3) | sub) + 1 */
+  int32_t py0, py1;    /* pixel rows the bounding box holds a centre of */
+} par_tri;
+typedef struct {
+  const pipeline *pl;
+  uint32_t n_prims, n_chunks;
+  int32_t width, height, band_rows, n_bands;
+  float *out_rgba;
+  par_tri **chunk_tris;
+  uint32_t *chunk_n;
+  atomic_uint next_chunk, next_band;
+  atomic_ullong n_raster_tris, n_clipped, n_fragments, n_shaded;
+  atomic_int error;
+} par_job;
+
+static void par_setup_chunk(par_job *j, uint32_t c) {
+  const viewport whole = {0.5f * (float)j->width, 0.5f * (float)j->height, 0.5f * (float)j->width, 0.5f * (float)j->height};
+  uint32_t p0 = c * PAR_CHUNK, p1 = p0 + PAR_CHUNK < j->n_prims ? p0 + PAR_CHUNK : j->n_prims;
+  par_tri *out = (par_tri *)malloc(sizeof(par_tri) * (size_t)(p1 - p0) * MAX_SUBTRIS);
+  if (!out) { atomic_store(&j->error, -3); return; }
+  uint32_t n_out = 0;
+  unsigned long long clipped = 0;
+  for (uint32_t prim = p0; prim < p1; ++prim) {
+    float clip[3][4], vary[3][NVARY];
+    const void *mat;
+    j->pl->fetch(j->pl->ctx, prim, clip, vary, &mat);
+    raster_tri tris[MAX_SUBTRIS];
+    int was_clipped;
+    int n = build_prim(clip, &whole, tris, &was_clipped);
+    clipped += (unsigned long long)was_clipped;
+    for (int s = 0; s < n; ++s) {
+      const raster_tri *t = &tris[s];
+      if (t->clipped < 0) continue;
+      int32_t minY = t->Y[0], maxY = t->Y[0];
+      for (int k = 1; k < 3; ++k) {
+        if (t->Y[k] < minY) minY = t->Y[k];
+        if (t->Y[k] > maxY) maxY = t->Y[k];
+      }
+      par_tri *o = &out[n_out++];
+      o->t = *t;
+      o->key = ((prim << 3) | (uint32_t)s) + 1u;
+      o->py0 = (minY - 128 + 255) >> 8;
+      o->py1 = (maxY - 128) >> 8;
+    }
+  }
+  j->chunk_tris[c] = out;
+  j->chunk_n[c] = n_out;
+  atomic_fetch_add(&j->n_raster_tris, n_out);
+  atomic_fetch_add(&j->n_clipped, clipped);
+}
+
+static void par_render_band(par_job *j, int32_t b, uint32_t *key, float *depth) {
+  const int32_t W = j->width, y0 = b * j->band_rows, y1 = y0 + j->band_rows < j->height ? y0 + j->band_rows : j->height;
+  const size_t rows = (size_t)(y1 - y0);
+  memset(key, 0, sizeof(uint32_t) * rows * (size_t)W);
+  memset(depth, 0, sizeof(float) * rows * (size_t)W);
+  memset(j->out_rgba + 4 * (size_t)y0 * W, 0, sizeof(float) * 4 * rows * (size_t)W);
+  unsigned long long fragments = 0, shaded = 0;
+  for (uint32_t c = 0; c < j->n_chunks; ++c) {
+    const par_tri *pt = j->chunk_tris[c];
+    for (uint32_t i = 0; i < j->chunk_n[c]; ++i) {
+      if (pt[i].py1 < y0 || pt[i].py0 >= y1) continue;
+      const raster_tri *t = &pt[i].t;
+      int32_t minX = t->X[0], maxX = t->X[0];
+      for (int k = 1; k < 3; ++k) {
+        if (t->X[k] < minX) minX = t->X[k];
+        if (t->X[k] > maxX) maxX = t->X[k];
+      }
+      int32_t px0 = (minX - 128 + 255) >> 8, px1 = (maxX - 128) >> 8;
+      int32_t py0 = pt[i].py0 < y0 ? y0 : pt[i].py0, py1 = pt[i].py1 > y1 - 1 ? y1 - 1 : pt[i].py1;
+      if (px0 < 0) px0 = 0;
+      if (px1 > W - 1) px1 = W - 1;
+      for (int32_t py = py0; py <= py1; ++py)
+        for (int32_t px = px0; px <= px1; ++px) {
+          int32_t Xc = px * SUBPIXEL_ONE + 128, Yc = py * SUBPIXEL_ONE + 128;
+          if (!covers(t, Xc, Yc)) continue;
+          ++fragments;
+          float z = tri_depth(t, Xc, Yc);
+          size_t o = (size_t)(py - y0) * W + px;
+          if (z >= depth[o]) {
+            depth[o] = z;
+            key[o] = pt[i].key;
+          }
+        }
+    }
+  }
+  /* shade the winning fragment of every covered pixel (the primitive is fetched and set up again: render_core's pass 2) */
+  const viewport whole = {0.5f * (float)W, 0.5f * (float)j->height, 0.5f * (float)W, 0.5f * (float)j->height};
+  uint32_t cached_prim = BBO_NO_PRIM;
+  float clip[3][4], vary[3][NVARY];
+  const void *mat = NULL;
+  raster_tri tris[MAX_SUBTRIS];
+  int n_tris = 0;
+  for (int32_t py = y0; py < y1; ++py)
+    for (int32_t px = 0; px < W; ++px) {
+      uint32_t k = key[(size_t)(py - y0) * W + px];
+      if (!k) continue;
+      ++shaded;
+      uint32_t prim = (k - 1u) >> 3, sub = (k - 1u) & 7u;
+      if (prim != cached_prim) {
+        int wc;
+        j->pl->fetch(j->pl->ctx, prim, clip, vary, &mat);
+        n_tris = build_prim(clip, &whole, tris, &wc);
+        cached_prim = prim;
+      }
+      if ((int)sub >= n_tris) { atomic_store(&j->error, -4); return; }
+      shade_pixel(j->pl, &tris[sub], vary, mat, px, py, j->out_rgba + 4 * ((size_t)py * W + px));
+    }
+  atomic_fetch_add(&j->n_fragments, fragments);
+  atomic_fetch_add(&j->n_shaded, shaded);
+}
+
+static void *par_setup_worker(void *arg) {
+  par_job *j = (par_job *)arg;
+  for (;;) {
+    uint32_t c = atomic_fetch_add(&j->next_chunk, 1u);
+    if (c >= j->n_chunks || atomic_load(&j->error)) break;
+    par_setup_chunk(j, c);
+  }
+  return NULL;
+}
+
+static void *par_band_worker(void *arg) {
+  par_job *j = (par_job *)arg;
+  uint32_t *key = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)j->band_rows * (size_t)j->width);
+  float *depth = (float *)malloc(sizeof(float) * (size_t)j->band_rows * (size_t)j->width);
+  if (!key || !depth) atomic_store(&j->error, -3);
+  else
+    for (;;) {
+      uint32_t b = atomic_fetch_add(&j->next_band, 1u);
+      if ((int32_t)b >= j->n_bands || atomic_load(&j->error)) break;
+      par_render_band(j, (int32_t)b, key, depth);
+    }
+  free(key);
+  free(depth);
+  return NULL;
+}
+
+static int par_run(par_job *j, void *(*fn)(void *), int n_threads) {
+  pthread_t *th = (pthread_t *)calloc((size_t)n_threads, sizeof(pthread_t));
+  if (!th) return -3;
+  int started = 0;
+  for (; started < n_threads; ++started)
+    if (pthread_create(&th[started], NULL, fn, j) != 0) break;
+  if (started == 0) fn(j); /* no thread could be started: this one does the work */
+  for (int i = 0; i < started; ++i) pthread_join(th[i], NULL);
+  free(th);
+  return atomic_load(&j->error);
+}
+
+int bbo_render_parallel(const bbo_frame_uniforms *frame, const bbo_view_uniforms *view, const bbo_draw *draws, uint32_t n_draws,
+                        int32_t width, int32_t height, uint32_t flags, int32_t n_threads, int32_t band_rows, float *out_rgba,
+                        bbo_stats *stats) {
+  if (!frame || !view || (!draws && n_draws) || width <= 0 || height <= 0 || !out_rgba) return -1;
+  if (flags & (BBO_FLAG_DEFERRED | BBO_FLAG_FORWARD_SHADE | BBO_FLAG_OUTPUT_UV)) return -1; /* the forward frame only */
+  if (n_threads < 1) n_threads = 1;
+  if (band_rows < 1) band_rows = 8;
+  draw_info *di = (draw_info *)calloc(n_draws ? n_draws : 1, sizeof(draw_info));
+  if (!di) return -3;
+  uint64_t total = 0;
+  for (uint32_t d = 0; d < n_draws; ++d) {
+    uint32_t n = draws[d].indices ? draws[d].n_indices : draws[d].n_vertices;
+    di[d].draw = &draws[d];
+    di[d].first_prim = (uint32_t)total;
+    di[d].tris_per_instance = n / 3;
+    total += (uint64_t)(n / 3) * draws[d].n_instances;
+    if (draws[d].indices)
+      for (uint32_t i = 0; i < n / 3 * 3; ++i)
+        if (draws[d].indices[i] >= draws[d].n_vertices) { free(di); return -5; }
+  }
+  if (total >= (1u << 29)) { free(di); return -2; }
+  uint32_t m = 0;
+  for (uint32_t d = 0; d < n_draws; ++d)
+    if (di[d].tris_per_instance && draws[d].n_instances) di[m++] = di[d];
+  pbr_ctx ctx;
+  ctx.fu = frame; ctx.vu = view; ctx.draws = di; ctx.n_draws = m; ctx.deferred = 0;
+  bbo_proj_view(view, &ctx.pv);
+  pipeline pl = {0, &ctx, pbr_fetch, frame, view, NULL, width, (flags & BBO_FLAG_LITERAL) != 0, 0};
+  par_job j;
+  memset(&j, 0, sizeof j);
+  j.pl = &pl;
+  j.n_prims = (uint32_t)total;
+  j.n_chunks = (uint32_t)((total + PAR_CHUNK - 1) / PAR_CHUNK);
+  j.width = width; j.height = height; j.band_rows = band_rows; j.n_bands = (height + band_rows - 1) / band_rows;
+  j.out_rgba = out_rgba;
+  j.chunk_tris = (par_tri **)calloc(j.n_chunks ? j.n_chunks : 1, sizeof(par_tri *));
+  j.chunk_n = (uint32_t *)calloc(j.n_chunks ? j.n_chunks : 1, sizeof(uint32_t));
+  int rc = (j.chunk_tris && j.chunk_n) ? 0 : -3;
+  if (!rc) rc = par_run(&j, par_setup_worker, n_threads);
+  if (!rc) rc = par_run(&j, par_band_worker, n_threads);
+  if (j.chunk_tris)
+    for (uint32_t c = 0; c < j.n_chunks; ++c) free(j.chunk_tris[c]);
+  free(j.chunk_tris);
+  free(j.chunk_n);
+  free(di);
+  if (!rc && stats) {
+    memset(stats, 0, sizeof *stats);
+    stats->n_prims = total;
+    stats->n_raster_tris = atomic_load(&j.n_raster_tris);
+    stats->n_clipped_prims = atomic_load(&j.n_clipped);
+    stats->n_fragments = atomic_load(&j.n_fragments);
+    stats->n_shaded = atomic_load(&j.n_shaded);
+  }
+  return rc;
 }
 
 int bbo_render_deferred(const bbo_frame_uniforms *frame, const bbo_view_uniforms *view, const bbo_draw *draws,

@@ -144,6 +144,13 @@ int bbo_render(const bbo_frame_uniforms *frame, const bbo_view_uniforms *view, c
                uint32_t n_draws, int32_t width, int32_t height, int32_t y0, int32_t y1, uint32_t flags,
                float *out_rgba, uint32_t *out_prim, float *out_depth, bbo_stats *stats);
 
+/* The same forward frame (flags: 0 or BBO_FLAG_LITERAL), whole, on `n_threads` threads: primitives set up once in parallel,
+ * then bands of `band_rows` rows taken from a queue.  Bit for bit the frame bbo_render makes; exists so that the CPU baseline
+ * bench.py reports can use every core of the host. */
+int bbo_render_parallel(const bbo_frame_uniforms *frame, const bbo_view_uniforms *view, const bbo_draw *draws,
+                        uint32_t n_draws, int32_t width, int32_t height, uint32_t flags, int32_t n_threads,
+                        int32_t band_rows, float *out_rgba, bbo_stats *stats);
+
 /* Deferred path: src/main.cpp:89-104 (G-buffer subpass, then brdf.frag over a full-screen triangle),
  * src/shaders/gbuffer.vert:17-36, gbuffer.frag:17-33, brdf.frag:11-73, attachments R16G16B16A16_SFLOAT
  * (src/main.cpp:443) cleared to 0.  out_rgba: the HDR colour of every pixel (alpha 1 everywhere: brdf.frag also runs

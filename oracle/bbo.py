@@ -95,6 +95,9 @@ def lib():
     if _lib is None:
         _lib = _load()
         L = _lib
+        L.bbo_render_parallel.restype = C.c_int
+        L.bbo_render_parallel.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Draw), C.c_uint32, C.c_int32, C.c_int32, C.c_uint32,
+                                          C.c_int32, C.c_int32, C.c_void_p, C.POINTER(Stats)]
         L.bbo_render.restype = C.c_int
         L.bbo_render.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Draw), C.c_uint32, C.c_int32, C.c_int32, C.c_int32,
                                  C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Stats)]
@@ -309,6 +312,22 @@ def render_bands(scene: Scene, flags=0, rows=32, threads=None):
     with ThreadPoolExecutor(max(1, min(threads, 16))) as ex:
         n = sum(ex.map(band, range(0, H, rows)))
     return rgba, int(n)
+
+
+def render_parallel(scene: Scene, flags=0, threads=None, rows=8, out=None):
+    """The whole forward frame on `threads` threads inside the C library (primitives set up once, bands from a queue): bit for bit
+    render()'s frame.  Returns (rgba, stats dict).  What bench.py's all-cores CPU baseline times."""
+    W, H = scene.width, scene.height
+    rgba = np.zeros((H, W, 4), np.float32) if out is None else out
+    arr = (Draw * max(1, len(scene.draws)))(*[d.c_struct() for d in scene.draws])
+    if threads is None:
+        threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    st = Stats()
+    rc = lib().bbo_render_parallel(_p(scene.frame), _p(scene.view), arr, len(scene.draws), W, H, flags, int(threads), int(rows),
+                                   _p(rgba), C.byref(st))
+    if rc != 0:
+        raise RuntimeError(f"bbo_render_parallel failed: {rc}")
+    return rgba, st.as_dict()
 
 
 def render_deferred(scene: Scene, y0=0, y1=None, want_gbuffer=True, flags=0):

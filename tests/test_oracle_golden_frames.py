@@ -106,3 +106,26 @@ def test_frozen_frames_carry_the_contract_revision_that_minted_them():
     assert all(a < b for a, b in zip(revs, revs[1:])), "one history entry per revision, strictly increasing: a re-mint needs a new revision"
     for name, digest in m["files"].items():
         assert hashlib.sha256(open(os.path.join(GOLDEN, name), "rb").read()).hexdigest() == digest, name
+
+
+def test_the_threaded_oracle_renders_the_same_frame(maps64):
+    """bbo_render_parallel (what bench.py's all-cores CPU baseline times): primitives set up once, bands from a queue -- the frame,
+    the shaded-pixel count and the fragment count of bbo_render, bit for bit, in both forms of the light loop, for any number of
+    threads and band heights that do not divide the frame"""
+    import numpy as np
+    from bibim_renderer_amd import configs
+    from oracle import bbo, scenes
+    sc = scenes.shaderball_scene(configs.C3.scaled(480, 270, 64), bbo.MaterialData(maps64))
+    ref, _, _, st = bbo.render(sc)
+    for threads, rows in ((1, 8), (3, 7), (8, 32), (5, 300)):
+        got, st2 = bbo.render_parallel(sc, threads=threads, rows=rows)
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (threads, rows)
+        assert all(st2[k] == st[k] for k in ("n_prims", "n_raster_tris", "n_clipped_prims", "n_fragments", "n_shaded")), (st, st2)
+    lit, _ = bbo.render_bands(sc, flags=bbo.FLAG_LITERAL)
+    got, _ = bbo.render_parallel(sc, flags=bbo.FLAG_LITERAL, threads=4)
+    assert np.array_equal(got.view(np.uint32), lit.view(np.uint32))
+    # an empty frame and the clipped ground plane alone
+    sc.draws = sc.draws[1:]
+    ref, _, _, st = bbo.render(sc)
+    got, st2 = bbo.render_parallel(sc, threads=4, rows=16)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)) and st2["n_clipped_prims"] == st["n_clipped_prims"] > 0
