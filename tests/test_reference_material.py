@@ -72,14 +72,14 @@ def test_light_gold_through_the_oracle_in_both_forms():
     # the statistics SURVEY 8(d) quotes for this set
     assert abs(float(maps["roughness"][..., 0].mean()) - 46.0) < 1.5 and int(maps["metallic"][..., 0].min()) == 255
     assert np.allclose(maps["albedo"][..., :3].reshape(-1, 3).mean(0), (243, 215, 148), atol=1.5)
-    sc = scenes.shaderball_scene(configs.C2, bbo.MaterialData(maps))
-    contract, n_c = bbo.render_bands(sc)
-    literal, n_l = bbo.render_bands(sc, flags=bbo.FLAG_LITERAL)
-    assert n_c == n_l > 0
-    assert np.isfinite(contract).all() and np.isfinite(literal).all()
-    assert float(literal[..., :3].max()) > 2.0      # a highlight is in the frame: this IS the smooth-metal corner
-    assert float(literal[..., :3].max()) > 500.0    # ... with values far above anything the seeded maps produce
-    assert_within_baseline(contract, literal)
+    for cfg, peak in ((configs.C2, 500.0), (configs.C3, 100.0)):   # (C3: the headline workload, 16 balls and 4 lights at 4K)
+        sc = scenes.shaderball_scene(cfg, bbo.MaterialData(maps))
+        contract, st_c = bbo.render_parallel(sc)
+        literal, st_l = bbo.render_parallel(sc, flags=bbo.FLAG_LITERAL)
+        assert st_c["n_shaded"] == st_l["n_shaded"] > 0
+        assert np.isfinite(contract).all() and np.isfinite(literal).all()
+        assert float(literal[..., :3].max()) > peak   # highlights far above anything the seeded maps produce (189): the smooth-metal corner
+        assert_within_baseline(contract, literal)
 
 
 def test_the_stand_in_has_light_golds_statistics_and_both_forms_agree_on_it():
