@@ -1189,13 +1189,14 @@ BB_DEV CookedLight cook_light(const Light &l) {
 // gizmo primitives are scissored to their rectangle and biased above everything else, pixels no overlay primitive
 // wins are left alone (no background fill).  OVERLAY = false with depth_io != nullptr stores the resolved depth.
 #ifndef BB_RASTER_WAVES
-#define BB_RASTER_WAVES 8
+#define BB_RASTER_WAVES 8  // waves per SIMD the 32 x 32 instantiation is compiled for (64 registers; 20.3 KB of LDS allow eight
+                           // workgroups per CU).  64 x 64 tiles hold 32 KB of keys: three.
 #endif
 #ifndef BB_RASTER_PREFETCH
 #define BB_RASTER_PREFETCH 1
 #endif
 template <int TILE_W, int TILE_H, bool OVERLAY = false>
-__global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(OVERLAY ? 7 : BB_RASTER_WAVES))) void k_raster(
+__global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(TILE_W > 32 ? 3 : (OVERLAY ? 7 : BB_RASTER_WAVES)))) void k_raster(
     // (first: what a tile needs before its first load -- these arrive in scalar registers with the wave, "kernarg preload";
     //  the Makefile asks for it.  Everything behind them comes with one scalar load from the kernel-argument segment.)
     uint32_t *__restrict__ tile_count, Counters *__restrict__ ctr, const BroadTri *__restrict__ broad_list,
@@ -1595,8 +1596,8 @@ __global__ __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(OV
   // fragment = ((clip slot + 1) << kFragPixBits | pixel in tile) << 32 | reference
   unsigned long long *my_frags = frags + (size_t)tile * TILE_PIXELS;
   const uint32_t n_clip_refs = s_n_clip_refs <= kClipRefs ? s_n_clip_refs : 0u;  // too many: k_shade looks the slots up
-  // (ONE returning LDS atomic per wave: the wave counts the covered pixels of all its passes first -- round 4 reserved per pass,
-  //  four dependent LDS round trips per wave of every ball tile)
+  // (The wave counts the covered pixels of ALL its passes first and gets the place of its run from a prefix over the four
+  //  waves' totals -- no atomic at all; round 4 reserved per pass, four dependent returning LDS atomics per wave of every ball tile.)
   constexpr int PASSES = TILE_PIXELS / kTileThreads;
   unsigned long long pass_mask[PASSES];
   uint32_t wave_total = 0u;
