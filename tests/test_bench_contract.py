@@ -353,3 +353,71 @@ def test_trace_durations_quoted_in_the_bench_line_come_from_the_committed_phases
     assert r["frames_in_flight_2"]["ms_per_step"] > 0 and r["single_frame_device_latency_ms"] > r["one_frame_in_flight"]["avg_kernel_ms"]
     assert d["parity_vs_literal"]["within_abs_1e-4"] is True and d["parity_vs_literal"]["bit_exact"] is False
     assert d["parity_vs_oracle"]["bit_exact"] is True
+
+
+def test_clock_sampler_reads_a_cards_hwmon_files(tmp_path, monkeypatch):
+    """ClockSampler: plain file reads of the hwmon files of the card with the device's PCI address -- rehearsed on a made-up
+    sysfs tree (the real one only exists on a GPU box); a device without readable files reports `available: False`"""
+    import glob as _glob
+    import bench
+    dev = tmp_path / "sys" / "devices" / "pci0000:00" / "0000:c1:00.0"
+    hw = dev / "hwmon" / "hwmon3"
+    hw.mkdir(parents=True)
+    (hw / "freq1_input").write_text("2100000000\n")
+    (hw / "freq2_input").write_text("2000000000\n")
+    (hw / "power1_input").write_text("650000000\n")
+    card = tmp_path / "sys" / "class" / "drm" / "card7"
+    card.mkdir(parents=True)
+    os.symlink(dev, card / "device")
+    other = tmp_path / "sys" / "class" / "drm" / "card8"
+    other.mkdir()
+    os.symlink(tmp_path / "sys" / "devices", other / "device")
+    real_glob = _glob.glob
+
+    def fake_glob(pattern, *a, **k):
+        if pattern == "/sys/class/drm/card*/device":
+            return real_glob(str(tmp_path / "sys" / "class" / "drm" / "card*" / "device"))
+        return real_glob(pattern, *a, **k)
+    monkeypatch.setattr(_glob, "glob", fake_glob)
+    s = bench.ClockSampler("0000:C1:00.0", period_s=0.005).start()
+    t0 = time.perf_counter()
+    time.sleep(0.06)
+    (hw / "freq1_input").write_text("1900000000\n")
+    time.sleep(0.06)
+    t1 = time.perf_counter()
+    s.stop()
+    out = s.summary(t0, t1)
+    assert out["available"] and out["samples"] >= 4 and out["source"].endswith("card7/device")
+    assert out["sclk_mhz"]["min"] == 1900.0 and out["sclk_mhz"]["max"] == 2100.0 and out["mclk_mhz"]["mean"] == 2000.0
+    assert out["power_w"]["mean"] == 650.0
+    short = s.summary(t1 + 10.0, t1 + 10.001)   # a window without a sample: the nearest ones on either side
+    assert short["available"] and short["samples"] >= 1
+    none = bench.ClockSampler("0000:ff:00.0")
+    assert none.summary(0.0, 1.0)["available"] is False
+    none.stop()
+
+
+def test_cpu_quota_reads_the_cgroup(tmp_path, monkeypatch):
+    import builtins
+    import bench
+    real_open = builtins.open
+
+    def fake(files):
+        def _open(name, *a, **k):
+            if str(name) in files:
+                if files[str(name)] is None:
+                    raise OSError(name)
+                return real_open(files[str(name)], *a, **k)
+            return real_open(name, *a, **k)
+        return _open
+    v2 = tmp_path / "cpu.max"
+    v2.write_text("1600000 100000\n")
+    monkeypatch.setattr(builtins, "open", fake({"/sys/fs/cgroup/cpu.max": str(v2)}))
+    assert bench.cpu_quota() == 16.0
+    v2.write_text("max 100000\n")
+    assert bench.cpu_quota() is None
+    q, per = tmp_path / "q", tmp_path / "p"
+    q.write_text("250000\n"); per.write_text("100000\n")
+    monkeypatch.setattr(builtins, "open", fake({"/sys/fs/cgroup/cpu.max": None, "/sys/fs/cgroup/cpu/cpu.cfs_quota_us": str(q),
+                                                "/sys/fs/cgroup/cpu/cpu.cfs_period_us": str(per)}))
+    assert bench.cpu_quota() == 2.5
