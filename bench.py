@@ -999,6 +999,7 @@ def main():
     # HERE, in front of the timed region, with one MIN and one MAX reduction -- a mismatch ends the run with a message instead of
     # a stall that the supervisor can only time out.
     if dist is not None:
+        torch.cuda.synchronize()   # (the library's own collectives of the warm-up steps are done before torch's communicator is used)
         trip = torch.tensor([args.steps, args.warmup, len(warm_blocks), event_stride, args.frames_in_flight, step_no[0]],
                             dtype=torch.int64, device="cuda")
         lo, hi = trip.clone(), trip.clone()
