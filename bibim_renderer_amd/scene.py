@@ -149,6 +149,24 @@ def draw_frame(renderer: Renderer, scene: _Scene, cam: FreeLookCamera, settings:
     renderer._check(rc)
 
 
+def frame_call(renderer: Renderer, scene: _Scene, cam: FreeLookCamera, settings: FrameSettings, material: int):
+    """draw_frame with its arguments marshalled ONCE: returns a zero-argument callable that submits one frame.  A 1080p frame is as
+    long as the host's own work per frame (bench.py's `host` block); building a numpy array and a dozen ctypes values per call is
+    harness overhead, not the renderer's.  The camera, settings and material are those at the time of the call to frame_call."""
+    fn = lib().bbs_draw_frame
+    pos = np.ascontiguousarray(np.asarray(cam.pos, np.float32))
+    args = (renderer._ctx, scene._h, _p(pos), C.c_float(cam.yaw), C.c_float(cam.pitch), C.c_int32(settings.enable_normal_map),
+            C.c_int32(settings.enable_tone_mapping), C.c_float(settings.exposure), C.c_float(settings.fov), C.c_float(settings.near),
+            C.c_float(settings.far), C.c_int32(material), C.c_int32(renderer.width), C.c_int32(renderer.height))
+    check = renderer._check
+
+    def submit(_keep=pos):
+        rc = fn(*args)
+        if rc:
+            check(rc)
+    return submit
+
+
 def config_scene(renderer: Renderer, cfg, ball_vertices=None):
     """ShaderBallScene + camera + settings of a bibim_renderer_amd.configs.Config."""
     scene = ShaderBallScene(renderer, ball_vertices, cfg.grid)

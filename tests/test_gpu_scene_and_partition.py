@@ -29,6 +29,26 @@ def test_draw_frame_through_the_shim_matches_oracle(maps256):
     scene.close(); r.close()
 
 
+def test_frame_call_submits_the_frame_draw_frame_submits(maps256):
+    """S.frame_call (bench.py's step: draw_frame with its arguments marshalled once) renders the same frame, bit for bit, and keeps
+    doing so over many submissions with frames in flight"""
+    cfg = configs.C3.scaled(640, 360, 256)
+    r = Renderer(cfg.width, cfg.height)
+    r.set_option("frames_in_flight", 3)
+    material = r.upload_material(maps256)
+    scene, cam, settings = S.config_scene(r, cfg)
+    S.draw_frame(r, scene, cam, settings, material)
+    want = r.read_framebuffer()
+    submit = S.frame_call(r, scene, cam, settings, material)
+    for _ in range(50):
+        submit()
+    got = r.read_framebuffer()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    ref, _, _, _ = bbo.render(scenes.shaderball_scene(cfg, bbo.MaterialData(maps256)))
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    scene.close(); r.close()
+
+
 def test_scene_render_pass_type_selects_the_deferred_path(maps256):
     """SceneBase::SceneRenderPassType (src/scene.h:77) drives drawFrame as it drives recordCommand (src/main.cpp:89-112)"""
     cfg = configs.C3.scaled(480, 270, 256)
