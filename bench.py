@@ -1163,9 +1163,19 @@ def main():
         # what limits the kernel, from THIS run: its vector-ALU issue floor (committed instruction counts of this workload and
         # these kernel sources / 2-cycle issue) against its duration alone on the GPU; no figure when no such summary exists
         if v and v.get("issue_floor_ms") and s1 > 0:
-            roofline["limiter"] = (f"k_shade alone {s1 * 1e3:.1f} us against a vector-ALU issue floor of {v['issue_floor_ms'] * 1e3:.1f} us "
-                                   f"({v['issue_floor_ms'] / s1:.2f}); the rest is dependent-load latency at the hardware's eight waves per "
-                                   "SIMD (DESIGN.md section 3, k_shade); HBM is not the limiter")
+            floor = v["issue_floor_ms"]
+            alone = roofline.get("trace_kernel_alone_ms") or s1     # (the kernel trace's duration when a summary of these kernels exists)
+            sclk = ((clocks_timed or {}).get("sclk_mhz") or {}).get("mean")
+            text = (f"k_shade alone {alone * 1e3:.1f} us ({'kernel trace' if roofline.get('trace_kernel_alone_ms') else 'HIP events'}) against a "
+                    f"vector-ALU issue floor of {floor * 1e3:.1f} us at 2 cycles per wave64 instruction and the nominal "
+                    f"{SHADER_CLOCK_GHZ} GHz ({floor / alone:.2f})")
+            if sclk:
+                floor_sclk = floor * SHADER_CLOCK_GHZ * 1e3 / sclk
+                v["issue_floor_ms_at_reported_sclk"] = round(floor_sclk, 5)
+                text += (f"; {floor_sclk * 1e3:.1f} us at the {sclk:.0f} MHz this GPU reported over the timed region ({floor_sclk / alone:.2f}), "
+                         "and 14 % more with each instruction class at its measured issue cost (profiles/*_k_shade_issue_floor.txt)")
+            roofline["limiter"] = text + ("; vector issue, the vector-memory return path and the wave slots all stand near their limits "
+                                          "(DESIGN.md section 3, k_shade); HBM is not the limiter")
         else:
             roofline["limiter"] = "no instruction-count summary of this workload on these kernel sources (profiles/*_pmc_sq.json)"
         # the reference's own setting, two frames in flight (src/main.cpp:38), and one frame's device latency
