@@ -1173,7 +1173,7 @@ def main():
                 floor_sclk = floor * SHADER_CLOCK_GHZ * 1e3 / sclk
                 v["issue_floor_ms_at_reported_sclk"] = round(floor_sclk, 5)
                 text += (f"; {floor_sclk * 1e3:.1f} us at the {sclk:.0f} MHz this GPU reported over the timed region ({floor_sclk / alone:.2f}), "
-                         "and 14 % more with each instruction class at its measured issue cost (profiles/*_k_shade_issue_floor.txt)")
+                         "more with each instruction class at its measured issue cost (C3: + 14 %, profiles/*_k_shade_issue_floor.txt)")
             roofline["limiter"] = text + ("; vector issue, the vector-memory return path and the wave slots all stand near their limits "
                                           "(DESIGN.md section 3, k_shade); HBM is not the limiter")
         else:
